@@ -1,0 +1,215 @@
+"""TEST INFRASTRUCTURE ONLY — CPU oracle for the SimLOD hot paths.
+
+Two back-ends behind one interface (`HostOctree`):
+
+* ``kind="ref"``   oracle/_ref/libref_{reset,update,render}.so — the reference's own sources
+                   (modules/progressive_octree/{reset,progressive_octree_voxels,render}.cu) compiled in place as
+                   single-thread host C++ through oracle/shim/ (built by `make -C oracle ref`; needs
+                   /root/reference at BUILD time only, the .so files travel to the GPU box).
+* ``kind="port"``  oracle/libsimlod_oracle.so — the independent C restatement (oracle/simlod_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the product
+package simlod_amd never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from simlod_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PORT = os.path.join(_HERE, "libsimlod_oracle.so")
+_REF = {k: os.path.join(_HERE, "_ref", f"libref_{k}.so") for k in ("reset", "update", "render")}
+
+REF_MOMENTARY_BYTES = 408_800_192   # what kernel_construct bump-allocates; the host only gives 300 MB
+
+dump_dtype = np.dtype([
+    ("key", "<u8"), ("level", "<u4"), ("X", "<u4"), ("Y", "<u4"), ("Z", "<u4"),
+    ("isLeaf", "<u4"), ("counter", "<u4"), ("numPoints", "<u4"), ("numVoxels", "<u4"), ("numVoxelsStored", "<u4"),
+    ("countIteration", "<u4"), ("hasGrid", "<u4"), ("gridPopcount", "<u4"), ("pointChunks", "<u4"),
+    ("voxelChunks", "<u4"), ("gridHash", "<u8"), ("pointsSum", "<u8"), ("pointsXor", "<u8"),
+    ("voxelPosSum", "<u8"), ("voxelPosXor", "<u8"), ("childMask", "<u8"), ("name", "u1", 24)])
+assert dump_dtype.itemsize == 136
+
+
+def build(ref=True):
+    """(Re)build the oracle libraries; `ref` is skipped silently when /root/reference is absent."""
+    subprocess.check_call(["make", "-C", _HERE, "port"] + (["ref"] if ref else []), stdout=subprocess.DEVNULL)
+
+
+def have_ref():
+    return all(os.path.exists(p) for p in _REF.values())
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+_port_lib = None
+
+
+def port_lib():
+    global _port_lib
+    if _port_lib is None:
+        if not os.path.exists(_PORT):
+            build(ref=False)
+        lib = ctypes.CDLL(_PORT)
+        lib.oracle_create.restype = ctypes.c_void_p
+        lib.oracle_create.argtypes = [ctypes.c_uint32]
+        lib.oracle_destroy.argtypes = [ctypes.c_void_p]
+        lib.oracle_last_error.argtypes = [ctypes.c_void_p]
+        lib.oracle_last_error.restype = ctypes.c_int
+        lib.oracle_reset.argtypes = [ctypes.c_void_p] * 7
+        lib.oracle_construct.argtypes = [ctypes.c_void_p] * 8
+        lib.oracle_render.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int]
+        lib.oracle_rebase.restype = ctypes.c_int64
+        lib.oracle_rebase.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                      ctypes.c_uint64, ctypes.c_uint64]
+        lib.oracle_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        lib.oracle_gather.restype = ctypes.c_uint32
+        lib.oracle_gather.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        lib.ref_call_construct.argtypes = [ctypes.c_void_p] * 11
+        lib.ref_call_render.argtypes = [ctypes.c_void_p] * 8
+        lib.ref_call_reset.argtypes = [ctypes.c_void_p] * 8
+        _port_lib = lib
+    return _port_lib
+
+
+class HostOctree:
+    """An octree living in host memory, driven through the reference's three-kernel launch sequence
+    (main_progressive_octree.cpp:333-361 reset, :364-428 update, :465-546 render)."""
+
+    def __init__(self, kind="port", *, persistent_bytes=1 << 30, max_nodes=263_157, ring_slots=abi.BATCH_STREAM_SIZE):
+        assert kind in ("port", "ref")
+        self.kind = kind
+        self.lib = port_lib()
+        self.max_nodes = max_nodes
+        self.nodes = np.zeros(max_nodes, dtype=abi.node_dtype)
+        self.persistent = np.zeros(persistent_bytes, dtype=np.uint8)
+        self.stats = np.zeros(1, dtype=abi.stats_dtype)
+        self.num_uploaded = np.zeros(1, dtype=np.uint32)
+        self.batch_sizes = np.zeros(abi.BATCH_STREAM_SIZE, dtype=np.uint32)
+        self.ring_slots = ring_slots
+        self.ring = np.zeros(ring_slots * abi.MAX_BATCH_SIZE, dtype=abi.point_dtype)
+        self.frame_start = np.zeros(1, dtype=np.uint64)
+        self.render_buffer = None
+        self.ctx = None
+        if kind == "port":
+            self.ctx = ctypes.c_void_p(self.lib.oracle_create(max_nodes))
+        else:
+            if not have_ref():
+                build(ref=True)
+            if not have_ref():
+                raise RuntimeError("oracle/_ref is not built and /root/reference is absent")
+            self.ref = {k: ctypes.CDLL(p) for k, p in _REF.items()}
+            self.momentary = np.zeros(REF_MOMENTARY_BYTES + 4096, dtype=np.uint8)
+            self.cudaprint = np.zeros(1024 * 1001, dtype=np.uint8)
+
+    def __del__(self):
+        if getattr(self, "ctx", None):
+            self.lib.oracle_destroy(self.ctx)
+            self.ctx = None
+
+    def _fn(self, lib, name):
+        return ctypes.cast(getattr(self.ref[lib], name), ctypes.c_void_p)
+
+    # -- launch sequence ------------------------------------------------------------------------------
+    def reset(self, uniforms):
+        u = np.ascontiguousarray(uniforms).reshape(1)
+        if self.kind == "port":
+            self.lib.oracle_reset(self.ctx, _ptr(u), _ptr(self.persistent), _ptr(self.nodes), _ptr(self.stats),
+                                  _ptr(self.num_uploaded), _ptr(self.batch_sizes))
+        else:
+            self.lib.ref_call_reset(self._fn("reset", "kernel"), _ptr(u), _ptr(self.persistent), _ptr(self.nodes),
+                                    _ptr(self.stats), _ptr(self.cudaprint), _ptr(self.num_uploaded), _ptr(self.batch_sizes))
+
+    def upload(self, points):
+        """What the uploader thread does (main_progressive_octree.cpp:1040-1050): copy one batch into the next
+        ring slot, publish its size, bump numBatchesUploaded."""
+        n = len(points)
+        assert n <= abi.MAX_BATCH_SIZE
+        idx = int(self.num_uploaded[0])
+        slot = idx % abi.BATCH_STREAM_SIZE
+        assert slot < self.ring_slots
+        self.ring[slot * abi.MAX_BATCH_SIZE: slot * abi.MAX_BATCH_SIZE + n] = points
+        self.batch_sizes[slot] = n
+        self.num_uploaded[0] = idx + 1
+
+    def construct(self, uniforms):
+        u = np.ascontiguousarray(uniforms).reshape(1)
+        if self.kind == "port":
+            self.lib.oracle_construct(self.ctx, _ptr(u), _ptr(self.ring), _ptr(self.persistent), _ptr(self.nodes),
+                                      _ptr(self.stats), _ptr(self.num_uploaded), _ptr(self.batch_sizes))
+        else:
+            self.lib.ref_call_construct(self._fn("update", "kernel_construct"), _ptr(u), _ptr(self.ring),
+                                        _ptr(self.momentary), _ptr(self.persistent), _ptr(self.nodes), _ptr(self.stats),
+                                        _ptr(self.frame_start), _ptr(self.cudaprint), _ptr(self.num_uploaded),
+                                        _ptr(self.batch_sizes))
+
+    def add_points(self, uniforms, points, batch=abi.MAX_BATCH_SIZE):
+        """Upload `points` in batches and run kernel_construct until everything is ingested."""
+        for i in range(0, len(points), batch):
+            self.upload(points[i:i + batch])
+            if (int(self.num_uploaded[0]) - int(self.stats["batchletIndex"][0])) >= min(self.ring_slots, abi.MAX_BATCHES_PER_LAUNCH):
+                self.construct(uniforms)
+        while int(self.stats["batchletIndex"][0]) < int(self.num_uploaded[0]):
+            before = int(self.stats["batchletIndex"][0])
+            self.construct(uniforms)
+            if int(self.stats["batchletIndex"][0]) == before:
+                break
+
+    def render(self, uniforms, edl=False):
+        """Returns (fb uint64[H*W] pre-EDL, color uint32[H*W] as written to the surface)."""
+        u = np.ascontiguousarray(uniforms).reshape(1)
+        W, H = int(u["width"][0]), int(u["height"][0])
+        color = np.zeros(W * H, dtype=np.uint32)
+        if self.kind == "port":
+            fb = np.zeros(W * H, dtype=np.uint64)
+            visible = np.zeros(abi.MAX_VISIBLE_NODES, dtype=abi.node_dtype)
+            self.lib.oracle_render(self.ctx, _ptr(u), _ptr(self.nodes), _ptr(self.stats), _ptr(fb), _ptr(color),
+                                   _ptr(visible), int(bool(edl)))
+            self.visible = visible[: int(self.stats["numVisibleNodes"][0])]
+            return fb, color
+        assert not edl, "oracle/_ref runs with the EDL pass disabled (SURVEY.md H4)"
+        need = 15_200_000 + 64 + 32 + 16_000_000 + W * H * 8 + W * H * 20 + 4096
+        if self.render_buffer is None or self.render_buffer.size < need:
+            self.render_buffer = np.zeros(need, dtype=np.uint8)
+        ctypes.c_int.in_dll(self.ref["render"], "simlod_shim_surface_width").value = W
+        self.lib.ref_call_render(self._fn("render", "kernel_render"), _ptr(self.render_buffer), _ptr(u), _ptr(self.nodes),
+                                 _ptr(color), _ptr(self.stats), _ptr(self.frame_start), _ptr(self.cudaprint))
+        # momentary layout of render.cu:1108-1123: visibleNodes, 7 counters (16 B each), Lines (32 B), 1M vertices, fb
+        off = 100_000 * 152 + 7 * 16 + 32 + 1_000_000 * 16
+        fb = self.render_buffer[off: off + W * H * 8].view(np.uint64).copy()
+        self.visible = self.render_buffer[: 100_000 * 152].view(abi.node_dtype)[: int(self.stats["numVisibleNodes"][0])].copy()
+        return fb, color
+
+    # -- inspection --------------------------------------------------------------------------------------
+    def last_error(self):
+        return self.lib.oracle_last_error(self.ctx) if self.kind == "port" else 0
+
+    def dump(self):
+        return dump_image(self.nodes, int(self.stats["numNodes"][0]))
+
+
+def dump_image(nodes, num_nodes):
+    """Canonical, order-independent description of a HOST-addressed octree image, sorted by (level,X,Y,Z)."""
+    out = np.zeros(num_nodes, dtype=dump_dtype)
+    port_lib().oracle_dump(_ptr(nodes), num_nodes, _ptr(out))
+    return out[np.argsort(out["key"], kind="stable")]
+
+
+def rebase_image(nodes, num_nodes, persistent, old_nodes_base, old_persistent_base):
+    """Rewrite every pointer of an image copied from (old_nodes_base, old_persistent_base) to where the numpy
+    arrays live now."""
+    r = port_lib().oracle_rebase(_ptr(nodes), num_nodes, _ptr(persistent), persistent.size, old_nodes_base, old_persistent_base)
+    if r < 0:
+        raise ValueError("octree image holds a pointer outside its persistent buffer")
+    return r
+
+
+def gather_samples(head_ptr, count):
+    out = np.zeros(count, dtype=abi.point_dtype)
+    got = port_lib().oracle_gather(ctypes.c_void_p(int(head_ptr)), count, _ptr(out))
+    return out[:got]
