@@ -1,0 +1,98 @@
+/* simlod_hip.h — C ABI of libsimlod_hip.so, the MI355X (gfx950) implementation of SimLOD's two hot paths.
+ *
+ * Drop-in boundary.  The reference host reaches its device code through exactly one surface:
+ *
+ *     CudaModularProgram({.modules = {...cu paths}, .kernels = {names}})      include/CudaModularProgram.h:166-190
+ *     program->kernels["name"]  -> CUfunction                                 include/CudaModularProgram.h:241-256
+ *     cuLaunchCooperativeKernel(fn, gx,gy,gz, bx,by,bz, smem, stream, void** args)
+ *                                         modules/progressive_octree/main_progressive_octree.cpp:351, :396, :507
+ *
+ * with three programs / kernels:
+ *     reset  : {reset.cu, utils.cu}                    -> "kernel"             main_progressive_octree.cpp:620-626
+ *     update : {progressive_octree_voxels.cu, utils.cu} -> "kernel_construct"  main_progressive_octree.cpp:603-610
+ *     render : {render.cu, utils.cu}                   -> "kernel_render"      main_progressive_octree.cpp:612-618
+ *
+ * This header exports that surface 1:1 (simlod_program_* / simlod_launch_cooperative, same argument arrays as
+ * the reference builds at main_progressive_octree.cpp:337-345, :374-382, :499-507) plus typed entry points for
+ * hosts that prefer not to build void* arrays.  All pointers are DEVICE pointers unless stated otherwise; all
+ * structs are the ones of simlod_abi.h.  Every function returns 0 on success or a hipError_t value; launches are
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream), like the reference's.
+ *
+ * Device-side conditions the reference reports by printf or by silently dropping data are
+ * reported in Stats.dbg (a field the reference never writes) as a bit mask of SIMLOD_ERR_*.
+ */
+#ifndef SIMLOD_HIP_H
+#define SIMLOD_HIP_H
+
+#include "simlod_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Stats.dbg bits */
+#define SIMLOD_ERR_MOMENTARY_TOO_SMALL 0x001u /* Uniforms.momentaryBufferCapacity cannot hold the scratch layout   */
+#define SIMLOD_ERR_SPILLED_OVERFLOW    0x002u /* more spilled points in one batch than the scratch can hold        */
+#define SIMLOD_ERR_SPILLING_OVERFLOW   0x004u /* > 100 000 spilling nodes in one round (voxels.cu:847)              */
+#define SIMLOD_ERR_NODES_EXHAUSTED     0x008u /* node array full (main_progressive_octree.cpp:552: 263 157 nodes)   */
+#define SIMLOD_ERR_CHUNK_DIR_OVERFLOW  0x010u /* per-batch chunk directory full                                     */
+#define SIMLOD_ERR_NULL_CHUNK          0x020u /* insert into a leaf without storage (voxels.cu:599-604)             */
+#define SIMLOD_ERR_BARRIER_TIMEOUT     0x040u /* in-kernel grid barrier of the expand phase gave up                 */
+#define SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW 0x080u /* > 1 000 000 recycled chunks (voxels.cu:856)                        */
+#define SIMLOD_ERR_VISIBLE_OVERFLOW    0x100u /* > 100 000 visible nodes (render.cu:1108)                           */
+
+/* Number of Node records the host's node buffer holds (default 263 157 = 40 000 000 / 152,
+ * main_progressive_octree.cpp:552).  Process-wide; set before the first reset if the host allocates differently. */
+int simlod_set_node_capacity(uint32_t numNodes);
+
+/* Byte offset of the uint64 framebuffer inside kernel_render's momentary `buffer` (identical to where the
+ * reference's bump allocator places it, render.cu:1108-1123) and the minimum size of that buffer. */
+uint64_t simlod_render_framebuffer_offset(void);
+uint64_t simlod_render_buffer_bytes(uint32_t width, uint32_t height);
+/* Minimum size of kernel_construct's momentary `buffer` (the host allocates 300 MB, main_progressive_octree.cpp:554). */
+uint64_t simlod_construct_buffer_min_bytes(void);
+
+/* ---- typed launches -------------------------------------------------------------------------------------- */
+/* reset.cu:20-29  `kernel` */
+int simlod_launch_reset(const SimlodUniforms* uniforms /*host*/, uint8_t* buffer_octree, SimlodNode* nodes,
+                        SimlodStats* stats, void* cudaprint, uint32_t* numBatchesUploaded, uint32_t* batchSizes,
+                        void* stream);
+
+/* progressive_octree_voxels.cu:804-816  `kernel_construct` */
+int simlod_launch_construct(const SimlodUniforms* uniforms /*host*/, SimlodPoint* points, uint32_t* buffer,
+                            uint8_t* buffer_persistent, SimlodNode* nodes, SimlodStats* stats,
+                            uint64_t* frameStartTimestamp, void* cudaprint, uint32_t* numBatchesUploaded_volatile,
+                            uint32_t* batchSizes, void* stream);
+
+/* render.cu:1084-1093  `kernel_render`; `colorbuffer` stands for the GL surface: a linear width*height RGBA8 image */
+int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms /*host*/, SimlodNode* nodes,
+                         uint32_t* colorbuffer, SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint,
+                         void* stream);
+
+/* ---- CudaModularProgram-shaped surface ------------------------------------------------------------------- */
+typedef struct SimlodProgram SimlodProgram;
+typedef struct SimlodFunction SimlodFunction;
+
+/* Mirrors CudaModularProgram's constructor: module paths are matched by file name (reset.cu,
+ * progressive_octree_voxels.cu, render.cu, utils.cu); the device code is precompiled for gfx950, nothing is
+ * compiled at run time.  Unknown kernel names make the call fail with hipErrorNotFound. */
+int simlod_program_create(SimlodProgram** out, const char* const* modules, int numModules,
+                          const char* const* kernels, int numKernels);
+void simlod_program_destroy(SimlodProgram* program);
+/* program->kernels[name]; NULL when absent */
+SimlodFunction* simlod_program_kernel(SimlodProgram* program, const char* name);
+/* cuOccupancyMaxActiveBlocksPerMultiprocessor stand-in used by main_progressive_octree.cpp:494-496 */
+int simlod_function_max_active_blocks(SimlodFunction* fn, int blockSize, int* numBlocks);
+/* cuLaunchCooperativeKernel stand-in.  `args` holds pointers to the kernel arguments in declaration order, the
+ * Uniforms struct by value (i.e. args[k] points at a host Uniforms).  The requested geometry is accepted and
+ * ignored: the implementation sizes its own launches for the 256 CUs / 8 XCDs of the device. */
+int simlod_launch_cooperative(SimlodFunction* fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by,
+                              unsigned bz, unsigned sharedMemBytes, void* stream, void** args);
+
+/* Version / build info string (static storage). */
+const char* simlod_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMLOD_HIP_H */

@@ -1,0 +1,634 @@
+// construct.hip — incremental octree/LOD builder for MI355X (gfx950): the `kernel_construct` entry point.
+//
+// Replaces modules/progressive_octree/progressive_octree_voxels.cu:804-1010 (one persistent cooperative CUDA
+// kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
+// memory image.  Design:
+//
+//   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, sample, alloc, insert,
+//     end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
+//     over 256 CUs / 8 XCDs costs 4-26 us; control flow stays on the device (a control block at byte 0 of the
+//     momentary buffer), inactive kernels exit at once, so the call is fully asynchronous like the reference's;
+//   * every point is read with one coalesced 16-byte load per phase and descends the tree ONCE: the leaf found
+//     by `count` is cached (4 B/point) and only points whose leaf was split re-descend, from that leaf down
+//     (the reference re-descends from the root in three phases and re-scans the batch in every split round);
+//   * per-leaf counters, slot reservations and voxel counters are aggregated per 64-lane wave by a ballot/
+//     readlane peel loop (cg::labeled_partition has no HIP equivalent);
+//   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of every
+//     list remembers its tail (8 spare bytes of Chunk), and a per-batch chunk directory gives O(1) slot->chunk;
+//   * new voxels are not copied through a 24-byte backlog record: `sample` leaves a 20-bit per-point mask of the
+//     levels the point won, `insert` regenerates the voxel from (node, cell) while the point is in registers.
+//
+// The result after every batch is the reference's: same topology, same per-node sample multisets, same occupancy
+// bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
+// chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
+// (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
+#include "simlod_device.hpp"
+#include "simlod_hip.h"
+#include "simlod_internal.hpp"
+
+namespace simlod {
+
+static constexpr uint32_t TPB = 256;
+static constexpr float F_GRID = 1048576.0f;      // 2^MAX_DEPTH, progressive_octree_voxels.cu:139
+static constexpr float F_FULL = 268435456.0f;    // MAX_DEPTH_GRIDSIZE, structures.cuh:26
+
+struct NodeDir {          // per node, valid for the batch whose tag it carries
+	uint32_t ptBase, ptFirst, ptTag, voxBase, voxFirst, voxTag, pad0, pad1;
+};
+
+__device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
+template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
+
+__device__ __forceinline__ void raise(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); }
+
+// Make batch #ordinal of this launch current, or deactivate (progressive_octree_voxels.cu:890-912).
+__device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
+	ctl->active = 0;
+	if (ordinal >= ctl->numBatches || ctl->stop) return;
+	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
+	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
+	a.stats->memCapacityReached = full ? 1 : 0;
+	if (full) { ctl->stop = 1; return; }
+	const uint32_t batchIndex = a.stats->batchletIndex;
+	const uint32_t slot = batchIndex % SIMLOD_BATCH_STREAM_SIZE;
+	uint32_t size = a.batchSizes[slot];
+	if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
+	ctl->batchIndex = batchIndex;
+	ctl->ringSlot = slot;
+	ctl->batchSize = size;
+	ctl->ordinal = ordinal;
+	ctl->numSpilling = 0;
+	ctl->roundSpill[0] = 0;
+	ctl->roundSpill[1] = 0;
+	ctl->numSpilled = 0;
+	ctl->dirCount = 0;
+	ctl->abortBatch = 0;
+	ctl->active = 1;
+}
+
+// ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
+__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	Ctl* ctl = ctl_of(a);
+	ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
+	ctl->stop = momentaryTooSmall ? 1u : 0u;
+	ctl->startNs = wall_ns();
+	*a.frameStart = ctl->startNs;
+	// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
+	const uint32_t uploaded = __hip_atomic_load(a.numBatchesUploaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const uint32_t first = a.stats->batchletIndex;
+	uint32_t n = uploaded - first;
+	if ((int32_t)n < 0) n = 0;
+	if (n > SIMLOD_MAX_BATCHES_PER_LAUNCH) n = SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	ctl->uploaded = uploaded;
+	ctl->firstBatch = first;
+	ctl->numBatches = n;
+	ctl->barrierCount = 0;
+	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
+	prepare_batch(a, ctl, 0);
+}
+
+// ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
+__device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, bool active, uint32_t* spillList,
+                                           uint32_t* spillCount) {
+	wave_group_by(leafIdx, active, [&](uint64_t, int leader, int rank, int cnt) {
+		if (rank == 0) {
+			(void)leader;
+			SimlodNode* leaf = a.nodes + leafIdx;
+			const uint32_t old = atomicAdd(&leaf->counter, (uint32_t)cnt);
+			// voxels.cu:211-217.  A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing.
+			if (old <= SIMLOD_MAX_POINTS_PER_NODE && old + (uint32_t)cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
+				const uint32_t s = atomicAdd(spillCount, 1u);
+				if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
+			}
+		}
+	});
+}
+
+__global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	const uint32_t n = ctl->batchSize;
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
+	const uint32_t stride = gridDim.x * TPB;
+	for (uint32_t base = blockIdx.x * TPB; base < n; base += stride) {
+		const uint32_t i = base + threadIdx.x;
+		const bool act = i < n;
+		uint32_t leafIdx = 0;
+		if (act) {
+			const float4 p = pts[i];
+			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
+			const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
+			const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
+			leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
+			leafOf[i] = leafIdx;
+		}
+		count_into(a, ctl, leafIdx, act, spillList, &ctl->numSpilling);
+	}
+}
+
+// ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
+// Persistent, one workgroup per CU, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
+__global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	if (ctl->numSpilling == 0) return;          // written by k_count, stable for the whole launch of this kernel
+
+	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	uint32_t* winMask = at<uint32_t>(a, a.offWin);
+	uint32_t* splitTag = at<uint32_t>(a, a.offSplitTag);
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodPoint* spilled = at<SimlodPoint>(a, a.offSpilled);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const uint32_t n = ctl->batchSize;
+	uint32_t generation = 0;
+
+	__shared__ uint32_t sh_childOffset, sh_spillBase, sh_numChunks, sh_ok;
+	__shared__ uint32_t sh_childCount[8];
+	__shared__ SimlodChunk* sh_chunks[MAX_SPILL_CHUNKS];
+
+	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS; ++round) {
+		uint32_t* listCur = at<uint32_t>(a, (round & 1) ? a.offSpillB : a.offSpillA);
+		uint32_t* listNext = at<uint32_t>(a, (round & 1) ? a.offSpillA : a.offSpillB);
+		uint32_t* countCur = round == 0 ? &ctl->numSpilling : &ctl->roundSpill[(round - 1) & 1];
+		uint32_t* countNext = &ctl->roundSpill[round & 1];
+		uint32_t numSpilling = *countCur;
+		if (numSpilling > SPILLING_CAPACITY) numSpilling = SPILLING_CAPACITY;
+		if (numSpilling == 0) break;
+		const uint32_t tag = ctl->ordinal * 32u + round + 1u;
+		const uint32_t numSpilledPrev = ctl->numSpilled;    // spilled points of EARLIER rounds (stable: see barrier below)
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;
+
+		// -- split: one workgroup per spilling node ------------------------------------------------------------
+		for (uint32_t s = blockIdx.x; s < numSpilling; s += gridDim.x) {
+			SimlodNode* node = a.nodes + listCur[s];
+			const uint32_t nodeIdx = listCur[s];
+			const uint32_t stored = node->numPoints;
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				uint32_t ok = 1, off = 0;
+				const uint32_t base = atomicAdd(&ctl->numSpilled, stored);
+				if (base + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; ok = 0; }
+				if (ok) {
+					off = atomicAdd(&a.stats->numNodes, 8u);   // voxels.cu:317
+					if (off + 8u > a.nodeCapacity) { atomicSub(&a.stats->numNodes, 8u); raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ctl->abortBatch = 1; ok = 0; }
+				}
+				sh_childOffset = off; sh_spillBase = base; sh_ok = ok; sh_numChunks = 0;
+			}
+			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
+			__syncthreads();
+			if (!sh_ok) continue;
+			const uint32_t childOffset = sh_childOffset, spillBase = sh_spillBase;
+			const uint32_t level = node->level, nX = node->X, nY = node->Y, nZ = node->Z;
+
+			// move the stored points to the spill buffer, already routed to the child they belong to (voxels.cu:253-289)
+			{
+				SimlodChunk* chunk = node->points;
+				uint32_t done = 0, ci = 0;
+				while (done < stored && chunk != nullptr) {
+					SimlodChunk* next = chunk->next;                      // issue the pointer chase early
+					const uint32_t inChunk = min(stored - done, SIMLOD_POINTS_PER_CHUNK);
+					const float4* src = reinterpret_cast<const float4*>(chunk->points);
+					for (uint32_t j = threadIdx.x; j < inChunk; j += TPB) {
+						const float4 p = src[j];
+						const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
+						const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
+						const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
+						const int c = child_index(X, Y, Z, (int)level);
+						const uint32_t dst = spillBase + done + j;
+						reinterpret_cast<float4*>(spilled)[dst] = p;
+						leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = childOffset + (uint32_t)c;
+						winMask[SIMLOD_MAX_BATCH_SIZE + dst] = level << 24;     // `sample` starts at the spilling node's level
+						atomicAdd(&sh_childCount[c], 1u);
+					}
+					if (threadIdx.x == 0 && ci < MAX_SPILL_CHUNKS) sh_chunks[ci] = chunk;
+					ci++; done += inChunk; chunk = next;
+				}
+				// chunks allocated for a partially stored batch never outnumber ceil(stored/1000) here: stored == counter
+				if (threadIdx.x == 0) sh_numChunks = min(ci, (uint32_t)MAX_SPILL_CHUNKS);
+			}
+			__syncthreads();
+
+			// the eight children (voxels.cu:318-343) — one lane each, counters pre-loaded with the routed points
+			if (threadIdx.x < 8) {
+				const uint32_t i = threadIdx.x;
+				SimlodNode c;
+				for (int k = 0; k < 8; k++) c.children[k] = nullptr;
+				c.counter = sh_childCount[i];
+				c.numPoints = 0;
+				c.level = level + 1;
+				c.X = 2 * nX + ((i >> 2) & 1u);
+				c.Y = 2 * nY + ((i >> 1) & 1u);
+				c.Z = 2 * nZ + (i & 1u);
+				c.countIteration = 0;
+				c.countFlag = 0;
+				for (int k = 0; k < 20; k++) c.name[k] = node->name[k];
+				if (c.level < 20) c.name[c.level] = (uint8_t)('0' + i);
+				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
+				c.grid = nullptr; c.points = nullptr; c.voxelChunks = nullptr;
+				c.numVoxels = 0; c.numVoxelsStored = 0;
+				a.nodes[childOffset + i] = c;
+				node->children[i] = a.nodes + childOffset + i;
+			}
+			// recycle the chunks: the pool is a stack whose top is stats->numAllocatedChunks (voxels.cu:346-357)
+			if (threadIdx.x == 0) {
+				const uint32_t k = sh_numChunks;
+				if (k > 0) {
+					const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)k));
+					for (uint32_t j = 0; j < k; j++) {
+						sh_chunks[j]->next = nullptr;
+						const unsigned long long q = old - k + j;
+						if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = sh_chunks[j]; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+					}
+				}
+				node->numPoints = 0;
+				node->points = nullptr;
+				if (node->grid == nullptr) node->grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+				splitTag[nodeIdx] = tag;
+			}
+			__syncthreads();
+			// clear the occupancy grid of EVERY spilling node, also one that already had a grid (the root), voxels.cu:371-382
+			{
+				uint4* g = reinterpret_cast<uint4*>(node->grid->values);
+				const uint4 z = make_uint4(0, 0, 0, 0);
+				for (uint32_t w = threadIdx.x; w < SIMLOD_GRID_NUM_WORDS / 4; w += TPB) g[w] = z;
+			}
+		}
+
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (round + 1 == SIMLOD_MAX_EXPAND_ROUNDS) break;   // the reference's 20th split is not followed by a count (voxels.cu:394-412)
+
+		// -- recount: only samples whose cached leaf was split in THIS round go one (or more) levels down ---------
+		const uint32_t total = n + numSpilledPrev;
+		const uint32_t stride = gridDim.x * TPB;
+		for (uint32_t base = blockIdx.x * TPB; base < total; base += stride) {
+			const uint32_t t = base + threadIdx.x;
+			bool act = t < total;
+			uint32_t idx = 0, leafIdx = 0;
+			if (act) {
+				idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+				leafIdx = leafOf[idx];
+				act = splitTag[leafIdx] == tag;
+			}
+			if (act) {
+				const float4 p = t < n ? pts[t] : reinterpret_cast<const float4*>(spilled)[t - n];
+				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
+				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
+				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
+				SimlodNode* from = a.nodes + leafIdx;
+				leafIdx = (uint32_t)(descend(from, (int)from->level, X, Y, Z) - a.nodes);
+				leafOf[idx] = leafIdx;
+			}
+			count_into(a, ctl, leafIdx, act, listNext, countNext);
+		}
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+	}
+}
+
+// ---- sample: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
+__global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t n = ctl->batchSize;
+	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
+	uint32_t* winMask = at<uint32_t>(a, a.offWin);
+	const uint32_t stride = gridDim.x * TPB;
+	for (uint32_t base = blockIdx.x * TPB; base < total; base += stride) {
+		const uint32_t t = base + threadIdx.x;
+		const bool act = t < total;
+		uint32_t idx = 0, startLevel = 0;
+		uint32_t X = 0, Y = 0, Z = 0, pX = 0, pY = 0, pZ = 0;
+		if (act) {
+			float4 p;
+			if (t < n) { idx = t; p = pts[t]; }
+			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
+			X = quantize(F_GRID, p.x, a.minx, a.size); Y = quantize(F_GRID, p.y, a.miny, a.size); Z = quantize(F_GRID, p.z, a.minz, a.size);
+			pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
+		}
+		SimlodNode* cur = a.nodes;
+		bool alive = act;
+		uint32_t wins = 0;
+#pragma unroll 1
+		for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
+			bool won = false;
+			if (alive && (uint32_t)level >= startLevel) {
+				SimlodOccupancyGrid* grid = cur->grid;
+				if (grid != nullptr) {
+					const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);          // voxels.cu:78-85
+					const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+					const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+					const uint32_t bit = 1u << (cell & 31u);
+					uint32_t* word = &grid->values[cell >> 5];
+					if ((*word & bit) == 0u) won = (atomicOr(word, bit) & bit) == 0u;          // voxels.cu:93-99
+				}
+			}
+			const uint32_t curIdx = (uint32_t)(cur - a.nodes);
+			wave_group_by<4>(curIdx, won, [&](uint64_t, int, int rank, int cnt) {
+				if (rank == 0) atomicAdd(&a.nodes[curIdx].numVoxels, (uint32_t)cnt);       // voxels.cu:101
+			});
+			if (won) wins |= 1u << level;
+			if (alive) {
+				SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
+				if (ch == nullptr) alive = false; else cur = ch;
+			}
+			if (!__any(alive)) break;
+		}
+		if (act) winMask[idx] = wins;
+	}
+}
+
+// ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
+// (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
+__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
+
+__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= numNodes) return;
+	SimlodNode* node = a.nodes + i;
+	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
+	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	const uint32_t tag = ctl->batchIndex + 1u;
+	node->countIteration = tag;
+
+	// -- points of leaves -------------------------------------------------------------------------------------
+	const uint32_t counter = node->counter, stored = node->numPoints;
+	if (stored < counter && node_is_leaf(node)) {
+		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
+		const uint32_t entries = required - first;
+		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
+		if (base + entries > a.dirCap) { raise(ctl, SIMLOD_ERR_CHUNK_DIR_OVERFLOW); return; }
+		SimlodChunk* head = node->points;
+		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+		uint32_t e = 0;
+		if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
+		const uint32_t additional = required - existing;
+		if (additional > 0) {
+			// pop from the recycle stack, allocate what the stack cannot serve (voxels.cu:505-516): one atomic each
+			const unsigned long long firstIdx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional);
+			const unsigned long long pool = a.stats->chunkPoolSize;     // raised only by k_end
+			const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
+			uint8_t* fresh = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
+			for (uint32_t k = 0; k < additional; k++) {
+				SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
+				                              : reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				c->next = nullptr;
+				if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
+				tail = c;
+				chunkDir[base + e++] = c;
+			}
+			tail_of(head) = tail;
+		}
+		NodeDir& d = nodeDir[i];
+		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
+	}
+
+	// -- voxels of inner nodes (and of the root while it is still a leaf) --------------------------------------
+	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
+	if (numVoxels > voxStored) {
+		const uint32_t required = (numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		SimlodChunk* head = node->voxelChunks;
+		const uint32_t existing = head == nullptr ? 0u : max(1u, (voxStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK);
+		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t entries = required - first;
+		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
+		if (base + entries > a.dirCap) { raise(ctl, SIMLOD_ERR_CHUNK_DIR_OVERFLOW); return; }
+		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+		uint32_t e = 0;
+		if (first < existing) chunkDir[base + e++] = tail;
+		if (required > existing) {
+			const uint32_t additional = required - existing;
+			uint8_t* fresh = persistent_alloc(a.pers, sizeof(SimlodChunk), additional);   // voxel chunks never come from the pool
+			for (uint32_t k = 0; k < additional; k++) {
+				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				c->next = nullptr;
+				if (tail == nullptr) { node->voxelChunks = c; head = c; } else tail->next = c;
+				tail = c;
+				chunkDir[base + e++] = c;
+			}
+			tail_of(head) = tail;
+		}
+		NodeDir& d = nodeDir[i];
+		d.voxBase = base; d.voxFirst = first; d.voxTag = tag;
+	}
+}
+
+// ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
+__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t n = ctl->batchSize;
+	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
+	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
+	const uint32_t* winMask = at<const uint32_t>(a, a.offWin);
+	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
+	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	const uint32_t tag = ctl->batchIndex + 1u;
+	const uint32_t stride = gridDim.x * TPB;
+	for (uint32_t base = blockIdx.x * TPB; base < total; base += stride) {
+		const uint32_t t = base + threadIdx.x;
+		const bool act = t < total;
+		float4 p = make_float4(0, 0, 0, 0);
+		uint32_t leafIdx = 0, wins = 0;
+		if (act) {
+			uint32_t idx;
+			if (t < n) { idx = t; p = pts[t]; } else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; }
+			leafIdx = leafOf[idx];
+			wins = winMask[idx] & 0xfffffu;
+		}
+		// -- the point itself ------------------------------------------------------------------------------------
+		wave_group_by(leafIdx, act, [&](uint64_t, int leader, int rank, int cnt) {
+			uint32_t slot0 = 0;
+			if (rank == 0) slot0 = atomicAdd(&a.nodes[leafIdx].numPoints, (uint32_t)cnt);      // voxels.cu:593
+			const uint32_t slot = (uint32_t)__shfl((int)slot0, leader, 64) + (uint32_t)rank;
+			const NodeDir d = nodeDir[leafIdx];
+			if (d.ptTag != tag) { if (rank == 0) raise(ctl, SIMLOD_ERR_NULL_CHUNK); return; }   // voxels.cu:599-604
+			SimlodChunk* chunk = chunkDir[d.ptBase + (slot / SIMLOD_POINTS_PER_CHUNK - d.ptFirst)];
+			reinterpret_cast<float4*>(chunk->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p;
+		});
+		// -- the voxels this sample created ------------------------------------------------------------------------
+		if (__any(wins != 0u)) {
+			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+			SimlodNode* cur = a.nodes;
+			bool alive = wins != 0u;
+#pragma unroll 1
+			for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
+				const bool won = alive && ((wins >> level) & 1u);
+				const uint32_t curIdx = (uint32_t)(cur - a.nodes);
+				wave_group_by<4>(curIdx, won, [&](uint64_t, int leader, int rank, int cnt) {
+					uint32_t slot0 = 0;
+					if (rank == 0) slot0 = atomicAdd(&cur->numVoxelsStored, (uint32_t)cnt);       // voxels.cu:685
+					const uint32_t slot = (uint32_t)__shfl((int)slot0, leader, 64) + (uint32_t)rank;
+					const NodeDir d = nodeDir[curIdx];
+					if (d.voxTag != tag) { if (rank == 0) raise(ctl, SIMLOD_ERR_NULL_CHUNK); return; }
+					// cell-centre position, voxels.cu:103-114, operation by operation
+					const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
+					const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+					const float nodeSize = a.size / exp2_int(cur->level);
+					const float nminx = ((float)cur->X + 0.0f) * nodeSize + a.minx;
+					const float nminy = ((float)cur->Y + 0.0f) * nodeSize + a.miny;
+					const float nminz = ((float)cur->Z + 0.0f) * nodeSize + a.minz;
+					float4 v;
+					v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
+					v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
+					v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
+					v.w = p.w;                                                                    // colour of the claiming point
+					SimlodChunk* chunk = chunkDir[d.voxBase + (slot / SIMLOD_POINTS_PER_CHUNK - d.voxFirst)];
+					reinterpret_cast<float4*>(chunk->points)[slot % SIMLOD_POINTS_PER_CHUNK] = v;
+				});
+				if (alive) {
+					if ((wins >> (level + 1)) == 0u) alive = false;       // nothing deeper to emit
+					else {
+						SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
+						if (ch == nullptr) alive = false; else cur = ch;
+					}
+				}
+				if (!__any(alive)) break;
+			}
+		}
+	}
+}
+
+// ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
+__global__ void k_end(BuildArgs a, uint32_t ordinal) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	Ctl* ctl = ctl_of(a);
+	if (ctl->active && ctl->abortBatch) ctl->stop = 1;       // scratch overflow: this batch is lost, report through Stats.dbg
+	if (ctl->active && !ctl->abortBatch) {
+		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
+		a.stats->batchletIndex += 1;
+		a.stats->numPointsProcessed += ctl->batchSize;
+		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
+		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
+	}
+	prepare_batch(a, ctl, ordinal + 1);
+}
+
+// ---- stats pass (voxels.cu:957-1009) -------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
+__global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};   // inner, leaves, nonempty, points, voxels, chunksP, chunksV
+	if (i < numNodes) {
+		const SimlodNode* n = a.nodes + i;
+		if (node_is_leaf(n)) {
+			v[1] = 1; v[3] = n->numPoints; v[5] = (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			v[2] = n->numPoints > 0 ? 1u : 0u;
+		} else {
+			v[0] = 1; v[4] = n->numVoxels; v[6] = (n->numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		}
+	}
+	for (int k = 0; k < 7; k++) {
+		const uint32_t s = wave_sum(v[k]);
+		if (lane_id() == 0 && s != 0u) atomicAdd(&ctl->statCounters[k], s);
+	}
+}
+
+__global__ void k_finish(BuildArgs a) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	Ctl* ctl = ctl_of(a);
+	SimlodStats* s = a.stats;
+	s->numInner = ctl->statCounters[0];
+	s->numLeaves = ctl->statCounters[1];
+	s->numNonemptyLeaves = ctl->statCounters[2];
+	s->numPoints = ctl->statCounters[3];
+	s->numVoxels = ctl->statCounters[4];
+	s->numChunksPoints = ctl->statCounters[5];
+	s->numChunksVoxels = ctl->statCounters[6];
+	s->allocatedBytes_momentary = a.scratchBytes;
+	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
+	s->frameID = (uint32_t)a.frameCounter;
+	s->dbg |= ctl->errors;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
+	uint64_t off = 4096;                                                       // Ctl
+	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
+	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	off += align_up((uint64_t)nodeCapacity * 4, 256);                          // splitTag
+	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
+	off += align_up((uint64_t)dirCap * 8, 256);
+	return off;
+}
+
+bool layout_construct(BuildArgs& a, uint64_t capacity) {
+	a.dirCap = 2 * a.nodeCapacity + 65536;
+	uint64_t off = 4096;
+	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
+	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
+	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
+	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
+	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
+	if (capacity < off + perBatch + 24ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch; return false; }
+	uint64_t cap = (capacity - off - perBatch - 1024) / 24;
+	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
+	a.spilledCap = (uint32_t)cap;
+	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offWin = off;      off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
+	a.scratchBytes = off;
+	return off <= capacity;
+}
+
+int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream) {
+	BuildArgs a{};
+	a.ring = points; a.mom = reinterpret_cast<uint8_t*>(buffer); a.pers = pers; a.nodes = nodes; a.stats = stats;
+	a.frameStart = frameStart; a.numBatchesUploaded = numBatchesUploaded; a.batchSizes = batchSizes;
+	const float bx = u->boxMax.x - u->boxMin.x, by = u->boxMax.y - u->boxMin.y, bz = u->boxMax.z - u->boxMin.z;
+	a.size = fmaxf(fmaxf(bx, by), bz);                                         // voxels.cu:860-863
+	a.minx = u->boxMin.x; a.miny = u->boxMin.y; a.minz = u->boxMin.z;
+	a.persCapacity = u->persistentBufferCapacity;
+	a.frameCounter = u->frameCounter;
+	a.nodeCapacity = node_capacity();
+	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
+	const DeviceInfo& dev = device_info();
+
+	hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, stream, a, fits ? 0u : 1u);
+	if (fits) {
+		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)a.nodeCapacity * 4, stream);
+		if (e != hipSuccess) return (int)e;
+		const uint32_t gridPoints = dev.numCUs * 8;                            // grid-stride, 8 workgroups per CU
+		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
+		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
+			hipLaunchKernelGGL(k_count, dim3(gridPoints), dim3(TPB), 0, stream, a);
+			hipLaunchKernelGGL(k_expand, dim3(dev.numCUs), dim3(TPB), 0, stream, a);
+			hipLaunchKernelGGL(k_sample, dim3(gridPoints), dim3(TPB), 0, stream, a);
+			hipLaunchKernelGGL(k_alloc, dim3(gridNodes), dim3(TPB), 0, stream, a);
+			hipLaunchKernelGGL(k_insert, dim3(gridPoints), dim3(TPB), 0, stream, a);
+			hipLaunchKernelGGL(k_end, dim3(1), dim3(64), 0, stream, a, b);
+		}
+		hipLaunchKernelGGL(k_stats, dim3(gridNodes), dim3(TPB), 0, stream, a);
+	}
+	hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, stream, a);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return (int)e;
+	return fits ? 0 : (int)hipErrorInvalidValue;
+}
+
+}  // namespace simlod

@@ -1,0 +1,131 @@
+// simlod_device.hpp — device-side building blocks shared by the gfx950 kernels.
+//
+// Hardware model these helpers are written for (MI355X / CDNA4): 64-lane wavefronts, 256 CUs in 8 XCDs with
+// private, mutually non-coherent L2s, device-scope atomics resolved at the memory side.  Hence:
+//   * wave_group_by(): 64-lane "match-any" peel loop on ballot/readlane — the replacement for CUDA's
+//     cg::labeled_partition (progressive_octree_voxels.cu:203-218), which HIP does not have;
+//   * grid_barrier(): monotonic-counter barrier with agent-scope release/acquire (only the rarely executed
+//     expand loop uses it; every other dependency is a kernel boundary, which is cheaper on this chip);
+//   * all arithmetic that feeds a comparison with the CPU oracle is written operation by operation and the
+//     translation unit is compiled with -ffp-contract=off (no FMA contraction, IEEE divide/sqrt).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "simlod_abi.h"
+
+#define SIMLOD_WAVE 64
+
+namespace simlod {
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+	int l = lane_id();
+	return l == 0 ? 0ull : (~0ull >> (64 - l));
+}
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+	uint32_t lo = readlane_u32((uint32_t)v, lane), hi = readlane_u32((uint32_t)(v >> 32), lane);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+// Partition the `active` lanes of a wave by `key` and run f(groupMask, leaderLane, rank, count) once per lane,
+// where lanes holding equal keys form a group.  MUST be called from wave-convergent code (every lane of the wave
+// reaches the call; lanes without work pass active = false).  After MAX_PEEL distinct keys the remaining lanes
+// are handed out as singleton groups — spatially coherent batches need 1-3 rounds, random ones gain nothing
+// from more.
+template <int MAX_PEEL = 6, class F>
+__device__ __forceinline__ void wave_group_by(uint32_t key, bool active, F&& f) {
+	uint64_t remaining = __ballot(active);
+	const int lane = lane_id();
+	const uint64_t lt = lanemask_lt();
+#pragma unroll 1
+	for (int it = 0; it < MAX_PEEL && remaining; ++it) {
+		const int leader = __ffsll((unsigned long long)remaining) - 1;
+		const uint32_t k = readlane_u32(key, leader);
+		const bool mine = active && key == k && ((remaining >> lane) & 1ull);
+		const uint64_t m = __ballot(mine);
+		if (mine) f(m, leader, (int)__popcll(m & lt), (int)__popcll(m));
+		remaining &= ~m;
+	}
+	if ((remaining >> lane) & 1ull) f(1ull << lane, lane, 0, 1);
+}
+
+// exact 2^level as fp32 (the reference's pow(2.0f, float(level)))
+__device__ __forceinline__ float exp2_int(uint32_t level) { return __uint_as_float((127u + level) << 23); }
+
+// fp32 -> u32 quantisation of one coordinate, progressive_octree_voxels.cu:148-155: scale * (p - min) / size,
+// evaluated left to right in fp32, truncated (v_cvt_u32_f32 saturates: NaN/negative -> 0).
+__device__ __forceinline__ uint32_t quantize(float scale, float p, float mn, float size) {
+	float v = scale * (p - mn);
+	v = v / size;
+	return (uint32_t)v;
+}
+
+__device__ __forceinline__ int child_index(uint32_t X, uint32_t Y, uint32_t Z, int level) {
+	const int s = SIMLOD_MAX_DEPTH - 1 - level;   // progressive_octree_voxels.cu:171-179
+	return (int)((((X >> s) & 1u) << 2) | (((Y >> s) & 1u) << 1) | ((Z >> s) & 1u));
+}
+
+__device__ __forceinline__ bool node_is_leaf(const SimlodNode* n) {
+	const ulonglong2* c = reinterpret_cast<const ulonglong2*>(n->children);
+	ulonglong2 a = c[0], b = c[1], d = c[2], e = c[3];
+	return (a.x | a.y | b.x | b.y | d.x | d.y | e.x | e.y) == 0ull;
+}
+
+// Descend from `cur` (at level `level`) to the leaf that owns (X,Y,Z); progressive_octree_voxels.cu:169-187.
+__device__ __forceinline__ SimlodNode* descend(SimlodNode* cur, int level, uint32_t X, uint32_t Y, uint32_t Z) {
+#pragma unroll 1
+	for (; level < SIMLOD_MAX_DEPTH; ++level) {
+		SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
+		if (ch == nullptr) break;
+		cur = ch;
+	}
+	return cur;
+}
+
+__device__ __forceinline__ uint64_t wall_ns() { return (uint64_t)wall_clock64() * 10ull; }   // 100 MHz constant clock
+
+// AllocatorGlobal::alloc for `count` objects of `size` bytes each, as ONE atomic (utils.h.cu:185-197 advances the
+// offset by 16*((size+16)/16) per object, so `count` objects advance it by count times that).  Returns the first.
+__device__ __forceinline__ uint8_t* persistent_alloc(uint8_t* pers, uint64_t size, uint32_t count) {
+	SimlodAllocatorGlobal* a = reinterpret_cast<SimlodAllocatorGlobal*>(pers);
+	unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a->offset),
+	                                   (unsigned long long)(SIMLOD_ALLOC_ROUND(size) * count));
+	return pers + old;
+}
+
+// ---- grid barrier (expand loop only) --------------------------------------------------------------------------
+// One monotonic device-scope counter, zeroed by the host-enqueued prologue of every launch.  Producer side: every
+// wave drains its stores, the block syncs, lane 0 issues the agent-scope release (L2 write-back), arrives, polls
+// relaxed, then ONE agent-scope acquire (L1 invalidate) and a block sync.  Returns false after ~0.2 s of polling.
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& generation, uint32_t numBlocks) {
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	__shared__ int ok;
+	generation += 1;
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t target = generation * numBlocks;
+		int good = 1;
+		uint64_t t0 = wall_clock64();
+		while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+			__builtin_amdgcn_s_sleep(8);
+			if (wall_clock64() - t0 > 20000000ull) { good = 0; break; }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		ok = good;
+	}
+	__syncthreads();
+	return ok != 0;
+}
+
+}  // namespace simlod

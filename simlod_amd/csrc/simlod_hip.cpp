@@ -1,0 +1,164 @@
+// simlod_hip.cpp — the C ABI of libsimlod_hip.so (include/simlod_hip.h): typed launches plus the
+// CudaModularProgram / cuLaunchCooperativeKernel shaped surface of the reference host
+// (include/CudaModularProgram.h:140-264, modules/progressive_octree/main_progressive_octree.cpp:333-546).
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "simlod_hip.h"
+#include "simlod_internal.hpp"
+
+namespace simlod {
+
+static std::atomic<uint32_t> g_nodeCapacity{263157u};   // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
+
+uint32_t node_capacity() { return g_nodeCapacity.load(); }
+
+const DeviceInfo& device_info() {
+	// one entry per device ordinal; a process drives one GPU (one rank per GPU), but stay correct if it switches
+	static DeviceInfo cache[64];
+	static std::atomic<bool> valid[64];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev < 0 || dev >= 64) dev = 0;
+	if (!valid[dev].load(std::memory_order_acquire)) {
+		hipDeviceProp_t prop;
+		DeviceInfo info{dev, 256u};
+		if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) info.numCUs = (uint32_t)prop.multiProcessorCount;
+		cache[dev] = info;
+		valid[dev].store(true, std::memory_order_release);
+	}
+	return cache[dev];
+}
+
+uint64_t render_buffer_bytes(uint32_t width, uint32_t height);
+
+enum KernelKind { KIND_RESET = 0, KIND_CONSTRUCT = 1, KIND_RENDER = 2 };
+
+}  // namespace simlod
+
+struct SimlodFunction {
+	simlod::KernelKind kind;
+	std::string name;
+};
+
+struct SimlodProgram {
+	std::vector<std::string> modules;
+	std::vector<SimlodFunction> functions;
+};
+
+using namespace simlod;
+
+extern "C" {
+
+int simlod_set_node_capacity(uint32_t numNodes) {
+	if (numNodes < 9) return (int)hipErrorInvalidValue;
+	g_nodeCapacity.store(numNodes);
+	return 0;
+}
+
+uint64_t simlod_render_framebuffer_offset(void) {
+	return (uint64_t)SIMLOD_MAX_VISIBLE_NODES * sizeof(SimlodNode) + 7 * 16 + 32 + 16000000ull;
+}
+
+uint64_t simlod_render_buffer_bytes(uint32_t width, uint32_t height) { return render_buffer_bytes(width, height); }
+
+uint64_t simlod_construct_buffer_min_bytes(void) {
+	BuildArgs a{};
+	a.nodeCapacity = node_capacity();
+	layout_construct(a, 0);
+	return a.scratchBytes + 24ull * 65536 + 1024;
+}
+
+int simlod_launch_reset(const SimlodUniforms* uniforms, uint8_t* buffer_octree, SimlodNode* nodes, SimlodStats* stats,
+                        void* cudaprint, uint32_t* numBatchesUploaded, uint32_t* batchSizes, void* stream) {
+	(void)cudaprint;   // CudaPrint's device side is a no-op (modules/CudaPrint/CudaPrint.cuh:49-51): accepted, unused
+	if (!uniforms || !buffer_octree || !nodes || !stats || !numBatchesUploaded || !batchSizes) return (int)hipErrorInvalidValue;
+	return launch_reset(uniforms, buffer_octree, nodes, stats, numBatchesUploaded, batchSizes, (hipStream_t)stream);
+}
+
+int simlod_launch_construct(const SimlodUniforms* uniforms, SimlodPoint* points, uint32_t* buffer, uint8_t* buffer_persistent,
+                            SimlodNode* nodes, SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint,
+                            uint32_t* numBatchesUploaded_volatile, uint32_t* batchSizes, void* stream) {
+	(void)cudaprint;
+	if (!uniforms || !points || !buffer || !buffer_persistent || !nodes || !stats || !frameStartTimestamp ||
+	    !numBatchesUploaded_volatile || !batchSizes) return (int)hipErrorInvalidValue;
+	return launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp,
+	                        numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
+}
+
+int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms, SimlodNode* nodes, uint32_t* colorbuffer,
+                         SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
+	(void)cudaprint;
+	if (!uniforms || !buffer || !nodes || !stats || !frameStartTimestamp) return (int)hipErrorInvalidValue;
+	return launch_render(buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream);
+}
+
+static bool ends_with(const std::string& s, const char* suffix) {
+	const size_t n = std::strlen(suffix);
+	return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+int simlod_program_create(SimlodProgram** out, const char* const* modules, int numModules, const char* const* kernels, int numKernels) {
+	if (!out) return (int)hipErrorInvalidValue;
+	*out = nullptr;
+	SimlodProgram* p = new SimlodProgram();
+	bool hasReset = false, hasUpdate = false, hasRender = false;
+	for (int i = 0; i < numModules; i++) {
+		p->modules.emplace_back(modules[i] ? modules[i] : "");
+		const std::string& m = p->modules.back();
+		hasReset |= ends_with(m, "reset.cu");
+		hasUpdate |= ends_with(m, "progressive_octree_voxels.cu");
+		hasRender |= ends_with(m, "render.cu");
+	}
+	for (int i = 0; i < numKernels; i++) {
+		const std::string k = kernels[i] ? kernels[i] : "";
+		SimlodFunction f;
+		f.name = k;
+		if (k == "kernel" && hasReset) f.kind = KIND_RESET;
+		else if (k == "kernel_construct" && hasUpdate) f.kind = KIND_CONSTRUCT;
+		else if (k == "kernel_render" && hasRender) f.kind = KIND_RENDER;
+		else { delete p; return (int)hipErrorNotFound; }
+		p->functions.push_back(f);
+	}
+	*out = p;
+	return 0;
+}
+
+void simlod_program_destroy(SimlodProgram* program) { delete program; }
+
+SimlodFunction* simlod_program_kernel(SimlodProgram* program, const char* name) {
+	if (!program || !name) return nullptr;
+	for (auto& f : program->functions) if (f.name == name) return &f;
+	return nullptr;
+}
+
+int simlod_function_max_active_blocks(SimlodFunction* fn, int blockSize, int* numBlocks) {
+	if (!fn || !numBlocks || blockSize <= 0) return (int)hipErrorInvalidValue;
+	*numBlocks = 2048 / blockSize > 0 ? (2048 / blockSize > 8 ? 8 : 2048 / blockSize) : 1;   // 32 waves per CU
+	return 0;
+}
+
+int simlod_launch_cooperative(SimlodFunction* fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz,
+                              unsigned sharedMemBytes, void* stream, void** args) {
+	(void)gx; (void)gy; (void)gz; (void)bx; (void)by; (void)bz; (void)sharedMemBytes;
+	if (!fn || !args) return (int)hipErrorInvalidValue;
+	switch (fn->kind) {
+	case KIND_RESET:      // main_progressive_octree.cpp:337-345
+		return simlod_launch_reset((const SimlodUniforms*)args[0], *(uint8_t**)args[1], *(SimlodNode**)args[2], *(SimlodStats**)args[3],
+		                           *(void**)args[4], *(uint32_t**)args[5], *(uint32_t**)args[6], stream);
+	case KIND_CONSTRUCT:  // main_progressive_octree.cpp:374-382
+		return simlod_launch_construct((const SimlodUniforms*)args[0], *(SimlodPoint**)args[1], *(uint32_t**)args[2], *(uint8_t**)args[3],
+		                               *(SimlodNode**)args[4], *(SimlodStats**)args[5], *(uint64_t**)args[6], *(void**)args[7],
+		                               *(uint32_t**)args[8], *(uint32_t**)args[9], stream);
+	case KIND_RENDER:     // main_progressive_octree.cpp:499-507
+		return simlod_launch_render(*(uint32_t**)args[0], (const SimlodUniforms*)args[1], *(SimlodNode**)args[2], *(uint32_t**)args[3],
+		                            *(SimlodStats**)args[4], *(uint64_t**)args[5], *(void**)args[6], stream);
+	}
+	return (int)hipErrorInvalidValue;
+}
+
+const char* simlod_build_info(void) { return "simlod_hip gfx950 (-ffp-contract=off, IEEE div/sqrt) " __DATE__ " " __TIME__; }
+
+}  // extern "C"

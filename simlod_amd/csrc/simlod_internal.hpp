@@ -1,0 +1,60 @@
+// simlod_internal.hpp — declarations shared by the translation units of libsimlod_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "simlod_abi.h"
+
+namespace simlod {
+
+static constexpr uint32_t CHUNK_QUEUE_CAPACITY = 1000000u;   // progressive_octree_voxels.cu:856
+static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octree_voxels.cu:847
+static constexpr int MAX_SPILL_CHUNKS = 64;                  // a spilling leaf stores <= 50 000 points = 50 chunks
+
+// Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
+// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
+struct Ctl {
+	uint32_t uploaded, firstBatch, numBatches, stop;
+	uint32_t active, batchSize, ringSlot, batchIndex;
+	uint32_t numSpilling;        // spilling leaves found by k_count; NOT modified by k_expand (its early-exit test must be stable)
+	uint32_t numSpilled, dirCount, errors;
+	uint32_t ordinal, abortBatch, barrierCount, pad0;
+	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]
+	uint32_t pad1[2];
+	uint64_t startNs;
+	uint32_t statCounters[8];
+};
+
+struct BuildArgs {
+	SimlodPoint* ring;
+	uint8_t*     mom;
+	uint8_t*     pers;
+	SimlodNode*  nodes;
+	SimlodStats* stats;
+	uint64_t*    frameStart;
+	uint32_t*    numBatchesUploaded;
+	uint32_t*    batchSizes;
+	float        minx, miny, minz, size;
+	uint64_t     persCapacity, frameCounter, scratchBytes;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offNodeDir, offChunkDir, offLeafOf, offWin, offSpilled;
+	uint32_t     nodeCapacity, spilledCap, dirCap, pad;
+};
+
+struct DeviceInfo {
+	int      device;
+	uint32_t numCUs;
+};
+
+const DeviceInfo& device_info();
+uint32_t node_capacity();
+
+bool layout_construct(BuildArgs& a, uint64_t capacity);
+int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
+int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
+                 uint32_t* batchSizes, hipStream_t stream);
+int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
+                  uint64_t* frameStart, hipStream_t stream);
+
+}  // namespace simlod

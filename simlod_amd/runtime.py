@@ -1,0 +1,212 @@
+"""Host side of the MI355X SimLOD hot paths: a headless mirror of what the reference host does around its three
+kernels (modules/progressive_octree/main_progressive_octree.cpp).
+
+    initCudaProgram()   :549-642   device buffers (nodes 40 MB, momentary 300 MB, render 200 MB, ring 50 x 16 MB, ...)
+    resetCUDA()         :333-361   launch `kernel`
+    uploader thread     :1040-1050 H2D copy of one batch into the ring, publish batchSizes[slot], numBatchesUploaded
+    updateOctree()      :364-428   launch `kernel_construct`
+    renderCUDA()        :465-546   launch `kernel_render`
+    stats readback      :1201      D2H copy of Stats
+
+Everything device-side goes through the C ABI of libsimlod_hip.so (include/simlod_hip.h); torch is used for device
+memory and streams only.  There is NO CPU fallback: without the compiled library or without a GPU this module
+raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsimlod_hip.so")
+_lib = None
+
+
+class SimlodError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsimlod_hip.so (built by `make -C simlod_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SimlodError(f"{_LIB_PATH} is missing: build it with `make -C simlod_amd/csrc` (no fallback path exists)")
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.simlod_set_node_capacity.argtypes = [u32]
+        L.simlod_render_framebuffer_offset.restype = u64
+        L.simlod_render_buffer_bytes.restype = u64
+        L.simlod_render_buffer_bytes.argtypes = [u32, u32]
+        L.simlod_construct_buffer_min_bytes.restype = u64
+        L.simlod_launch_reset.argtypes = [vp] * 8
+        L.simlod_launch_construct.argtypes = [vp] * 11
+        L.simlod_launch_render.argtypes = [vp] * 8
+        L.simlod_program_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+        L.simlod_program_destroy.argtypes = [vp]
+        L.simlod_program_kernel.restype = vp
+        L.simlod_program_kernel.argtypes = [vp, ctypes.c_char_p]
+        L.simlod_function_max_active_blocks.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.simlod_launch_cooperative.argtypes = [vp] + [ctypes.c_uint] * 7 + [vp, ctypes.POINTER(vp)]
+        L.simlod_build_info.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "simlod_set_node_capacity", "simlod_render_framebuffer_offset", "simlod_render_buffer_bytes",
+    "simlod_construct_buffer_min_bytes", "simlod_launch_reset", "simlod_launch_construct", "simlod_launch_render",
+    "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
+    "simlod_launch_cooperative", "simlod_build_info",
+]
+
+
+def _check(code, what):
+    if code != 0:
+        raise SimlodError(f"{what} failed with hipError {code}")
+
+
+class Program:
+    """CudaModularProgram look-alike (include/CudaModularProgram.h:140-264): modules -> kernels[name]."""
+
+    def __init__(self, modules, kernels):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        m = (ctypes.c_char_p * len(modules))(*[s.encode() for s in modules])
+        k = (ctypes.c_char_p * len(kernels))(*[s.encode() for s in kernels])
+        _check(L.simlod_program_create(ctypes.byref(self._h), m, len(modules), k, len(kernels)), "simlod_program_create")
+        self.kernels = {name: L.simlod_program_kernel(self._h, name.encode()) for name in kernels}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().simlod_program_destroy(self._h)
+            self._h = None
+
+
+class DeviceOctree:
+    """Device buffers of initCudaProgram() + the three launches, on one GPU."""
+
+    def __init__(self, device="cuda:0", *, persistent_bytes=4 << 30, momentary_bytes=300_000_000, max_nodes=263_157,
+                 ring_slots=abi.BATCH_STREAM_SIZE, max_pixels=1920 * 1080):
+        if not torch.cuda.is_available():
+            raise SimlodError("no GPU visible: the SimLOD hot paths only exist as gfx950 kernels")
+        self.L = lib()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.max_nodes = max_nodes
+        _check(self.L.simlod_set_node_capacity(max_nodes), "simlod_set_node_capacity")
+        z = dict(dtype=torch.uint8, device=self.device)
+        # H11: the reference renders before any reset and relies on fresh VRAM reading as zero
+        self.nodes = torch.zeros(max_nodes * 152, **z)
+        self.stats = torch.zeros(112, **z)
+        self.persistent = torch.empty(persistent_bytes, **z)
+        self.persistent[:1 << 20].zero_()
+        self.momentary = torch.empty(momentary_bytes, **z)
+        self.momentary[:1 << 20].zero_()
+        self.ring_slots = ring_slots
+        self.ring = torch.empty(ring_slots * abi.MAX_BATCH_SIZE * 16, **z)
+        self.batch_sizes = torch.zeros(abi.BATCH_STREAM_SIZE, dtype=torch.int32, device=self.device)
+        self.num_uploaded = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.frame_start = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.render_buffer = torch.empty(int(self.L.simlod_render_buffer_bytes(max_pixels, 1)), **z)
+        self.colorbuffer = torch.zeros(max_pixels, dtype=torch.int32, device=self.device)
+        self.persistent_bytes, self.momentary_bytes = persistent_bytes, momentary_bytes
+        self.uploaded_host = 0
+        self.processed_host = 0
+        self.upload_stream = torch.cuda.Stream(device=self.device)
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def uniforms(self, width, height, transform, box_size, **kw):
+        return abi.make_uniforms(width, height, transform, box_size, persistent_capacity=self.persistent_bytes,
+                                 momentary_capacity=self.momentary_bytes, **kw)
+
+    @staticmethod
+    def _u(uniforms):
+        u = np.ascontiguousarray(uniforms).reshape(1)
+        return u, ctypes.c_void_p(u.ctypes.data)
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _p(self, t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    # -- the launch surface ------------------------------------------------------------------------------------
+    def reset(self, uniforms):
+        u, up = self._u(uniforms)
+        _check(self.L.simlod_launch_reset(up, self._p(self.persistent), self._p(self.nodes), self._p(self.stats), None,
+                                          self._p(self.num_uploaded), self._p(self.batch_sizes), self._stream()), "reset")
+        self.uploaded_host = 0
+        self.processed_host = 0
+
+    def upload(self, points, *, stream=None):
+        """One batch into the next ring slot (host numpy array or device tensor of 16-byte records)."""
+        n = len(points)
+        assert n <= abi.MAX_BATCH_SIZE
+        slot = self.uploaded_host % abi.BATCH_STREAM_SIZE
+        assert slot < self.ring_slots, "ring smaller than BATCH_STREAM_SIZE: consume before uploading more"
+        dst = self.ring[slot * abi.MAX_BATCH_SIZE * 16: slot * abi.MAX_BATCH_SIZE * 16 + n * 16]
+        if isinstance(points, torch.Tensor):
+            dst.copy_(points.reshape(-1).view(torch.uint8), non_blocking=True)
+        else:
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(points).view(np.uint8).reshape(-1)), non_blocking=True)
+        self.batch_sizes[slot] = n
+        self.uploaded_host += 1
+        self.num_uploaded.fill_(self.uploaded_host)
+
+    def construct(self, uniforms):
+        u, up = self._u(uniforms)
+        _check(self.L.simlod_launch_construct(up, self._p(self.ring), self._p(self.momentary), self._p(self.persistent),
+                                              self._p(self.nodes), self._p(self.stats), self._p(self.frame_start), None,
+                                              self._p(self.num_uploaded), self._p(self.batch_sizes), self._stream()), "kernel_construct")
+
+    def render(self, uniforms):
+        u, up = self._u(uniforms)
+        W, H = int(u["width"][0]), int(u["height"][0])
+        need = int(self.L.simlod_render_buffer_bytes(W, H))
+        if self.render_buffer.numel() < need:
+            self.render_buffer = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self.colorbuffer.numel() < W * H:
+            self.colorbuffer = torch.zeros(W * H, dtype=torch.int32, device=self.device)
+        _check(self.L.simlod_launch_render(self._p(self.render_buffer), up, self._p(self.nodes), self._p(self.colorbuffer),
+                                           self._p(self.stats), self._p(self.frame_start), None, self._stream()), "kernel_render")
+        return W, H
+
+    # -- readback ------------------------------------------------------------------------------------------------
+    def read_stats(self):
+        return self.stats.cpu().numpy().view(abi.stats_dtype)[0].copy()
+
+    def framebuffer(self, W, H):
+        off = int(self.L.simlod_render_framebuffer_offset())
+        return self.render_buffer[off: off + W * H * 8].cpu().numpy().view(np.uint64).copy()
+
+    def color(self, W, H):
+        return self.colorbuffer[: W * H].cpu().numpy().view(np.uint32).copy()
+
+    def add_points(self, uniforms, points, batch=abi.MAX_BATCH_SIZE):
+        """Upload `points` batch by batch and launch kernel_construct whenever 20 batches (one launch's worth) wait."""
+        pending = 0
+        for i in range(0, len(points), batch):
+            self.upload(points[i:i + batch])
+            pending += 1
+            if pending == min(abi.MAX_BATCHES_PER_LAUNCH, self.ring_slots):
+                self.construct(uniforms)
+                pending = 0
+        if pending:
+            self.construct(uniforms)
+
+    def download_image(self):
+        """(nodes, persistent, numNodes, device base addresses) — the octree image as host arrays, pointers untouched."""
+        torch.cuda.synchronize(self.device)
+        stats = self.read_stats()
+        used = int(stats["allocatedBytes_persistent"])
+        if used == 0:   # before the first construct the stats pass has not run: read the allocator header
+            used = int(self.persistent[8:16].cpu().numpy().view(np.uint64)[0])
+        n = int(stats["numNodes"])
+        nodes = self.nodes[: n * 152].cpu().numpy().view(abi.node_dtype).copy()
+        pers = self.persistent[:used].cpu().numpy().copy()
+        return nodes, pers, n, self.nodes.data_ptr(), self.persistent.data_ptr()
