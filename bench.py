@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — SimLOD hot paths on MI355X: octree ingest (kernel_construct) + software raster (kernel_render).
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+
+Workload at N=1 = BASELINE.json configs[1]: "Morro Bay 36M (.simlod, 16 B/point) single-batch ingest + 1080p raster".
+The real file is not available offline, so the input is the synthetic stand-in of simlod_amd/synthetic.terrain():
+36 M XYZRGBA points over a 6 km x 4 km x 0.4 km fractal terrain, emitted swath by swath, split in 36 ring batches of
+1 M points that are resident in HBM before the timed region starts.
+
+One STEP = the reference's whole ingest of that file through its launch surface: `kernel` (reset) + republishing the
+36 ring slots + two `kernel_construct` launches (20 + 16 batches, main_progressive_octree.cpp:364-428 /
+progressive_octree_voxels.cu:883).  value = points inserted per second over exactly K such steps (max over ranks).
+The raster half of the metric is measured right after, on the octree of the last step: K frames of `kernel_render` at
+1920x1080 (HQS, the reference's default, and plain) and reported under "raster".
+
+N>1 (weak scaling): every rank owns a spatial sub-octree (its own 36 M-point terrain tile) — no data-path collective
+for ingest; a frame is composed with ONE all-reduce(MIN) over the uint64 framebuffers plus an all-gather of the
+visible-node records, both over RCCL.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable)
+W, H = 1920, 1080
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=36_000_000)
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--cpu-points", type=int, default=6_000_000, help="bounded sample for the CPU baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def collect_profile(L):
+    from simlod_amd.runtime import lib  # noqa: F401
+
+    class Entry(ctypes.Structure):
+        _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("total_ms", ctypes.c_double)]
+    buf = (Entry * 64)()
+    cnt = ctypes.c_int(0)
+    L.simlod_profile_collect(ctypes.byref(buf), 64, ctypes.byref(cnt))
+    return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(cnt.value)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from simlod_amd import abi, camera, synthetic
+    from simlod_amd.runtime import DeviceOctree, lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    n_points = args.points
+    batch = abi.MAX_BATCH_SIZE
+    n_batches = (n_points + batch - 1) // batch
+    assert n_batches <= abi.BATCH_STREAM_SIZE, "the workload must fit the 50-slot ring (resident input)"
+    pts, box = synthetic.terrain(n_points, seed=7 + rank)     # rank r owns tile r of the tiled terrain (pre-partitioned)
+    dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=300_000_000, max_pixels=W * H)
+    L = lib()
+    sizes = torch.tensor([min(batch, n_points - i * batch) for i in range(n_batches)], dtype=torch.int32, device=dev.device)
+    ring_view = dev.ring.view(torch.uint8)
+    for i in range(n_batches):           # H2D once, outside every timed region: inputs are resident in HBM
+        chunk = pts[i * batch:(i + 1) * batch]
+        ring_view[i * batch * 16: i * batch * 16 + len(chunk) * 16].copy_(torch.from_numpy(chunk.view(np.uint8).reshape(-1)))
+    T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886, (box[0] / 2, box[1] / 2, 0.35 * box[2])),
+                               camera.perspective(aspect=W / H))
+    u = dev.uniforms(W, H, T, box, hqs=True)
+
+    def ingest_step():
+        dev.reset(u)
+        dev.batch_sizes[:n_batches] = sizes           # what the uploader's cuMemsetD32Async pair publishes
+        dev.num_uploaded.fill_(n_batches)
+        dev.uploaded_host = n_batches
+        return dev.drain(u)      # relaunch until Stats.batchletIndex == 36, as the reference's frame loop does
+
+    for _ in range(args.warmup):
+        ingest_step()
+    torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    launches = 0
+    for _ in range(args.steps):
+        launches += ingest_step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ms_per_step = float(tmax.item()) * 1e3 / args.steps
+    stats = dev.read_stats()
+    assert int(stats["numPointsProcessed"]) == n_points and int(stats["numPoints"]) == n_points, "ingest lost points"
+    assert int(stats["dbg"]) == 0, f"device error bits {int(stats['dbg']):#x}"
+    value = world * n_points / (ms_per_step * 1e-3) / 1e6
+
+    # ---- raster ------------------------------------------------------------------------------------------------
+    def compose():
+        if world > 1:
+            off = int(L.simlod_render_framebuffer_offset())
+            fb = dev.render_buffer[off: off + W * H * 8].view(torch.int64)
+            dist.all_reduce(fb, op=dist.ReduceOp.MIN)     # exact for the 64-bit depth|colour words (sign bit never set)
+            nvis = torch.zeros(1, dtype=torch.int64, device=dev.device)
+            nvis[0] = int(0)
+            vis = dev.render_buffer[: 4096 * 152]         # fixed-size slice of the visible-node records
+            out = [torch.empty_like(vis) for _ in range(world)]
+            dist.all_gather(out, vis)
+
+    raster = {}
+    for name, hqs in (("hqs", 1), ("plain", 0)):
+        u["useHighQualityShading"] = hqs
+        for _ in range(2):
+            dev.render(u); compose()
+        torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.frames):
+            dev.render(u); compose()
+        torch.cuda.synchronize(); barrier()
+        dtf = time.perf_counter() - t0
+        tm = torch.tensor([dtf], dtype=torch.float64, device=dev.device)
+        st = dev.read_stats()
+        samples = torch.tensor([float(int(st["numVisiblePoints"]) + int(st["numVisibleVoxels"]))], dtype=torch.float64, device=dev.device)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX); dist.all_reduce(samples, op=dist.ReduceOp.SUM)
+        ms = float(tm.item()) * 1e3 / args.frames
+        raster[name] = {"value": float(samples.item()) / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,
+                        "visible_samples": int(samples.item()), "visible_nodes": int(st["numVisibleNodes"])}
+    u["useHighQualityShading"] = 1
+
+    # ---- per-kernel attribution with HIP events on the launch stream (separate, untimed pass) --------------------
+    roofline, chain, kernels = None, None, {}
+    if rank == 0 and not args.no_profile:
+        L.simlod_profile_enable(1)
+        ingest_step()
+        prof_c = collect_profile(L)
+        dev.render(u)
+        prof_r = collect_profile(L)
+        L.simlod_profile_enable(0)
+        st = dev.read_stats()
+        new_voxels = int(st["numVoxels"])
+        kernels = {k: {"launches": n, "total_ms": ms, "avg_ms": ms / max(n, 1)} for k, (n, ms) in {**prof_c, **prof_r}.items()}
+        chain_ms = sum(ms for k, (n, ms) in prof_c.items())
+        chain_bytes = 32.0 * n_points + 16.0 * new_voxels                  # 32 B/point + 16 B/new voxel
+        chain = {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms, "what": "whole kernel_construct chain, one 36 M ingest"}
+        per_point = {"k_count": 16.0, "k_sample": 16.0, "k_insert": 32.0}   # algorithmic bytes per point per kernel
+        dom = max((k for k in prof_c if k in per_point), key=lambda k: prof_c[k][1])
+        active = n_batches                                                   # launches that had a batch to process
+        bytes_per_launch = per_point[dom] * batch + (16.0 * new_voxels / n_batches if dom == "k_insert" else 0.0)
+        avg_ms = prof_c[dom][1] / active
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active}
+
+    # ---- CPU baseline: the oracle's serial C restatement on a bounded sample of the same workload ------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        m = min(args.cpu_points, n_points)
+        host = oracle.HostOctree("port", persistent_bytes=2 << 30, ring_slots=max(1, min(abi.BATCH_STREAM_SIZE, (m + batch - 1) // batch)))
+        uh = abi.make_uniforms(W, H, T, box, persistent_capacity=2 << 30, momentary_capacity=300_000_000, hqs=True)
+        host.reset(uh)
+        for i in range(0, m, batch):
+            host.upload(pts[i:i + batch])
+        t0 = time.perf_counter()
+        while int(host.stats["batchletIndex"][0]) < int(host.num_uploaded[0]):
+            host.construct(uh)
+        tc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        host.render(uh)
+        tr = time.perf_counter() - t0
+        vs = int(host.stats["numVisiblePoints"][0]) + int(host.stats["numVisibleVoxels"][0])
+        cpu = {"value": m / tc / 1e6, "unit": "M points/s inserted", "cores": 1, "kind": "port",
+               "sample": f"first {m} points ({(m + batch - 1) // batch} batches) of the same terrain, oracle/simlod_oracle.c -O3, 1 thread",
+               "raster_value": vs / tr / 1e6, "raster_unit": "M samples/s @1920x1080 (HQS)", "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": "M points/sec inserted into octree (raster M samples/s @1080p under 'raster')",
+            "value": value, "unit": "M points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32+u32 (fp32 quantise/project, fp64 pixel coordinate, integer octree/atomics)", "data": "synthetic",
+            "config": {"workload": f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M "
+                                   f"ring batches resident in HBM, reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
+                                   f"(<= 20 batches and <= 10 ms each, Stats read back between launches); "
+                                   f"raster 1920x1080", "points_per_gpu": n_points, "parallelism": f"spatial sub-octree per GPU x{world}"},
+            "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu,
+            "octree": {k: int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels", "allocatedBytes_persistent")},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

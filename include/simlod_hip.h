@@ -89,6 +89,18 @@ int simlod_function_max_active_blocks(SimlodFunction* fn, int blockSize, int* nu
 int simlod_launch_cooperative(SimlodFunction* fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by,
                               unsigned bz, unsigned sharedMemBytes, void* stream, void** args);
 
+/* ---- measurement aid (not part of the reference surface) ------------------------------------------------------
+ * When enabled, every internal kernel launch is bracketed by HIP events recorded on the launch stream, so that
+ * bench.py can attribute device time to the kernels rocprofv3 lists.  Off by default (zero overhead). */
+typedef struct SimlodProfileEntry {
+	char     name[48];     /* internal kernel name, e.g. "k_insert", "r_draw<MODE_MIN64>" */
+	uint32_t launches;
+	uint32_t pad;
+	double   total_ms;
+} SimlodProfileEntry;
+int simlod_profile_enable(int on);
+int simlod_profile_collect(SimlodProfileEntry* out, int capacity, int* count);
+
 /* Version / build info string (static storage). */
 const char* simlod_build_info(void);
 

@@ -63,6 +63,7 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->numSpilled = 0;
 	ctl->dirCount = 0;
 	ctl->abortBatch = 0;
+	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
 	ctl->active = 1;
 }
 
@@ -609,23 +610,24 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
 	const DeviceInfo& dev = device_info();
 
-	hipLaunchKernelGGL(k_begin, dim3(1), dim3(64), 0, stream, a, fits ? 0u : 1u);
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u);
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)a.nodeCapacity * 4, stream);
 		if (e != hipSuccess) return (int)e;
 		const uint32_t gridPoints = dev.numCUs * 8;                            // grid-stride, 8 workgroups per CU
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
-			hipLaunchKernelGGL(k_count, dim3(gridPoints), dim3(TPB), 0, stream, a);
-			hipLaunchKernelGGL(k_expand, dim3(dev.numCUs), dim3(TPB), 0, stream, a);
-			hipLaunchKernelGGL(k_sample, dim3(gridPoints), dim3(TPB), 0, stream, a);
-			hipLaunchKernelGGL(k_alloc, dim3(gridNodes), dim3(TPB), 0, stream, a);
-			hipLaunchKernelGGL(k_insert, dim3(gridPoints), dim3(TPB), 0, stream, a);
-			hipLaunchKernelGGL(k_end, dim3(1), dim3(64), 0, stream, a, b);
+			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_expand, dim3(dev.numCUs), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_sample, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_alloc, dim3(gridNodes), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
 		}
-		hipLaunchKernelGGL(k_stats, dim3(gridNodes), dim3(TPB), 0, stream, a);
+		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
-	hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, stream, a);
+	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a);
+	if (profile_enabled()) profile_close(stream);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return (int)e;
 	return fits ? 0 : (int)hipErrorInvalidValue;

@@ -370,7 +370,7 @@ uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream) {
-	hipLaunchKernelGGL(k_reset, dim3(64), dim3(TPB), 0, stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter);
+	SIMLOD_LAUNCH(k_reset, dim3(64), dim3(TPB), stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter);
 	return (int)hipGetLastError();
 }
 
@@ -399,17 +399,18 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	const uint32_t gridPixels = dev.numCUs * 8;
 	const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 	const uint32_t gridDraw = dev.numCUs * 8;
-	hipLaunchKernelGGL(r_clear, dim3(gridPixels), dim3(TPB), 0, stream, a);
-	hipLaunchKernelGGL(r_vis1, dim3(gridNodes), dim3(TPB), 0, stream, a);
-	hipLaunchKernelGGL(r_vis2, dim3(gridNodes), dim3(TPB), 0, stream, a);
+	SIMLOD_LAUNCH(r_clear, dim3(gridPixels), dim3(TPB), stream, a);
+	SIMLOD_LAUNCH(r_vis1, dim3(gridNodes), dim3(TPB), stream, a);
+	SIMLOD_LAUNCH(r_vis2, dim3(gridNodes), dim3(TPB), stream, a);
 	if (a.hqs) {
-		hipLaunchKernelGGL(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(TPB), 0, stream, a);
-		hipLaunchKernelGGL(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(TPB), 0, stream, a);
-		hipLaunchKernelGGL(r_resolve, dim3(gridPixels), dim3(TPB), 0, stream, a);
+		SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_resolve, dim3(gridPixels), dim3(TPB), stream, a);
 	} else {
-		hipLaunchKernelGGL(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(TPB), 0, stream, a);
+		SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(TPB), stream, a);
 	}
-	hipLaunchKernelGGL(r_output, dim3(gridPixels), dim3(TPB), 0, stream, a);
+	SIMLOD_LAUNCH(r_output, dim3(gridPixels), dim3(TPB), stream, a);
+	if (profile_enabled()) profile_close(stream);
 	return (int)hipGetLastError();
 }
 

@@ -34,6 +34,27 @@ const DeviceInfo& device_info() {
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height);
 
+// ---- optional per-kernel profiling ------------------------------------------------------------------------------
+struct ProfileMark { const char* name; hipEvent_t ev; };
+static std::atomic<bool> g_profile{false};
+static std::vector<ProfileMark> g_marks;
+static std::vector<hipEvent_t> g_eventPool;
+
+bool profile_enabled() { return g_profile.load(std::memory_order_relaxed); }
+
+static hipEvent_t take_event() {
+	if (!g_eventPool.empty()) { hipEvent_t e = g_eventPool.back(); g_eventPool.pop_back(); return e; }
+	hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void profile_mark(const char* kernelName, hipStream_t stream) {
+	hipEvent_t e = take_event();
+	(void)hipEventRecord(e, stream);
+	g_marks.push_back({kernelName, e});
+}
+
+void profile_close(hipStream_t stream) { profile_mark(nullptr, stream); }
+
 enum KernelKind { KIND_RESET = 0, KIND_CONSTRUCT = 1, KIND_RENDER = 2 };
 
 }  // namespace simlod
@@ -157,6 +178,38 @@ int simlod_launch_cooperative(SimlodFunction* fn, unsigned gx, unsigned gy, unsi
 		                            *(SimlodStats**)args[4], *(uint64_t**)args[5], *(void**)args[6], stream);
 	}
 	return (int)hipErrorInvalidValue;
+}
+
+int simlod_profile_enable(int on) {
+	g_profile.store(on != 0);
+	return 0;
+}
+
+// Synchronises the device, folds the marks recorded since the last call into per-kernel totals and clears them.
+int simlod_profile_collect(SimlodProfileEntry* out, int capacity, int* count) {
+	if (!out || !count) return (int)hipErrorInvalidValue;
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess) return (int)e;
+	int n = 0;
+	for (size_t i = 0; i + 1 < g_marks.size(); i++) {
+		if (g_marks[i].name == nullptr) continue;       // end-of-call marker
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, g_marks[i].ev, g_marks[i + 1].ev) != hipSuccess) continue;
+		int k = 0;
+		for (; k < n; k++) if (std::strcmp(out[k].name, g_marks[i].name) == 0) break;
+		if (k == n) {
+			if (n >= capacity) continue;
+			std::memset(&out[n], 0, sizeof(out[n]));
+			std::strncpy(out[n].name, g_marks[i].name, sizeof(out[n].name) - 1);
+			n++;
+		}
+		out[k].launches += 1;
+		out[k].total_ms += ms;
+	}
+	for (auto& m : g_marks) g_eventPool.push_back(m.ev);
+	g_marks.clear();
+	*count = n;
+	return 0;
 }
 
 const char* simlod_build_info(void) { return "simlod_hip gfx950 (-ffp-contract=off, IEEE div/sqrt) " __DATE__ " " __TIME__; }

@@ -47,6 +47,18 @@ struct DeviceInfo {
 };
 
 const DeviceInfo& device_info();
+
+// Optional per-kernel timing with HIP events on the launch stream (simlod_profile_* in simlod_hip.h).  Disabled by
+// default: LAUNCH() then is a bare hipLaunchKernelGGL.
+bool profile_enabled();
+void profile_mark(const char* kernelName, hipStream_t stream);   // records "kernelName starts now"
+void profile_close(hipStream_t stream);                           // records the end of the last kernel of a call
+
+#define SIMLOD_LAUNCH(kernel, grid, block, stream, ...)                           \
+	do {                                                                          \
+		if (::simlod::profile_enabled()) ::simlod::profile_mark(#kernel, stream); \
+		hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);          \
+	} while (0)
 uint32_t node_capacity();
 
 bool layout_construct(BuildArgs& a, uint64_t capacity);

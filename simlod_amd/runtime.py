@@ -187,17 +187,35 @@ class DeviceOctree:
     def color(self, W, H):
         return self.colorbuffer[: W * H].cpu().numpy().view(np.uint32).copy()
 
-    def add_points(self, uniforms, points, batch=abi.MAX_BATCH_SIZE):
-        """Upload `points` batch by batch and launch kernel_construct whenever 20 batches (one launch's worth) wait."""
-        pending = 0
-        for i in range(0, len(points), batch):
-            self.upload(points[i:i + batch])
-            pending += 1
-            if pending == min(abi.MAX_BATCHES_PER_LAUNCH, self.ring_slots):
-                self.construct(uniforms)
-                pending = 0
-        if pending:
+    def processed(self):
+        """Stats.batchletIndex as the host sees it after the stream drained (main_progressive_octree.cpp:1201-1216)."""
+        torch.cuda.current_stream().synchronize()
+        return int(self.stats[76:80].cpu().numpy().view(np.uint32)[0])
+
+    def drain(self, uniforms, max_launches=1000):
+        """Launch kernel_construct until every uploaded batch is ingested.  One launch takes at most 20 batches and stops
+        early once it has run for 10 ms (progressive_octree_voxels.cu:883, :939-949) — the reference host simply launches
+        again next frame; so does this loop.  Returns the number of launches."""
+        launches = 0
+        while self.processed() < self.uploaded_host and launches < max_launches:
+            before = self.processed()
             self.construct(uniforms)
+            launches += 1
+            if self.processed() == before:
+                st = self.read_stats()
+                raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, "
+                                  f"memCapacityReached={int(st['memCapacityReached'])})")
+        return launches
+
+    def add_points(self, uniforms, points, batch=abi.MAX_BATCH_SIZE):
+        """Upload `points` batch by batch; ingest whenever the ring would overflow and at the end."""
+        for i in range(0, len(points), batch):
+            if self.uploaded_host - self.processed_host >= self.ring_slots:
+                self.drain(uniforms)
+                self.processed_host = self.uploaded_host
+            self.upload(points[i:i + batch])
+        self.drain(uniforms)
+        self.processed_host = self.uploaded_host
 
     def download_image(self):
         """(nodes, persistent, numNodes, device base addresses) — the octree image as host arrays, pointers untouched."""
