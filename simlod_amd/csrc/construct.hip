@@ -60,6 +60,9 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->numSpilling = 0;
 	ctl->roundSpill[0] = 0;
 	ctl->roundSpill[1] = 0;
+	ctl->numWork = 0;
+	ctl->spilledSnap[0] = ctl->spilledSnap[1] = 0;
+	ctl->workSnap[0] = ctl->workSnap[1] = 0;
 	ctl->numSpilled = 0;
 	ctl->dirCount = 0;
 	ctl->abortBatch = 0;
@@ -90,65 +93,97 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall) {
 }
 
 // ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
-__device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, bool active, uint32_t* spillList,
-                                           uint32_t* spillCount) {
-	wave_group_by(leafIdx, active, [&](uint64_t, int leader, int rank, int cnt) {
-		if (rank == 0) {
-			(void)leader;
-			SimlodNode* leaf = a.nodes + leafIdx;
-			const uint32_t old = atomicAdd(&leaf->counter, (uint32_t)cnt);
-			// voxels.cu:211-217.  A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing.
-			if (old <= SIMLOD_MAX_POINTS_PER_NODE && old + (uint32_t)cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
-				const uint32_t s = atomicAdd(spillCount, 1u);
-				if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
-			}
-		}
-	});
+static constexpr uint32_t PPT = 4;                 // points per thread per chunk
+static constexpr uint32_t PPB = TPB * PPT;         // points per workgroup chunk
+
+// One arrival-counter update for `cnt` samples (voxels.cu:203-218): exactly one caller sees the counter cross the limit.
+__device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt, uint32_t* spillList, uint32_t* spillCount) {
+	SimlodNode* leaf = a.nodes + leafIdx;
+	const uint32_t old = atomicAdd(&leaf->counter, cnt);
+	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
+	if (old <= SIMLOD_MAX_POINTS_PER_NODE && old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
+		const uint32_t s = atomicAdd(spillCount, 1u);
+		if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
+	}
+}
+
+__device__ __forceinline__ void flush_counts(const BuildArgs& a, Ctl* ctl, BlockTable& tbl, uint32_t* spillList, uint32_t* spillCount) {
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = tbl.keys[e];
+		if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], spillList, spillCount);
+	}
 }
 
 __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
+	__shared__ BlockTable tbl;
 	const uint32_t n = ctl->batchSize;
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
-	const uint32_t stride = gridDim.x * TPB;
-	for (uint32_t base = blockIdx.x * TPB; base < n; base += stride) {
-		const uint32_t i = base + threadIdx.x;
-		const bool act = i < n;
-		uint32_t leafIdx = 0;
-		if (act) {
-			const float4 p = pts[i];
-			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
-			const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
-			const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-			leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
-			leafOf[i] = leafIdx;
+	const uint32_t numChunks = (n + PPB - 1) / PPB;
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		table_init(tbl);
+		__syncthreads();
+		float4 p[PPT];
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t i = chunk * PPB + j * TPB + threadIdx.x;
+			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
 		}
-		count_into(a, ctl, leafIdx, act, spillList, &ctl->numSpilling);
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t i = chunk * PPB + j * TPB + threadIdx.x;
+			if (i >= n) continue;
+			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
+			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
+			const uint32_t Z = quantize(F_GRID, p[j].z, a.minz, a.size);
+			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
+			leafOf[i] = leafIdx;
+			uint32_t rank;
+			if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, spillList, &ctl->numSpilling);
+		}
+		__syncthreads();
+		flush_counts(a, ctl, tbl, spillList, &ctl->numSpilling);
+		__syncthreads();
 	}
 }
 
 // ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
 // Persistent, one workgroup per CU, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
+// Per round:  A) one workgroup per spilling leaf: eight children, occupancy grid (allocated, cleared), the leaf's chunk
+//                list is walked ONCE by one lane which turns every chunk into a work item and recycles the chunks;
+//             -- barrier --
+//             B) all workgroups: spill-copy work items (1000 stored points each, routed to the child they belong to)
+//                and the recount of the batch samples whose cached leaf was split; both feed the children's arrival
+//                counters, whoever sees a counter cross the limit appends the child to the next round's list;
+//             -- barrier --
+struct SpillWork {
+	const SimlodChunk* chunk;
+	uint32_t childOffset, dstBase, count, level;
+	uint32_t pad0, pad1;
+};
+
 __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
-	if (ctl->numSpilling == 0) return;          // written by k_count, stable for the whole launch of this kernel
+	if (ctl->numSpilling == 0) return;          // written by k_count, never modified here: a stable early-exit test
 
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
 	uint32_t* splitTag = at<uint32_t>(a, a.offSplitTag);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
-	SimlodPoint* spilled = at<SimlodPoint>(a, a.offSpilled);
+	SpillWork* work = at<SpillWork>(a, a.offWork);
+	float4* spilled = at<float4>(a, a.offSpilled);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const uint32_t n = ctl->batchSize;
 	uint32_t generation = 0;
 
-	__shared__ uint32_t sh_childOffset, sh_spillBase, sh_numChunks, sh_ok;
+	__shared__ BlockTable tbl;
+	__shared__ uint32_t sh_childOffset, sh_ok;
 	__shared__ uint32_t sh_childCount[8];
-	__shared__ SimlodChunk* sh_chunks[MAX_SPILL_CHUNKS];
+	__shared__ SimlodOccupancyGrid* sh_grid;
 
 	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS; ++round) {
 		uint32_t* listCur = at<uint32_t>(a, (round & 1) ? a.offSpillB : a.offSpillA);
@@ -159,73 +194,38 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 		if (numSpilling > SPILLING_CAPACITY) numSpilling = SPILLING_CAPACITY;
 		if (numSpilling == 0) break;
 		const uint32_t tag = ctl->ordinal * 32u + round + 1u;
-		const uint32_t numSpilledPrev = ctl->numSpilled;    // spilled points of EARLIER rounds (stable: see barrier below)
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;
+		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;   // last read one round ago, appended to only after the barrier below
 
-		// -- split: one workgroup per spilling node ------------------------------------------------------------
+		// -- A: split ---------------------------------------------------------------------------------------------
 		for (uint32_t s = blockIdx.x; s < numSpilling; s += gridDim.x) {
-			SimlodNode* node = a.nodes + listCur[s];
 			const uint32_t nodeIdx = listCur[s];
-			const uint32_t stored = node->numPoints;
+			SimlodNode* node = a.nodes + nodeIdx;
 			__syncthreads();
 			if (threadIdx.x == 0) {
 				uint32_t ok = 1, off = 0;
-				const uint32_t base = atomicAdd(&ctl->numSpilled, stored);
-				if (base + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; ok = 0; }
-				if (ok) {
-					off = atomicAdd(&a.stats->numNodes, 8u);   // voxels.cu:317
-					if (off + 8u > a.nodeCapacity) { atomicSub(&a.stats->numNodes, 8u); raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ctl->abortBatch = 1; ok = 0; }
+				off = atomicAdd(&a.stats->numNodes, 8u);   // voxels.cu:317
+				if (off + 8u > a.nodeCapacity) { atomicSub(&a.stats->numNodes, 8u); raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ctl->abortBatch = 1; ok = 0; }
+				SimlodOccupancyGrid* grid = node->grid;
+				if (ok && grid == nullptr) {               // voxels.cu:363-365
+					grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+					node->grid = grid;
 				}
-				sh_childOffset = off; sh_spillBase = base; sh_ok = ok; sh_numChunks = 0;
+				sh_childOffset = off; sh_ok = ok; sh_grid = grid;
 			}
-			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
 			__syncthreads();
 			if (!sh_ok) continue;
-			const uint32_t childOffset = sh_childOffset, spillBase = sh_spillBase;
-			const uint32_t level = node->level, nX = node->X, nY = node->Y, nZ = node->Z;
-
-			// move the stored points to the spill buffer, already routed to the child they belong to (voxels.cu:253-289)
-			{
-				SimlodChunk* chunk = node->points;
-				uint32_t done = 0, ci = 0;
-				while (done < stored && chunk != nullptr) {
-					SimlodChunk* next = chunk->next;                      // issue the pointer chase early
-					const uint32_t inChunk = min(stored - done, SIMLOD_POINTS_PER_CHUNK);
-					const float4* src = reinterpret_cast<const float4*>(chunk->points);
-					for (uint32_t j = threadIdx.x; j < inChunk; j += TPB) {
-						const float4 p = src[j];
-						const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
-						const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
-						const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-						const int c = child_index(X, Y, Z, (int)level);
-						const uint32_t dst = spillBase + done + j;
-						reinterpret_cast<float4*>(spilled)[dst] = p;
-						leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = childOffset + (uint32_t)c;
-						winMask[SIMLOD_MAX_BATCH_SIZE + dst] = level << 24;     // `sample` starts at the spilling node's level
-						atomicAdd(&sh_childCount[c], 1u);
-					}
-					if (threadIdx.x == 0 && ci < MAX_SPILL_CHUNKS) sh_chunks[ci] = chunk;
-					ci++; done += inChunk; chunk = next;
-				}
-				// chunks allocated for a partially stored batch never outnumber ceil(stored/1000) here: stored == counter
-				if (threadIdx.x == 0) sh_numChunks = min(ci, (uint32_t)MAX_SPILL_CHUNKS);
-			}
-			__syncthreads();
-
-			// the eight children (voxels.cu:318-343) — one lane each, counters pre-loaded with the routed points
-			if (threadIdx.x < 8) {
+			const uint32_t childOffset = sh_childOffset;
+			const uint32_t level = node->level;
+			if (threadIdx.x < 8) {                          // the eight children, voxels.cu:318-343
 				const uint32_t i = threadIdx.x;
 				SimlodNode c;
 				for (int k = 0; k < 8; k++) c.children[k] = nullptr;
-				c.counter = sh_childCount[i];
-				c.numPoints = 0;
+				c.counter = 0; c.numPoints = 0;
 				c.level = level + 1;
-				c.X = 2 * nX + ((i >> 2) & 1u);
-				c.Y = 2 * nY + ((i >> 1) & 1u);
-				c.Z = 2 * nZ + (i & 1u);
-				c.countIteration = 0;
-				c.countFlag = 0;
+				c.X = 2 * node->X + ((i >> 2) & 1u);
+				c.Y = 2 * node->Y + ((i >> 1) & 1u);
+				c.Z = 2 * node->Z + (i & 1u);
+				c.countIteration = 0; c.countFlag = 0;
 				for (int k = 0; k < 20; k++) c.name[k] = node->name[k];
 				if (c.level < 20) c.name[c.level] = (uint8_t)('0' + i);
 				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
@@ -234,56 +234,108 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 				a.nodes[childOffset + i] = c;
 				node->children[i] = a.nodes + childOffset + i;
 			}
-			// recycle the chunks: the pool is a stack whose top is stats->numAllocatedChunks (voxels.cu:346-357)
-			if (threadIdx.x == 0) {
-				const uint32_t k = sh_numChunks;
-				if (k > 0) {
-					const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)k));
-					for (uint32_t j = 0; j < k; j++) {
-						sh_chunks[j]->next = nullptr;
-						const unsigned long long q = old - k + j;
-						if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = sh_chunks[j]; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+			if (threadIdx.x == 64) {
+				// One lane walks the chunk list (a pointer chase nobody can parallelise), emits one work item per chunk,
+				// and hands the chunks back to the recycle stack (voxels.cu:346-357; nothing pops before k_alloc).
+				const uint32_t stored = node->numPoints;
+				const uint32_t numChunks = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+				const uint32_t spillBase = atomicAdd(&ctl->numSpilled, stored);
+				SimlodChunk* chunk = node->points;
+				if (spillBase + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; chunk = nullptr; }
+				// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
+				const uint32_t linked = chunk != nullptr ? numChunks : 0u;
+				if (linked > 0) {
+					const uint32_t w0 = atomicAdd(&ctl->numWork, linked);
+					const unsigned long long top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)linked));
+					for (uint32_t ci = 0; ci < linked && chunk != nullptr; ci++) {
+						SimlodChunk* next = chunk->next;
+						if (w0 + ci < a.workCap) {
+							SpillWork w;
+							w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
+							w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
+							work[w0 + ci] = w;
+						} else { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; }
+						chunk->next = nullptr;
+						const unsigned long long q = top - linked + ci;
+						if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+						chunk = next;
 					}
 				}
 				node->numPoints = 0;
 				node->points = nullptr;
-				if (node->grid == nullptr) node->grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
 				splitTag[nodeIdx] = tag;
 			}
-			__syncthreads();
-			// clear the occupancy grid of EVERY spilling node, also one that already had a grid (the root), voxels.cu:371-382
+			// meanwhile the other lanes clear the occupancy grid — of EVERY spilling node, also one that already had a
+			// grid (the root), voxels.cu:371-382
 			{
-				uint4* g = reinterpret_cast<uint4*>(node->grid->values);
+				uint4* g = reinterpret_cast<uint4*>(sh_grid->values);
 				const uint4 z = make_uint4(0, 0, 0, 0);
-				for (uint32_t w = threadIdx.x; w < SIMLOD_GRID_NUM_WORDS / 4; w += TPB) g[w] = z;
+				if (threadIdx.x >= 128) for (uint32_t w = threadIdx.x - 128; w < SIMLOD_GRID_NUM_WORDS / 4; w += TPB - 128) g[w] = z;
 			}
 		}
 
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-		if (round + 1 == SIMLOD_MAX_EXPAND_ROUNDS) break;   // the reference's 20th split is not followed by a count (voxels.cu:394-412)
+		// numSpilled / numWork are stable between this barrier and the next round's split phase: snapshot them for round+1
+		const uint32_t workEnd = min(ctl->numWork, a.workCap);
+		const uint32_t workBegin = ctl->workSnap[round & 1];
+		const uint32_t numSpilledPrev = ctl->spilledSnap[round & 1];
+		if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->workSnap[(round + 1) & 1] = workEnd; ctl->spilledSnap[(round + 1) & 1] = min(ctl->numSpilled, a.spilledCap); }
 
-		// -- recount: only samples whose cached leaf was split in THIS round go one (or more) levels down ---------
-		const uint32_t total = n + numSpilledPrev;
-		const uint32_t stride = gridDim.x * TPB;
-		for (uint32_t base = blockIdx.x * TPB; base < total; base += stride) {
-			const uint32_t t = base + threadIdx.x;
-			bool act = t < total;
-			uint32_t idx = 0, leafIdx = 0;
-			if (act) {
-				idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-				leafIdx = leafOf[idx];
-				act = splitTag[leafIdx] == tag;
-			}
-			if (act) {
-				const float4 p = t < n ? pts[t] : reinterpret_cast<const float4*>(spilled)[t - n];
+		// -- B1: move the stored points of the split leaves into the spill buffer, routed to their child (voxels.cu:253-289)
+		for (uint32_t w = workBegin + blockIdx.x; w < workEnd; w += gridDim.x) {
+			const SpillWork item = work[w];
+			__syncthreads();
+			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
+			__syncthreads();
+			const float4* src = reinterpret_cast<const float4*>(item.chunk->points);
+			for (uint32_t j = threadIdx.x; j < item.count; j += TPB) {
+				const float4 p = src[j];
 				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
 				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
 				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-				SimlodNode* from = a.nodes + leafIdx;
-				leafIdx = (uint32_t)(descend(from, (int)from->level, X, Y, Z) - a.nodes);
-				leafOf[idx] = leafIdx;
+				const int c = child_index(X, Y, Z, (int)item.level);
+				const uint32_t dst = item.dstBase + j;
+				spilled[dst] = p;
+				leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = item.childOffset + (uint32_t)c;
+				winMask[SIMLOD_MAX_BATCH_SIZE + dst] = item.level << 24;     // `sample` starts at the spilling node's level
+				atomicAdd(&sh_childCount[c], 1u);
 			}
-			count_into(a, ctl, leafIdx, act, listNext, countNext);
+			__syncthreads();
+			if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0 && round + 1 < SIMLOD_MAX_EXPAND_ROUNDS)
+				count_into(a, ctl, item.childOffset + threadIdx.x, sh_childCount[threadIdx.x], listNext, countNext);
+			else if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0)
+				atomicAdd(&a.nodes[item.childOffset + threadIdx.x].counter, sh_childCount[threadIdx.x]);
+		}
+
+		// -- B2: recount — only samples whose cached leaf was split in THIS round go one (or more) levels down ------------
+		// (the reference's 20th split is not followed by a count, voxels.cu:394-412)
+		if (round + 1 < SIMLOD_MAX_EXPAND_ROUNDS) {
+			const uint32_t total = n + numSpilledPrev;
+			const uint32_t numChunks = (total + PPB - 1) / PPB;
+			for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+				__syncthreads();
+				table_init(tbl);
+				__syncthreads();
+#pragma unroll
+				for (uint32_t j = 0; j < PPT; j++) {
+					const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+					if (t >= total) continue;
+					const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+					uint32_t leafIdx = leafOf[idx];
+					if (splitTag[leafIdx] != tag) continue;
+					const float4 p = t < n ? pts[t] : spilled[t - n];
+					const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
+					const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
+					const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
+					SimlodNode* from = a.nodes + leafIdx;
+					leafIdx = (uint32_t)(descend(from, (int)from->level, X, Y, Z) - a.nodes);
+					leafOf[idx] = leafIdx;
+					uint32_t rank;
+					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
+				}
+				__syncthreads();
+				flush_counts(a, ctl, tbl, listNext, countNext);
+			}
 		}
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 	}
@@ -293,53 +345,58 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
+	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
 	const uint32_t n = ctl->batchSize;
 	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	const uint32_t stride = gridDim.x * TPB;
-	for (uint32_t base = blockIdx.x * TPB; base < total; base += stride) {
-		const uint32_t t = base + threadIdx.x;
-		const bool act = t < total;
-		uint32_t idx = 0, startLevel = 0;
-		uint32_t X = 0, Y = 0, Z = 0, pX = 0, pY = 0, pZ = 0;
-		if (act) {
+	const uint32_t numChunks = (total + PPB - 1) / PPB;
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		__syncthreads();
+		table_init(tbl);
+		__syncthreads();
+#pragma unroll 1
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			if (t >= total) continue;
+			uint32_t idx, startLevel = 0;
 			float4 p;
 			if (t < n) { idx = t; p = pts[t]; }
 			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
-			X = quantize(F_GRID, p.x, a.minx, a.size); Y = quantize(F_GRID, p.y, a.miny, a.size); Z = quantize(F_GRID, p.z, a.minz, a.size);
-			pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
-		}
-		SimlodNode* cur = a.nodes;
-		bool alive = act;
-		uint32_t wins = 0;
+			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+			SimlodNode* cur = a.nodes;
+			uint32_t wins = 0;
 #pragma unroll 1
-		for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
-			bool won = false;
-			if (alive && (uint32_t)level >= startLevel) {
-				SimlodOccupancyGrid* grid = cur->grid;
-				if (grid != nullptr) {
-					const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);          // voxels.cu:78-85
-					const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-					const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-					const uint32_t bit = 1u << (cell & 31u);
-					uint32_t* word = &grid->values[cell >> 5];
-					if ((*word & bit) == 0u) won = (atomicOr(word, bit) & bit) == 0u;          // voxels.cu:93-99
+			for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
+				if ((uint32_t)level >= startLevel) {
+					SimlodOccupancyGrid* grid = cur->grid;
+					if (grid != nullptr) {
+						const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);          // voxels.cu:78-85
+						const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+						const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+						const uint32_t bit = 1u << (cell & 31u);
+						uint32_t* word = &grid->values[cell >> 5];
+						if ((*word & bit) == 0u && (atomicOr(word, bit) & bit) == 0u) {          // voxels.cu:93-99
+							wins |= 1u << level;
+							const uint32_t curIdx = (uint32_t)(cur - a.nodes);
+							uint32_t rank;
+							if (table_add(tbl, curIdx, 1u, &rank) < 0) atomicAdd(&cur->numVoxels, 1u);   // voxels.cu:101
+						}
+					}
 				}
-			}
-			const uint32_t curIdx = (uint32_t)(cur - a.nodes);
-			wave_group_by<4>(curIdx, won, [&](uint64_t, int, int rank, int cnt) {
-				if (rank == 0) atomicAdd(&a.nodes[curIdx].numVoxels, (uint32_t)cnt);       // voxels.cu:101
-			});
-			if (won) wins |= 1u << level;
-			if (alive) {
 				SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
-				if (ch == nullptr) alive = false; else cur = ch;
+				if (ch == nullptr) break;
+				cur = ch;
 			}
-			if (!__any(alive)) break;
+			winMask[idx] = wins;
 		}
-		if (act) winMask[idx] = wins;
+		__syncthreads();
+		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+			const uint32_t key = tbl.keys[e];
+			if (key != TBL_EMPTY) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
+		}
 	}
 }
 
@@ -425,9 +482,32 @@ __global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
+struct InsertShared {
+	BlockTable tbl;                       // node -> count, then node -> first reserved slot / running cursor
+	uint32_t dirBase[TBL_CAP];            // chunk-directory base of the node for this batch, or 0xffffffff
+	uint32_t dirFirst[TBL_CAP];
+};
+
+// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
+__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, const SimlodNode* node, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
+	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+	const float nodeSize = a.size / exp2_int(node->level);
+	const float nminx = ((float)node->X + 0.0f) * nodeSize + a.minx;
+	const float nminy = ((float)node->Y + 0.0f) * nodeSize + a.miny;
+	const float nminz = ((float)node->Z + 0.0f) * nodeSize + a.minz;
+	float4 v;
+	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
+	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
+	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
+	v.w = colorBits;                       // colour of the claiming point
+	return v;
+}
+
 __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
+	__shared__ InsertShared sh;
 	const uint32_t n = ctl->batchSize;
 	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
@@ -437,67 +517,109 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	const uint32_t tag = ctl->batchIndex + 1u;
-	const uint32_t stride = gridDim.x * TPB;
-	for (uint32_t base = blockIdx.x * TPB; base < total; base += stride) {
-		const uint32_t t = base + threadIdx.x;
-		const bool act = t < total;
-		float4 p = make_float4(0, 0, 0, 0);
-		uint32_t leafIdx = 0, wins = 0;
-		if (act) {
-			uint32_t idx;
-			if (t < n) { idx = t; p = pts[t]; } else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; }
-			leafIdx = leafOf[idx];
-			wins = winMask[idx] & 0xfffffu;
+	const uint32_t numChunks = (total + PPB - 1) / PPB;
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		// ======== points: reserve one slot range per (workgroup, leaf), then store ========
+		__syncthreads();
+		table_init(sh.tbl);
+		__syncthreads();
+		uint32_t ticket[PPT];                          // entry | rank << TBL_BITS, or 0xffffffff (no room in the table)
+		uint32_t wins[PPT];
+		bool anyWins = false;
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			ticket[j] = 0xffffffffu; wins[j] = 0;
+			if (t >= total) continue;
+			const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+			wins[j] = winMask[idx] & 0xfffffu;
+			anyWins |= wins[j] != 0u;
+			uint32_t rank;
+			const int e = table_add(sh.tbl, leafOf[idx], 1u, &rank);
+			if (e >= 0) ticket[j] = (uint32_t)e | (rank << TBL_BITS);
 		}
-		// -- the point itself ------------------------------------------------------------------------------------
-		wave_group_by(leafIdx, act, [&](uint64_t, int leader, int rank, int cnt) {
-			uint32_t slot0 = 0;
-			if (rank == 0) slot0 = atomicAdd(&a.nodes[leafIdx].numPoints, (uint32_t)cnt);      // voxels.cu:593
-			const uint32_t slot = (uint32_t)__shfl((int)slot0, leader, 64) + (uint32_t)rank;
-			const NodeDir d = nodeDir[leafIdx];
-			if (d.ptTag != tag) { if (rank == 0) raise(ctl, SIMLOD_ERR_NULL_CHUNK); return; }   // voxels.cu:599-604
-			SimlodChunk* chunk = chunkDir[d.ptBase + (slot / SIMLOD_POINTS_PER_CHUNK - d.ptFirst)];
-			reinterpret_cast<float4*>(chunk->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p;
-		});
-		// -- the voxels this sample created ------------------------------------------------------------------------
-		if (__any(wins != 0u)) {
-			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
-			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-			SimlodNode* cur = a.nodes;
-			bool alive = wins != 0u;
+		__syncthreads();
+		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+			const uint32_t key = sh.tbl.keys[e];
+			if (key == TBL_EMPTY) continue;
+			const NodeDir d = nodeDir[key];
+			sh.tbl.vals[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);              // voxels.cu:593
+			sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
+			sh.dirFirst[e] = d.ptFirst;
+		}
+		__syncthreads();
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			if (t >= total) continue;
+			const float4 p = t < n ? pts[t] : spilled[t - n];
+			uint32_t slot, base, first;
+			if (ticket[j] != 0xffffffffu) {
+				const uint32_t e = ticket[j] & (TBL_CAP - 1);
+				slot = sh.tbl.vals[e] + (ticket[j] >> TBL_BITS); base = sh.dirBase[e]; first = sh.dirFirst[e];
+			} else {
+				const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+				const NodeDir d = nodeDir[leafIdx];
+				slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u); base = d.ptTag == tag ? d.ptBase : 0xffffffffu; first = d.ptFirst;
+			}
+			if (base == 0xffffffffu) { raise(ctl, SIMLOD_ERR_NULL_CHUNK); continue; }           // voxels.cu:599-604
+			SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
+			reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p;
+		}
+
+		// ======== voxels: the samples that won a cell in `sample` regenerate their voxel(s) ========
+		if (!__syncthreads_or(anyWins ? 1 : 0)) continue;
+		table_init(sh.tbl);
+		__syncthreads();
+		for (int pass = 0; pass < 2; pass++) {
+			// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
 #pragma unroll 1
-			for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
-				const bool won = alive && ((wins >> level) & 1u);
-				const uint32_t curIdx = (uint32_t)(cur - a.nodes);
-				wave_group_by<4>(curIdx, won, [&](uint64_t, int leader, int rank, int cnt) {
-					uint32_t slot0 = 0;
-					if (rank == 0) slot0 = atomicAdd(&cur->numVoxelsStored, (uint32_t)cnt);       // voxels.cu:685
-					const uint32_t slot = (uint32_t)__shfl((int)slot0, leader, 64) + (uint32_t)rank;
-					const NodeDir d = nodeDir[curIdx];
-					if (d.voxTag != tag) { if (rank == 0) raise(ctl, SIMLOD_ERR_NULL_CHUNK); return; }
-					// cell-centre position, voxels.cu:103-114, operation by operation
-					const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
-					const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-					const float nodeSize = a.size / exp2_int(cur->level);
-					const float nminx = ((float)cur->X + 0.0f) * nodeSize + a.minx;
-					const float nminy = ((float)cur->Y + 0.0f) * nodeSize + a.miny;
-					const float nminz = ((float)cur->Z + 0.0f) * nodeSize + a.minz;
-					float4 v;
-					v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
-					v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
-					v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
-					v.w = p.w;                                                                    // colour of the claiming point
-					SimlodChunk* chunk = chunkDir[d.voxBase + (slot / SIMLOD_POINTS_PER_CHUNK - d.voxFirst)];
-					reinterpret_cast<float4*>(chunk->points)[slot % SIMLOD_POINTS_PER_CHUNK] = v;
-				});
-				if (alive) {
-					if ((wins >> (level + 1)) == 0u) alive = false;       // nothing deeper to emit
-					else {
-						SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
-						if (ch == nullptr) alive = false; else cur = ch;
+			for (uint32_t j = 0; j < PPT; j++) {
+				if (wins[j] == 0u) continue;
+				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+				const float4 p = t < n ? pts[t] : spilled[t - n];
+				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+				const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+				SimlodNode* cur = a.nodes;
+#pragma unroll 1
+				for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
+					if ((wins[j] >> level) & 1u) {
+						const uint32_t curIdx = (uint32_t)(cur - a.nodes);
+						if (pass == 0) {
+							uint32_t rank;
+							(void)table_add(sh.tbl, curIdx, 1u, &rank);
+						} else {
+							const int e = table_find(sh.tbl, curIdx);
+							uint32_t slot, base, first;
+							if (e >= 0) { slot = atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+							else {
+								const NodeDir d = nodeDir[curIdx];
+								slot = atomicAdd(&cur->numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
+							}
+							if (base == 0xffffffffu) raise(ctl, SIMLOD_ERR_NULL_CHUNK);
+							else {
+								SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
+								reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, cur, level, pX, pY, pZ, p.w);
+							}
+						}
 					}
+					if ((wins[j] >> (level + 1)) == 0u) break;          // nothing deeper to emit
+					SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
+					if (ch == nullptr) break;
+					cur = ch;
 				}
-				if (!__any(alive)) break;
+			}
+			__syncthreads();
+			if (pass == 0) {
+				for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+					const uint32_t key = sh.tbl.keys[e];
+					if (key == TBL_EMPTY) continue;
+					const NodeDir d = nodeDir[key];
+					sh.tbl.vals[e] = atomicAdd(&a.nodes[key].numVoxelsStored, sh.tbl.vals[e]);   // voxels.cu:685
+					sh.dirBase[e] = d.voxTag == tag ? d.voxBase : 0xffffffffu;
+					sh.dirFirst[e] = d.voxFirst;
+				}
+				__syncthreads();
 			}
 		}
 	}
@@ -583,12 +705,16 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
+	const uint64_t fixedEnd = off;
 	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
-	if (capacity < off + perBatch + 24ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch; return false; }
-	uint64_t cap = (capacity - off - perBatch - 1024) / 24;
+	if (capacity < off + perBatch + (uint64_t)SPILLING_CAPACITY * 32 + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch; return false; }
+	uint64_t cap = (capacity - off - perBatch - (uint64_t)SPILLING_CAPACITY * 32 - 4096) * 1000 / (24 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
 	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
 	a.spilledCap = (uint32_t)cap;
+	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + SPILLING_CAPACITY;
+	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
+	(void)fixedEnd;
 	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
 	a.offWin = off;      off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
 	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;

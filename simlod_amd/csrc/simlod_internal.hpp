@@ -21,7 +21,10 @@ struct Ctl {
 	uint32_t numSpilled, dirCount, errors;
 	uint32_t ordinal, abortBatch, barrierCount, pad0;
 	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]
-	uint32_t pad1[2];
+	uint32_t numWork;            // spill-copy work items appended so far in this batch (monotonic)
+	uint32_t pad1;
+	uint32_t spilledSnap[2];     // numSpilled / numWork as they were BEFORE round r's split phase: slot [r & 1]
+	uint32_t workSnap[2];
 	uint64_t startNs;
 	uint32_t statCounters[8];
 };
@@ -37,8 +40,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offNodeDir, offChunkDir, offLeafOf, offWin, offSpilled;
-	uint32_t     nodeCapacity, spilledCap, dirCap, pad;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offNodeDir, offChunkDir, offWork, offLeafOf, offWin, offSpilled;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
 };
 
 struct DeviceInfo {
