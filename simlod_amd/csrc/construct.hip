@@ -22,6 +22,8 @@
 // bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
 // chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
 // (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
+#include <cstdlib>
+
 #include "simlod_device.hpp"
 #include "simlod_hip.h"
 #include "simlod_internal.hpp"
@@ -341,8 +343,98 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 	}
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
 // ---- sample: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
+// The reference tests the sample's cell in EVERY node of the path, root first.  Occupancy is hierarchical, though: a
+// cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit in a node
+// had, in the same pass, been offered to all its ancestors — so "bit set in node N" implies "covering bit set in every
+// ancestor of N".  This kernel therefore walks the path BOTTOM-UP and stops at the first level whose bit is already
+// set, or where its own atomicOr lost the race (the winner keeps climbing).  Same bitsets, same voxel counts, one
+// winner per cell as in the reference; what it removes is the contention: measured on MI355X, a top-down pass issued
+// 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
+// (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
+// NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
+struct SampleShared {
+	BlockTable tbl;                              // node -> voxels created by this workgroup
+	uint32_t   path[SIMLOD_MAX_DEPTH][TPB];      // node index at every level of the current sample's path
+};
+
 __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	__shared__ SampleShared sh;
+	const uint32_t n = ctl->batchSize;
+	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
+	uint32_t* winMask = at<uint32_t>(a, a.offWin);
+	const uint32_t numChunks = (total + PPB - 1) / PPB;
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		__syncthreads();
+		table_init(sh.tbl);
+		__syncthreads();
+		uint32_t issued = 0;
+#pragma unroll 1
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			if (t >= total) continue;
+			uint32_t idx, startLevel = 0;
+			float4 p;
+			if (t < n) { idx = t; p = pts[t]; }
+			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
+			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+			// top-down: record the path (children pointers only)
+			SimlodNode* cur = a.nodes;
+			int leafLevel = 0;
+#pragma unroll 1
+			for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
+				sh.path[level][threadIdx.x] = (uint32_t)(cur - a.nodes);
+				SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
+				leafLevel = level;
+				if (ch == nullptr) break;
+				cur = ch;
+				leafLevel = level + 1;
+			}
+			// bottom-up over the nodes that own a grid: the inner nodes of the path (and the root while it is still a leaf)
+			uint32_t wins = 0;
+			int level = leafLevel > 0 ? leafLevel - 1 : 0;
+			if (leafLevel == SIMLOD_MAX_DEPTH) level = SIMLOD_MAX_DEPTH - 1;     // path[] holds levels 0..19; a level-20 leaf has its parent at 19
+#pragma unroll 1
+			for (; level >= (int)startLevel; --level) {
+				const uint32_t nodeIdx = sh.path[level][threadIdx.x];
+				SimlodNode* node = a.nodes + nodeIdx;
+				SimlodOccupancyGrid* grid = node->grid;
+				if (grid == nullptr) break;                                              // voxels.cu:56 (a leaf root before its first split has one; other leaves do not)
+				const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);          // voxels.cu:78-85
+				const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
+				const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+				const uint32_t bit = cell & 31u;
+				uint32_t* word = &grid->values[cell >> 5];
+				if (((*word >> bit) & 1u) != 0u) break;                                  // voxels.cu:93-94; ancestors are set as well
+				issued++;
+				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) break;              // voxels.cu:96; lost: the winner climbs on
+				wins |= 1u << level;                                                     // first point in the cell, voxels.cu:99
+				uint32_t rank;
+				if (table_add(sh.tbl, nodeIdx, 1u, &rank) < 0) atomicAdd(&node->numVoxels, 1u);   // voxels.cu:101
+			}
+			winMask[idx] = wins;
+		}
+		if (a.variant & 64u) { issued = wave_sum_u32(issued); if (lane_id() == 0) atomicAdd(&ctl->dbgCounters[0], issued); }
+		__syncthreads();
+		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+			const uint32_t key = sh.tbl.keys[e];
+			if (key != TBL_EMPTY) atomicAdd(&a.nodes[key].numVoxels, sh.tbl.vals[e]);
+		}
+	}
+}
+
+// ---- sample (inline-atomic variant kept for A/B): 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
+__global__ __launch_bounds__(TPB) void k_sample_inline(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
 	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
@@ -681,6 +773,7 @@ __global__ void k_finish(BuildArgs a) {
 	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
 	s->frameID = (uint32_t)a.frameCounter;
 	s->dbg |= ctl->errors;
+	if (a.variant & 64u) { s->numVisiblePoints += ctl->dbgCounters[0]; s->numVisibleVoxels += ctl->dbgCounters[1]; ctl->dbgCounters[0] = 0; ctl->dbgCounters[1] = 0; }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -733,6 +826,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.persCapacity = u->persistentBufferCapacity;
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
+	{ const char* v = getenv("SIMLOD_VARIANT"); a.variant = v ? (uint32_t)atoi(v) : 0u; }
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
 	const DeviceInfo& dev = device_info();
 
@@ -745,7 +839,8 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_expand, dim3(dev.numCUs), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_sample, dim3(gridPoints), dim3(TPB), stream, a);
+			if (a.variant & 32u) SIMLOD_LAUNCH(k_sample_inline, dim3(gridPoints), dim3(TPB), stream, a);
+			else SIMLOD_LAUNCH(k_sample, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_alloc, dim3(gridNodes), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);

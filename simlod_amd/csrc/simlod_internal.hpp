@@ -25,6 +25,7 @@ struct Ctl {
 	uint32_t pad1;
 	uint32_t spilledSnap[2];     // numSpilled / numWork as they were BEFORE round r's split phase: slot [r & 1]
 	uint32_t workSnap[2];
+	uint32_t dbgCounters[8];     // experiment counters (SIMLOD_VARIANT & 64)
 	uint64_t startNs;
 	uint32_t statCounters[8];
 };
@@ -42,6 +43,7 @@ struct BuildArgs {
 	uint64_t     persCapacity, frameCounter, scratchBytes;
 	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offNodeDir, offChunkDir, offWork, offLeafOf, offWin, offSpilled;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
+	uint32_t     variant, padv;      // experiment switch (SIMLOD_VARIANT), 0 in production
 };
 
 struct DeviceInfo {

@@ -1,0 +1,31 @@
+import sys, os, json, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from simlod_amd import abi, camera, synthetic
+from simlod_amd.runtime import DeviceOctree, lib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 36_000_000
+kind = sys.argv[2] if len(sys.argv) > 2 else "terrain"
+pts, box = (synthetic.terrain(n, seed=7) if kind == "terrain" else synthetic.hotspot(n) if kind == "hotspot" else synthetic.uniform_cube(n))
+W, H = 1920, 1080
+T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886 * box[0] / 6000, (box[0] / 2, box[1] / 2, 0.35 * box[2])), camera.perspective(aspect=W / H))
+dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, max_pixels=W * H)
+u = dev.uniforms(W, H, T, box, hqs=True)
+L = lib()
+for rep in range(2):
+    dev.reset(u)
+    if rep == 1: L.simlod_profile_enable(1)
+    dev.add_points(u, pts)
+    torch.cuda.synchronize()
+prof = bench.collect_profile(L)
+st = dev.read_stats()
+nb = (n + 999999) // 1000000
+print("atomics issued new/old kernel", int(st["numVisiblePoints"]), int(st["numVisibleVoxels"]));print("variant", os.environ.get("SIMLOD_VARIANT", "0"), "pts", int(st["numPoints"]), "voxels", int(st["numVoxels"]), "dbg", int(st["dbg"]))
+print({k: (c, round(ms, 2), "%.0f us/batch" % (ms * 1e3 / nb)) for k, (c, ms) in prof.items() if k.startswith("k_")})
+for hq in (1, 0):
+    u["useHighQualityShading"] = hq
+    dev.render(u); torch.cuda.synchronize()
+    dev.render(u)
+    pr = bench.collect_profile(L)
+    print("hqs" if hq else "plain", {k: round(ms, 3) for k, (c, ms) in pr.items()})
