@@ -22,8 +22,6 @@
 // bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
 // chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
 // (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
-#include <cstdlib>
-
 #include "simlod_device.hpp"
 #include "simlod_hip.h"
 #include "simlod_internal.hpp"
@@ -92,6 +90,22 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall) {
 	ctl->barrierCount = 0;
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
 	prepare_batch(a, ctl, 0);
+}
+
+// ---- parents: node index -> parent index, rebuilt at the start of every launch from the children pointers -----------
+// (a momentary table: nothing but the octree image itself and the recycle stack has to survive between launches)
+__global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= numNodes) return;
+	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
+	if (i == 0) parentOf[0] = 0xffffffffu;
+	const SimlodNode* n = a.nodes + i;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const SimlodNode* c = n->children[k];
+		if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
+	}
 }
 
 // ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
 	uint32_t* splitTag = at<uint32_t>(a, a.offSplitTag);
+	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SpillWork* work = at<SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
@@ -235,6 +250,7 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 				c.numVoxels = 0; c.numVoxelsStored = 0;
 				a.nodes[childOffset + i] = c;
 				node->children[i] = a.nodes + childOffset + i;
+				parentOf[childOffset + i] = nodeIdx;
 			}
 			if (threadIdx.x == 64) {
 				// One lane walks the chunk list (a pointer chase nobody can parallelise), emits one work item per chunk,
@@ -343,11 +359,6 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 	}
 }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-	return v;
-}
-
 // ---- sample: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
 // The reference tests the sample's cell in EVERY node of the path, root first.  Occupancy is hierarchical, though: a
 // cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit in a node
@@ -358,83 +369,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
 // (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
 // NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
-struct SampleShared {
-	BlockTable tbl;                              // node -> voxels created by this workgroup
-	uint32_t   path[SIMLOD_MAX_DEPTH][TPB];      // node index at every level of the current sample's path
-};
-
 __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	__shared__ SampleShared sh;
-	const uint32_t n = ctl->batchSize;
-	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const float4* spilled = at<const float4>(a, a.offSpilled);
-	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	const uint32_t numChunks = (total + PPB - 1) / PPB;
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		__syncthreads();
-		table_init(sh.tbl);
-		__syncthreads();
-		uint32_t issued = 0;
-#pragma unroll 1
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			uint32_t idx, startLevel = 0;
-			float4 p;
-			if (t < n) { idx = t; p = pts[t]; }
-			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
-			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
-			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-			// top-down: record the path (children pointers only)
-			SimlodNode* cur = a.nodes;
-			int leafLevel = 0;
-#pragma unroll 1
-			for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
-				sh.path[level][threadIdx.x] = (uint32_t)(cur - a.nodes);
-				SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
-				leafLevel = level;
-				if (ch == nullptr) break;
-				cur = ch;
-				leafLevel = level + 1;
-			}
-			// bottom-up over the nodes that own a grid: the inner nodes of the path (and the root while it is still a leaf)
-			uint32_t wins = 0;
-			int level = leafLevel > 0 ? leafLevel - 1 : 0;
-			if (leafLevel == SIMLOD_MAX_DEPTH) level = SIMLOD_MAX_DEPTH - 1;     // path[] holds levels 0..19; a level-20 leaf has its parent at 19
-#pragma unroll 1
-			for (; level >= (int)startLevel; --level) {
-				const uint32_t nodeIdx = sh.path[level][threadIdx.x];
-				SimlodNode* node = a.nodes + nodeIdx;
-				SimlodOccupancyGrid* grid = node->grid;
-				if (grid == nullptr) break;                                              // voxels.cu:56 (a leaf root before its first split has one; other leaves do not)
-				const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);          // voxels.cu:78-85
-				const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
-				const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-				const uint32_t bit = cell & 31u;
-				uint32_t* word = &grid->values[cell >> 5];
-				if (((*word >> bit) & 1u) != 0u) break;                                  // voxels.cu:93-94; ancestors are set as well
-				issued++;
-				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) break;              // voxels.cu:96; lost: the winner climbs on
-				wins |= 1u << level;                                                     // first point in the cell, voxels.cu:99
-				uint32_t rank;
-				if (table_add(sh.tbl, nodeIdx, 1u, &rank) < 0) atomicAdd(&node->numVoxels, 1u);   // voxels.cu:101
-			}
-			winMask[idx] = wins;
-		}
-		if (a.variant & 64u) { issued = wave_sum_u32(issued); if (lane_id() == 0) atomicAdd(&ctl->dbgCounters[0], issued); }
-		__syncthreads();
-		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-			const uint32_t key = sh.tbl.keys[e];
-			if (key != TBL_EMPTY) atomicAdd(&a.nodes[key].numVoxels, sh.tbl.vals[e]);
-		}
-	}
-}
-
-// ---- sample (inline-atomic variant kept for A/B): 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
-__global__ __launch_bounds__(TPB) void k_sample_inline(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
 	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
@@ -442,6 +377,8 @@ __global__ __launch_bounds__(TPB) void k_sample_inline(BuildArgs a) {
 	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
+	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
+	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
@@ -456,31 +393,29 @@ __global__ __launch_bounds__(TPB) void k_sample_inline(BuildArgs a) {
 			float4 p;
 			if (t < n) { idx = t; p = pts[t]; }
 			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
-			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
 			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-			SimlodNode* cur = a.nodes;
+			// the leaf was cached by count/expand; grids live in the inner nodes above it (and in a root that is still a leaf)
+			const uint32_t leafIdx = leafOf[idx];
+			uint32_t nodeIdx = leafIdx == 0u ? 0u : parentOf[leafIdx];
 			uint32_t wins = 0;
 #pragma unroll 1
-			for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
-				if ((uint32_t)level >= startLevel) {
-					SimlodOccupancyGrid* grid = cur->grid;
-					if (grid != nullptr) {
-						const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);          // voxels.cu:78-85
-						const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-						const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-						const uint32_t bit = 1u << (cell & 31u);
-						uint32_t* word = &grid->values[cell >> 5];
-						if ((*word & bit) == 0u && (atomicOr(word, bit) & bit) == 0u) {          // voxels.cu:93-99
-							wins |= 1u << level;
-							const uint32_t curIdx = (uint32_t)(cur - a.nodes);
-							uint32_t rank;
-							if (table_add(tbl, curIdx, 1u, &rank) < 0) atomicAdd(&cur->numVoxels, 1u);   // voxels.cu:101
-						}
-					}
-				}
-				SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
-				if (ch == nullptr) break;
-				cur = ch;
+			while (nodeIdx != 0xffffffffu) {
+				SimlodNode* node = a.nodes + nodeIdx;
+				const uint32_t level = node->level;
+				if (level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) break;    // voxels.cu:449: the traverse loop samples levels 0..19 only
+				SimlodOccupancyGrid* grid = node->grid;
+				if (grid == nullptr) break;                                              // voxels.cu:56
+				const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
+				const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
+				const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+				const uint32_t bit = cell & 31u;
+				uint32_t* word = &grid->values[cell >> 5];
+				if (((*word >> bit) & 1u) != 0u) break;                                  // voxels.cu:93-94; the ancestors are set as well
+				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) break;              // voxels.cu:96; lost: the winner climbs on
+				wins |= 1u << level;                                                     // first point in the cell, voxels.cu:99
+				uint32_t rank;
+				if (table_add(tbl, nodeIdx, 1u, &rank) < 0) atomicAdd(&node->numVoxels, 1u);   // voxels.cu:101
+				nodeIdx = parentOf[nodeIdx];
 			}
 			winMask[idx] = wins;
 		}
@@ -608,6 +543,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 	const uint32_t* winMask = at<const uint32_t>(a, a.offWin);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
 	const uint32_t tag = ctl->batchIndex + 1u;
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
@@ -670,13 +606,17 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 				if (wins[j] == 0u) continue;
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				const float4 p = t < n ? pts[t] : spilled[t - n];
-				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
 				const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-				SimlodNode* cur = a.nodes;
+				// climb from the cached leaf through its ancestors: the won levels are the deepest ones of the path
+				const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+				uint32_t curIdx = leafIdx == 0u ? 0u : parentOf[leafIdx];
+				uint32_t left = wins[j];
 #pragma unroll 1
-				for (int level = 0; level < SIMLOD_MAX_DEPTH; ++level) {
-					if ((wins[j] >> level) & 1u) {
-						const uint32_t curIdx = (uint32_t)(cur - a.nodes);
+				while (left != 0u && curIdx != 0xffffffffu) {
+					SimlodNode* cur = a.nodes + curIdx;
+					const int level = (int)cur->level;
+					if ((left >> level) & 1u) {
+						left &= ~(1u << level);
 						if (pass == 0) {
 							uint32_t rank;
 							(void)table_add(sh.tbl, curIdx, 1u, &rank);
@@ -695,10 +635,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 							}
 						}
 					}
-					if ((wins[j] >> (level + 1)) == 0u) break;          // nothing deeper to emit
-					SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
-					if (ch == nullptr) break;
-					cur = ch;
+					curIdx = parentOf[curIdx];
 				}
 			}
 			__syncthreads();
@@ -773,7 +710,6 @@ __global__ void k_finish(BuildArgs a) {
 	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
 	s->frameID = (uint32_t)a.frameCounter;
 	s->dbg |= ctl->errors;
-	if (a.variant & 64u) { s->numVisiblePoints += ctl->dbgCounters[0]; s->numVisibleVoxels += ctl->dbgCounters[1]; ctl->dbgCounters[0] = 0; ctl->dbgCounters[1] = 0; }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -783,7 +719,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	uint64_t off = 4096;                                                       // Ctl
 	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	off += align_up((uint64_t)nodeCapacity * 4, 256);                          // splitTag
+	off += 2 * align_up((uint64_t)nodeCapacity * 4, 256);                      // splitTag, parentOf
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
 	return off;
@@ -796,6 +732,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
 	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
 	const uint64_t fixedEnd = off;
@@ -826,7 +763,6 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.persCapacity = u->persistentBufferCapacity;
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
-	{ const char* v = getenv("SIMLOD_VARIANT"); a.variant = v ? (uint32_t)atoi(v) : 0u; }
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
 	const DeviceInfo& dev = device_info();
 
@@ -834,13 +770,13 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)a.nodeCapacity * 4, stream);
 		if (e != hipSuccess) return (int)e;
+		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * 8;                            // grid-stride, 8 workgroups per CU
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_expand, dim3(dev.numCUs), dim3(TPB), stream, a);
-			if (a.variant & 32u) SIMLOD_LAUNCH(k_sample_inline, dim3(gridPoints), dim3(TPB), stream, a);
-			else SIMLOD_LAUNCH(k_sample, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_sample, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_alloc, dim3(gridNodes), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);

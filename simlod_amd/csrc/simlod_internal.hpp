@@ -25,7 +25,6 @@ struct Ctl {
 	uint32_t pad1;
 	uint32_t spilledSnap[2];     // numSpilled / numWork as they were BEFORE round r's split phase: slot [r & 1]
 	uint32_t workSnap[2];
-	uint32_t dbgCounters[8];     // experiment counters (SIMLOD_VARIANT & 64)
 	uint64_t startNs;
 	uint32_t statCounters[8];
 };
@@ -41,9 +40,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offNodeDir, offChunkDir, offWork, offLeafOf, offWin, offSpilled;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offParent, offNodeDir, offChunkDir, offWork, offLeafOf, offWin, offSpilled;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
-	uint32_t     variant, padv;      // experiment switch (SIMLOD_VARIANT), 0 in production
 };
 
 struct DeviceInfo {

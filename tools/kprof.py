@@ -21,7 +21,7 @@ for rep in range(2):
 prof = bench.collect_profile(L)
 st = dev.read_stats()
 nb = (n + 999999) // 1000000
-print("atomics issued new/old kernel", int(st["numVisiblePoints"]), int(st["numVisibleVoxels"]));print("variant", os.environ.get("SIMLOD_VARIANT", "0"), "pts", int(st["numPoints"]), "voxels", int(st["numVoxels"]), "dbg", int(st["dbg"]))
+print("variant", os.environ.get("SIMLOD_VARIANT", "0"), "pts", int(st["numPoints"]), "voxels", int(st["numVoxels"]), "dbg", int(st["dbg"]))
 print({k: (c, round(ms, 2), "%.0f us/batch" % (ms * 1e3 / nb)) for k, (c, ms) in prof.items() if k.startswith("k_")})
 for hq in (1, 0):
     u["useHighQualityShading"] = hq
