@@ -67,6 +67,10 @@ def port_lib():
         lib.oracle_rebase.restype = ctypes.c_int64
         lib.oracle_rebase.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint64]
+        lib.oracle_rebase_to.restype = ctypes.c_int64
+        lib.oracle_rebase_to.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_uint64] * 4
+        lib.oracle_check_invariants.restype = ctypes.c_int
+        lib.oracle_check_invariants.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5
         lib.oracle_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         lib.oracle_gather.restype = ctypes.c_uint32
         lib.oracle_gather.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
@@ -213,3 +217,20 @@ def gather_samples(head_ptr, count):
     out = np.zeros(count, dtype=abi.point_dtype)
     got = port_lib().oracle_gather(ctypes.c_void_p(int(head_ptr)), count, _ptr(out))
     return out[:got]
+
+
+def rebase_image_to(nodes, num_nodes, persistent, old_nodes_base, old_persistent_base, new_nodes_base, new_persistent_base):
+    """Rewrite the pointers of a host-resident image for a foreign address space (e.g. device buffers before an upload)."""
+    r = port_lib().oracle_rebase_to(_ptr(nodes), num_nodes, _ptr(persistent), persistent.size, old_nodes_base, old_persistent_base,
+                                    new_nodes_base, new_persistent_base)
+    if r < 0:
+        raise ValueError("octree image holds a pointer outside its persistent buffer")
+    return r
+
+
+def check_invariants(nodes, num_nodes):
+    """Structural invariants of a HOST-addressed image; returns dict of totals or raises AssertionError(rule)."""
+    tot = np.zeros(5, dtype=np.uint64)
+    rule = port_lib().oracle_check_invariants(_ptr(nodes), num_nodes, *[ctypes.c_void_p(tot.ctypes.data + 8 * k) for k in range(5)])
+    assert rule == 0, f"octree image violates structural rule #{rule} (oracle/oracle_support.c: oracle_check_invariants)"
+    return dict(points=int(tot[0]), voxels=int(tot[1]), point_chunks=int(tot[2]), voxel_chunks=int(tot[3]), grids=int(tot[4]))

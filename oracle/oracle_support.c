@@ -45,12 +45,23 @@ void ref_call_reset(void* fn, const SimlodUniforms* u, uint8_t* persistent, Siml
  * outside the persistent buffer. */
 static int in_range(uint64_t p, uint64_t base, uint64_t size) { return p >= base && p < base + size; }
 
+/* General form: the image is resident (and walked) at (nodes, pers), was valid at (oldNodes, oldPers) and is rewritten to be
+ * valid at (newNodes, newPers) — e.g. device addresses before an upload.  After a rewrite to foreign addresses the host copy
+ * can no longer be walked. */
+int64_t oracle_rebase_to(SimlodNode* nodes, uint32_t numNodes, uint8_t* pers, uint64_t persSize,
+                         uint64_t oldNodes, uint64_t oldPers, uint64_t newNodes, uint64_t newPers);
+
 int64_t oracle_rebase(SimlodNode* nodes, uint32_t numNodes, uint8_t* pers, uint64_t persSize,
                       uint64_t oldNodes, uint64_t oldPers) {
+	return oracle_rebase_to(nodes, numNodes, pers, persSize, oldNodes, oldPers, (uint64_t)(uintptr_t)nodes, (uint64_t)(uintptr_t)pers);
+}
+
+int64_t oracle_rebase_to(SimlodNode* nodes, uint32_t numNodes, uint8_t* pers, uint64_t persSize,
+                         uint64_t oldNodes, uint64_t oldPers, uint64_t newNodes, uint64_t newPers) {
 	int64_t chunks = 0;
-	const uint64_t newNodes = (uint64_t)(uintptr_t)nodes, newPers = (uint64_t)(uintptr_t)pers;
+	const uint64_t hereP = (uint64_t)(uintptr_t)pers;
 	SimlodAllocatorGlobal* a = (SimlodAllocatorGlobal*)pers;
-	a->buffer = pers;
+	a->buffer = (uint8_t*)(uintptr_t)newPers;
 	for (uint32_t i = 0; i < numNodes; i++) {
 		SimlodNode* n = &nodes[i];
 		for (int k = 0; k < 8; k++) {
@@ -64,15 +75,15 @@ int64_t oracle_rebase(SimlodNode* nodes, uint32_t numNodes, uint8_t* pers, uint6
 			uint64_t p = (uint64_t)(uintptr_t)*heads[h];
 			if (!p) continue;
 			if (!in_range(p, oldPers, persSize)) return -1;
-			SimlodChunk* c = (SimlodChunk*)(uintptr_t)(p - oldPers + newPers);
-			*heads[h] = c;
+			*heads[h] = (SimlodChunk*)(uintptr_t)(p - oldPers + newPers);
+			SimlodChunk* c = (SimlodChunk*)(uintptr_t)(p - oldPers + hereP);       /* walk through the resident copy */
 			while (c) {
 				chunks++;
 				uint64_t nx = (uint64_t)(uintptr_t)c->next;
 				if (!nx) break;
 				if (!in_range(nx, oldPers, persSize)) return -1;
 				c->next = (SimlodChunk*)(uintptr_t)(nx - oldPers + newPers);
-				c = c->next;
+				c = (SimlodChunk*)(uintptr_t)(nx - oldPers + hereP);
 			}
 		}
 	}
@@ -148,4 +159,50 @@ uint32_t oracle_gather(const SimlodChunk* head, uint32_t count, SimlodPoint* out
 		out[i] = cur->points[i % SIMLOD_POINTS_PER_CHUNK];
 	}
 	return i;
+}
+
+/* Structural invariants every octree image must satisfy after a completed kernel_construct, whatever the input was
+ * (size-independent properties for the full-size tests).  Returns 0 or the number of the first violated rule. */
+int oracle_check_invariants(const SimlodNode* nodes, uint32_t numNodes, uint64_t* totalPoints, uint64_t* totalVoxels,
+                            uint64_t* pointChunks, uint64_t* voxelChunks, uint64_t* grids) {
+	uint64_t tp = 0, tv = 0, pc = 0, vc = 0, g = 0;
+	if (numNodes == 0 || (numNodes - 1) % 8 != 0) return 1;                       /* nodes are created 8 at a time */
+	for (uint32_t i = 0; i < numNodes; i++) {
+		const SimlodNode* n = &nodes[i];
+		int kids = 0;
+		for (int k = 0; k < 8; k++) if (n->children[k]) kids++;
+		if (kids != 0 && kids != 8) return 2;
+		if (n->grid) g++;
+		if (kids == 8) {
+			if (n->numPoints != 0 || n->points != NULL) return 3;                   /* inner nodes keep no points */
+			if (!n->grid) return 4;
+			for (int k = 0; k < 8; k++) {
+				const SimlodNode* c = n->children[k];
+				if (c->level != n->level + 1) return 5;
+				if (c->X != 2 * n->X + (uint32_t)((k >> 2) & 1) || c->Y != 2 * n->Y + (uint32_t)((k >> 1) & 1) || c->Z != 2 * n->Z + (uint32_t)(k & 1)) return 6;
+				if (c->level < 20 && c->name[c->level] != (uint8_t)('0' + k)) return 7;
+			}
+		} else {
+			if (n->counter != n->numPoints) return 8;                                /* everything counted was stored */
+			if (n->numPoints > SIMLOD_MAX_POINTS_PER_NODE && n->level < SIMLOD_MAX_DEPTH) return 9;
+			if (i != 0 && n->grid) return 10;                                        /* only inner nodes and the root own a grid */
+		}
+		if (n->numVoxels != n->numVoxelsStored) return 11;
+		if (n->grid) {
+			uint32_t pcnt = 0;
+			for (uint32_t w = 0; w < SIMLOD_GRID_NUM_WORDS; w++) pcnt += (uint32_t)__builtin_popcount(n->grid->values[w]);
+			if (i != 0 && pcnt != n->numVoxels) return 12;                          /* the root may hold duplicates (grid cleared at its split) */
+			if (i == 0 && pcnt > n->numVoxels) return 12;
+		} else if (n->numVoxels != 0) return 13;
+		uint32_t l = 0;
+		for (const SimlodChunk* c = n->points; c; c = c->next) l++;
+		if (l != (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK) return 14;
+		pc += l; l = 0;
+		for (const SimlodChunk* c = n->voxelChunks; c; c = c->next) l++;
+		if (l != (n->numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK) return 15;
+		vc += l;
+		tp += n->numPoints; tv += n->numVoxels;
+	}
+	*totalPoints = tp; *totalVoxels = tv; *pointChunks = pc; *voxelChunks = vc; *grids = g;
+	return 0;
 }

@@ -1,0 +1,79 @@
+"""Multi-GPU layer (new design — the reference is single-GPU): one process per GPU, every rank owns
+the sub-octrees of a set of top-level cells of the SAME global cube, so node coordinates, names, voxel grids and the
+LOD maths are those of the single-GPU octree.
+
+  ingest   a point belongs to the rank that owns its level-`level` cell (level 1 = the eight octants).  Pre-partitioned
+           inputs (BASELINE config 4: tiles assigned by octant) need no exchange at all; a mixed batch is routed with
+           ONE collective (exchange_points).
+  render   every rank rasterises its own visible nodes; the frame is the element-wise MIN of the uint64 framebuffers
+           (depth bits << 32 | colour, exactly what atomicMin builds on one GPU, render.cu:95-100) — one all-reduce —
+           and the visible-node records are all-gathered so every rank holds the merged list (stats, LOD bookkeeping).
+
+All functions take torch tensors living wherever the process group's backend wants them (CUDA for nccl/RCCL, CPU for
+gloo in the tests); nothing here launches kernels.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import abi
+
+
+def cell_of(x, y, z, box_size, level=1):
+    """Level-`level` octree cell of every point (the reference's quantisation, progressive_octree_voxels.cu:148-150:
+    X = uint32(2^20 * (p - min) / size) with boxMin = 0) as a Morton-like code x<<2|y<<1|z per level."""
+    size = np.float32(max(box_size))
+    q = [np.minimum((np.float32(2 ** 20) * np.asarray(v, dtype=np.float32) / size).astype(np.uint32), np.uint32(2 ** 20 - 1)) for v in (x, y, z)]
+    code = np.zeros(len(q[0]), dtype=np.uint32)
+    for lv in range(level):
+        s = np.uint32(19 - lv)
+        code = (code << np.uint32(3)) | (((q[0] >> s) & 1) << np.uint32(2)) | (((q[1] >> s) & 1) << np.uint32(1)) | ((q[2] >> s) & 1)
+    return code
+
+
+def owner_of(points, box_size, world, level=1):
+    """Rank that owns each point: cells are dealt round-robin (world 8, level 1: octant k -> rank k)."""
+    return (cell_of(points["x"], points["y"], points["z"], box_size, level) % np.uint32(world)).astype(np.int64)
+
+
+def exchange_points(points, owners, group=None):
+    """Route one mixed batch: returns the records (from every rank, rank order, original order inside a rank) that THIS rank
+    owns.  Implemented as an all-gather of size-padded buffers so that it runs on gloo as well as on RCCL."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = points.device if isinstance(points, torch.Tensor) else torch.device("cpu")
+    rec = points if isinstance(points, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(points).view(np.uint8).reshape(-1, 16))
+    own = owners if isinstance(owners, torch.Tensor) else torch.from_numpy(np.asarray(owners, dtype=np.int64))
+    counts = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    cap = int(max(int(c.item()) for c in all_counts))
+    pad_r = torch.zeros((cap, 16), dtype=torch.uint8, device=dev); pad_r[: rec.shape[0]] = rec
+    pad_o = torch.full((cap,), -1, dtype=torch.int64, device=dev); pad_o[: rec.shape[0]] = own
+    gr = [torch.empty_like(pad_r) for _ in range(world)]
+    go = [torch.empty_like(pad_o) for _ in range(world)]
+    dist.all_gather(gr, pad_r, group=group)
+    dist.all_gather(go, pad_o, group=group)
+    mine = [gr[r][go[r] == rank] for r in range(world)]
+    return torch.cat(mine, dim=0)
+
+
+def compose_min(framebuffer_u64_as_i64, group=None):
+    """In-place all-reduce(MIN) over the 64-bit depth|colour words.  The sign bit of a stored word is never set (a sample
+    with negative depth bits never beats the +inf clear value, render.cu:95-100), so signed MIN == unsigned MIN."""
+    dist.all_reduce(framebuffer_u64_as_i64, op=dist.ReduceOp.MIN, group=group)
+    return framebuffer_u64_as_i64
+
+
+def gather_visible(visible_bytes, count, group=None, capacity=4096):
+    """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, capacity, 152], counts)."""
+    world = dist.get_world_size(group)
+    dev = visible_bytes.device
+    n = min(int(count), capacity)
+    buf = torch.zeros((capacity, 152), dtype=torch.uint8, device=dev)
+    buf[:n] = visible_bytes[: n * 152].view(n, 152)
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    dist.all_gather(cnts, cnt, group=group)
+    return torch.stack(bufs), torch.cat(cnts)

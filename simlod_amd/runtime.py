@@ -217,6 +217,16 @@ class DeviceOctree:
         self.drain(uniforms)
         self.processed_host = self.uploaded_host
 
+    def upload_image(self, nodes, persistent, num_nodes, stats=None):
+        """Load an octree image whose pointers were already rewritten for THIS object's device buffers (self.nodes.data_ptr(),
+        self.persistent.data_ptr()) — e.g. one built by another implementation.  Only what kernel_render needs is set."""
+        assert num_nodes <= self.max_nodes and persistent.size <= self.persistent.numel()
+        self.nodes[: num_nodes * 152].copy_(torch.from_numpy(nodes[:num_nodes].view(np.uint8).reshape(-1)))
+        self.persistent[: persistent.size].copy_(torch.from_numpy(persistent))
+        st = np.zeros(1, dtype=abi.stats_dtype) if stats is None else np.array(stats, dtype=abi.stats_dtype).reshape(1).copy()
+        st["numNodes"] = num_nodes
+        self.stats.copy_(torch.from_numpy(st.view(np.uint8).reshape(-1)))
+
     def download_image(self):
         """(nodes, persistent, numNodes, device base addresses) — the octree image as host arrays, pointers untouched."""
         torch.cuda.synchronize(self.device)

@@ -1,0 +1,88 @@
+"""world_size-2 gloo test of the multi-GPU layer (simlod_amd/distributed.py): spatial ownership, batch routing and the
+MIN composition of per-rank framebuffers.  Each rank builds/rasterises its sub-octrees with the CPU oracle; the composed
+frame must equal the single-process frame of the whole data set bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from simlod_amd import abi, camera, distributed, synthetic
+    W = H = 256
+    pts, box = synthetic.uniform_cube(800_000, seed=21)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    u = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
+    o = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=2)
+    o.reset(u)
+    batch = 400_000
+    for i in range(0, len(pts), batch):
+        # every rank "reads" half of the mixed batch, then the batch is routed to the owners of the octants
+        # (contiguous halves: concatenated in rank order they keep the file order, so the serial first-writer-wins voxel
+        # colours are those of the single-process run)
+        part = pts[i + rank * batch // world: i + (rank + 1) * batch // world]
+        mine = distributed.exchange_points(part, distributed.owner_of(part, box, world))
+        mine = mine.numpy().reshape(-1).view(abi.point_dtype)
+        owners = distributed.owner_of(mine, box, world)
+        assert (owners == rank).all()
+        o.upload(mine); o.construct(u)
+    fb, _ = o.render(u)
+    t = torch.from_numpy(fb.view(np.int64).copy())
+    distributed.compose_min(t)
+    vis_bytes = torch.from_numpy(np.ascontiguousarray(o.visible).view(np.uint8).reshape(-1).copy())
+    recs, cnts = distributed.gather_visible(vis_bytes, len(o.visible))
+    np.save(os.path.join(out_dir, f"fb_{rank}.npy"), t.numpy().view(np.uint64))
+    np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([int(o.stats["numPoints"][0]), int(cnts.sum()), int(o.stats["numVisibleNodes"][0])]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_ingest_and_min_composition(built_libs, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import oracle
+    from simlod_amd import abi, camera, synthetic
+    W = H = 256
+    pts, box = synthetic.uniform_cube(800_000, seed=21)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    u = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
+    o = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=2)
+    o.reset(u)
+    for i in range(0, len(pts), 400_000):
+        o.upload(pts[i:i + 400_000]); o.construct(u)
+    fb, _ = o.render(u)
+    f0, f1 = np.load(tmp_path / "fb_0.npy"), np.load(tmp_path / "fb_1.npy")
+    m0, m1 = np.load(tmp_path / "meta_0.npy"), np.load(tmp_path / "meta_1.npy")
+    assert np.array_equal(f0, f1), "all-reduce must leave the same frame on every rank"
+    assert m0[0] + m1[0] == len(pts), "every point is owned by exactly one rank"
+    assert m0[1] == m1[1] == m0[2] + m1[2] == int(o.stats["numVisibleNodes"][0]), "merged visible-node list"
+    diff = int((f0 != fb).sum())
+    assert diff == 0, f"{diff} pixels of the composed frame differ from the single-process frame"
+    assert int((fb != abi.CLEAR_PIXEL).sum()) > 5000
+
+
+def test_ownership_is_a_partition():
+    sys.path.insert(0, ROOT)
+    from simlod_amd import distributed, synthetic
+    pts, box = synthetic.uniform_cube(100_000, seed=3)
+    for world in (1, 2, 4, 8):
+        own = distributed.owner_of(pts, box, world)
+        assert own.min() >= 0 and own.max() < world
+        if world == 8:      # level 1: octant k -> rank k, x is the most significant bit (progressive_octree_voxels.cu:179)
+            exp = ((pts["x"] >= 0.5).astype(int) << 2) | ((pts["y"] >= 0.5).astype(int) << 1) | (pts["z"] >= 0.5).astype(int)
+            assert np.array_equal(own, exp)

@@ -1,0 +1,51 @@
+"""Host-side pieces: camera recipe, synthetic generators, Uniforms packing."""
+import numpy as np
+
+from simlod_amd import abi, camera, synthetic
+
+
+def test_uniform_cube_is_mt19937_uniform_real():
+    pts, box = synthetic.uniform_cube(4, seed=1234)
+    # std::mt19937(1234) + std::uniform_real_distribution<float>: first draws (checked against libstdc++)
+    assert np.allclose(pts["x"][0], 0.191519454) and np.allclose(pts["y"][0], 0.497663677) and np.allclose(pts["z"][0], 0.622108757)
+    assert pts["color"][0] >> 24 == 255 and (pts["color"][0] & 0xff) == int(255 * pts["x"][0])
+    assert box.tolist() == [1, 1, 1]
+
+
+def test_generators_are_deterministic_and_in_box():
+    for gen, kw in ((synthetic.terrain, dict(n=50_000, seed=3, box=(600.0, 400.0, 40.0), tile=50.0)), (synthetic.hotspot, dict(n=10_000))):
+        a, box = gen(**kw)
+        b, _ = gen(**kw)
+        assert a.tobytes() == b.tobytes()
+        for k, ax in enumerate("xyz"):
+            assert a[ax].min() >= 0 and a[ax].max() < box[k]
+
+
+def test_orbit_camera_geometry():
+    # OrbitControls.h:140-159: the eye sits `radius` away from `target`, looking at it, z up
+    yaw, pitch, radius, target = camera.PRESETS["morro_bay_bird"]
+    view = camera.orbit_view(yaw, pitch, radius, target)
+    eye = np.linalg.inv(view)[:3, 3]
+    assert abs(np.linalg.norm(eye - np.asarray(target)) - radius) < 1e-6
+    t_cam = view @ np.array([*target, 1.0])
+    assert np.allclose(t_cam[:3], (0, 0, -radius), atol=1e-6)          # target straight ahead on -z
+    up_cam = view[:3, :3] @ np.array([0, 0, 1.0])
+    assert up_cam[1] > 0                                                 # world z points up on screen
+
+
+def test_projection_puts_target_in_the_image_centre():
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), 512, 512)
+    c = T.astype(np.float64) @ np.array([0.5, 0.5, 0.3, 1.0])
+    assert abs(c[0] / c[3]) < 1e-5 and abs(c[1] / c[3]) < 1e-5 and c[3] > 0
+
+
+def test_uniforms_packing():
+    T = np.arange(16, dtype=np.float32).reshape(4, 4)
+    u = abi.make_uniforms(640, 480, T, (3, 2, 1), persistent_capacity=123, momentary_capacity=456, hqs=True, point_size=2)
+    raw = u.tobytes()
+    assert len(raw) == 480
+    assert np.frombuffer(raw, np.float32, 2, 0).tolist() == [640, 480]
+    assert np.frombuffer(raw, np.float32, 16, 208).reshape(4, 4).tolist() == T.tolist()      # transform rows
+    assert np.frombuffer(raw, np.uint64, 2, 400).tolist() == [123, 456]
+    assert np.frombuffer(raw, np.float32, 3, 436).tolist() == [3, 2, 1]
+    assert raw[460] == 1 and np.frombuffer(raw, np.int32, 1, 468)[0] == 2

@@ -1,0 +1,71 @@
+"""Pins the C restatement (oracle/simlod_oracle.c) against the reference ITSELF: oracle/_ref = the reference's own
+reset.cu / progressive_octree_voxels.cu / render.cu compiled in place as single-thread host code (oracle/Makefile).
+A serial run has one legal outcome, so the two must agree on every byte that is not an address: node records, chunk
+contents at identical allocator offsets, occupancy grids, Stats, pre-EDL framebuffers."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from cases import CASES, batches_of, case, uniforms_for
+from util import STATS_BUILD_FIELDS, STATS_RENDER_FIELDS, assert_dumps_equal, assert_stats_equal
+
+pytestmark = pytest.mark.skipif(not (oracle.have_ref() or os.path.isdir("/root/reference")),
+                                reason="oracle/_ref not built and /root/reference absent")
+
+NODE_VALUE_FIELDS = ["counter", "numPoints", "level", "X", "Y", "Z", "countIteration", "name", "numVoxels", "numVoxelsStored"]
+
+
+def _run(kind, name):
+    pts, box, batch, T = case(name)
+    u = uniforms_for(box, T)
+    o = oracle.HostOctree(kind, persistent_bytes=1 << 30, ring_slots=8)
+    o.reset(u)
+    for b in batches_of(name, pts, batch):
+        o.upload(b)
+    while int(o.stats["batchletIndex"][0]) < int(o.num_uploaded[0]):
+        o.construct(u)
+    return o, box, T
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_restatement_equals_reference_build(built_libs, name):
+    ref, box, T = _run("ref", name)
+    port, _, _ = _run("port", name)
+    assert port.last_error() == 0
+    assert_stats_equal(port.stats[0], ref.stats[0], STATS_BUILD_FIELDS, name)
+    n = int(ref.stats["numNodes"][0])
+    for f in NODE_VALUE_FIELDS:
+        assert np.array_equal(ref.nodes[f][:n], port.nodes[f][:n]), f"Node.{f}"
+    # same allocation order -> same offsets inside the persistent buffer for grids and chunk lists
+    for f in ("grid", "points", "voxelChunks"):
+        ra = np.where(ref.nodes[f][:n] != 0, ref.nodes[f][:n] - np.uint64(ref.persistent.ctypes.data), 0)
+        pa = np.where(port.nodes[f][:n] != 0, port.nodes[f][:n] - np.uint64(port.persistent.ctypes.data), 0)
+        assert np.array_equal(ra, pa), f"Node.{f} offsets"
+    ca = np.where(ref.nodes["children"][:n] != 0, ref.nodes["children"][:n] - np.uint64(ref.nodes.ctypes.data), 0)
+    cb = np.where(port.nodes["children"][:n] != 0, port.nodes["children"][:n] - np.uint64(port.nodes.ctypes.data), 0)
+    assert np.array_equal(ca, cb), "children indices"
+    assert_dumps_equal(port.dump(), ref.dump(), name)       # includes every stored point, voxel position and grid bit
+    for hqs in (False, True):
+        u = uniforms_for(box, T, hqs=hqs)
+        fa, _ = ref.render(u)
+        fb, _ = port.render(u)
+        assert np.array_equal(fa, fb), f"{name}: pre-EDL framebuffer differs (hqs={hqs})"
+        assert_stats_equal(port.stats[0], ref.stats[0], STATS_RENDER_FIELDS, name)
+        va, vb = ref.visible, port.visible
+        assert len(va) == len(vb) and np.array_equal(va["name"], vb["name"]), "visible-node list order"
+
+
+def test_point_size_and_color_modes_match_reference(built_libs):
+    ref, box, T = _run("ref", "uniform_3x40k")
+    port, _, _ = _run("port", "uniform_3x40k")
+    for kw in (dict(point_size=2), dict(point_size=3)):
+        u = uniforms_for(box, T, **kw)
+        assert np.array_equal(ref.render(u)[0], port.render(u)[0]), kw
+    for field in ("colorByNode", "colorByLOD"):
+        u = uniforms_for(box, T)
+        u[field] = 1
+        for hqs in (0, 1):
+            u["useHighQualityShading"] = hqs
+            assert np.array_equal(ref.render(u)[0], port.render(u)[0]), (field, hqs)
