@@ -139,9 +139,11 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
 	const uint32_t numChunks = (n + PPB - 1) / PPB;
+	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
+	// other's slowest descent; one flush at the end.
+	table_init(tbl);
+	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		table_init(tbl);
-		__syncthreads();
 		float4 p[PPT];
 #pragma unroll
 		for (uint32_t j = 0; j < PPT; j++) {
@@ -160,10 +162,9 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 			uint32_t rank;
 			if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, spillList, &ctl->numSpilling);
 		}
-		__syncthreads();
-		flush_counts(a, ctl, tbl, spillList, &ctl->numSpilling);
-		__syncthreads();
 	}
+	__syncthreads();
+	flush_counts(a, ctl, tbl, spillList, &ctl->numSpilling);
 }
 
 // ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
@@ -181,7 +182,9 @@ struct SpillWork {
 	uint32_t pad0, pad1;
 };
 
-__global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
+static constexpr uint32_t ETPB = 1024;             // k_expand: ONE workgroup per CU (256 barrier participants), 16 waves each
+
+__global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
 	if (ctl->numSpilling == 0) return;          // written by k_count, never modified here: a stable early-exit test
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 			{
 				uint4* g = reinterpret_cast<uint4*>(sh_grid->values);
 				const uint4 z = make_uint4(0, 0, 0, 0);
-				if (threadIdx.x >= 128) for (uint32_t w = threadIdx.x - 128; w < SIMLOD_GRID_NUM_WORDS / 4; w += TPB - 128) g[w] = z;
+				if (threadIdx.x >= 128) for (uint32_t w = threadIdx.x - 128; w < SIMLOD_GRID_NUM_WORDS / 4; w += ETPB - 128) g[w] = z;
 			}
 		}
 
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
 			__syncthreads();
 			const float4* src = reinterpret_cast<const float4*>(item.chunk->points);
-			for (uint32_t j = threadIdx.x; j < item.count; j += TPB) {
+			for (uint32_t j = threadIdx.x; j < item.count; j += ETPB) {
 				const float4 p = src[j];
 				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
 				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
@@ -329,30 +332,27 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 		// (the reference's 20th split is not followed by a count, voxels.cu:394-412)
 		if (round + 1 < SIMLOD_MAX_EXPAND_ROUNDS) {
 			const uint32_t total = n + numSpilledPrev;
-			const uint32_t numChunks = (total + PPB - 1) / PPB;
-			for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-				__syncthreads();
-				table_init(tbl);
-				__syncthreads();
-#pragma unroll
-				for (uint32_t j = 0; j < PPT; j++) {
-					const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-					if (t >= total) continue;
-					const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-					uint32_t leafIdx = leafOf[idx];
-					if (splitTag[leafIdx] != tag) continue;
-					const float4 p = t < n ? pts[t] : spilled[t - n];
-					const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
-					const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
-					const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-					SimlodNode* from = a.nodes + leafIdx;
-					leafIdx = (uint32_t)(descend(from, (int)from->level, X, Y, Z) - a.nodes);
-					leafOf[idx] = leafIdx;
-					uint32_t rank;
-					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
-				}
-				__syncthreads();
-				flush_counts(a, ctl, tbl, listNext, countNext);
+			__syncthreads();
+			table_init(tbl);                           // one table for the whole scan of this workgroup, one flush
+			__syncthreads();
+			for (uint32_t t = blockIdx.x * ETPB + threadIdx.x; t < total; t += gridDim.x * ETPB) {
+				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+				uint32_t leafIdx = leafOf[idx];
+				if (splitTag[leafIdx] != tag) continue;
+				const float4 p = t < n ? pts[t] : spilled[t - n];
+				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
+				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
+				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
+				SimlodNode* from = a.nodes + leafIdx;
+				leafIdx = (uint32_t)(descend(from, (int)from->level, X, Y, Z) - a.nodes);
+				leafOf[idx] = leafIdx;
+				uint32_t rank;
+				if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
+			}
+			__syncthreads();
+			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += ETPB) {
+				const uint32_t key = tbl.keys[e];
+				if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], listNext, countNext);
 			}
 		}
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
@@ -369,7 +369,9 @@ __global__ __launch_bounds__(TPB) void k_expand(BuildArgs a) {
 // 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
 // (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
 // NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
+template <uint32_t SPT>
 __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
+	constexpr uint32_t SPB = TPB * SPT;
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
 	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
@@ -380,14 +382,13 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
 	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	const uint32_t numChunks = (total + PPB - 1) / PPB;
+	const uint32_t numChunks = (total + SPB - 1) / SPB;
+	table_init(tbl);                                   // lives for the whole workgroup: no barrier inside the chunk loop
+	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		__syncthreads();
-		table_init(tbl);
-		__syncthreads();
 #pragma unroll 1
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+		for (uint32_t j = 0; j < SPT; j++) {
+			const uint32_t t = chunk * SPB + j * TPB + threadIdx.x;
 			if (t >= total) continue;
 			uint32_t idx, startLevel = 0;
 			float4 p;
@@ -419,11 +420,11 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 			}
 			winMask[idx] = wins;
 		}
-		__syncthreads();
-		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-			const uint32_t key = tbl.keys[e];
-			if (key != TBL_EMPTY) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
-		}
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = tbl.keys[e];
+		if (key != TBL_EMPTY) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
 	}
 }
 
@@ -510,7 +511,8 @@ __global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
 struct InsertShared {
-	BlockTable tbl;                       // node -> count, then node -> first reserved slot / running cursor
+	BlockTable tbl;                       // node -> count (step 1), then node -> running cursor (step 3)
+	uint32_t base[TBL_CAP];               // first slot of the range this workgroup reserved in the node
 	uint32_t dirBase[TBL_CAP];            // chunk-directory base of the node for this batch, or 0xffffffff
 	uint32_t dirFirst[TBL_CAP];
 };
@@ -546,71 +548,84 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
 	const uint32_t tag = ctl->batchIndex + 1u;
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
+	// Three workgroup-wide steps, each over ALL chunks this workgroup owns, so that barriers are paid per workgroup and not
+	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
+	// global atomic each, (3) store — the slot inside the range comes from an LDS cursor.
+
+	// ======== points ========
+	table_init(sh.tbl);
+	__syncthreads();
+	bool anyWins = false;
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		// ======== points: reserve one slot range per (workgroup, leaf), then store ========
-		__syncthreads();
-		table_init(sh.tbl);
-		__syncthreads();
-		uint32_t ticket[PPT];                          // entry | rank << TBL_BITS, or 0xffffffff (no room in the table)
-		uint32_t wins[PPT];
-		bool anyWins = false;
 #pragma unroll
 		for (uint32_t j = 0; j < PPT; j++) {
 			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			ticket[j] = 0xffffffffu; wins[j] = 0;
 			if (t >= total) continue;
 			const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-			wins[j] = winMask[idx] & 0xfffffu;
-			anyWins |= wins[j] != 0u;
+			anyWins |= (winMask[idx] & 0xfffffu) != 0u;
 			uint32_t rank;
-			const int e = table_add(sh.tbl, leafOf[idx], 1u, &rank);
-			if (e >= 0) ticket[j] = (uint32_t)e | (rank << TBL_BITS);
+			(void)table_add(sh.tbl, leafOf[idx], 1u, &rank);
 		}
-		__syncthreads();
-		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-			const uint32_t key = sh.tbl.keys[e];
-			if (key == TBL_EMPTY) continue;
-			const NodeDir d = nodeDir[key];
-			sh.tbl.vals[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);              // voxels.cu:593
-			sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
-			sh.dirFirst[e] = d.ptFirst;
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = sh.tbl.keys[e];
+		if (key == TBL_EMPTY) continue;
+		const NodeDir d = nodeDir[key];
+		sh.base[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);                      // voxels.cu:593
+		sh.tbl.vals[e] = 0;                                                                    // becomes the cursor
+		sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
+		sh.dirFirst[e] = d.ptFirst;
+	}
+	__syncthreads();
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		float4 p[PPT];
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? pts[t] : spilled[t - n]);
 		}
-		__syncthreads();
 #pragma unroll
 		for (uint32_t j = 0; j < PPT; j++) {
 			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 			if (t >= total) continue;
-			const float4 p = t < n ? pts[t] : spilled[t - n];
+			const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+			const int e = table_find(sh.tbl, leafIdx);
 			uint32_t slot, base, first;
-			if (ticket[j] != 0xffffffffu) {
-				const uint32_t e = ticket[j] & (TBL_CAP - 1);
-				slot = sh.tbl.vals[e] + (ticket[j] >> TBL_BITS); base = sh.dirBase[e]; first = sh.dirFirst[e];
-			} else {
-				const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+			if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+			else {                                                                                // table had no room for this leaf
 				const NodeDir d = nodeDir[leafIdx];
 				slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u); base = d.ptTag == tag ? d.ptBase : 0xffffffffu; first = d.ptFirst;
 			}
 			if (base == 0xffffffffu) { raise(ctl, SIMLOD_ERR_NULL_CHUNK); continue; }           // voxels.cu:599-604
 			SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
-			reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p;
+			reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p[j];
 		}
+	}
 
-		// ======== voxels: the samples that won a cell in `sample` regenerate their voxel(s) ========
-		if (!__syncthreads_or(anyWins ? 1 : 0)) continue;
-		table_init(sh.tbl);
-		__syncthreads();
-		for (int pass = 0; pass < 2; pass++) {
-			// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
+	// ======== voxels: the samples that won a cell in `sample` regenerate their voxel(s) ========
+	if (!__syncthreads_or(anyWins ? 1 : 0)) return;
+	table_init(sh.tbl);
+	__syncthreads();
+	for (int pass = 0; pass < 2; pass++) {
+		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
+		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 #pragma unroll 1
 			for (uint32_t j = 0; j < PPT; j++) {
-				if (wins[j] == 0u) continue;
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-				const float4 p = t < n ? pts[t] : spilled[t - n];
-				const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+				if (t >= total) continue;
+				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+				uint32_t left = winMask[idx] & 0xfffffu;
+				if (left == 0u) continue;
 				// climb from the cached leaf through its ancestors: the won levels are the deepest ones of the path
-				const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+				const uint32_t leafIdx = leafOf[idx];
 				uint32_t curIdx = leafIdx == 0u ? 0u : parentOf[leafIdx];
-				uint32_t left = wins[j];
+				float4 p = make_float4(0, 0, 0, 0);
+				uint32_t pX = 0, pY = 0, pZ = 0;
+				if (pass == 1) {
+					p = t < n ? pts[t] : spilled[t - n];
+					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
+				}
 #pragma unroll 1
 				while (left != 0u && curIdx != 0xffffffffu) {
 					SimlodNode* cur = a.nodes + curIdx;
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 						} else {
 							const int e = table_find(sh.tbl, curIdx);
 							uint32_t slot, base, first;
-							if (e >= 0) { slot = atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+							if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
 							else {
 								const NodeDir d = nodeDir[curIdx];
 								slot = atomicAdd(&cur->numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
@@ -638,18 +653,19 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 					curIdx = parentOf[curIdx];
 				}
 			}
-			__syncthreads();
-			if (pass == 0) {
-				for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-					const uint32_t key = sh.tbl.keys[e];
-					if (key == TBL_EMPTY) continue;
-					const NodeDir d = nodeDir[key];
-					sh.tbl.vals[e] = atomicAdd(&a.nodes[key].numVoxelsStored, sh.tbl.vals[e]);   // voxels.cu:685
-					sh.dirBase[e] = d.voxTag == tag ? d.voxBase : 0xffffffffu;
-					sh.dirFirst[e] = d.voxFirst;
-				}
-				__syncthreads();
+		}
+		__syncthreads();
+		if (pass == 0) {
+			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+				const uint32_t key = sh.tbl.keys[e];
+				if (key == TBL_EMPTY) continue;
+				const NodeDir d = nodeDir[key];
+				sh.base[e] = atomicAdd(&a.nodes[key].numVoxelsStored, sh.tbl.vals[e]);            // voxels.cu:685
+				sh.tbl.vals[e] = 0;
+				sh.dirBase[e] = d.voxTag == tag ? d.voxBase : 0xffffffffu;
+				sh.dirFirst[e] = d.voxFirst;
 			}
+			__syncthreads();
 		}
 	}
 }
@@ -771,12 +787,17 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)a.nodeCapacity * 4, stream);
 		if (e != hipSuccess) return (int)e;
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
-		const uint32_t gridPoints = dev.numCUs * 8;                            // grid-stride, 8 workgroups per CU
+		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
+		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);                            // grid-stride, 8 workgroups per CU
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_expand, dim3(dev.numCUs), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_sample, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_expand, dim3(dev.numCUs), dim3(ETPB), stream, a);
+			switch (sampleSpt) {
+			case 1: SIMLOD_LAUNCH(k_sample<1>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			case 2: SIMLOD_LAUNCH(k_sample<2>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			default: SIMLOD_LAUNCH(k_sample<4>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			}
 			SIMLOD_LAUNCH(k_alloc, dim3(gridNodes), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);

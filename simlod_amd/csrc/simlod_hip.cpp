@@ -2,6 +2,7 @@
 // CudaModularProgram / cuLaunchCooperativeKernel shaped surface of the reference host
 // (include/CudaModularProgram.h:140-264, modules/progressive_octree/main_progressive_octree.cpp:333-546).
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,11 @@ namespace simlod {
 static std::atomic<uint32_t> g_nodeCapacity{263157u};   // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
 
 uint32_t node_capacity() { return g_nodeCapacity.load(); }
+
+int tune(const char* envName, int dflt) {
+	const char* v = std::getenv(envName);
+	return v ? std::atoi(v) : dflt;
+}
 
 const DeviceInfo& device_info() {
 	// one entry per device ordinal; a process drives one GPU (one rank per GPU), but stay correct if it switches

@@ -63,6 +63,7 @@ void profile_close(hipStream_t stream);                           // records the
 		hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);          \
 	} while (0)
 uint32_t node_capacity();
+int tune(const char* envName, int dflt);     // integer tuning knob from the environment (read once per call site)
 
 bool layout_construct(BuildArgs& a, uint64_t capacity);
 int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,

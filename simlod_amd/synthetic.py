@@ -96,6 +96,49 @@ def terrain(n=36_000_000, seed=7, box=(6000.0, 4000.0, 400.0), tile=250.0, chunk
     return out, box.astype(np.float32)
 
 
+def terrain_scan(n=36_000_000, seed=7, box=(6000.0, 4000.0, 400.0), swath=250.0, chunk=4_000_000):
+    """The same fractal terrain as terrain(), but emitted in ACQUISITION order, the order an airborne LiDAR file (and hence
+    a .simlod converted from it, tools/las2simlod.mjs keeps the record order) stores its points: parallel flight swaths of
+    `swath` metres, each covered by zig-zag scan lines across the swath, consecutive records one point spacing apart.
+    Consecutive records are therefore spatial neighbours — unlike terrain(), whose records are shuffled inside 250 m tiles."""
+    rng = np.random.RandomState(seed)
+    box = np.asarray(box, dtype=np.float64)
+    spacing = float(np.sqrt(box[0] * box[1] / n))                  # mean point spacing for n points over the footprint
+    nsw = int(np.ceil(box[1] / swath))
+    per_line = max(2, int(round(swath / spacing)))
+    hrng = np.random.RandomState(seed + 1)
+    hstate = hrng.get_state()
+    out = np.empty(n, dtype=abi.point_dtype)
+    counts = np.full(nsw, n // nsw, dtype=np.int64)
+    counts[: n - counts.sum()] += 1
+    pos = 0
+    for s in range(nsw):
+        m_total = int(counts[s])
+        lines = int(np.ceil(m_total / per_line))
+        dx = box[0] / lines
+        for c0 in range(0, m_total, chunk):
+            m = min(chunk, m_total - c0)
+            k = np.arange(c0, c0 + m, dtype=np.int64)
+            line, i = k // per_line, k % per_line
+            i = np.where(line % 2 == 0, i, per_line - 1 - i)        # zig-zag mirror
+            along = (line.astype(np.float64) + rng.random_sample(m) * 0.6) * dx
+            if s % 2 == 1:
+                along = box[0] - along                               # the aircraft turns around for the next swath
+            across = s * swath + (i.astype(np.float64) + rng.random_sample(m) * 0.6) * (swath / per_line)
+            x = np.clip(along, 0, box[0] * 0.999999).astype(np.float32)
+            y = np.clip(across, 0, box[1] * 0.999999).astype(np.float32)
+            hrng.set_state(hstate)
+            z = _height(x, y, hrng, box) + rng.random_sample(m).astype(np.float32) * np.float32(0.15)
+            t = np.clip(z / np.float32(box[2]), 0, 1)
+            r = (60 + 180 * t).astype(np.uint32)
+            g = (90 + 120 * (1 - np.abs(t - 0.5) * 2)).astype(np.uint32)
+            b = (50 + 100 * (1 - t)).astype(np.uint32)
+            out[pos:pos + m] = _pack(x, y, z, r, g, b)
+            pos += m
+    assert pos == n
+    return out, box.astype(np.float32)
+
+
 def hotspot(n=1_000_000, seed=11, level=6, cell=(21, 40, 13), box=(1.0, 1.0, 1.0)):
     """BASELINE config 5: every point inside ONE level-`level` octree cell of the unit cube (uniform inside it), so
     the first batch forces `level`+ split rounds and a camera aimed at the cell piles all samples on few pixels."""

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 36_000_000
 kind = sys.argv[2] if len(sys.argv) > 2 else "terrain"
-pts, box = (synthetic.terrain(n, seed=7) if kind == "terrain" else synthetic.hotspot(n) if kind == "hotspot" else synthetic.uniform_cube(n))
+pts, box = (synthetic.terrain(n, seed=7) if kind == "terrain" else synthetic.terrain_scan(n, seed=7) if kind == "scan" else synthetic.hotspot(n) if kind == "hotspot" else synthetic.uniform_cube(n))
 W, H = 1920, 1080
 T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886 * box[0] / 6000, (box[0] / 2, box[1] / 2, 0.35 * box[2])), camera.perspective(aspect=W / H))
 dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, max_pixels=W * H)
