@@ -37,8 +37,11 @@ struct RenderArgs {
 	int32_t      W, H, pointSize;
 	uint32_t     numPixels, nodeCapacity, frameCounter;
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
-	uint64_t     offWork, offDepth, offColor;
+	uint64_t     offWork, offDepth, offColor, offOverflow;
 };
+
+// work area: one draw cursor per draw mode
+static constexpr int WORK_WORDS = 4;
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
 enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4 };
@@ -50,14 +53,15 @@ __global__ __launch_bounds__(TPB) void r_clear(RenderArgs a) {
 	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) fb[i] = SIMLOD_CLEAR_PIXEL;
 	if (a.hqs) {
 		uint32_t* depth = reinterpret_cast<uint32_t*>(a.mom + a.offDepth);
-		uint4* color = reinterpret_cast<uint4*>(a.mom + a.offColor);
-		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) { depth[i] = 0x7f800000u; color[i] = make_uint4(0, 0, 0, 0); }
+		unsigned long long* packed = reinterpret_cast<unsigned long long*>(a.mom + a.offColor);
+		uint4* overflow = reinterpret_cast<uint4*>(a.mom + a.offOverflow);
+		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) { depth[i] = 0x7f800000u; packed[i] = 0ull; overflow[i] = make_uint4(0, 0, 0, 0); }
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		*a.frameStart = wall_ns();                                    // render.cu:1100-1102
 		for (int k = 0; k < 7; k++) *counter_at(a, k) = 0;
 		uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
-		work[0] = work[1] = work[2] = work[3] = 0;
+		for (int k = 0; k < WORK_WORDS; k++) work[k] = 0;
 		uint32_t* lines = reinterpret_cast<uint32_t*>(a.mom + R_OFF_LINES);
 		lines[0] = 0;                                                  // lines->count = 0, render.cu:1118
 	}
@@ -188,7 +192,8 @@ struct DrawCtx {
 	uint32_t numPixels;
 	uint64_t* fb;
 	uint32_t* depth;
-	unsigned long long* color;   // fb_color viewed as 2 x u64 per pixel: {R | G << 32, B | count << 32}
+	unsigned long long* color;   // HQS colour sums, packed: B (14 bits) | G << 14 | R << 28 | count << 42
+	unsigned long long* overflow;// 2 x u64 per pixel {R | G << 32, B | count << 32}: samples beyond the 64th of a pixel
 };
 
 template <int MODE>
@@ -219,8 +224,18 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 		} else {
 			const float fbDepth = __uint_as_float(c.depth[pixel]);
 			if (depth < fbDepth * 1.01f) {                                                                 // render.cu:485-493
-				atomicAdd(&c.color[2 * pixel + 0], (unsigned long long)(color & 0xffu) | ((unsigned long long)((color >> 8) & 0xffu) << 32));
-				atomicAdd(&c.color[2 * pixel + 1], (unsigned long long)((color >> 16) & 0xffu) | (1ull << 32));
+				// ONE 64-bit atomic per accepted sample: the sums of R, G, B and the count share a word (14 + 14 + 14 + 22 bits).
+				// The first 64 samples of a pixel fit without carry (64 * 255 < 2^14); a sample that finds count >= 64 takes its
+				// addend back and goes to the 32-bit-per-channel overflow plane.  All arithmetic is modular, so transient carries
+				// of samples that are about to retract do not disturb the final sums (at most 64 samples ever stay).
+				const unsigned long long r = color & 0xffu, g = (color >> 8) & 0xffu, b = (color >> 16) & 0xffu;
+				const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
+				const unsigned long long old = atomicAdd(&c.color[pixel], pk);
+				if ((old >> 42) >= 64ull) {
+					atomicAdd(&c.color[pixel], 0ull - pk);
+					atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
+					atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
+				}
 			}
 		}
 	}
@@ -251,15 +266,15 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 	c.fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
 	c.depth = reinterpret_cast<uint32_t*>(a.mom + a.offDepth);
 	c.color = reinterpret_cast<unsigned long long*>(a.mom + a.offColor);
-	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork) + MODE;
+	c.overflow = reinterpret_cast<unsigned long long*>(a.mom + a.offOverflow);
+	uint32_t* cursor = reinterpret_cast<uint32_t*>(a.mom + a.offWork) + MODE;
 	const uint32_t numVisible = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
 	const SimlodNode* visible = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE);
-	while (true) {                                     // workgroup-level node queue, render.cu:179-207
-		__syncthreads();
-		if (threadIdx.x == 0) sh_idx = atomicAdd(work, 1u);
-		__syncthreads();
-		const uint32_t idx = sh_idx;
-		if (idx >= numVisible) break;
+	// Workgroup-level node queue (render.cu:179-207).  The first node of a workgroup is its own index — 2048 workgroups
+	// fetching their first item from ONE counter would serialise at ~11 ns per atomic (22 us of start-up) — the following
+	// ones come from a shared cursor that starts behind the statically assigned range.
+	uint32_t idx = blockIdx.x;
+	while (idx < numVisible) {
 		const SimlodNode* node = visible + idx;
 		uint32_t overrideColor = 0; bool useOverride = false;
 		if (MODE != MODE_DEPTH) {
@@ -268,6 +283,10 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 		}
 		draw_list<MODE>(c, node->points, node->numPoints, overrideColor, useOverride);
 		draw_list<MODE>(c, node->voxelChunks, node->numVoxels, overrideColor, useOverride);
+		__syncthreads();
+		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
+		__syncthreads();
+		idx = sh_idx;
 	}
 }
 
@@ -275,10 +294,13 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 __global__ __launch_bounds__(TPB) void r_resolve(RenderArgs a) {
 	uint64_t* fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
 	const uint32_t* depth = reinterpret_cast<const uint32_t*>(a.mom + a.offDepth);
-	const uint4* color = reinterpret_cast<const uint4*>(a.mom + a.offColor);
+	const unsigned long long* packed = reinterpret_cast<const unsigned long long*>(a.mom + a.offColor);
+	const uint4* overflow = reinterpret_cast<const uint4*>(a.mom + a.offOverflow);
 	const uint32_t stride = gridDim.x * TPB;
 	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) {
-		const uint4 s = color[i];
+		const unsigned long long pk = packed[i];
+		uint4 s = overflow[i];                           // {R, G, B, count} of the samples beyond the 64th
+		s.x += (uint32_t)((pk >> 28) & 0x3fffu); s.y += (uint32_t)((pk >> 14) & 0x3fffu); s.z += (uint32_t)(pk & 0x3fffu); s.w += (uint32_t)(pk >> 42);
 		if (s.w == 0u) continue;
 		const uint32_t rgba = ((s.x / s.w) & 0xffu) | (((s.y / s.w) & 0xffu) << 8) | (((s.z / s.w) & 0xffu) << 16) | (255u << 24);
 		fb[i] = ((uint64_t)depth[i] << 32) | rgba;
@@ -365,7 +387,7 @@ static inline uint64_t align16(uint64_t v) { return (v + 15) / 16 * 16; }
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 	const uint64_t px = (uint64_t)width * height;
-	return R_OFF_FB + align16(px * 8) + 16 + align16(px * 4) + px * 16 + 256;
+	return R_OFF_FB + align16(px * 8) + 256 + align16(px * 4) + align16(px * 8) + px * 16 + 256;
 }
 
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
@@ -392,8 +414,9 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.frameCounter = (uint32_t)u->frameCounter;
 	a.showPoints = u->showPoints; a.colorByNode = u->colorByNode; a.colorByLOD = u->colorByLOD; a.hqs = u->useHighQualityShading;
 	a.offWork = R_OFF_FB + align16((uint64_t)a.numPixels * 8);
-	a.offDepth = a.offWork + 16;
+	a.offDepth = a.offWork + 256;
 	a.offColor = a.offDepth + align16((uint64_t)a.numPixels * 4);
+	a.offOverflow = a.offColor + align16((uint64_t)a.numPixels * 8);
 
 	const DeviceInfo& dev = device_info();
 	const uint32_t gridPixels = dev.numCUs * 8;

@@ -259,3 +259,5 @@ def test_full_size_36m_properties(built_libs):
     u["useHighQualityShading"] = 1
     dev.render(u); fh = dev.framebuffer(Wd, Hd)
     assert np.array_equal(fh >> np.uint64(32), f1 >> np.uint64(32)), "HQS resolves to the same nearest depth per pixel as the 64-bit min"
+    fho, _, _ = _oracle_render(nodes, nn, u)
+    assert np.array_equal(fh, fho), f"{int((fh != fho).sum())} HQS pixels differ from the oracle at 1080p (averaged colours incl. the >64-samples-per-pixel path)"
