@@ -607,6 +607,145 @@ static float max8(const float f[8]) { /* render.cu:718-729 */
 	return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
+/* ---- debug lines: node boxes + view frustum (only when Uniforms.showBoundingBox), render.cu:637-688, 1197-1233,
+ *      rasterization.cuh:5-47 (drawLine, drawBoundingBox) and :90-183 (rasterizeLines), math.cuh:22-152 (Frustum) ---- */
+typedef struct { float nx, ny, nz, c; } OPlane;
+typedef struct { float x, y, z; uint32_t color; } OVertex;
+
+static OPlane make_plane(float x, float y, float z, float w) { /* createPlane, math.cuh:55-64 */
+	float len = sqrtf(x * x + y * y + z * z);
+	OPlane p = {x / len, y / len, z / len, w / len};
+	return p;
+}
+
+static void frustum_planes(const SimlodMat4* m, OPlane P[6]) { /* Frustum::fromWorldViewProj, math.cuh:69-108 */
+	const simlod_float4* R = m->rows;
+	float m0 = R[0].x, m1 = R[1].x, m2 = R[2].x, m3 = R[3].x, m4 = R[0].y, m5 = R[1].y, m6 = R[2].y, m7 = R[3].y;
+	float m8 = R[0].z, m9 = R[1].z, m10 = R[2].z, m11 = R[3].z, m12 = R[0].w, m13 = R[1].w, m14 = R[2].w, m15 = R[3].w;
+	P[0] = make_plane(m3 - m0, m7 - m4, m11 - m8, m15 - m12);
+	P[1] = make_plane(m3 + m0, m7 + m4, m11 + m8, m15 + m12);
+	P[2] = make_plane(m3 + m1, m7 + m5, m11 + m9, m15 + m13);
+	P[3] = make_plane(m3 - m1, m7 - m5, m11 - m9, m15 - m13);
+	P[4] = make_plane(m3 - m2, m7 - m6, m11 - m10, m15 - m14);
+	P[5] = make_plane(m3 + m2, m7 + m6, m11 + m10, m15 + m14);
+}
+
+static float plane_dist(const OPlane* p, float x, float y, float z) { return (p->nx * x + p->ny * y + p->nz * z) + p->c; } /* math.cuh:22-25 */
+
+static int frustum_contains(const OPlane P[6], float x, float y, float z) { /* math.cuh:138-151 */
+	for (int i = 0; i < 6; i++) if (plane_dist(&P[i], x, y, z) < 0) return 0;
+	return 1;
+}
+
+static float dist_to_plane(float ox, float oy, float oz, float dx, float dy, float dz, const OPlane* p) { /* math.cuh:27-53 */
+	const float INF = 1.0f / 0.0f;
+	float denom = p->nx * dx + p->ny * dy + p->nz * dz;
+	if (denom < 0.0f) return INF;
+	if (denom == 0.0f) return plane_dist(p, ox, oy, oz) == 0.0f ? 0.0f : INF;
+	float t = -((ox * p->nx + oy * p->ny + oz * p->nz) + p->c) / denom;
+	return ((double)t >= 0.0) ? t : INF;
+}
+
+static void frustum_intersect_ray(const OPlane P[6], float ox, float oy, float oz, float dx, float dy, float dz, float out[3]) { /* math.cuh:110-136 */
+	const float INF = 1.0f / 0.0f;
+	float farthest = -INF;
+	for (int i = 0; i < 6; i++) {
+		float d = dist_to_plane(ox, oy, oz, dx, dy, dz, &P[i]);
+		if (d > 0 && d != INF) farthest = fmaxf(farthest, d);
+	}
+	out[0] = ox + dx * farthest; out[1] = oy + dy * farthest; out[2] = oz + dz * farthest;
+}
+
+static void emit_line(OVertex* v, uint32_t* count, uint32_t cap, const float a[3], const float b[3], uint32_t color) { /* drawLine */
+	if (*count + 2 > cap) return;
+	v[*count].x = a[0]; v[*count].y = a[1]; v[*count].z = a[2]; v[*count].color = color;
+	v[*count + 1].x = b[0]; v[*count + 1].y = b[1]; v[*count + 1].z = b[2]; v[*count + 1].color = color;
+	*count += 2;
+}
+
+static void emit_box(OVertex* v, uint32_t* count, uint32_t cap, const float pos[3], const float size[3], uint32_t color) { /* drawBoundingBox */
+	float mn[3], mx[3];
+	for (int k = 0; k < 3; k++) { mn[k] = pos[k] - size[k] / 2.0f; mx[k] = pos[k] + size[k] / 2.0f; }
+	const int E[12][6] = { /* corner selectors (0 = min, 1 = max) in the order of rasterization.cuh:30-46 */
+		{0,0,0, 1,0,0}, {1,0,0, 1,1,0}, {1,1,0, 0,1,0}, {0,1,0, 0,0,0},
+		{0,0,1, 1,0,1}, {1,0,1, 1,1,1}, {1,1,1, 0,1,1}, {0,1,1, 0,0,1},
+		{1,0,0, 1,0,1}, {1,1,0, 1,1,1}, {0,1,0, 0,1,1}, {0,0,0, 0,0,1}};
+	for (int e = 0; e < 12; e++) {
+		float a[3], b[3];
+		for (int k = 0; k < 3; k++) { a[k] = E[e][k] ? mx[k] : mn[k]; b[k] = E[e][3 + k] ? mx[k] : mn[k]; }
+		emit_line(v, count, cap, a, b, color);
+	}
+}
+
+static void rasterize_line(const SimlodUniforms* u, const OPlane P[6], OVertex s, OVertex e, uint64_t* fb, int width, int height) { /* rasterization.cuh:98-180 */
+	float dx = e.x - s.x, dy = e.y - s.y, dz = e.z - s.z;
+	float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);   /* normalize(): v * rsqrtf(dot(v, v)), helper_math.h:1323-1327 */
+	dx = dx * inv; dy = dy * inv; dz = dz * inv;
+	if (!frustum_contains(P, s.x, s.y, s.z)) { float I[3]; frustum_intersect_ray(P, s.x, s.y, s.z, dx, dy, dz, I); s.x = I[0]; s.y = I[1]; s.z = I[2]; }
+	if (!frustum_contains(P, e.x, e.y, e.z)) { float I[3]; frustum_intersect_ray(P, e.x, e.y, e.z, dx * -1.0f, dy * -1.0f, dz * -1.0f, I); e.x = I[0]; e.y = I[1]; e.z = I[2]; }
+	vec4 a = xform(&u->transform, s.x, s.y, s.z), b = xform(&u->transform, e.x, e.y, e.z);
+	a.x = a.x / a.w; a.y = a.y / a.w; a.z = a.z / a.w;
+	b.x = b.x / b.w; b.y = b.y / b.w; b.z = b.z / b.w;
+	float sx0 = (a.x * 0.5f + 0.5f) * (float)width, sy0 = (a.y * 0.5f + 0.5f) * (float)height;
+	float sx1 = (b.x * 0.5f + 0.5f) * (float)width, sy1 = (b.y * 0.5f + 0.5f) * (float)height;
+	float ddx = sx1 - sx0, ddy = sy1 - sy0, ddz = 1.0f - 1.0f;
+	float steps = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+	steps = fmaxf(0.0f, fminf(steps, 400.0f));
+	float stepSize = (float)(1.0 / (double)steps);
+	for (float t = 0; (double)t <= 1.0; t += stepSize) {
+		float nx = (float)((1.0 - (double)t) * (double)a.x + (double)(t * b.x));
+		float ny = (float)((1.0 - (double)t) * (double)a.y + (double)(t * b.y));
+		float depth = (float)((1.0 - (double)t) * (double)a.w + (double)(t * b.w));
+		if ((double)nx < -1.0 || (double)nx > 1.0) continue;
+		if ((double)ny < -1.0 || (double)ny > 1.0) continue;
+		int x = to_int_trunc(((double)nx * 0.5 + 0.5) * (double)width);
+		int y = to_int_trunc(((double)ny * 0.5 + 0.5) * (double)height);
+		x = clampi(x, 0, width - 1); y = clampi(y, 0, height - 1);
+		uint32_t dbits; memcpy(&dbits, &depth, 4);
+		uint64_t enc = ((uint64_t)dbits << 32) | s.color;
+		if (enc < fb[x + width * y]) fb[x + width * y] = enc;
+	}
+}
+
+static void draw_debug_lines(const SimlodUniforms* u, const SimlodNode* visible, uint32_t numVisible, float cubeSize, const float cmin[3],
+                             uint64_t* fb, int W, int H) {
+	const uint32_t cap = 1000000u; /* render.cu:1119 */
+	OVertex* v = (OVertex*)malloc((size_t)cap * sizeof(OVertex));
+	uint32_t count = 0;
+	{ /* view frustum, render.cu:1197-1223 */
+		const float fend = 0.99995f;
+		const float C[8][2][3] = {{{1, 1, -1}, {1, 1, fend}}, {{1, -1, -1}, {1, -1, fend}}, {{-1, 1, -1}, {-1, 1, fend}}, {{-1, -1, -1}, {-1, -1, fend}},
+		                          {{-1, -1, fend}, {1, -1, fend}}, {{-1, 1, fend}, {1, 1, fend}}, {{-1, -1, fend}, {-1, 1, fend}}, {{1, -1, fend}, {1, 1, fend}}};
+		for (int l = 0; l < 8; l++) {
+			float p[2][3];
+			for (int k = 0; k < 2; k++) {
+				vec4 q = xform(&u->transformInv_updateBound, C[l][k][0], C[l][k][1], C[l][k][2]);
+				p[k][0] = q.x / q.w; p[k][1] = q.y / q.w; p[k][2] = q.z / q.w;
+			}
+			emit_line(v, &count, cap, p[0], p[1], 0x000000ffu);
+		}
+	}
+	for (uint32_t i = 0; i < numVisible; i++) { /* drawNodesBoundingBoxes, render.cu:637-688: four coincident boxes per node */
+		const SimlodNode* n = &visible[i];
+		if (n->numPoints == 0 && n->numVoxels == 0) continue;
+		float scale = cubeSize / ldexpf(1.0f, (int)n->level);
+		float pos[3] = {cmin[0] + ((float)n->X + 0.5f) * scale, cmin[1] + ((float)n->Y + 0.5f) * scale, cmin[2] + ((float)n->Z + 0.5f) * scale};
+		float size[3] = {scale, scale, scale};
+		for (int r = 0; r < 4; r++) emit_box(v, &count, cap, pos, size, 0x0000ff00u);
+	}
+	OPlane P[6];
+	frustum_planes(&u->transform, P);
+	for (uint32_t l = 0; l + 1 < count; l += 2) rasterize_line(u, P, v[l], v[l + 1], fb, W, H);
+	free(v);
+}
+
+/* test hook: rasterise an explicit vertex list (pairs) into fb */
+void oracle_rasterize_lines(const SimlodUniforms* u, const OVertex* v, uint32_t count, uint64_t* fb) {
+	OPlane P[6];
+	frustum_planes(&u->transform, P);
+	for (uint32_t l = 0; l + 1 < count; l += 2) rasterize_line(u, P, v[l], v[l + 1], fb, (int)u->width, (int)u->height);
+}
+
 /* kernel_render, render.cu:1084-1355.
  *   fb         out, W*H uint64: the pre-EDL framebuffer (depth bits << 32 | colour)
  *   colorOut   out, W*H uint32 or NULL: what surf2Dwrite would have stored (after EDL when edl != 0)
@@ -693,6 +832,7 @@ void oracle_render(OracleCtx* c, const SimlodUniforms* u, SimlodNode* nodes, Sim
 			free(r.fbDepth); free(r.fbColor);
 		}
 	}
+	if (u->showBoundingBox) draw_debug_lines(u, visible, numVisible, cubeSize, cmin, fb, W, H);   /* render.cu:1197-1235 */
 	/* stats, render.cu:1244-1252 */
 	stats->numVisibleNodes = numVisible; stats->numVisibleInner = visInner; stats->numVisibleLeaves = visLeaves;
 	stats->numVisiblePoints = visPoints; stats->numVisibleVoxels = visVoxels;

@@ -37,11 +37,18 @@ struct RenderArgs {
 	int32_t      W, H, pointSize;
 	uint32_t     numPixels, nodeCapacity, frameCounter;
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
-	uint64_t     offWork, offDepth, offColor, offOverflow;
+	uint64_t     offWork, offItems, offDepth, offColor, offOverflow;
+	uint32_t     itemCap, pad;
 };
 
-// work area: one draw cursor per draw mode
+// work area: [0..2] draw cursors of the three draw modes, [3] number of draw items
 static constexpr int WORK_WORDS = 4;
+static constexpr uint32_t ITEM_CHUNKS = 8;          // a draw item = up to 8 consecutive chunks (8000 samples) of one visible node
+
+struct DrawItem {
+	const SimlodChunk* first;
+	uint32_t samples, visibleIdx;
+};
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
 enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4 };
@@ -91,7 +98,7 @@ __device__ bool intersects_frustum(const SimlodMat4& m, const float mn[3], const
 	for (int i = 0; i < 6; i++) {
 		const float x = P[i][0], y = P[i][1], z = P[i][2], w = P[i][3];
 		float d2 = x * x; d2 = d2 + y * y; d2 = d2 + z * z;
-		const float len = __fsqrt_rn(d2);
+		const float len = sqrtf(d2);
 		const float nx = x / len, ny = y / len, nz = z / len, c = w / len;
 		const float vx = nx > 0.0f ? mx[0] : mn[0];
 		const float vy = ny > 0.0f ? mx[1] : mn[1];
@@ -163,6 +170,35 @@ __global__ __launch_bounds__(TPB) void r_vis2(RenderArgs a) {
 		}
 	} else if (n->visible) {
 		make_visible(a, n);
+	}
+}
+
+// ---- draw items: cut every visible node's chunk lists into pieces of <= 8 chunks -------------------------------------
+// The reference gives one workgroup a whole node (render.cu:179-207): a 50 000-point leaf next to a 300-voxel node.  One
+// lane per visible node walks the node's two lists ONCE per frame (the only serial pointer chase left in a frame) and
+// emits evenly sized items, so that the draw kernels are balanced over all 256 CUs whatever the node sizes are.
+__global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
+	const uint32_t numVisible = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= numVisible || !a.showPoints) return;
+	const SimlodNode* node = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE) + i;
+	uint32_t* numItems = reinterpret_cast<uint32_t*>(a.mom + a.offWork) + 3;
+	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
+	const SimlodChunk* heads[2] = {node->points, node->voxelChunks};
+	const uint32_t counts[2] = {node->numPoints, node->numVoxels};
+	for (int l = 0; l < 2; l++) {
+		uint32_t left = counts[l];
+		if (left == 0 || heads[l] == nullptr) continue;
+		const uint32_t pieces = (left + ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK - 1) / (ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK);
+		const uint32_t base = atomicAdd(numItems, pieces);
+		const SimlodChunk* chunk = heads[l];
+		for (uint32_t p = 0; p < pieces && chunk != nullptr; p++) {
+			const uint32_t take = min(left, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK);
+			if (base + p < a.itemCap) { DrawItem it; it.first = chunk; it.samples = take; it.visibleIdx = i; items[base + p] = it; }
+			else atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);
+			left -= take;
+			for (uint32_t k = 0; k < ITEM_CHUNKS && chunk != nullptr && left > 0; k++) chunk = chunk->next;
+		}
 	}
 }
 
@@ -267,26 +303,175 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 	c.depth = reinterpret_cast<uint32_t*>(a.mom + a.offDepth);
 	c.color = reinterpret_cast<unsigned long long*>(a.mom + a.offColor);
 	c.overflow = reinterpret_cast<unsigned long long*>(a.mom + a.offOverflow);
-	uint32_t* cursor = reinterpret_cast<uint32_t*>(a.mom + a.offWork) + MODE;
-	const uint32_t numVisible = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
+	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
+	uint32_t* cursor = work + MODE;
+	const uint32_t numItems = min(work[3], a.itemCap);
+	const DrawItem* items = reinterpret_cast<const DrawItem*>(a.mom + a.offItems);
 	const SimlodNode* visible = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE);
-	// Workgroup-level node queue (render.cu:179-207).  The first node of a workgroup is its own index — 2048 workgroups
-	// fetching their first item from ONE counter would serialise at ~11 ns per atomic (22 us of start-up) — the following
-	// ones come from a shared cursor that starts behind the statically assigned range.
+	// Workgroup-level queue of draw items.  The first item of a workgroup is its own index — 2048 workgroups fetching
+	// their first item from ONE counter would serialise at ~11 ns per atomic — the following ones come from a shared
+	// cursor that starts behind the statically assigned range.
 	uint32_t idx = blockIdx.x;
-	while (idx < numVisible) {
-		const SimlodNode* node = visible + idx;
+	while (idx < numItems) {
+		const DrawItem it = items[idx];
 		uint32_t overrideColor = 0; bool useOverride = false;
-		if (MODE != MODE_DEPTH) {
-			if (a.colorByNode) { overrideColor = node_color(node); useOverride = true; }
-			else if (a.colorByLOD) { overrideColor = lod_color((int)node->level); useOverride = true; }
+		if (MODE != MODE_DEPTH && (a.colorByNode || a.colorByLOD)) {
+			const SimlodNode* node = visible + it.visibleIdx;
+			overrideColor = a.colorByNode ? node_color(node) : lod_color((int)node->level);
+			useOverride = true;
 		}
-		draw_list<MODE>(c, node->points, node->numPoints, overrideColor, useOverride);
-		draw_list<MODE>(c, node->voxelChunks, node->numVoxels, overrideColor, useOverride);
+		draw_list<MODE>(c, it.first, it.samples, overrideColor, useOverride);
 		__syncthreads();
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
 		__syncthreads();
 		idx = sh_idx;
+	}
+}
+
+// ---- debug lines (Uniforms.showBoundingBox): node boxes + view frustum -----------------------------------------------
+// render.cu:637-688 (four coincident boxes per visible node), :1197-1223 (frustum), rasterization.cuh:5-47 (drawLine,
+// drawBoundingBox), :90-183 (rasterizeLines), math.cuh:22-152.  Off by default in the reference (main.cpp:125).
+struct LinePlane { float nx, ny, nz, c; };
+
+__device__ __forceinline__ LinePlane make_plane(float x, float y, float z, float w) {
+	float d2 = x * x; d2 = d2 + y * y; d2 = d2 + z * z;
+	const float len = sqrtf(d2);
+	LinePlane p = {x / len, y / len, z / len, w / len};
+	return p;
+}
+
+__device__ void frustum_planes(const SimlodMat4& m, LinePlane P[6]) {
+	const simlod_float4* R = m.rows;
+	const float m0 = R[0].x, m1 = R[1].x, m2 = R[2].x, m3 = R[3].x, m4 = R[0].y, m5 = R[1].y, m6 = R[2].y, m7 = R[3].y;
+	const float m8 = R[0].z, m9 = R[1].z, m10 = R[2].z, m11 = R[3].z, m12 = R[0].w, m13 = R[1].w, m14 = R[2].w, m15 = R[3].w;
+	P[0] = make_plane(m3 - m0, m7 - m4, m11 - m8, m15 - m12);
+	P[1] = make_plane(m3 + m0, m7 + m4, m11 + m8, m15 + m12);
+	P[2] = make_plane(m3 + m1, m7 + m5, m11 + m9, m15 + m13);
+	P[3] = make_plane(m3 - m1, m7 - m5, m11 - m9, m15 - m13);
+	P[4] = make_plane(m3 - m2, m7 - m6, m11 - m10, m15 - m14);
+	P[5] = make_plane(m3 + m2, m7 + m6, m11 + m10, m15 + m14);
+}
+
+__device__ __forceinline__ float plane_dist(const LinePlane& p, float x, float y, float z) {
+	float d = p.nx * x; d = d + p.ny * y; d = d + p.nz * z; d = d + p.c;
+	return d;
+}
+
+__device__ bool frustum_contains(const LinePlane P[6], float x, float y, float z) {
+	bool in = true;
+	for (int i = 0; i < 6; i++) if (plane_dist(P[i], x, y, z) < 0.0f) in = false;
+	return in;
+}
+
+__device__ float dist_to_plane(float ox, float oy, float oz, float dx, float dy, float dz, const LinePlane& p) {
+	const float INF = __uint_as_float(0x7f800000u);
+	float denom = p.nx * dx; denom = denom + p.ny * dy; denom = denom + p.nz * dz;
+	if (denom < 0.0f) return INF;
+	if (denom == 0.0f) return plane_dist(p, ox, oy, oz) == 0.0f ? 0.0f : INF;
+	float num = ox * p.nx; num = num + oy * p.ny; num = num + oz * p.nz; num = num + p.c;
+	const float t = -num / denom;
+	return t >= 0.0f ? t : INF;
+}
+
+__device__ void frustum_intersect_ray(const LinePlane P[6], float ox, float oy, float oz, float dx, float dy, float dz, float out[3]) {
+	const float INF = __uint_as_float(0x7f800000u);
+	float farthest = -INF;
+	for (int i = 0; i < 6; i++) {
+		const float d = dist_to_plane(ox, oy, oz, dx, dy, dz, P[i]);
+		if (d > 0.0f && d != INF) farthest = fmaxf(farthest, d);
+	}
+	out[0] = ox + dx * farthest; out[1] = oy + dy * farthest; out[2] = oz + dz * farthest;
+}
+
+__device__ __forceinline__ void put_line(float4* v, uint32_t at, float ax, float ay, float az, float bx, float by, float bz, uint32_t color) {
+	v[at] = make_float4(ax, ay, az, __uint_as_float(color));
+	v[at + 1] = make_float4(bx, by, bz, __uint_as_float(color));
+}
+
+static constexpr uint32_t LINE_VERTEX_CAP = 1000000u;     // render.cu:1119
+
+__global__ __launch_bounds__(TPB) void r_lines_emit(RenderArgs a, SimlodMat4 inv) {
+	const uint32_t numVisible = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	uint32_t* count = reinterpret_cast<uint32_t*>(a.mom + R_OFF_LINES);
+	float4* v = reinterpret_cast<float4*>(a.mom + R_OFF_VERTICES);
+	if (i == 0) {      // the view frustum as seen by the frozen visibility transform, render.cu:1197-1223
+		const float fend = 0.99995f;
+		const float C[8][2][3] = {{{1, 1, -1}, {1, 1, fend}}, {{1, -1, -1}, {1, -1, fend}}, {{-1, 1, -1}, {-1, 1, fend}}, {{-1, -1, -1}, {-1, -1, fend}},
+		                          {{-1, -1, fend}, {1, -1, fend}}, {{-1, 1, fend}, {1, 1, fend}}, {{-1, -1, fend}, {-1, 1, fend}}, {{1, -1, fend}, {1, 1, fend}}};
+		const uint32_t at = atomicAdd(count, 16u);
+		for (int l = 0; l < 8; l++) {
+			float p[2][3];
+			for (int k = 0; k < 2; k++) {
+				const float qx = dot_row(inv.rows[0], C[l][k][0], C[l][k][1], C[l][k][2]), qy = dot_row(inv.rows[1], C[l][k][0], C[l][k][1], C[l][k][2]);
+				const float qz = dot_row(inv.rows[2], C[l][k][0], C[l][k][1], C[l][k][2]), qw = dot_row(inv.rows[3], C[l][k][0], C[l][k][1], C[l][k][2]);
+				p[k][0] = qx / qw; p[k][1] = qy / qw; p[k][2] = qz / qw;
+			}
+			if (at + 2 * l + 2 <= LINE_VERTEX_CAP) put_line(v, at + 2 * l, p[0][0], p[0][1], p[0][2], p[1][0], p[1][1], p[1][2], 0x000000ffu);
+		}
+	}
+	if (i >= numVisible) return;
+	const SimlodNode* n = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE) + i;
+	if (n->numPoints == 0 && n->numVoxels == 0) return;
+	const float scale = a.cubeSize / exp2_int(n->level);
+	const float pos[3] = {a.minx + ((float)n->X + 0.5f) * scale, a.miny + ((float)n->Y + 0.5f) * scale, a.minz + ((float)n->Z + 0.5f) * scale};
+	float mn[3], mx[3];
+	for (int k = 0; k < 3; k++) { mn[k] = pos[k] - scale / 2.0f; mx[k] = pos[k] + scale / 2.0f; }
+	const uint32_t at0 = atomicAdd(count, 96u);                  // 4 boxes x 12 edges x 2 vertices
+	if (at0 + 96u > LINE_VERTEX_CAP) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); return; }
+	const int E[12][6] = {{0,0,0, 1,0,0}, {1,0,0, 1,1,0}, {1,1,0, 0,1,0}, {0,1,0, 0,0,0}, {0,0,1, 1,0,1}, {1,0,1, 1,1,1}, {1,1,1, 0,1,1}, {0,1,1, 0,0,1},
+	                      {1,0,0, 1,0,1}, {1,1,0, 1,1,1}, {0,1,0, 0,1,1}, {0,0,0, 0,0,1}};
+	for (int r = 0; r < 4; r++)
+		for (int e = 0; e < 12; e++)
+			put_line(v, at0 + (uint32_t)(r * 12 + e) * 2u, E[e][0] ? mx[0] : mn[0], E[e][1] ? mx[1] : mn[1], E[e][2] ? mx[2] : mn[2],
+			         E[e][3] ? mx[0] : mn[0], E[e][4] ? mx[1] : mn[1], E[e][5] ? mx[2] : mn[2], 0x0000ff00u);
+}
+
+__device__ __forceinline__ int to_int_like_the_host(double v) {   // the oracle's cvttsd2si behaviour: out of range -> INT_MIN
+	return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;
+}
+
+__global__ __launch_bounds__(TPB) void r_lines_raster(RenderArgs a) {
+	const uint32_t count = min(*reinterpret_cast<const uint32_t*>(a.mom + R_OFF_LINES), LINE_VERTEX_CAP);
+	const uint32_t l = blockIdx.x * TPB + threadIdx.x;
+	if (2 * l + 1 >= count) return;
+	const float4* v = reinterpret_cast<const float4*>(a.mom + R_OFF_VERTICES);
+	uint64_t* fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
+	float4 s = v[2 * l], e = v[2 * l + 1];
+	LinePlane P[6];
+	frustum_planes(a.transform, P);
+	float dx = e.x - s.x, dy = e.y - s.y, dz = e.z - s.z;
+	float d2 = dx * dx; d2 = d2 + dy * dy; d2 = d2 + dz * dz;
+	const float inv = 1.0f / sqrtf(d2);                    // normalize(): v * rsqrtf(dot(v, v))
+	dx = dx * inv; dy = dy * inv; dz = dz * inv;
+	if (!frustum_contains(P, s.x, s.y, s.z)) { float I[3]; frustum_intersect_ray(P, s.x, s.y, s.z, dx, dy, dz, I); s.x = I[0]; s.y = I[1]; s.z = I[2]; }
+	if (!frustum_contains(P, e.x, e.y, e.z)) { float I[3]; frustum_intersect_ray(P, e.x, e.y, e.z, dx * -1.0f, dy * -1.0f, dz * -1.0f, I); e.x = I[0]; e.y = I[1]; e.z = I[2]; }
+	float ax = dot_row(a.transform.rows[0], s.x, s.y, s.z), ay = dot_row(a.transform.rows[1], s.x, s.y, s.z);
+	const float aw = dot_row(a.transform.rows[3], s.x, s.y, s.z);
+	float bx = dot_row(a.transform.rows[0], e.x, e.y, e.z), by = dot_row(a.transform.rows[1], e.x, e.y, e.z);
+	const float bw = dot_row(a.transform.rows[3], e.x, e.y, e.z);
+	ax = ax / aw; ay = ay / aw; bx = bx / bw; by = by / bw;
+	const float sx0 = (ax * 0.5f + 0.5f) * (float)a.W, sy0 = (ay * 0.5f + 0.5f) * (float)a.H;
+	const float sx1 = (bx * 0.5f + 0.5f) * (float)a.W, sy1 = (by * 0.5f + 0.5f) * (float)a.H;
+	const float ddx = sx1 - sx0, ddy = sy1 - sy0;
+	float st2 = ddx * ddx; st2 = st2 + ddy * ddy; st2 = st2 + 0.0f;
+	float steps = sqrtf(st2);
+	steps = fmaxf(0.0f, fminf(steps, 400.0f));
+	const float stepSize = (float)(1.0 / (double)steps);
+	const uint32_t color = __float_as_uint(s.w);
+#pragma unroll 1
+	for (float t = 0.0f; (double)t <= 1.0; t += stepSize) {
+		const float tbx = t * bx, tby = t * by, tbw = t * bw;
+		const float nx = (float)((1.0 - (double)t) * (double)ax + (double)tbx);
+		const float ny = (float)((1.0 - (double)t) * (double)ay + (double)tby);
+		const float depth = (float)((1.0 - (double)t) * (double)aw + (double)tbw);
+		if ((double)nx < -1.0 || (double)nx > 1.0) continue;
+		if ((double)ny < -1.0 || (double)ny > 1.0) continue;
+		int x = to_int_like_the_host(((double)nx * 0.5 + 0.5) * (double)a.W);
+		int y = to_int_like_the_host(((double)ny * 0.5 + 0.5) * (double)a.H);
+		x = min(max(x, 0), a.W - 1); y = min(max(y, 0), a.H - 1);
+		const unsigned long long enc = ((unsigned long long)__float_as_uint(depth) << 32) | color;
+		atomicMin(reinterpret_cast<unsigned long long*>(&fb[x + a.W * y]), enc);   // rasterization.cuh:175-178
 	}
 }
 
@@ -383,11 +568,12 @@ __global__ __launch_bounds__(TPB) void k_reset(uint8_t* pers, SimlodNode* nodes,
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
+static constexpr uint32_t MAX_DRAW_ITEMS = 400000;   // 100 000 visible nodes x 2 lists + 1.6 G visible samples / 8000
 static inline uint64_t align16(uint64_t v) { return (v + 15) / 16 * 16; }
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 	const uint64_t px = (uint64_t)width * height;
-	return R_OFF_FB + align16(px * 8) + 256 + align16(px * 4) + align16(px * 8) + px * 16 + 256;
+	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + 256;
 }
 
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
@@ -414,7 +600,9 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.frameCounter = (uint32_t)u->frameCounter;
 	a.showPoints = u->showPoints; a.colorByNode = u->colorByNode; a.colorByLOD = u->colorByLOD; a.hqs = u->useHighQualityShading;
 	a.offWork = R_OFF_FB + align16((uint64_t)a.numPixels * 8);
-	a.offDepth = a.offWork + 256;
+	a.offItems = a.offWork + 256;
+	a.itemCap = MAX_DRAW_ITEMS;
+	a.offDepth = a.offItems + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem);
 	a.offColor = a.offDepth + align16((uint64_t)a.numPixels * 4);
 	a.offOverflow = a.offColor + align16((uint64_t)a.numPixels * 8);
 
@@ -425,12 +613,17 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	SIMLOD_LAUNCH(r_clear, dim3(gridPixels), dim3(TPB), stream, a);
 	SIMLOD_LAUNCH(r_vis1, dim3(gridNodes), dim3(TPB), stream, a);
 	SIMLOD_LAUNCH(r_vis2, dim3(gridNodes), dim3(TPB), stream, a);
+	SIMLOD_LAUNCH(r_items, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a);
 	if (a.hqs) {
 		SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(r_resolve, dim3(gridPixels), dim3(TPB), stream, a);
 	} else {
 		SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(TPB), stream, a);
+	}
+	if (u->showBoundingBox) {
+		SIMLOD_LAUNCH(r_lines_emit, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a, u->transformInv_updateBound);
+		SIMLOD_LAUNCH(r_lines_raster, dim3((LINE_VERTEX_CAP / 2 + TPB - 1) / TPB), dim3(TPB), stream, a);
 	}
 	SIMLOD_LAUNCH(r_output, dim3(gridPixels), dim3(TPB), stream, a);
 	if (profile_enabled()) profile_close(stream);

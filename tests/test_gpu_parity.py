@@ -148,7 +148,7 @@ def test_render_of_a_reference_built_image_matches_golden_hash(built_libs, name,
     assert_stats_equal(dev.read_stats(), g[f"render_stats_{mode}"][0], STATS_RENDER_FIELDS, name)
 
 
-@pytest.mark.parametrize("variant", ["plain", "hqs", "plain_ps2", "hqs_ps3", "by_node", "by_lod_hqs"])
+@pytest.mark.parametrize("variant", ["plain", "hqs", "plain_ps2", "hqs_ps3", "by_node", "by_lod_hqs", "plain_boxes", "hqs_boxes"])
 def test_render_bit_exact_on_device_built_octree(built_libs, variant):
     """Build on the GPU, render on the GPU, then hand the downloaded image to the oracle's rasteriser: same image in, the
     pre-EDL uint64 framebuffer must be bit-identical; the EDL'd RGBA8 output within 1 per channel (log2/exp)."""
@@ -162,6 +162,7 @@ def test_render_bit_exact_on_device_built_octree(built_libs, variant):
     u["pointSize"] = 2 if "ps2" in variant else 3 if "ps3" in variant else 1
     u["colorByNode"] = 1 if "by_node" in variant else 0
     u["colorByLOD"] = 1 if "by_lod" in variant else 0
+    u["showBoundingBox"] = 1 if "boxes" in variant else 0        # debug lines: node boxes + frustum (rasterization.cuh:90-183)
     dev.render(u)
     fb_dev, col_dev, ds = dev.framebuffer(Wd, Hd), dev.color(Wd, Hd), dev.read_stats()
     nodes, pers, nn = host_image_of(dev)

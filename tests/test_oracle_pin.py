@@ -63,6 +63,11 @@ def test_point_size_and_color_modes_match_reference(built_libs):
     for kw in (dict(point_size=2), dict(point_size=3)):
         u = uniforms_for(box, T, **kw)
         assert np.array_equal(ref.render(u)[0], port.render(u)[0]), kw
+    for hqs in (0, 1):                      # debug lines: node boxes + frustum, rasterization.cuh:90-183
+        u = uniforms_for(box, T, hqs=bool(hqs))
+        u["showBoundingBox"] = 1
+        fa, fb = ref.render(u)[0], port.render(u)[0]
+        assert np.array_equal(fa, fb) and int(((fa & np.uint64(0xffffffff)) == np.uint64(0xff00)).sum()) > 500
     for field in ("colorByNode", "colorByLOD"):
         u = uniforms_for(box, T)
         u[field] = 1
