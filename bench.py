@@ -70,11 +70,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ            # launched through torch.distributed.run (also with one rank)
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run"
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     n_points = args.points
@@ -110,7 +113,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev.device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     ms_per_step = float(tmax.item()) * 1e3 / args.steps
     stats = dev.read_stats()
@@ -119,16 +122,14 @@ def main():
     value = world * n_points / (ms_per_step * 1e-3) / 1e6
 
     # ---- raster ------------------------------------------------------------------------------------------------
+    from simlod_amd import distributed
+    fb_off = int(L.simlod_render_framebuffer_offset())
+
     def compose():
-        if world > 1:
-            off = int(L.simlod_render_framebuffer_offset())
-            fb = dev.render_buffer[off: off + W * H * 8].view(torch.int64)
-            dist.all_reduce(fb, op=dist.ReduceOp.MIN)     # exact for the 64-bit depth|colour words (sign bit never set)
-            nvis = torch.zeros(1, dtype=torch.int64, device=dev.device)
-            nvis[0] = int(0)
-            vis = dev.render_buffer[: 4096 * 152]         # fixed-size slice of the visible-node records
-            out = [torch.empty_like(vis) for _ in range(world)]
-            dist.all_gather(out, vis)
+        """One frame across ranks: all-reduce(MIN) of the uint64 framebuffers + all-gather of the visible nodes."""
+        if use_dist:
+            distributed.compose_min(dev.render_buffer[fb_off: fb_off + W * H * 8].view(torch.int64))
+            distributed.gather_visible(dev.render_buffer, 4096, capacity=4096)
 
     raster = {}
     for name, hqs in (("hqs", 1), ("plain", 0)):
@@ -144,7 +145,7 @@ def main():
         tm = torch.tensor([dtf], dtype=torch.float64, device=dev.device)
         st = dev.read_stats()
         samples = torch.tensor([float(int(st["numVisiblePoints"]) + int(st["numVisibleVoxels"]))], dtype=torch.float64, device=dev.device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX); dist.all_reduce(samples, op=dist.ReduceOp.SUM)
         ms = float(tm.item()) * 1e3 / args.frames
         raster[name] = {"value": float(samples.item()) / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,
@@ -216,7 +217,7 @@ def main():
             "octree": {k: int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels", "allocatedBytes_persistent")},
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
