@@ -73,7 +73,18 @@ def main():
     use_dist = "WORLD_SIZE" in os.environ            # launched through torch.distributed.run (also with one rank)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout must carry ONE JSON line only
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run"
 
     def barrier():
