@@ -1,0 +1,298 @@
+// simlod_headless.cpp — headless replay of the reference host's launch sequence on MI355X.
+//
+// What modules/progressive_octree/main_progressive_octree.cpp does around its three kernels, without window, GL or ImGui,
+// written against the SAME driver-API calls (shim/cuda.h, shim/CudaModularProgram.h):
+//
+//   initCuda()          main.cpp:272-281     context, upload stream, CU count
+//   initCudaProgram()   main.cpp:549-642     device buffers with the reference's sizes, three CudaModularPrograms
+//   getUniforms()       main.cpp:283-331     Uniforms from a camera (orbit controls, include/OrbitControls.h:140-159)
+//   resetCUDA()         main.cpp:333-361     `kernel`
+//   uploader            main.cpp:963-1063    pinned batch -> ring slot, batchSizes[slot], numBatchesUploaded on stream_upload,
+//                                            back-pressure: at most 50 M points ahead of Stats.numPointsProcessed (:1012)
+//   updateOctree()      main.cpp:364-428     `kernel_construct`, numSMs x 256 cooperative geometry
+//   renderCUDA()        main.cpp:465-546     `kernel_render`, occupancy x numSMs workgroups; linear RGBA8 instead of a GL surface
+//   frame loop          main.cpp:1159-1226   render, update, async Stats copy, until numPointsProcessed == numPointsTotal
+//
+// Usage: simlod_headless <file.simlod | synthetic:N> [out.ppm] [width height]
+// Prints the Stats the reference shows in its UI and the update/render kernel timings of "benchmark mode" (main.cpp:411-422).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "CudaModularProgram.h"
+#include "cuda.h"
+#include "simlod_abi.h"
+
+using Point = SimlodPoint;
+using Uniforms = SimlodUniforms;
+using Stats = SimlodStats;
+
+constexpr uint64_t BATCH_STREAM_SIZE = SIMLOD_BATCH_STREAM_SIZE;
+constexpr uint64_t MAX_BATCH_SIZE = SIMLOD_MAX_BATCH_SIZE;
+
+static CUdevice device;
+static CUcontext context;
+static int numSMs;
+static CUstream stream_upload;
+static CUdeviceptr cptr_buffer, cptr_buffer_persistent, cptr_nodes, cptr_renderbuffer, cptr_stats, cptr_numBatchesUploaded, cptr_batchSizes,
+    cptr_frameStart, cptr_colorbuffer, cptr_cudaprint = 0;
+static CUdeviceptr cptr_points_ring[BATCH_STREAM_SIZE];
+static CUevent ce_render_start, ce_render_end, ce_update_start, ce_update_end;
+static CudaModularProgram *cuda_program_update, *cuda_program_render, *cuda_program_reset;
+static uint64_t momentaryBufferCapacity, persistentBufferCapacity, frameCounter = 0;
+static Stats stats;
+static void* h_stats_pinned;
+static simlod_float3 boxSize;
+static int width = 1920, height = 1080;
+static float transform[16];   // row-major world-view-projection (what glm::transpose leaves in Uniforms.transform)
+
+struct {
+	bool useHighQualityShading = true;
+	bool showBoundingBox = false;
+	bool showPoints = true;
+	float minNodeSize = 64.0f;
+	int pointSize = 1;
+} settings;   // main.cpp:123-139
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void initCuda() {   // main.cpp:272-281
+	cuInit(0);
+	cuDeviceGet(&device, 0);
+	cuCtxCreate(&context, 0, device);
+	cuStreamCreate(&stream_upload, CU_STREAM_NON_BLOCKING);
+	cuCtxGetDevice(&device);
+	cuDeviceGetAttribute(&numSMs, CU_DEVICE_ATTRIBUTE_MULTIPROCESSOR_COUNT, device);
+}
+
+static void initCudaProgram() {   // main.cpp:549-642
+	uint64_t nodesCapacity = 200000, estimatedNodeSize = 200;
+	uint64_t cptr_buffer_bytes = 300000000, cptr_nodes_bytes = nodesCapacity * estimatedNodeSize, cptr_renderbuffer_bytes = 200000000;
+	momentaryBufferCapacity = cptr_buffer_bytes;
+	cuMemAlloc(&cptr_buffer, cptr_buffer_bytes);
+	cuMemAlloc(&cptr_nodes, cptr_nodes_bytes);
+	cuMemAlloc(&cptr_renderbuffer, cptr_renderbuffer_bytes);
+	cuMemAlloc(&cptr_stats, sizeof(Stats));
+	cuMemAlloc(&cptr_numBatchesUploaded, 4);
+	cuMemAlloc(&cptr_batchSizes, 4 * BATCH_STREAM_SIZE);
+	cuMemAlloc(&cptr_frameStart, 8);
+	cuMemAllocHost(&h_stats_pinned, sizeof(Stats));
+	cuMemAlloc(&cptr_colorbuffer, (size_t)width * height * 4);      // stands for the GL colour attachment
+	uint64_t cptr_points_bytes = MAX_BATCH_SIZE * sizeof(Point);
+	CUdeviceptr devicemem = 0;
+	cuMemAlloc(&devicemem, BATCH_STREAM_SIZE * cptr_points_bytes);
+	for (uint64_t i = 0; i < BATCH_STREAM_SIZE; i++) cptr_points_ring[i] = devicemem + i * cptr_points_bytes;
+	size_t availableMem = 0, totalMem = 0;
+	cuMemGetInfo(&availableMem, &totalMem);
+	size_t cptr_buffer_persistent_bytes = std::min<size_t>((size_t)((double)availableMem * 0.80), (size_t)64 << 30);
+	persistentBufferCapacity = cptr_buffer_persistent_bytes;
+	void* p = nullptr;   // 80 % of a 288 GB device: not zero-filled (the allocator header is written by `kernel`)
+	if (hipMalloc(&p, cptr_buffer_persistent_bytes) != hipSuccess) { std::fprintf(stderr, "persistent buffer allocation failed\n"); std::exit(1); }
+	cptr_buffer_persistent = (CUdeviceptr)(uintptr_t)p;
+
+	cuda_program_update = new CudaModularProgram({.modules = {"./modules/progressive_octree/progressive_octree_voxels.cu", "./modules/progressive_octree/utils.cu"},
+	                                              .kernels = {"kernel_construct"}});
+	cuda_program_render = new CudaModularProgram({.modules = {"./modules/progressive_octree/render.cu", "./modules/progressive_octree/utils.cu"},
+	                                              .kernels = {"kernel_render"}});
+	cuda_program_reset = new CudaModularProgram({.modules = {"./modules/progressive_octree/reset.cu", "./modules/progressive_octree/utils.cu"},
+	                                             .kernels = {"kernel"}});
+	cuEventCreate(&ce_render_start, 0); cuEventCreate(&ce_render_end, 0);
+	cuEventCreate(&ce_update_start, 0); cuEventCreate(&ce_update_end, 0);
+}
+
+static Uniforms getUniforms() {   // main.cpp:283-331
+	Uniforms u;
+	std::memset(&u, 0, sizeof(u));
+	const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+	std::memcpy(&u.world, ident, 64); std::memcpy(&u.view, ident, 64); std::memcpy(&u.proj, ident, 64);
+	std::memcpy(&u.transform, transform, 64);
+	std::memcpy(&u.transform_updateBound, transform, 64);
+	std::memcpy(&u.transformInv_updateBound, ident, 64);
+	u.width = (float)width; u.height = (float)height;
+	u.fovy_rad = 3.1415f * 60.0f / 180.0f;
+	u.boxMin = {0.0f, 0.0f, 0.0f};
+	u.boxMax = boxSize;
+	u.frameCounter = frameCounter;
+	u.showBoundingBox = settings.showBoundingBox;
+	u.doUpdateVisibility = true;
+	u.showPoints = settings.showPoints;
+	u.LOD = 0.2f;
+	u.minNodeSize = settings.minNodeSize;
+	u.pointSize = settings.pointSize;
+	u.useHighQualityShading = settings.useHighQualityShading;
+	u.persistentBufferCapacity = persistentBufferCapacity;
+	u.momentaryBufferCapacity = momentaryBufferCapacity;
+	u.enableEDL = true;
+	u.edlStrength = 0.8f;
+	return u;
+}
+
+static void resetCUDA() {   // main.cpp:333-361
+	Uniforms uniforms = getUniforms();
+	void* args[] = {&uniforms, &cptr_buffer_persistent, &cptr_nodes, &cptr_stats, &cptr_cudaprint, &cptr_numBatchesUploaded, &cptr_batchSizes};
+	auto res_launch = cuLaunchCooperativeKernel(cuda_program_reset->kernels["kernel"], 1, 1, 1, 1, 1, 1, 0, 0, args);
+	if (res_launch != CUDA_SUCCESS) std::printf("CUDA kernel 'reset' failed.\n");
+	cuCtxSynchronize();
+}
+
+static double kernelUpdateDuration = 0, kernelRenderDuration = 0;
+static int numUpdateLaunches = 0, numFrames = 0;
+
+static void updateOctree() {   // main.cpp:364-428
+	Uniforms uniforms = getUniforms();
+	int workgroupSize = 256, numGroups = 1 * numSMs;
+	auto ptrPoints = cptr_points_ring[0];
+	void* args[] = {&uniforms, &ptrPoints, &cptr_buffer, &cptr_buffer_persistent, &cptr_nodes, &cptr_stats, &cptr_frameStart, &cptr_cudaprint,
+	                &cptr_numBatchesUploaded, &cptr_batchSizes};
+	cuEventRecord(ce_update_start, 0);
+	auto res_launch = cuLaunchCooperativeKernel(cuda_program_update->kernels["kernel_construct"], numGroups, 1, 1, workgroupSize, 1, 1, 0, 0, args);
+	if (res_launch != CUDA_SUCCESS) { const char* str; cuGetErrorString(res_launch, &str); std::printf("error: %s \n", str); }
+	cuEventRecord(ce_update_end, 0);
+	cuCtxSynchronize();   // benchmark mode, main.cpp:411-422
+	float duration;
+	cuEventElapsedTime(&duration, ce_update_start, ce_update_end);
+	kernelUpdateDuration += duration;
+	numUpdateLaunches++;
+}
+
+static void renderCUDA() {   // main.cpp:465-546
+	Uniforms uniforms = getUniforms();
+	int workgroupSize = 256, numGroups;
+	cuOccupancyMaxActiveBlocksPerMultiprocessor(&numGroups, cuda_program_render->kernels["kernel_render"], workgroupSize, 0);
+	numGroups *= numSMs;
+	void* args[] = {&cptr_renderbuffer, &uniforms, &cptr_nodes, &cptr_colorbuffer, &cptr_stats, &cptr_frameStart, &cptr_cudaprint};
+	cuEventRecord(ce_render_start, 0);
+	auto res_launch = cuLaunchCooperativeKernel(cuda_program_render->kernels["kernel_render"], numGroups, 1, 1, workgroupSize, 1, 1, 0, 0, args);
+	if (res_launch != CUDA_SUCCESS) { const char* str; cuGetErrorString(res_launch, &str); std::printf("error: %s \n", str); }
+	cuEventRecord(ce_render_end, 0);
+	cuCtxSynchronize();
+	float duration;
+	cuEventElapsedTime(&duration, ce_render_start, ce_render_end);
+	kernelRenderDuration += duration;
+	numFrames++;
+}
+
+// ---- camera: OrbitControls::update (include/OrbitControls.h:140-159) + glm::perspective + main.cpp:286-298 ------------------
+static void mul4(const double a[16], const double b[16], double out[16]) {
+	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j]; out[4 * i + j] = s; }
+}
+
+static void setCamera(double yaw, double pitch, double radius, const double target[3]) {
+	const double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+	// world = T(target) * Rz(yaw) * Rx(pitch) * flip * T(0,0,radius); its rotation part R and translation t:
+	const double Rz[16] = {cy, -sy, 0, 0, sy, cy, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+	const double Rx[16] = {1, 0, 0, 0, 0, cp, -sp, 0, 0, sp, cp, 0, 0, 0, 0, 1};
+	const double flip[16] = {1, 0, 0, 0, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+	double a[16], R[16];
+	mul4(Rz, Rx, a); mul4(a, flip, R);
+	const double eye[3] = {target[0] + R[2] * radius, target[1] + R[6] * radius, target[2] + R[10] * radius};
+	double view[16] = {0};   // inverse of a rigid transform: R^T, -R^T eye
+	for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) view[4 * i + j] = R[4 * j + i]; view[4 * i + 3] = -(R[i] * eye[0] + R[4 + i] * eye[1] + R[8 + i] * eye[2]); }
+	view[15] = 1;
+	const double fovy = 3.14159265358979323846 * 60.0 / 180.0, aspect = (double)width / height, zn = 0.1, zf = 2000000.0, t = std::tan(fovy / 2);
+	double proj[16] = {0};
+	proj[0] = 1 / (aspect * t); proj[5] = 1 / t; proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2 * zf * zn) / (zf - zn); proj[14] = -1;
+	float v32[16], p32[16];
+	for (int i = 0; i < 16; i++) { v32[i] = (float)view[i]; p32[i] = (float)proj[i]; }
+	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0; for (int k = 0; k < 4; k++) s += p32[4 * i + k] * v32[4 * k + j]; transform[4 * i + j] = s; }
+}
+
+int main(int argc, char** argv) {
+	if (argc < 2) { std::printf("usage: %s <file.simlod | synthetic:N> [out.ppm] [width height]\n", argv[0]); return 2; }
+	const std::string path = argv[1];
+	const char* outPath = argc > 2 ? argv[2] : nullptr;
+	if (argc > 4) { width = std::atoi(argv[3]); height = std::atoi(argv[4]); }
+
+	// reload(): a .simlod file is a 24-byte bounding box followed by 16-byte XYZRGBA records (main.cpp:722-745, tools/las2simlod.mjs:96-147)
+	std::vector<Point> points;
+	if (path.rfind("synthetic:", 0) == 0) {
+		const size_t n = std::strtoull(path.c_str() + 10, nullptr, 10);
+		points.resize(n);
+		uint32_t s = 1234567u;
+		auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; };
+		for (auto& p : points) { p.x = rnd(); p.y = rnd(); const float h = 0.25f + 0.2f * std::sin(6.0f * p.x) * std::cos(5.0f * p.y); p.z = h + 0.002f * rnd();
+			p.color = (uint32_t)(255 * p.x) | ((uint32_t)(255 * p.y) << 8) | ((uint32_t)(255 * p.z * 2) << 16) | (255u << 24); }
+		boxSize = {1.0f, 1.0f, 1.0f};
+	} else {
+		FILE* f = std::fopen(path.c_str(), "rb");
+		if (!f) { std::perror(path.c_str()); return 1; }
+		float bbox[6];
+		if (std::fread(bbox, 4, 6, f) != 6) { std::fprintf(stderr, "short header\n"); return 1; }
+		std::fseek(f, 0, SEEK_END); const long bytes = std::ftell(f); std::fseek(f, 24, SEEK_SET);
+		points.resize((size_t)(bytes - 24) / 16);
+		if (std::fread(points.data(), 16, points.size(), f) != points.size()) { std::fprintf(stderr, "short read\n"); return 1; }
+		std::fclose(f);
+		boxSize = {bbox[3] - bbox[0], bbox[4] - bbox[1], bbox[5] - bbox[2]};
+		for (auto& p : points) { p.x -= bbox[0]; p.y -= bbox[1]; p.z -= bbox[2]; }   // main.cpp:868
+	}
+	const uint64_t numPointsTotal = points.size();
+	const uint64_t numBatchesTotal = (numPointsTotal + MAX_BATCH_SIZE - 1) / MAX_BATCH_SIZE;
+
+	initCuda();
+	initCudaProgram();
+	const double target[3] = {boxSize.x * 0.5, boxSize.y * 0.5, boxSize.z * 0.3};
+	setCamera(-0.207, -0.797, 1.1 * std::max(boxSize.x, std::max(boxSize.y, boxSize.z)), target);
+	resetCUDA();
+
+	// pinned staging slots, as the reference's pinnedMemPool (main.cpp:141-222)
+	void* pinned[4];
+	CUevent uploadEnd[4];
+	for (int i = 0; i < 4; i++) { cuMemAllocHost(&pinned[i], MAX_BATCH_SIZE * sizeof(Point)); cuEventCreate(&uploadEnd[i], 0); cuEventRecord(uploadEnd[i], stream_upload); }
+
+	uint64_t batchStreamUploadIndex = 0, numPointsUploaded = 0;
+	bool lastBatchFinishedDevice = false;
+	const double loadStart = now();
+	while (!lastBatchFinishedDevice) {
+		// ---- uploader (main.cpp:1003-1056); here on the frame thread, same stream protocol
+		for (int k = 0; k < 4; k++) {
+			const bool everythingIsDone = batchStreamUploadIndex == numBatchesTotal;
+			const bool processingLagsBehind = numPointsUploaded > stats.numPointsProcessed + BATCH_STREAM_SIZE * MAX_BATCH_SIZE;
+			if (everythingIsDone || processingLagsBehind) break;
+			const int slot = (int)(batchStreamUploadIndex % 4);
+			cuEventSynchronize(uploadEnd[slot]);
+			const uint64_t first = batchStreamUploadIndex * MAX_BATCH_SIZE;
+			const uint32_t count = (uint32_t)std::min<uint64_t>(MAX_BATCH_SIZE, numPointsTotal - first);
+			std::memcpy(pinned[slot], points.data() + first, (size_t)count * sizeof(Point));
+			const int uploadRingIndex = (int)(batchStreamUploadIndex % BATCH_STREAM_SIZE);
+			cuMemcpyHtoDAsync(cptr_points_ring[uploadRingIndex], pinned[slot], (size_t)count * sizeof(Point), stream_upload);
+			cuEventRecord(uploadEnd[slot], stream_upload);
+			cuMemsetD32Async(cptr_batchSizes + 4 * uploadRingIndex, count, 1, stream_upload);
+			cuMemsetD32Async(cptr_numBatchesUploaded, (unsigned)(batchStreamUploadIndex + 1), 1, stream_upload);
+			batchStreamUploadIndex++;
+			numPointsUploaded += count;
+		}
+		// ---- frame (main.cpp:1159-1226): render first, then update, then the Stats copy
+		renderCUDA();
+		updateOctree();
+		cuMemcpyDtoHAsync(h_stats_pinned, cptr_stats, sizeof(Stats), 0);
+		cuCtxSynchronize();
+		std::memcpy(&stats, h_stats_pinned, sizeof(Stats));
+		lastBatchFinishedDevice = stats.numPointsProcessed == numPointsTotal || stats.memCapacityReached;
+		frameCounter++;
+		if (frameCounter > 100000) { std::fprintf(stderr, "no progress\n"); return 1; }
+	}
+	const double totalUpdateDuration = 1000.0 * (now() - loadStart);
+	renderCUDA();   // the frame that shows the finished octree
+	cuMemcpyDtoH(&stats, cptr_stats, sizeof(Stats));
+
+	std::printf("points %llu batches %llu frames %d\n", (unsigned long long)numPointsTotal, (unsigned long long)numBatchesTotal, numFrames);
+	std::printf("numNodes %u numInner %u numLeaves %u numPoints %u numVoxels %u persistentBytes %llu chunkPoolSize %llu dbg %u\n", stats.numNodes, stats.numInner,
+	            stats.numLeaves, stats.numPoints, stats.numVoxels, (unsigned long long)stats.allocatedBytes_persistent, (unsigned long long)stats.chunkPoolSize, stats.dbg);
+	std::printf("visible nodes %u points %u voxels %u\n", stats.numVisibleNodes, stats.numVisiblePoints, stats.numVisibleVoxels);
+	std::printf("load+build wall %.1f ms (incl. H2D), update kernel %.2f ms total over %d launches = %.1f M points/s, render kernel %.3f ms/frame\n", totalUpdateDuration,
+	            kernelUpdateDuration, numUpdateLaunches, numPointsTotal / (kernelUpdateDuration * 1e-3) / 1e6, kernelRenderDuration / numFrames);
+	if (outPath) {
+		std::vector<uint32_t> img((size_t)width * height);
+		cuMemcpyDtoH(img.data(), cptr_colorbuffer, img.size() * 4);
+		FILE* f = std::fopen(outPath, "wb");
+		std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+		for (int y = height - 1; y >= 0; y--) for (int x = 0; x < width; x++) { const uint32_t c = img[(size_t)y * width + x]; const unsigned char rgb[3] = {(unsigned char)c, (unsigned char)(c >> 8), (unsigned char)(c >> 16)}; std::fwrite(rgb, 1, 3, f); }
+		std::fclose(f);
+	}
+	return stats.dbg == 0 ? 0 : 3;
+}

@@ -262,3 +262,35 @@ def test_full_size_36m_properties(built_libs):
     assert np.array_equal(fh >> np.uint64(32), f1 >> np.uint64(32)), "HQS resolves to the same nearest depth per pixel as the 64-bit min"
     fho, _, _ = _oracle_render(nodes, nn, u)
     assert np.array_equal(fh, fho), f"{int((fh != fho).sum())} HQS pixels differ from the oracle at 1080p (averaged colours incl. the >64-samples-per-pixel path)"
+
+
+# ---- the reference host's launch sequence in C++ (harness/simlod_headless.cpp on shim/cuda.h) ------------------------------------
+def test_headless_cpp_host_replay(built_libs, tmp_path):
+    """A .simlod file goes through the C++ replay of main_progressive_octree.cpp's init / reset / uploader / frame loop; the octree
+    it reports must be the one the oracle builds from the same file."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "simlod_headless")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "harness")])
+    pts, box = synthetic.terrain(2_500_000, seed=5, box=(1500.0, 1000.0, 100.0), tile=125.0)
+    path = str(tmp_path / "terrain.simlod")
+    synthetic.write_simlod(path, pts, box)
+    ppm = str(tmp_path / "frame.ppm")
+    out = subprocess.run([exe, path, ppm, "640", "360"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"numNodes (\d+) numInner (\d+) numLeaves (\d+) numPoints (\d+) numVoxels (\d+) persistentBytes (\d+) chunkPoolSize (\d+) dbg (\d+)", out.stdout)
+    assert m, out.stdout
+    got = [int(v) for v in m.groups()]
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    u = uniforms_for(box, T, persistent=8 << 30)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    s = ref.stats[0]
+    assert got == [int(s[k]) for k in ("numNodes", "numInner", "numLeaves", "numPoints", "numVoxels", "allocatedBytes_persistent", "chunkPoolSize")] + [0]
+    assert os.path.getsize(ppm) == 15 + 640 * 360 * 3
+    img = np.fromfile(ppm, dtype=np.uint8, offset=15).reshape(360, 640, 3)
+    assert (img != np.array([0x11, 0x22, 0x33], dtype=np.uint8)).any(axis=2).sum() > 5000      # something other than background was drawn
