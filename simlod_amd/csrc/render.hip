@@ -38,7 +38,7 @@ struct RenderArgs {
 	uint32_t     numPixels, nodeCapacity, frameCounter;
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
 	uint64_t     offWork, offItems, offDepth, offColor, offOverflow;
-	uint32_t     itemCap, pad;
+	uint32_t     itemCap, useTiles;
 };
 
 // work area: [0..2] draw cursors of the three draw modes, [3] number of draw items
@@ -48,7 +48,9 @@ static constexpr uint32_t ITEM_CHUNKS = 8;          // a draw item = up to 8 con
 struct DrawItem {
 	const SimlodChunk* first;
 	uint32_t samples, visibleIdx;
+	int32_t  tileX, tileY;                          // origin of the 32x32-pixel LDS tile, or tileX < 0: no tile
 };
+static constexpr int TILE = 32;                     // LDS tile edge for nodes that are small on screen (BASELINE config 5)
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
 enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4 };
@@ -184,6 +186,25 @@ __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 	const SimlodNode* node = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE) + i;
 	uint32_t* numItems = reinterpret_cast<uint32_t*>(a.mom + a.offWork) + 3;
 	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
+	// Screen box of the node's cube: a node that fits a 32x32-pixel tile is accumulated in LDS and flushed once per touched
+	// pixel (samples that fall outside the tile anyway take the global path, so this is an optimisation hint only).
+	int tileX = -1, tileY = -1;
+	if (a.useTiles) {
+		const float nodeSize = a.cubeSize / exp2_int(node->level);
+		float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+		bool front = true;
+		for (int k = 0; k < 8; k++) {
+			const float x = a.minx + ((float)node->X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)node->Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
+			const float z = a.minz + ((float)node->Z + ((k & 1) ? 1.0f : 0.0f)) * nodeSize;
+			const float cw = dot_row(a.transform.rows[3], x, y, z);
+			if (!(cw > 0.0f)) { front = false; break; }
+			const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
+			mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx); mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+		}
+		if (front && mxx - mnx + (float)a.pointSize + 2.0f <= (float)TILE && mxy - mny + (float)a.pointSize + 2.0f <= (float)TILE && mnx > -1.0e6f && mny > -1.0e6f) {
+			tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0);
+		}
+	}
 	const SimlodChunk* heads[2] = {node->points, node->voxelChunks};
 	const uint32_t counts[2] = {node->numPoints, node->numVoxels};
 	for (int l = 0; l < 2; l++) {
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 		const SimlodChunk* chunk = heads[l];
 		for (uint32_t p = 0; p < pieces && chunk != nullptr; p++) {
 			const uint32_t take = min(left, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK);
-			if (base + p < a.itemCap) { DrawItem it; it.first = chunk; it.samples = take; it.visibleIdx = i; items[base + p] = it; }
+			if (base + p < a.itemCap) { DrawItem it; it.first = chunk; it.samples = take; it.visibleIdx = i; it.tileX = tileX; it.tileY = tileY; items[base + p] = it; }
 			else atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);
 			left -= take;
 			for (uint32_t k = 0; k < ITEM_CHUNKS && chunk != nullptr && left > 0; k++) chunk = chunk->next;
@@ -230,6 +251,8 @@ struct DrawCtx {
 	uint32_t* depth;
 	unsigned long long* color;   // HQS colour sums, packed: B (14 bits) | G << 14 | R << 28 | count << 42
 	unsigned long long* overflow;// 2 x u64 per pixel {R | G << 32, B | count << 32}: samples beyond the 64th of a pixel
+	unsigned long long* tile;    // LDS: TILE*TILE x 2 words (MIN64: word 0 = min; DEPTH: low 32 bits of word 0; COLOR: both words)
+	int tileX, tileY;            // tile origin; tileX < 0: no tile
 };
 
 template <int MODE>
@@ -252,6 +275,23 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 		const int px = min(max(x + ox, 0), c.W), py = min(max(y + oy, 0), c.H);   // render.cu:91-92 clamps to W, not W-1
 		const uint32_t pixel = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
 		if (pixel >= c.numPixels) continue;                 // only reachable for pointSize >= 4 (out of bounds in the reference)
+		if (c.tileX >= 0) {                                 // LDS-staged accumulation for nodes that are small on screen
+			const unsigned tx = (unsigned)(px - c.tileX), ty = (unsigned)(py - c.tileY);
+			if (tx < (unsigned)TILE && ty < (unsigned)TILE) {
+				const unsigned t = tx + ty * TILE;
+				if (MODE == MODE_MIN64) {
+					const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
+					if (enc < c.tile[2 * t]) atomicMin(&c.tile[2 * t], enc);
+				} else if (MODE == MODE_DEPTH) {
+					uint32_t* d = reinterpret_cast<uint32_t*>(&c.tile[2 * t]);
+					if (dbits < *d) atomicMin(d, dbits);
+				} else if (depth < __uint_as_float(c.depth[pixel]) * 1.01f) {
+					atomicAdd(&c.tile[2 * t + 0], (unsigned long long)(color & 0xffu) | ((unsigned long long)((color >> 8) & 0xffu) << 32));
+					atomicAdd(&c.tile[2 * t + 1], (unsigned long long)((color >> 16) & 0xffu) | (1ull << 32));
+				}
+				continue;
+			}
+		}
 		if (MODE == MODE_MIN64) {
 			const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
 			if (enc < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), enc);   // render.cu:95-100
@@ -291,10 +331,37 @@ __device__ __forceinline__ void draw_list(const DrawCtx& c, const SimlodChunk* c
 }
 
 template <int MODE>
+__device__ __forceinline__ void tile_clear(unsigned long long* tile) {
+	for (int t = threadIdx.x; t < TILE * TILE; t += TPB) { tile[2 * t] = MODE == MODE_COLOR ? 0ull : ~0ull; tile[2 * t + 1] = 0ull; }
+}
+
+// One global atomic per TOUCHED pixel of the tile; the merged values go through the same test-before-atomic as single samples.
+template <int MODE>
+__device__ __forceinline__ void tile_flush(const DrawCtx& c) {
+	for (int t = threadIdx.x; t < TILE * TILE; t += TPB) {
+		const int px = c.tileX + (t % TILE), py = c.tileY + (t / TILE);
+		const uint32_t pixel = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
+		if (pixel >= c.numPixels) continue;
+		if (MODE == MODE_MIN64) {
+			const unsigned long long v = c.tile[2 * t];
+			if (v != ~0ull && v < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), v);
+		} else if (MODE == MODE_DEPTH) {
+			const uint32_t v = (uint32_t)c.tile[2 * t];
+			if (v != 0xffffffffu && v < c.depth[pixel]) atomicMin(&c.depth[pixel], v);
+		} else {
+			const unsigned long long rg = c.tile[2 * t], bc = c.tile[2 * t + 1];
+			if ((bc >> 32) != 0ull) { atomicAdd(&c.overflow[2 * pixel + 0], rg); atomicAdd(&c.overflow[2 * pixel + 1], bc); }   // exact: resolve adds both planes
+		}
+	}
+}
+
+template <int MODE>
 __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 	if (!a.showPoints) return;
 	__shared__ uint32_t sh_idx;
+	__shared__ unsigned long long sh_tile[TILE * TILE * 2];
 	DrawCtx c;
+	c.tile = sh_tile; c.tileX = -1; c.tileY = -1;
 	c.r0 = a.transform.rows[0]; c.r1 = a.transform.rows[1]; c.r3 = a.transform.rows[3];
 	c.width = a.width; c.height = a.height;
 	c.wlim = (double)a.width - 2.0; c.hlim = (double)a.height - 2.0;
@@ -320,7 +387,10 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 			overrideColor = a.colorByNode ? node_color(node) : lod_color((int)node->level);
 			useOverride = true;
 		}
+		c.tileX = it.tileX; c.tileY = it.tileY;
+		if (it.tileX >= 0) { tile_clear<MODE>(sh_tile); __syncthreads(); }
 		draw_list<MODE>(c, it.first, it.samples, overrideColor, useOverride);
+		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
 		__syncthreads();
@@ -602,6 +672,7 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.offWork = R_OFF_FB + align16((uint64_t)a.numPixels * 8);
 	a.offItems = a.offWork + 256;
 	a.itemCap = MAX_DRAW_ITEMS;
+	a.useTiles = (uint32_t)tune("SIMLOD_RASTER_LDS_TILES", 1);
 	a.offDepth = a.offItems + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem);
 	a.offColor = a.offDepth + align16((uint64_t)a.numPixels * 4);
 	a.offOverflow = a.offColor + align16((uint64_t)a.numPixels * 8);

@@ -1,0 +1,40 @@
+"""BASELINE config 5 A/B: every point inside ONE level-6 octree cell, camera aimed at it so that all samples land in a small screen
+region; LDS-tiled accumulation (SIMLOD_RASTER_LDS_TILES=1, default) vs plain global atomics (=0).  Prints one JSON line."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from simlod_amd import abi, camera, synthetic
+from simlod_amd.runtime import DeviceOctree
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+span_px = float(sys.argv[2]) if len(sys.argv) > 2 else 128.0
+pts, box = synthetic.hotspot(n, seed=11)
+W, H = 1920, 1080
+cell = np.array([21, 40, 13], dtype=np.float64) / 64 + 1 / 128          # centre of the level-6 cell
+size = 1 / 64
+dist = size * (H / span_px) / (2 * np.tan(np.radians(30)))             # the cell spans ~span_px pixels vertically
+T = camera.lookat_transform(cell + np.array([0.6, -0.7, 0.4]) / np.linalg.norm([0.6, -0.7, 0.4]) * dist, cell, W, H)
+dev = DeviceOctree("cuda:0", persistent_bytes=6 << 30, momentary_bytes=2_000_000_000, max_pixels=W * H)
+u = dev.uniforms(W, H, T, box, min_node_size=8.0)
+dev.reset(u)
+t0 = time.time(); dev.add_points(u, pts); torch.cuda.synchronize(); t_ingest = time.time() - t0
+st = dev.read_stats()
+out = {"points": n, "span_px": span_px, "ingest_s_incl_h2d": t_ingest, "dbg": int(st["dbg"]), "numNodes": int(st["numNodes"])}
+fbs = {}
+for tiles in (1, 0):
+    os.environ["SIMLOD_RASTER_LDS_TILES"] = str(tiles)
+    for mode, hqs in (("plain", 0), ("hqs", 1)):
+        u["useHighQualityShading"] = hqs
+        for _ in range(3):
+            dev.render(u)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            dev.render(u)
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / 20
+        s = dev.read_stats()
+        samples = int(s["numVisiblePoints"]) + int(s["numVisibleVoxels"])
+        fbs[(tiles, mode)] = dev.framebuffer(W, H)
+        out[f"{mode}_tiles{tiles}"] = {"ms_per_frame": ms, "visible_samples": samples, "visible_nodes": int(s["numVisibleNodes"]), "G_samples_per_s": samples / ms / 1e6,
+                                       "pixels_touched": int((fbs[(tiles, mode)] != abi.CLEAR_PIXEL).sum())}
+out["frames_identical"] = bool(np.array_equal(fbs[(1, "plain")], fbs[(0, "plain")]) and np.array_equal(fbs[(1, "hqs")], fbs[(0, "hqs")]))
+print(json.dumps(out))
