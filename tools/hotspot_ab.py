@@ -14,7 +14,7 @@ cell = np.array([21, 40, 13], dtype=np.float64) / 64 + 1 / 128          # centre
 size = 1 / 64
 dist = size * (H / span_px) / (2 * np.tan(np.radians(30)))             # the cell spans ~span_px pixels vertically
 T = camera.lookat_transform(cell + np.array([0.6, -0.7, 0.4]) / np.linalg.norm([0.6, -0.7, 0.4]) * dist, cell, W, H)
-dev = DeviceOctree("cuda:0", persistent_bytes=6 << 30, momentary_bytes=2_000_000_000, max_pixels=W * H)
+dev = DeviceOctree("cuda:0", persistent_bytes=(96 << 30) if n > 50_000_000 else (6 << 30), momentary_bytes=2_000_000_000, max_pixels=W * H)
 u = dev.uniforms(W, H, T, box, min_node_size=8.0)
 dev.reset(u)
 t0 = time.time(); dev.add_points(u, pts); torch.cuda.synchronize(); t_ingest = time.time() - t0
