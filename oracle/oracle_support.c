@@ -206,3 +206,29 @@ int oracle_check_invariants(const SimlodNode* nodes, uint32_t numNodes, uint64_t
 	*totalPoints = tp; *totalVoxels = tv; *pointChunks = pc; *voxelChunks = vc; *grids = g;
 	return 0;
 }
+
+/* Analysis helper (tools/analyze_candidates.py): for every point of a batch, the deepest grid-owning node of its path, the
+ * byte address of the occupancy word it would probe, and whether that bit is already set. */
+void oracle_probe_batch(const SimlodNode* nodes, const SimlodPoint* pts, uint32_t n, float minx, float miny, float minz, float size,
+                        uint32_t* outNode, uint64_t* outWordAddr, uint8_t* outSet) {
+	for (uint32_t i = 0; i < n; i++) {
+		const SimlodPoint* p = &pts[i];
+		uint32_t X = (uint32_t)(1048576.0f * (p->x - minx) / size), Y = (uint32_t)(1048576.0f * (p->y - miny) / size), Z = (uint32_t)(1048576.0f * (p->z - minz) / size);
+		uint32_t pX = (uint32_t)(268435456.0f * (p->x - minx) / size), pY = (uint32_t)(268435456.0f * (p->y - miny) / size), pZ = (uint32_t)(268435456.0f * (p->z - minz) / size);
+		const SimlodNode* cur = &nodes[0]; const SimlodNode* deepest = cur->grid ? cur : NULL;
+		for (int level = 0; level < SIMLOD_MAX_DEPTH; level++) {
+			int s = SIMLOD_MAX_DEPTH - level - 1;
+			const SimlodNode* ch = cur->children[(((X >> s) & 1u) << 2) | (((Y >> s) & 1u) << 1) | ((Z >> s) & 1u)];
+			if (!ch) break;
+			if (cur->grid) deepest = cur;
+			cur = ch;
+		}
+		outNode[i] = 0xffffffffu; outWordAddr[i] = 0; outSet[i] = 1;
+		if (!deepest) continue;
+		uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - deepest->level;
+		uint32_t cell = ((pX >> sh) & 127u) + ((pY >> sh) & 127u) * 128u + ((pZ >> sh) & 127u) * 16384u;
+		outNode[i] = (uint32_t)(deepest - nodes);
+		outWordAddr[i] = (uint64_t)(uintptr_t)&deepest->grid->values[cell >> 5];
+		outSet[i] = (uint8_t)((deepest->grid->values[cell >> 5] >> (cell & 31u)) & 1u);
+	}
+}

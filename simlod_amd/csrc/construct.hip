@@ -369,12 +369,35 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 // 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
 // (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
 // NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
+// Per-workgroup set of (node, cell) claims.  While the octree is still shallow the deepest grid of a sample is coarse: on the
+// terrain workload the 1 M points of an early batch fall into 4 nodes and ~1000 occupancy words, 890 k of them see a clear
+// bit (tools/analyze_candidates.py), and thousands of atomicOr per word serialise at ~11 ns each.  So only the FIRST sample of
+// a workgroup that sees a clear cell issues the global atomicOr; the others know the cell is being taken care of and stop,
+// exactly as if they had lost the race.  key = table entry of the node (10 bits) << 21 | cell (21 bits).
+static constexpr int SET_BITS = 12;
+static constexpr int SET_CAP = 1 << SET_BITS;
+
+// true: the caller is the first of its workgroup to claim `key` (or the set has no room: claim anyway, merely redundant)
+__device__ __forceinline__ bool set_insert(uint32_t* set, uint32_t key) {
+	uint32_t h = (key * 2654435761u) >> (32 - SET_BITS);
+#pragma unroll 1
+	for (int probe = 0; probe < 8; ++probe) {
+		uint32_t k = set[h];
+		if (k == TBL_EMPTY) k = atomicCAS(&set[h], TBL_EMPTY, key);
+		if (k == TBL_EMPTY) return true;
+		if (k == key) return false;
+		h = (h + 1) & (SET_CAP - 1);
+	}
+	return true;
+}
+
 template <uint32_t SPT>
 __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 	constexpr uint32_t SPB = TPB * SPT;
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
 	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
+	__shared__ uint32_t claimed[SET_CAP];              // (node, cell) pairs this workgroup already claimed
 	const uint32_t n = ctl->batchSize;
 	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
@@ -384,6 +407,7 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
 	const uint32_t numChunks = (total + SPB - 1) / SPB;
 	table_init(tbl);                                   // lives for the whole workgroup: no barrier inside the chunk loop
+	for (uint32_t i = threadIdx.x; i < (uint32_t)SET_CAP; i += TPB) claimed[i] = TBL_EMPTY;
 	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 #pragma unroll 1
@@ -412,10 +436,12 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 				const uint32_t bit = cell & 31u;
 				uint32_t* word = &grid->values[cell >> 5];
 				if (((*word >> bit) & 1u) != 0u) break;                                  // voxels.cu:93-94; the ancestors are set as well
+				uint32_t rank;
+				const int e = table_add(tbl, nodeIdx, 0u, &rank);
+				if (e >= 0 && !set_insert(claimed, ((uint32_t)e << 21) | cell)) break;  // a sample of this workgroup already claims the cell
 				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) break;              // voxels.cu:96; lost: the winner climbs on
 				wins |= 1u << level;                                                     // first point in the cell, voxels.cu:99
-				uint32_t rank;
-				if (table_add(tbl, nodeIdx, 1u, &rank) < 0) atomicAdd(&node->numVoxels, 1u);   // voxels.cu:101
+				if (e >= 0) atomicAdd(&tbl.vals[e], 1u); else atomicAdd(&node->numVoxels, 1u);   // voxels.cu:101
 				nodeIdx = parentOf[nodeIdx];
 			}
 			winMask[idx] = wins;
@@ -424,7 +450,7 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 	__syncthreads();
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
+		if (key != TBL_EMPTY && tbl.vals[e] != 0u) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
 	}
 }
 
