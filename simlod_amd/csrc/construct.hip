@@ -36,6 +36,13 @@ struct NodeDir {          // per node, valid for the batch whose tag it carries
 	uint32_t ptBase, ptFirst, ptTag, voxBase, voxFirst, voxTag, pad0, pad1;
 };
 
+// Leaf chunk table: slot k of leaf i's point list -> chunk, LEAF_SLOTS entries per node.  A leaf that can still split stores
+// at most MAX_POINTS_PER_NODE points between batches (= 50 chunks), so the split reads its whole list from here with all
+// lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by k_alloc; survives between
+// launches like the recycle stack does, and is refilled by k_parents whenever k_begin finds its stamp stale.
+static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
+static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
+
 __device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
 template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
 
@@ -89,6 +96,8 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall) {
 	ctl->numBatches = n;
 	ctl->barrierCount = 0;
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
+	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first) ? 1u : 0u;
+	ctl->tableMagic = 0;                        // valid again once k_finish has run
 	prepare_batch(a, ctl, 0);
 }
 
@@ -105,6 +114,11 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 	for (int k = 0; k < 8; k++) {
 		const SimlodNode* c = n->children[k];
 		if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
+	}
+	if (ctl_of(a)->rebuildLeafChunks && node_is_leaf(n)) {
+		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
+		const SimlodChunk* c = n->points;
+		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
 	}
 }
 
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	uint32_t* splitTag = at<uint32_t>(a, a.offSplitTag);
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	SpillWork* work = at<SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
@@ -214,6 +229,9 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 		if (numSpilling > SPILLING_CAPACITY) numSpilling = SPILLING_CAPACITY;
 		if (numSpilling == 0) break;
 		const uint32_t tag = ctl->ordinal * 32u + round + 1u;
+		const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
+		uint64_t t0 = timer ? wall_ns() : 0, t1;
+		if (timer && round == 0) ctl->expandNs[6] += 1;
 		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;   // last read one round ago, appended to only after the barrier below
 
 		// -- A: split ---------------------------------------------------------------------------------------------
@@ -255,36 +273,44 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				node->children[i] = a.nodes + childOffset + i;
 				parentOf[childOffset + i] = nodeIdx;
 			}
-			if (threadIdx.x == 64) {
-				// One lane walks the chunk list (a pointer chase nobody can parallelise), emits one work item per chunk,
-				// and hands the chunks back to the recycle stack (voxels.cu:346-357; nothing pops before k_alloc).
+			if (threadIdx.x >= 64 && threadIdx.x < 128) {
+				// Wave 1 turns every chunk of the leaf into a work item and hands the chunks back to the recycle stack
+				// (voxels.cu:346-357; nothing pops before k_alloc).  Chunk k comes from the leaf chunk table, not from a walk.
+				const uint32_t lane = threadIdx.x - 64;
 				const uint32_t stored = node->numPoints;
-				const uint32_t numChunks = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-				const uint32_t spillBase = atomicAdd(&ctl->numSpilled, stored);
-				SimlodChunk* chunk = node->points;
-				if (spillBase + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; chunk = nullptr; }
+				SimlodChunk* const head = node->points;
 				// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
-				const uint32_t linked = chunk != nullptr ? numChunks : 0u;
-				if (linked > 0) {
-					const uint32_t w0 = atomicAdd(&ctl->numWork, linked);
-					const unsigned long long top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)linked));
-					for (uint32_t ci = 0; ci < linked && chunk != nullptr; ci++) {
-						SimlodChunk* next = chunk->next;
-						if (w0 + ci < a.workCap) {
-							SpillWork w;
-							w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
-							w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
-							work[w0 + ci] = w;
-						} else { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; }
-						chunk->next = nullptr;
-						const unsigned long long q = top - linked + ci;
-						if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
-						chunk = next;
+				const uint32_t numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+				uint32_t spillBase = 0, w0 = 0, ok = 1;
+				unsigned long long top = 0;
+				if (lane == 0) {
+					spillBase = atomicAdd(&ctl->numSpilled, stored);
+					if (spillBase + stored > a.spilledCap || numChunks > LEAF_SLOTS) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; ok = 0; }
+					if (ok && numChunks > 0) {
+						w0 = atomicAdd(&ctl->numWork, numChunks);
+						top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
 					}
 				}
-				node->numPoints = 0;
-				node->points = nullptr;
-				splitTag[nodeIdx] = tag;
+				spillBase = __shfl(spillBase, 0); w0 = __shfl(w0, 0); ok = __shfl(ok, 0);
+				top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
+				SimlodChunk* const* slots = leafChunks + (uint64_t)nodeIdx * LEAF_SLOTS;
+				for (uint32_t ci = lane; ok && ci < numChunks; ci += 64) {
+					SimlodChunk* chunk = slots[ci];
+					if (w0 + ci < a.workCap) {
+						SpillWork w;
+						w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
+						w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
+						work[w0 + ci] = w;
+					} else { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; }
+					chunk->next = nullptr;
+					const unsigned long long q = top - numChunks + ci;
+					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+				}
+				if (lane == 0) {
+					node->numPoints = 0;
+					node->points = nullptr;
+					splitTag[nodeIdx] = tag;
+				}
 			}
 			// meanwhile the other lanes clear the occupancy grid — of EVERY spilling node, also one that already had a
 			// grid (the root), voxels.cu:371-382
@@ -295,7 +321,9 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			}
 		}
 
+		if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
 		// numSpilled / numWork are stable between this barrier and the next round's split phase: snapshot them for round+1
 		const uint32_t workEnd = min(ctl->numWork, a.workCap);
 		const uint32_t workBegin = ctl->workSnap[round & 1];
@@ -328,6 +356,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				atomicAdd(&a.nodes[item.childOffset + threadIdx.x].counter, sh_childCount[threadIdx.x]);
 		}
 
+		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; }
 		// -- B2: recount — only samples whose cached leaf was split in THIS round go one (or more) levels down ------------
 		// (the reference's 20th split is not followed by a count, voxels.cu:394-412)
 		if (round + 1 < SIMLOD_MAX_EXPAND_ROUNDS) {
@@ -355,7 +384,9 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], listNext, countNext);
 			}
 		}
+		if (timer) { t1 = wall_ns(); ctl->expandNs[3] += t1 - t0; t0 = t1; }
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (timer) { t1 = wall_ns(); ctl->expandNs[4] += t1 - t0; ctl->expandNs[5] += 1; }
 	}
 }
 
@@ -468,6 +499,7 @@ __global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	const uint32_t tag = ctl->batchIndex + 1u;
 	node->countIteration = tag;
 
@@ -498,6 +530,7 @@ __global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
 				if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
 				tail = c;
 				chunkDir[base + e++] = c;
+				if (existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;
 			}
 			tail_of(head) = tail;
 		}
@@ -752,6 +785,8 @@ __global__ void k_finish(BuildArgs a) {
 	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
 	s->frameID = (uint32_t)a.frameCounter;
 	s->dbg |= ctl->errors;
+	ctl->tableBatch = s->batchletIndex;
+	ctl->tableMagic = TABLE_MAGIC;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -764,6 +799,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	off += 2 * align_up((uint64_t)nodeCapacity * 4, 256);                      // splitTag, parentOf
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
+	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
 	return off;
 }
 
@@ -777,6 +813,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
+	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	const uint64_t fixedEnd = off;
 	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;

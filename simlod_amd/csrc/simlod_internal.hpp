@@ -19,7 +19,8 @@ struct Ctl {
 	uint32_t active, batchSize, ringSlot, batchIndex;
 	uint32_t numSpilling;        // spilling leaves found by k_count; NOT modified by k_expand (its early-exit test must be stable)
 	uint32_t numSpilled, dirCount, errors;
-	uint32_t ordinal, abortBatch, barrierCount, pad0;
+	uint32_t ordinal, abortBatch, barrierCount;
+	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
 	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]
 	uint32_t numWork;            // spill-copy work items appended so far in this batch (monotonic)
 	uint32_t pad1;
@@ -27,6 +28,8 @@ struct Ctl {
 	uint32_t workSnap[2];
 	uint64_t startNs;
 	uint32_t statCounters[8];
+	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish)
+	uint64_t expandNs[8];              // byte 144: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls); tools/kprof.py
 };
 
 struct BuildArgs {
@@ -40,7 +43,7 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offParent, offNodeDir, offChunkDir, offWork, offLeafOf, offWin, offSpilled;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offWork, offLeafOf, offWin, offSpilled;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
 };
 

@@ -226,6 +226,7 @@ class DeviceOctree:
         st = np.zeros(1, dtype=abi.stats_dtype) if stats is None else np.array(stats, dtype=abi.stats_dtype).reshape(1).copy()
         st["numNodes"] = num_nodes
         self.stats.copy_(torch.from_numpy(st.view(np.uint8).reshape(-1)))
+        self.momentary[:4096].zero_()          # control block: the builder's side tables describe the previous octree
 
     def download_image(self):
         """(nodes, persistent, numNodes, device base addresses) — the octree image as host arrays, pointers untouched."""
