@@ -101,6 +101,18 @@ typedef struct SimlodProfileEntry {
 int simlod_profile_enable(int on);
 int simlod_profile_collect(SimlodProfileEntry* out, int capacity, int* count);
 
+/* ---- loader side -------------------------------------------------------------------------------
+ * Replaces the parse loop of loadLasNative (modules/progressive_octree/LasLoader.cpp:169-227, called by the loader threads at
+ * main_progressive_octree.cpp:866-870): `records` = numPoints raw LAS point records of bytesPerPoint bytes each, in DEVICE
+ * memory (16-byte aligned), exactly the bytes the reference reads from offsetToPointData + bytesPerPoint * firstPoint;
+ * `format` = LasHeader.format (RGB is taken for 2, 3, 5 and 7, as in the reference); scale = LasHeader.scale;
+ * offset[k] = LasHeader.offset[k] + translation[k] (the sum the reference forms at LasLoader.cpp:197-199, translation = -boxMin).
+ * out = numPoints Points, e.g. a slot of the batch ring.  Positions and r,g,b are bit-identical to the reference's; alpha,
+ * which the reference leaves uninitialised, is 255.  Returns 0 or a hipError_t (invalid value: bytesPerPoint outside [12, 255],
+ * RGB beyond the record, misaligned pointers). */
+int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format,
+                      const double scale[3], const double offset[3], SimlodPoint* out, void* stream);
+
 /* Version / build info string (static storage). */
 const char* simlod_build_info(void);
 

@@ -234,3 +234,64 @@ def check_invariants(nodes, num_nodes):
     rule = port_lib().oracle_check_invariants(_ptr(nodes), num_nodes, *[ctypes.c_void_p(tot.ctypes.data + 8 * k) for k in range(5)])
     assert rule == 0, f"octree image violates structural rule #{rule} (oracle/oracle_support.c: oracle_check_invariants)"
     return dict(points=int(tot[0]), voxels=int(tot[1]), point_chunks=int(tot[2]), voxel_chunks=int(tot[3]), grids=int(tot[4]))
+
+
+# ---- loader row: LAS point records -> Points ----------------------------------------------------------
+_REF_LAS = os.path.join(_HERE, "_ref", "libref_las.so")
+
+
+def have_ref_las():
+    return os.path.exists(_REF_LAS)
+
+
+class _RefLasHeader(ctypes.Structure):
+    _fields_ = [("versionMajor", ctypes.c_int32), ("versionMinor", ctypes.c_int32), ("headerSize", ctypes.c_uint64),
+                ("offsetToPointData", ctypes.c_uint64), ("format", ctypes.c_uint64), ("bytesPerPoint", ctypes.c_uint64),
+                ("numPoints", ctypes.c_uint64), ("scale", ctypes.c_double * 3), ("offset", ctypes.c_double * 3),
+                ("min", ctypes.c_double * 3), ("max", ctypes.c_double * 3)]
+
+
+def ref_las_header(path):
+    """The reference's own loadHeader (LasLoader.h:21-55) through oracle/_ref/libref_las.so, as a dict."""
+    lib = ctypes.CDLL(_REF_LAS)
+    h = _RefLasHeader()
+    lib.ref_las_header(path.encode(), ctypes.byref(h))
+    return {k: (tuple(getattr(h, k)) if k in ("scale", "offset", "min", "max") else int(getattr(h, k))) for k, _ in _RefLasHeader._fields_}
+
+
+def ref_las_load(path, first, count, translation):
+    """The reference's own loadLasNative (LasLoader.cpp:169-227).  Returns `count` Points pre-filled with 0xAA bytes: the
+    reference never writes alpha nor, for formats without colour, r/g/b — those bytes come back as it happened to leave them."""
+    lib = ctypes.CDLL(_REF_LAS)
+    out = np.full(count * 16, 0xAA, dtype=np.uint8)
+    t = (ctypes.c_double * 3)(*translation)
+    lib.ref_las_load(path.encode(), ctypes.c_uint64(first), ctypes.c_uint64(count), _ptr(out), t)
+    return out.view(abi.point_dtype)
+
+
+def decode_las_port(records, bytes_per_point, fmt, scale, offset):
+    """numpy restatement of the parse loop LasLoader.cpp:177-225: `records` = raw bytes, offset = header.offset + translation
+    (the caller forms the sum, LasLoader.cpp:197-199).  fp64 multiply, fp64 add, round to fp32; colour channel c > 255 ? c / 256 : c
+    for formats 2, 3, 5, 7.  Undefined-in-the-reference bytes: alpha = 255, colourless formats r = g = b = 0."""
+    rec = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, bytes_per_point)
+    n = len(rec)
+    out = np.zeros(n, dtype=abi.point_dtype)
+    xyz = np.ascontiguousarray(rec[:, 0:12]).view("<i4").reshape(n, 3).astype(np.float64)
+    for k, name in enumerate("xyz"):
+        out[name] = (xyz[:, k] * np.float64(scale[k]) + np.float64(offset[k])).astype(np.float32)
+    rgb_off = 0
+    if fmt == 2:
+        rgb_off = 20
+    elif fmt == 3:
+        rgb_off = 28
+    if fmt == 5:
+        rgb_off = 28
+    if fmt == 7:
+        rgb_off = 30
+    color = np.full(n, 0xff000000, dtype=np.uint32)
+    if rgb_off > 0:
+        c = np.ascontiguousarray(rec[:, rgb_off:rgb_off + 6]).view("<u2").reshape(n, 3).astype(np.uint32)
+        c = np.where(c > 255, c // 256, c)
+        color |= c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)
+    out["color"] = color
+    return out

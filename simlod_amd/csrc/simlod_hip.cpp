@@ -115,6 +115,11 @@ int simlod_launch_construct(const SimlodUniforms* uniforms, SimlodPoint* points,
 	                        numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
 }
 
+int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double scale[3],
+                      const double offset[3], SimlodPoint* out, void* stream) {
+	return launch_decode_las(records, numPoints, bytesPerPoint, format, scale, offset, out, (hipStream_t)stream);
+}
+
 int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms, SimlodNode* nodes, uint32_t* colorbuffer,
                          SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
 	(void)cudaprint;

@@ -73,6 +73,8 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
                      SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream);
+int launch_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double* scale,
+                      const double* offset, SimlodPoint* out, hipStream_t stream);
 int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
                   uint64_t* frameStart, hipStream_t stream);
 

@@ -52,6 +52,8 @@ def lib():
         L.simlod_function_max_active_blocks.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.simlod_launch_cooperative.argtypes = [vp] + [ctypes.c_uint] * 7 + [vp, ctypes.POINTER(vp)]
         L.simlod_build_info.restype = ctypes.c_char_p
+        L.simlod_decode_las.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double), vp, vp]
         _lib = L
     return _lib
 
@@ -60,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "simlod_set_node_capacity", "simlod_render_framebuffer_offset", "simlod_render_buffer_bytes",
     "simlod_construct_buffer_min_bytes", "simlod_launch_reset", "simlod_launch_construct", "simlod_launch_render",
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
-    "simlod_launch_cooperative", "simlod_build_info",
+    "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las",
 ]
 
 
@@ -113,6 +115,7 @@ class DeviceOctree:
         self.frame_start = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.render_buffer = torch.empty(int(self.L.simlod_render_buffer_bytes(max_pixels, 1)), **z)
         self.colorbuffer = torch.zeros(max_pixels, dtype=torch.int32, device=self.device)
+        self.las_stage = None
         self.persistent_bytes, self.momentary_bytes = persistent_bytes, momentary_bytes
         self.uploaded_host = 0
         self.processed_host = 0
@@ -157,6 +160,42 @@ class DeviceOctree:
         self.batch_sizes[slot] = n
         self.uploaded_host += 1
         self.num_uploaded.fill_(self.uploaded_host)
+
+    def upload_las(self, records, header, translation):
+        """One batch of RAW LAS point records (uint8 host array or device tensor) into the next ring slot, decoded on the
+        device (simlod_decode_las); translation = -boxMin as at main_progressive_octree.cpp:868."""
+        from . import lasio
+        bpp = int(header.bytesPerPoint)
+        raw = records if isinstance(records, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(records).reshape(-1))
+        n = raw.numel() // bpp
+        assert n <= abi.MAX_BATCH_SIZE
+        slot = self.uploaded_host % abi.BATCH_STREAM_SIZE
+        assert slot < self.ring_slots, "ring smaller than BATCH_STREAM_SIZE: consume before uploading more"
+        if self.las_stage is None or self.las_stage.numel() < raw.numel():
+            self.las_stage = torch.empty(max(raw.numel(), 1 << 20), dtype=torch.uint8, device=self.device)
+        self.las_stage[: raw.numel()].copy_(raw.reshape(-1).view(torch.uint8), non_blocking=True)
+        scale = (ctypes.c_double * 3)(*header.scale)
+        offset = (ctypes.c_double * 3)(*lasio.decode_offset(header, translation))
+        dst = self.ring.data_ptr() + slot * abi.MAX_BATCH_SIZE * 16
+        _check(self.L.simlod_decode_las(self._p(self.las_stage), ctypes.c_uint64(n), ctypes.c_uint32(bpp), ctypes.c_uint32(int(header.format)),
+                                        scale, offset, ctypes.c_void_p(dst), self._stream()), "simlod_decode_las")
+        self.batch_sizes[slot] = n
+        self.uploaded_host += 1
+        self.num_uploaded.fill_(self.uploaded_host)
+
+    def add_las(self, uniforms, path, translation=None, batch=abi.MAX_BATCH_SIZE):
+        """Stream a LAS file through the ring: read raw bytes, decode on the device, ingest."""
+        from . import lasio
+        h = lasio.load_header(path)
+        t = tuple(-float(v) for v in h.min) if translation is None else translation
+        for first, count in lasio.batches(h, batch):
+            if self.uploaded_host - self.processed_host >= self.ring_slots:
+                self.drain(uniforms)
+                self.processed_host = self.uploaded_host
+            self.upload_las(lasio.read_records(path, h, first, count), h, t)
+        self.drain(uniforms)
+        self.processed_host = self.uploaded_host
+        return h
 
     def construct(self, uniforms):
         u, up = self._u(uniforms)
