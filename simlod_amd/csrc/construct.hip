@@ -43,6 +43,24 @@ struct NodeDir {          // per node, valid for the batch whose tag it carries
 static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
 static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
 
+// Ancestor paths: PATH_WORDS 64-bit entries per node, entry k = the k-th ancestor (parent first), zero-terminated.
+// An entry packs everything `sample` and `insert` need to know about that ancestor — its occupancy grid (offset into the
+// persistent buffer), level and node index — so a sample reads its whole root path with independent loads instead of chasing
+// parent -> node -> grid pointers level by level (the chain of dependent L2 round trips that bounded k_sample).
+// Rebuilt for every node at the start of a launch (k_paths), extended for the eight children at a split (k_expand).
+static constexpr uint32_t PATH_WORDS = SIMLOD_MAX_DEPTH + 1;
+static constexpr unsigned long long PATH_VALID = 1ull << 63;
+
+__device__ __forceinline__ unsigned long long path_pack(const uint8_t* pers, uint32_t nodeIdx, uint32_t level, const SimlodOccupancyGrid* grid) {
+	const unsigned long long off = (unsigned long long)(reinterpret_cast<const uint8_t*>(grid) - pers) >> 4;     // grids are 16-byte aligned allocations
+	return PATH_VALID | ((unsigned long long)nodeIdx << 41) | ((unsigned long long)level << 36) | off;
+}
+__device__ __forceinline__ uint32_t path_node(unsigned long long e) { return (uint32_t)(e >> 41) & 0x7ffffu; }
+__device__ __forceinline__ uint32_t path_level(unsigned long long e) { return (uint32_t)(e >> 36) & 31u; }
+__device__ __forceinline__ SimlodOccupancyGrid* path_grid(uint8_t* pers, unsigned long long e) {
+	return reinterpret_cast<SimlodOccupancyGrid*>(pers + ((e & 0xfffffffffull) << 4));
+}
+
 __device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
 template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
 
@@ -120,6 +138,21 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 		const SimlodChunk* c = n->points;
 		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
 	}
+}
+
+// ---- paths: every node's ancestor list, from the parent table (one thread per node, depth <= 20 steps) ---------------------
+__global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= numNodes) return;
+	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
+	unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
+	uint32_t k = 0;
+	for (uint32_t cur = parentOf[i]; cur != 0xffffffffu && k < PATH_WORDS - 1; cur = parentOf[cur]) {
+		const SimlodNode* n = a.nodes + cur;
+		rec[k++] = path_pack(a.pers, cur, n->level, n->grid);
+	}
+	rec[k] = 0;
 }
 
 // ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
@@ -209,6 +242,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
 	SpillWork* work = at<SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
@@ -256,7 +290,8 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			const uint32_t level = node->level;
 			if (threadIdx.x < 8) {                          // the eight children, voxels.cu:318-343
 				const uint32_t i = threadIdx.x;
-				SimlodNode c;
+				// written field by field straight to the node array (a 152-byte local would live in scratch memory)
+				SimlodNode& c = a.nodes[childOffset + i];
 				for (int k = 0; k < 8; k++) c.children[k] = nullptr;
 				c.counter = 0; c.numPoints = 0;
 				c.level = level + 1;
@@ -265,13 +300,21 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				c.Z = 2 * node->Z + (i & 1u);
 				c.countIteration = 0; c.countFlag = 0;
 				for (int k = 0; k < 20; k++) c.name[k] = node->name[k];
-				if (c.level < 20) c.name[c.level] = (uint8_t)('0' + i);
+				if (level + 1 < 20) c.name[level + 1] = (uint8_t)('0' + i);
 				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
 				c.grid = nullptr; c.points = nullptr; c.voxelChunks = nullptr;
 				c.numVoxels = 0; c.numVoxelsStored = 0;
-				a.nodes[childOffset + i] = c;
 				node->children[i] = a.nodes + childOffset + i;
 				parentOf[childOffset + i] = nodeIdx;
+				// the child's ancestors: this node (its grid is final now), then this node's own ancestors
+				const unsigned long long* mine = paths + (uint64_t)nodeIdx * PATH_WORDS;
+				unsigned long long* theirs = paths + (uint64_t)(childOffset + i) * PATH_WORDS;
+				theirs[0] = path_pack(a.pers, nodeIdx, level, sh_grid);
+				for (uint32_t k = 0; k + 1 < PATH_WORDS; k++) {
+					const unsigned long long e = k + 2 < PATH_WORDS ? mine[k] : 0ull;
+					theirs[k + 1] = e;
+					if (e == 0ull) break;
+				}
 			}
 			if (threadIdx.x >= 64 && threadIdx.x < 128) {
 				// Wave 1 turns every chunk of the leaf into a work item and hands the chunks back to the recycle stack
@@ -434,12 +477,13 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
-	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
+	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
 	const uint32_t numChunks = (total + SPB - 1) / SPB;
 	table_init(tbl);                                   // lives for the whole workgroup: no barrier inside the chunk loop
 	for (uint32_t i = threadIdx.x; i < (uint32_t)SET_CAP; i += TPB) claimed[i] = TBL_EMPTY;
 	__syncthreads();
+	constexpr int WIN = 3;                             // ancestors fetched and probed together
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 #pragma unroll 1
 		for (uint32_t j = 0; j < SPT; j++) {
@@ -452,28 +496,46 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
 			// the leaf was cached by count/expand; grids live in the inner nodes above it (and in a root that is still a leaf)
 			const uint32_t leafIdx = leafOf[idx];
-			uint32_t nodeIdx = leafIdx == 0u ? 0u : parentOf[leafIdx];
+			const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
 			uint32_t wins = 0;
+			bool go = true;
 #pragma unroll 1
-			while (nodeIdx != 0xffffffffu) {
-				SimlodNode* node = a.nodes + nodeIdx;
-				const uint32_t level = node->level;
-				if (level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) break;    // voxels.cu:449: the traverse loop samples levels 0..19 only
-				SimlodOccupancyGrid* grid = node->grid;
-				if (grid == nullptr) break;                                              // voxels.cu:56
-				const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
-				const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
-				const uint32_t cell = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-				const uint32_t bit = cell & 31u;
-				uint32_t* word = &grid->values[cell >> 5];
-				if (((*word >> bit) & 1u) != 0u) break;                                  // voxels.cu:93-94; the ancestors are set as well
-				uint32_t rank;
-				const int e = table_add(tbl, nodeIdx, 0u, &rank);
-				if (e >= 0 && !set_insert(claimed, ((uint32_t)e << 21) | cell)) break;  // a sample of this workgroup already claims the cell
-				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) break;              // voxels.cu:96; lost: the winner climbs on
-				wins |= 1u << level;                                                     // first point in the cell, voxels.cu:99
-				if (e >= 0) atomicAdd(&tbl.vals[e], 1u); else atomicAdd(&node->numVoxels, 1u);   // voxels.cu:101
-				nodeIdx = parentOf[nodeIdx];
+			for (uint32_t k0 = 0; go && k0 < PATH_WORDS - 1; k0 += WIN) {
+				unsigned long long ent[WIN];
+				uint32_t* word[WIN];
+				uint32_t seen[WIN], cell[WIN];
+#pragma unroll
+				for (int w = 0; w < WIN; w++) {              // independent loads: the entries ...
+					if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; ent[w] = (k0 + w == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
+					else ent[w] = k0 + w < PATH_WORDS - 1 ? rec[k0 + w] : 0ull;
+				}
+#pragma unroll
+				for (int w = 1; w < WIN; w++) if (ent[w - 1] == 0ull) ent[w] = 0ull;   // what lies behind the terminator was never written
+#pragma unroll
+				for (int w = 0; w < WIN; w++) {              // ... then the occupancy words of all of them
+					const uint32_t level = path_level(ent[w]);
+					const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
+					const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
+					cell[w] = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+					word[w] = &path_grid(a.pers, ent[w])->values[cell[w] >> 5];
+					// voxels.cu:449: the traverse loop samples levels 0..19 only; spilled samples start at the spilling node's level
+					if (ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { ent[w] = 0ull; seen[w] = 0u; }
+					else seen[w] = *word[w];        // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
+				}
+#pragma unroll
+				for (int w = 0; w < WIN; w++) {              // bottom-up: claim while winning
+					if (!go) break;
+					if (ent[w] == 0ull) { go = false; break; }
+					const uint32_t bit = cell[w] & 31u;
+					if (((seen[w] >> bit) & 1u) != 0u) { go = false; break; }               // voxels.cu:93-94; the ancestors are set as well
+					const uint32_t nodeIdx = path_node(ent[w]);
+					uint32_t rank;
+					const int e = table_add(tbl, nodeIdx, 0u, &rank);
+					if (e >= 0 && !set_insert(claimed, ((uint32_t)e << 21) | cell[w])) { go = false; break; }   // a sample of this workgroup already claims the cell
+					if (((atomicOr(word[w], 1u << bit) >> bit) & 1u) != 0u) { go = false; break; }              // voxels.cu:96; lost: the winner climbs on
+					wins |= 1u << path_level(ent[w]);                                       // first point in the cell, voxels.cu:99
+					if (e >= 0) atomicAdd(&tbl.vals[e], 1u); else atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u);   // voxels.cu:101
+				}
 			}
 			winMask[idx] = wins;
 		}
@@ -577,13 +639,17 @@ struct InsertShared {
 };
 
 // cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
-__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, const SimlodNode* node, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
 	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
 	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-	const float nodeSize = a.size / exp2_int(node->level);
-	const float nminx = ((float)node->X + 0.0f) * nodeSize + a.minx;
-	const float nminy = ((float)node->Y + 0.0f) * nodeSize + a.miny;
-	const float nminz = ((float)node->Z + 0.0f) * nodeSize + a.minz;
+	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
+	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
+	const uint32_t nsh = 28u - (uint32_t)level;
+	const uint32_t nX = level == 0 ? 0u : pX >> nsh, nY = level == 0 ? 0u : pY >> nsh, nZ = level == 0 ? 0u : pZ >> nsh;
+	const float nodeSize = a.size / exp2_int((uint32_t)level);
+	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
+	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
+	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
 	float4 v;
 	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
 	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
@@ -604,7 +670,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 	const uint32_t* winMask = at<const uint32_t>(a, a.offWin);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
-	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
+	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
 	const uint32_t tag = ctl->batchIndex + 1u;
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
 	// Three workgroup-wide steps, each over ALL chunks this workgroup owns, so that barriers are paid per workgroup and not
@@ -676,9 +742,9 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
 				uint32_t left = winMask[idx] & 0xfffffu;
 				if (left == 0u) continue;
-				// climb from the cached leaf through its ancestors: the won levels are the deepest ones of the path
+				// the won levels are among the deepest ancestors of the cached leaf: read them off its path
 				const uint32_t leafIdx = leafOf[idx];
-				uint32_t curIdx = leafIdx == 0u ? 0u : parentOf[leafIdx];
+				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
 				float4 p = make_float4(0, 0, 0, 0);
 				uint32_t pX = 0, pY = 0, pZ = 0;
 				if (pass == 1) {
@@ -686,30 +752,30 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
 				}
 #pragma unroll 1
-				while (left != 0u && curIdx != 0xffffffffu) {
-					SimlodNode* cur = a.nodes + curIdx;
-					const int level = (int)cur->level;
-					if ((left >> level) & 1u) {
-						left &= ~(1u << level);
-						if (pass == 0) {
-							uint32_t rank;
-							(void)table_add(sh.tbl, curIdx, 1u, &rank);
-						} else {
-							const int e = table_find(sh.tbl, curIdx);
-							uint32_t slot, base, first;
-							if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
-							else {
-								const NodeDir d = nodeDir[curIdx];
-								slot = atomicAdd(&cur->numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
-							}
-							if (base == 0xffffffffu) raise(ctl, SIMLOD_ERR_NULL_CHUNK);
-							else {
-								SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
-								reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, cur, level, pX, pY, pZ, p.w);
-							}
+				for (uint32_t k = 0; left != 0u && k < PATH_WORDS - 1; k++) {
+					const unsigned long long ent = leafIdx == 0u ? (k == 0 ? PATH_VALID : 0ull) : rec[k];   // a root that is still a leaf samples itself
+					if (ent == 0ull) break;
+					const uint32_t curIdx = path_node(ent);
+					const int level = (int)path_level(ent);
+					if (((left >> level) & 1u) == 0u) continue;
+					left &= ~(1u << level);
+					if (pass == 0) {
+						uint32_t rank;
+						(void)table_add(sh.tbl, curIdx, 1u, &rank);
+					} else {
+						const int e = table_find(sh.tbl, curIdx);
+						uint32_t slot, base, first;
+						if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+						else {
+							const NodeDir d = nodeDir[curIdx];
+							slot = atomicAdd(&a.nodes[curIdx].numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
+						}
+						if (base == 0xffffffffu) raise(ctl, SIMLOD_ERR_NULL_CHUNK);
+						else {
+							SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
+							reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, level, pX, pY, pZ, p.w);
 						}
 					}
-					curIdx = parentOf[curIdx];
 				}
 			}
 		}
@@ -800,6 +866,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
+	off += align_up((uint64_t)nodeCapacity * PATH_WORDS * 8, 256);
 	return off;
 }
 
@@ -814,6 +881,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
+	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	const uint64_t fixedEnd = off;
 	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
@@ -850,6 +918,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)a.nodeCapacity * 4, stream);
 		if (e != hipSuccess) return (int)e;
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
 		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);                            // grid-stride, 8 workgroups per CU
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
@@ -859,6 +928,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			switch (sampleSpt) {
 			case 1: SIMLOD_LAUNCH(k_sample<1>, dim3(gridPoints), dim3(TPB), stream, a); break;
 			case 2: SIMLOD_LAUNCH(k_sample<2>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			case 8: SIMLOD_LAUNCH(k_sample<8>, dim3(gridPoints), dim3(TPB), stream, a); break;
 			default: SIMLOD_LAUNCH(k_sample<4>, dim3(gridPoints), dim3(TPB), stream, a); break;
 			}
 			SIMLOD_LAUNCH(k_alloc, dim3(gridNodes), dim3(TPB), stream, a);

@@ -43,7 +43,7 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offWork, offLeafOf, offWin, offSpilled;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offWin, offSpilled;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
 };
 

@@ -25,7 +25,13 @@ def _device(**kw):
     from simlod_amd.runtime import DeviceOctree
     kw.setdefault("persistent_bytes", 1 << 30)
     kw.setdefault("max_pixels", 1920 * 1080)
-    return DeviceOctree("cuda:0", **kw)
+    dev = DeviceOctree("cuda:0", **kw)
+    # The reference host never clears its momentary / render / persistent buffers (main_progressive_octree.cpp:549-586 only
+    # cuMemAlloc's them): poison them so that any kernel that trusts bytes it did not write itself faults or miscompares here.
+    dev.momentary.fill_(0xA5)
+    dev.render_buffer.fill_(0xA5)
+    dev.persistent.fill_(0xA5)
+    return dev
 
 
 def _ingest(dev, u, batches):

@@ -45,7 +45,7 @@ int main() {
 	const uint32_t maxWords = 64u << 20;   // 256 MB
 	CK(hipMalloc(&buf, (size_t)maxWords * 4)); CK(hipMalloc(&sink, 64)); CK(hipMemset(buf, 0, (size_t)maxWords * 4));
 	const uint32_t n = 1u << 20;
-	for (uint32_t words : {1u << 16, 1u << 20, 36u << 20}) {
+	for (uint32_t words : {64u, 1024u, 6400u, 1u << 16, 1u << 20, 36u << 20}) {
 		printf("region %6.1f MB, %u threads: ", words * 4.0 / 1e6, n);
 		float t;
 		t = run<0, 1>(buf, words, n, sink); printf("ret-atomicOr x1 %.1f us (%.2f G/s) | ", t * 1e3, n / t / 1e6);
