@@ -32,9 +32,9 @@ extern "C" {
 
 /* Stats.dbg bits */
 #define SIMLOD_ERR_MOMENTARY_TOO_SMALL 0x001u /* Uniforms.momentaryBufferCapacity cannot hold the scratch layout   */
-#define SIMLOD_ERR_SPILLED_OVERFLOW    0x002u /* more spilled points in one batch than the scratch can hold        */
-#define SIMLOD_ERR_SPILLING_OVERFLOW   0x004u /* > 100 000 spilling nodes in one round (voxels.cu:847)              */
-#define SIMLOD_ERR_NODES_EXHAUSTED     0x008u /* node array full (main_progressive_octree.cpp:552: 263 157 nodes)   */
+#define SIMLOD_ERR_SPILLED_OVERFLOW    0x002u /* spill space exhausted: some splits were DEFERRED to a later batch (no point lost) */
+#define SIMLOD_ERR_SPILLING_OVERFLOW   0x004u /* > 100 000 spilling nodes in one round (voxels.cu:847): the rest is deferred */
+#define SIMLOD_ERR_NODES_EXHAUSTED     0x008u /* node array full (main_progressive_octree.cpp:552: 263 157 nodes): leaves stop splitting */
 #define SIMLOD_ERR_CHUNK_DIR_OVERFLOW  0x010u /* per-batch chunk directory full                                     */
 #define SIMLOD_ERR_NULL_CHUNK          0x020u /* insert into a leaf without storage (voxels.cu:599-604)             */
 #define SIMLOD_ERR_BARRIER_TIMEOUT     0x040u /* in-kernel grid barrier of the expand phase gave up                 */

@@ -228,10 +228,12 @@ def rebase_image_to(nodes, num_nodes, persistent, old_nodes_base, old_persistent
     return r
 
 
-def check_invariants(nodes, num_nodes):
-    """Structural invariants of a HOST-addressed image; returns dict of totals or raises AssertionError(rule)."""
+def check_invariants(nodes, num_nodes, allow_overfull=False):
+    """Structural invariants of a HOST-addressed image; returns dict of totals or raises AssertionError(rule).
+    allow_overfull: accept leaves above 50 000 points (splits deferred for lack of scratch space)."""
     tot = np.zeros(5, dtype=np.uint64)
-    rule = port_lib().oracle_check_invariants(_ptr(nodes), num_nodes, *[ctypes.c_void_p(tot.ctypes.data + 8 * k) for k in range(5)])
+    rule = port_lib().oracle_check_invariants_ex(_ptr(nodes), num_nodes, *[ctypes.c_void_p(tot.ctypes.data + 8 * k) for k in range(5)],
+                                                 ctypes.c_int(1 if allow_overfull else 0))
     assert rule == 0, f"octree image violates structural rule #{rule} (oracle/oracle_support.c: oracle_check_invariants)"
     return dict(points=int(tot[0]), voxels=int(tot[1]), point_chunks=int(tot[2]), voxel_chunks=int(tot[3]), grids=int(tot[4]))
 

@@ -163,8 +163,10 @@ uint32_t oracle_gather(const SimlodChunk* head, uint32_t count, SimlodPoint* out
 
 /* Structural invariants every octree image must satisfy after a completed kernel_construct, whatever the input was
  * (size-independent properties for the full-size tests).  Returns 0 or the number of the first violated rule. */
-int oracle_check_invariants(const SimlodNode* nodes, uint32_t numNodes, uint64_t* totalPoints, uint64_t* totalVoxels,
-                            uint64_t* pointChunks, uint64_t* voxelChunks, uint64_t* grids) {
+/* allowOverfull: leaves above the 50 000-point limit are legitimate where splits were deferred for lack of scratch space
+ * (the HIP builder's answer to a regime in which the reference drops points). */
+int oracle_check_invariants_ex(const SimlodNode* nodes, uint32_t numNodes, uint64_t* totalPoints, uint64_t* totalVoxels,
+                               uint64_t* pointChunks, uint64_t* voxelChunks, uint64_t* grids, int allowOverfull) {
 	uint64_t tp = 0, tv = 0, pc = 0, vc = 0, g = 0;
 	if (numNodes == 0 || (numNodes - 1) % 8 != 0) return 1;                       /* nodes are created 8 at a time */
 	for (uint32_t i = 0; i < numNodes; i++) {
@@ -184,7 +186,7 @@ int oracle_check_invariants(const SimlodNode* nodes, uint32_t numNodes, uint64_t
 			}
 		} else {
 			if (n->counter != n->numPoints) return 8;                                /* everything counted was stored */
-			if (n->numPoints > SIMLOD_MAX_POINTS_PER_NODE && n->level < SIMLOD_MAX_DEPTH) return 9;
+			if (!allowOverfull && n->numPoints > SIMLOD_MAX_POINTS_PER_NODE && n->level < SIMLOD_MAX_DEPTH) return 9;
 			if (i != 0 && n->grid) return 10;                                        /* only inner nodes and the root own a grid */
 		}
 		if (n->numVoxels != n->numVoxelsStored) return 11;
@@ -205,6 +207,11 @@ int oracle_check_invariants(const SimlodNode* nodes, uint32_t numNodes, uint64_t
 	}
 	*totalPoints = tp; *totalVoxels = tv; *pointChunks = pc; *voxelChunks = vc; *grids = g;
 	return 0;
+}
+
+int oracle_check_invariants(const SimlodNode* nodes, uint32_t numNodes, uint64_t* totalPoints, uint64_t* totalVoxels,
+                            uint64_t* pointChunks, uint64_t* voxelChunks, uint64_t* grids) {
+	return oracle_check_invariants_ex(nodes, numNodes, totalPoints, totalVoxels, pointChunks, voxelChunks, grids, 0);
 }
 
 /* Analysis helper (tools/analyze_candidates.py): for every point of a batch, the deepest grid-owning node of its path, the

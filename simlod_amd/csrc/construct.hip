@@ -89,6 +89,7 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->spilledSnap[0] = ctl->spilledSnap[1] = 0;
 	ctl->workSnap[0] = ctl->workSnap[1] = 0;
 	ctl->numSpilled = 0;
+	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
 	ctl->dirCount = 0;
 	ctl->abortBatch = 0;
 	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
@@ -159,14 +160,20 @@ __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
 static constexpr uint32_t PPT = 4;                 // points per thread per chunk
 static constexpr uint32_t PPB = TPB * PPT;         // points per workgroup chunk
 
-// One arrival-counter update for `cnt` samples (voxels.cu:203-218): exactly one caller sees the counter cross the limit.
+// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  A leaf is queued for splitting by whoever sees its counter
+// cross the limit — or, if it is already over the limit because an earlier batch could not split it (spill space, node array or
+// spill list exhausted: the split is deferred, nothing is lost), by whoever touches it first in this batch.  The exchange on the
+// per-node tag makes that exactly one caller per leaf and batch.
 __device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt, uint32_t* spillList, uint32_t* spillCount) {
 	SimlodNode* leaf = a.nodes + leafIdx;
 	const uint32_t old = atomicAdd(&leaf->counter, cnt);
 	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
-	if (old <= SIMLOD_MAX_POINTS_PER_NODE && old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
-		const uint32_t s = atomicAdd(spillCount, 1u);
-		if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
+	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
+		const uint32_t tag = ctl->batchIndex + 1u;
+		if (atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag) {
+			const uint32_t s = atomicAdd(spillCount, 1u);
+			if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
+		}
 	}
 }
 
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	uint32_t generation = 0;
 
 	__shared__ BlockTable tbl;
-	__shared__ uint32_t sh_childOffset, sh_ok;
+	__shared__ uint32_t sh_childOffset, sh_ok, sh_spillBase;
 	__shared__ uint32_t sh_childCount[8];
 	__shared__ SimlodOccupancyGrid* sh_grid;
 
@@ -274,15 +281,29 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			SimlodNode* node = a.nodes + nodeIdx;
 			__syncthreads();
 			if (threadIdx.x == 0) {
-				uint32_t ok = 1, off = 0;
-				off = atomicAdd(&a.stats->numNodes, 8u);   // voxels.cu:317
-				if (off + 8u > a.nodeCapacity) { atomicSub(&a.stats->numNodes, 8u); raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ctl->abortBatch = 1; ok = 0; }
-				SimlodOccupancyGrid* grid = node->grid;
-				if (ok && grid == nullptr) {               // voxels.cu:363-365
-					grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
-					node->grid = grid;
+				// Reserve eight node slots and the spill space for the stored points TOGETHER (one 64-bit word), before anything is
+				// modified: a leaf that cannot be served now stays a leaf — too full, but intact — and is queued again by a later batch.
+				const uint32_t stored = node->numPoints;
+				uint32_t ok = 1, off = 0, base = 0;
+				unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				for (;;) {
+					off = (uint32_t)(cur >> 32); base = (uint32_t)cur;
+					if (off + 8u > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ok = 0; break; }
+					if ((unsigned long long)base + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ok = 0; break; }
+					const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + (8ull << 32) + stored);
+					if (prev == cur) break;
+					cur = prev;
 				}
-				sh_childOffset = off; sh_ok = ok; sh_grid = grid;
+				SimlodOccupancyGrid* grid = node->grid;
+				if (ok) {
+					atomicAdd(&a.stats->numNodes, 8u);         // voxels.cu:317
+					atomicAdd(&ctl->numSpilled, stored);
+					if (grid == nullptr) {                     // voxels.cu:363-365
+						grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+						node->grid = grid;
+					}
+				}
+				sh_childOffset = off; sh_ok = ok; sh_grid = grid; sh_spillBase = base;
 			}
 			__syncthreads();
 			if (!sh_ok) continue;
@@ -324,30 +345,38 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				SimlodChunk* const head = node->points;
 				// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
 				const uint32_t numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
-				uint32_t spillBase = 0, w0 = 0, ok = 1;
+				const uint32_t spillBase = sh_spillBase;
+				uint32_t w0 = 0;
 				unsigned long long top = 0;
-				if (lane == 0) {
-					spillBase = atomicAdd(&ctl->numSpilled, stored);
-					if (spillBase + stored > a.spilledCap || numChunks > LEAF_SLOTS) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; ok = 0; }
-					if (ok && numChunks > 0) {
-						w0 = atomicAdd(&ctl->numWork, numChunks);
-						top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
-					}
+				if (lane == 0 && numChunks > 0) {
+					w0 = atomicAdd(&ctl->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
+					top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
 				}
-				spillBase = __shfl(spillBase, 0); w0 = __shfl(w0, 0); ok = __shfl(ok, 0);
+				w0 = __shfl(w0, 0);
 				top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
 				SimlodChunk* const* slots = leafChunks + (uint64_t)nodeIdx * LEAF_SLOTS;
-				for (uint32_t ci = lane; ok && ci < numChunks; ci += 64) {
-					SimlodChunk* chunk = slots[ci];
+				auto emit = [&](uint32_t ci, SimlodChunk* chunk) {
 					if (w0 + ci < a.workCap) {
 						SpillWork w;
 						w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
 						w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
 						work[w0 + ci] = w;
-					} else { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ctl->abortBatch = 1; }
-					chunk->next = nullptr;
+					} else raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW);
 					const unsigned long long q = top - numChunks + ci;
 					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+				};
+				SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
+				if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
+				for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
+					SimlodChunk* chunk = slots[ci];
+					emit(ci, chunk);
+					chunk->next = nullptr;
+				}
+				if (lane == 0) for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
+					SimlodChunk* next = beyond->next;
+					emit(ci, beyond);
+					beyond->next = nullptr;
+					beyond = next;
 				}
 				if (lane == 0) {
 					node->numPoints = 0;
@@ -862,7 +891,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	uint64_t off = 4096;                                                       // Ctl
 	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	off += 2 * align_up((uint64_t)nodeCapacity * 4, 256);                      // splitTag, parentOf
+	off += 3 * align_up((uint64_t)nodeCapacity * 4, 256);                      // splitTag, retryTag, parentOf
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
@@ -877,6 +906,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
 	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
@@ -885,11 +915,12 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	const uint64_t fixedEnd = off;
 	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
-	if (capacity < off + perBatch + (uint64_t)SPILLING_CAPACITY * 32 + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch; return false; }
-	uint64_t cap = (capacity - off - perBatch - (uint64_t)SPILLING_CAPACITY * 32 - 4096) * 1000 / (24 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
+	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
+	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
+	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (24 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
 	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
 	a.spilledCap = (uint32_t)cap;
-	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + SPILLING_CAPACITY;
+	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 spilled points + one partial chunk per split
 	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
 	(void)fixedEnd;
 	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
@@ -915,7 +946,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 
 	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u);
 	if (fits) {
-		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)a.nodeCapacity * 4, stream);
+		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // splitTag and retryTag
 		if (e != hipSuccess) return (int)e;
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);

@@ -95,7 +95,7 @@ uint64_t simlod_construct_buffer_min_bytes(void) {
 	BuildArgs a{};
 	a.nodeCapacity = node_capacity();
 	layout_construct(a, 0);
-	return a.scratchBytes + 24ull * 65536 + 1024;
+	return a.scratchBytes + 4096 + 26ull * 65536;   // the smallest capacity layout_construct accepts, plus a page of slack
 }
 
 int simlod_launch_reset(const SimlodUniforms* uniforms, uint8_t* buffer_octree, SimlodNode* nodes, SimlodStats* stats,

@@ -28,8 +28,9 @@ struct Ctl {
 	uint32_t workSnap[2];
 	uint64_t startNs;
 	uint32_t statCounters[8];
+	unsigned long long reserve;        // k_expand: nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves both or neither
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish)
-	uint64_t expandNs[8];              // byte 144: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls); tools/kprof.py
+	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls); tools/kprof.py
 };
 
 struct BuildArgs {
@@ -43,7 +44,7 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offWin, offSpilled;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offWin, offSpilled;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
 };
 

@@ -15,7 +15,7 @@ import oracle
 from cases import CASES, H, W, batches_of, case, uniforms_for
 from simlod_amd import abi, camera, synthetic
 from test_golden import load_golden
-from util import (STATS_BUILD_FIELDS, STATS_RENDER_FIELDS, assert_dumps_equal, assert_stats_equal, host_image_of,
+from util import (STATS_BUILD_FIELDS, STATS_RENDER_FIELDS, assert_dumps_equal, assert_stats_equal, host_image_of, points_multiset_hash,
                   voxel_colors_are_member)
 
 pytestmark = pytest.mark.gpu
@@ -123,6 +123,37 @@ def test_too_small_momentary_buffer_is_reported_not_silently_overrun(built_libs)
         dev.construct(u)
     s = dev.read_stats()
     assert int(s["dbg"]) & 0x1 and int(s["batchletIndex"]) == 0
+
+
+def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs):
+    """Scattered input makes hundreds of leaves cross the limit in the same batch.  With a momentary buffer that can hold only
+    a fraction of their stored points (the reference drops points here) the splits that do not fit are deferred:
+    the leaves stay intact, grow past 50 000, and split in a later batch.  Every point must be in the octree, the image must
+    be structurally sound, and once scratch space is plentiful again the late splits must have caught up."""
+    from simlod_amd.runtime import lib
+    n = 6_000_000
+    pts, box = synthetic.uniform_cube(n, seed=99)
+    pts["z"] *= np.float32(0.02)                                  # a slab: ~2-D density, leaves fill up together
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    small = int(lib().simlod_construct_buffer_min_bytes()) + 6_000_000      # ~250 k spilled points per batch instead of millions
+    dev = _device(ring_slots=8, momentary_bytes=small)
+    u = dev.uniforms(W, H, T, box)
+    _ingest(dev, u, [pts[i:i + 1_000_000] for i in range(0, n, 1_000_000)])
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) & ~0x2 == 0, f"unexpected device error bits {int(ds['dbg']):#x}"
+    assert int(ds["dbg"]) & 0x2, "the test is meant to exhaust the spill space"
+    assert int(ds["numPoints"]) == n and int(ds["numPointsProcessed"]) == n
+    nodes, pers, nn = host_image_of(dev)
+    tot = oracle.check_invariants(nodes, nn, allow_overfull=True)
+    assert tot["points"] == n
+    assert voxel_colors_are_member(nodes, nn, pts, box) == int(nodes["numVoxelsStored"][:nn].sum())
+    d = oracle.dump_image(nodes, nn)
+    leaves = d[d["isLeaf"] == 1]
+    assert (leaves["numPoints"] > abi.MAX_POINTS_PER_NODE).any(), "expected leaves whose split is still pending"
+    # the multiset of stored points is the input
+    hs, hx = points_multiset_hash(pts)
+    with np.errstate(over="ignore"):
+        assert hs == np.uint64(d["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(d["pointsXor"])
 
 
 # ---- render --------------------------------------------------------------------------------------------------------------
@@ -249,14 +280,9 @@ def test_full_size_36m_properties(built_libs):
     assert int(s["allocatedBytes_persistent"]) == expect
     # multiset of stored points == multiset of input points (order-independent 128-bit hash, same mixer as oracle_dump)
     d = oracle.dump_image(nodes, nn)
-    w = pts.view(np.uint32).reshape(-1, 4).astype(np.uint64)
-    def mix(x):
-        x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xbf58476d1ce4e5b9); x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94d049bb133111eb)
-        return x ^ (x >> np.uint64(31))
+    hs, hx = points_multiset_hash(pts)
     with np.errstate(over="ignore"):
-        a = (w[:, 0] << np.uint64(32)) | w[:, 1]; b = (w[:, 2] << np.uint64(32)) | w[:, 3]
-        h = mix(a ^ mix(b + np.uint64(0x9e3779b97f4a7c15)))
-        assert np.uint64(h.sum()) == np.uint64(d["pointsSum"].sum()) and np.bitwise_xor.reduce(mix(h + np.uint64(1))) == np.bitwise_xor.reduce(d["pointsXor"])
+        assert hs == np.uint64(d["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(d["pointsXor"])
     # frames
     dev.render(u); f1 = dev.framebuffer(Wd, Hd); r1 = dev.read_stats()
     dev.render(u); f2 = dev.framebuffer(Wd, Hd)

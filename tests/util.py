@@ -69,3 +69,17 @@ def voxel_colors_are_member(nodes, n, points, box_size):
         assert ok.all(), f"node level={lvl} XYZ=({nd['X']},{nd['Y']},{nd['Z']}): {int((~ok).sum())} voxels carry a colour no point of their cell has"
         checked += nv
     return checked
+
+
+def points_multiset_hash(pts):
+    """(sum, xor) order-independent hash of a set of 16-byte points — the same mixer as oracle_dump's pointsSum / pointsXor."""
+    w = pts.view(np.uint32).reshape(-1, 4).astype(np.uint64)
+
+    def mix(x):
+        x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xbf58476d1ce4e5b9); x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94d049bb133111eb)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        a = (w[:, 0] << np.uint64(32)) | w[:, 1]
+        b = (w[:, 2] << np.uint64(32)) | w[:, 3]
+        h = mix(a ^ mix(b + np.uint64(0x9e3779b97f4a7c15)))
+        return np.uint64(h.sum()), np.bitwise_xor.reduce(mix(h + np.uint64(1)))
