@@ -16,7 +16,7 @@ The raster half of the metric is measured right after, on the octree of the last
 1920x1080 (HQS, the reference's default, and plain) and reported under "raster".
 
 N>1 (weak scaling): every rank owns a spatial sub-octree (its own 36 M-point terrain tile) — no data-path collective
-for ingest; a frame is composed with ONE all-reduce(MIN) over the uint64 framebuffers plus an all-gather of the
+for ingest; a frame is composed exactly (distributed.render_frame: MIN/SUM all-reduces between the passes) plus an all-gather of the
 visible-node records, both over RCCL.
 """
 import argparse
@@ -134,23 +134,25 @@ def main():
 
     # ---- raster ------------------------------------------------------------------------------------------------
     from simlod_amd import distributed
-    fb_off = int(L.simlod_render_framebuffer_offset())
 
-    def compose():
-        """One frame across ranks: all-reduce(MIN) of the uint64 framebuffers + all-gather of the visible nodes."""
+    def frame():
+        """One frame: a single launch on one GPU; across ranks the exact composition of distributed.render_frame —
+        HQS: all-reduce(MIN) of the depth plane and all-reduce(SUM) of the colour sums between the passes; plain: all-reduce(MIN)
+        of the uint64 framebuffer; plus the all-gather of the visible-node records."""
         if use_dist:
-            distributed.compose_min(dev.render_buffer[fb_off: fb_off + W * H * 8].view(torch.int64))
-            distributed.gather_visible(dev.render_buffer, 4096, capacity=4096)
+            distributed.render_frame(dev, u)
+        else:
+            dev.render(u)
 
     raster = {}
     for name, hqs in (("hqs", 1), ("plain", 0)):
         u["useHighQualityShading"] = hqs
         for _ in range(2):
-            dev.render(u); compose()
+            frame()
         torch.cuda.synchronize(); barrier()
         t0 = time.perf_counter()
         for _ in range(args.frames):
-            dev.render(u); compose()
+            frame()
         torch.cuda.synchronize(); barrier()
         dtf = time.perf_counter() - t0
         tm = torch.tensor([dtf], dtype=torch.float64, device=dev.device)

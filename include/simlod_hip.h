@@ -69,6 +69,23 @@ int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms /*host
                          uint32_t* colorbuffer, SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint,
                          void* stream);
 
+/* kernel_render in four parts, for frames composed across GPUs (the reference is single-GPU).  Every rank calls the
+ * parts in order on its own octree and reduces the named plane of the render buffer over all ranks in between:
+ *   part 0  clear, visibility, first pass — plain: the 64-bit atomicMin pass and the debug lines; HQS: the depth pass
+ *           HQS: all-reduce(MIN, 32-bit) of the depth plane   [simlod_render_depth_plane_offset, width*height uint32]
+ *   part 1  HQS only: colour pass, sums folded into the sum planes
+ *           HQS: all-reduce(SUM, 32-bit) of the sum planes     [simlod_render_sum_planes_offset, width*height x {R,G,B,count} uint32]
+ *   part 2  HQS only: resolve (render.cu:607-632), then the debug lines
+ *           all-reduce(MIN, 64-bit) of the framebuffer          [simlod_render_framebuffer_offset, width*height uint64; the stored
+ *           words never have the sign bit set, so a signed MIN will do] — for HQS only needed when showBoundingBox is set
+ *   part 3  Stats, EDL, RGBA8 output
+ * With one rank and no reductions the four parts produce exactly the frame of simlod_launch_render. */
+int simlod_launch_render_part(uint32_t part, uint32_t* buffer, const SimlodUniforms* uniforms /*host*/, SimlodNode* nodes,
+                              uint32_t* colorbuffer, SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint,
+                              void* stream);
+uint64_t simlod_render_depth_plane_offset(uint32_t width, uint32_t height);
+uint64_t simlod_render_sum_planes_offset(uint32_t width, uint32_t height);
+
 /* ---- CudaModularProgram-shaped surface ------------------------------------------------------------------- */
 typedef struct SimlodProgram SimlodProgram;
 typedef struct SimlodFunction SimlodFunction;

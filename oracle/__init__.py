@@ -164,6 +164,39 @@ class HostOctree:
             if int(self.stats["batchletIndex"][0]) == before:
                 break
 
+    # -- a frame in parts (oracle_render_part), the CPU stand-in for DeviceOctree in distributed.render_frame ------------------
+    def render_part(self, uniforms, part, edl=False):
+        import torch
+        assert self.kind == "port"
+        u = np.ascontiguousarray(uniforms).reshape(1)
+        W, H = int(u["width"][0]), int(u["height"][0])
+        if part == 0:
+            self._fb = np.zeros(W * H, dtype=np.uint64)
+            self._color = np.zeros(W * H, dtype=np.uint32)
+            self._visible = np.zeros(abi.MAX_VISIBLE_NODES, dtype=abi.node_dtype)
+            self._depth = np.zeros(W * H, dtype=np.uint32)
+            self._sums = np.zeros(W * H * 4, dtype=np.uint32)
+        self.lib.oracle_render_part(self.ctx, _ptr(u), _ptr(self.nodes), _ptr(self.stats), _ptr(self._fb), _ptr(self._color),
+                                    _ptr(self._visible), int(bool(edl)), int(part), _ptr(self._depth), _ptr(self._sums))
+        self.visible = self._visible[: int(self.stats["numVisibleNodes"][0])]
+
+    def depth_plane(self):
+        import torch
+        return torch.from_numpy(self._depth.view(np.int32))
+
+    def sum_planes(self):
+        import torch
+        return torch.from_numpy(self._sums.view(np.int32))
+
+    def framebuffer_words(self):
+        import torch
+        return torch.from_numpy(self._fb.view(np.int64))
+
+    def visible_records(self):
+        import torch
+        n = int(self.stats["numVisibleNodes"][0])
+        return torch.from_numpy(self._visible.view(np.uint8).reshape(-1)), n
+
     def render(self, uniforms, edl=False):
         """Returns (fb uint64[H*W] pre-EDL, color uint32[H*W] as written to the surface)."""
         u = np.ascontiguousarray(uniforms).reshape(1)

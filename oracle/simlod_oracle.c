@@ -752,92 +752,99 @@ void oracle_rasterize_lines(const SimlodUniforms* u, const OVertex* v, uint32_t 
  *   visible    scratch/out, capacity SIMLOD_MAX_VISIBLE_NODES Node copies (render.cu:1108)
  *   edl        0: skip the EDL pass (matches oracle/_ref), 1: EDL over every full 16x16 tile
  */
-void oracle_render(OracleCtx* c, const SimlodUniforms* u, SimlodNode* nodes, SimlodStats* stats,
-                   uint64_t* fb, uint32_t* colorOut, SimlodNode* visible, int edl) {
+/* kernel_render in the four parts of simlod_launch_render_part (include/simlod_hip.h): between the parts a multi-GPU frame reduces
+ * depthPlane (MIN), sumPlanes (SUM) and fb (MIN) over the ranks.  depthPlane: W*H uint32, sumPlanes: W*H x {R,G,B,count} uint32. */
+void oracle_render_part(OracleCtx* c, const SimlodUniforms* u, SimlodNode* nodes, SimlodStats* stats,
+                        uint64_t* fb, uint32_t* colorOut, SimlodNode* visible, int edl, int part, uint32_t* depthPlane, uint32_t* sumPlanes) {
 	int W = (int)u->width, H = (int)u->height;
 	size_t numPixels = (size_t)W * (size_t)H;
-	for (size_t i = 0; i < numPixels; i++) fb[i] = SIMLOD_CLEAR_PIXEL; /* :1126-1131 */
 	float cubeSize = octree_size(u);
 	float cmin[3] = {u->boxMin.x, u->boxMin.y, u->boxMin.z};
-
-	/* compute_visibility_disjunct pass 1, render.cu:762-901 */
-	for (uint32_t i = 0; i < stats->numNodes; i++) {
-		SimlodNode* n = &nodes[i];
-		float nodeSize = cubeSize / ldexpf(1.0f, (int)n->level);
-		float mn[3], mx[3];
-		uint32_t XYZ[3] = {n->X, n->Y, n->Z};
-		for (int a = 0; a < 3; a++) {
-			mn[a] = cmin[a] + ((float)XYZ[a] + 0.0f) * nodeSize;
-			mx[a] = cmin[a] + ((float)XYZ[a] + 1.0f) * nodeSize;
-		}
-		float sx[8], sy[8];
-		for (int k = 0; k < 8; k++) { /* order p000,p001,p010,p011,p100,p101,p110,p111 (:783-790) */
-			float x = (k & 4) ? mx[0] : mn[0], y = (k & 2) ? mx[1] : mn[1], z = (k & 1) ? mx[2] : mn[2];
-			vec4 ndc = xform(&u->transform_updateBound, x, y, z);
-			sx[k] = ((ndc.x / ndc.w) * 0.5f + 0.5f) * u->width;
-			sy[k] = ((ndc.y / ndc.w) * 0.5f + 0.5f) * u->height;
-		}
-		float dx = max8(sx) - min8(sx), dy = max8(sy) - min8(sy);
-		int vis = intersects_frustum(&u->transform_updateBound, mn, mx) && (n->numPoints > 0 || n->numVoxels > 0);
-		n->visible = (uint8_t)vis;
-		n->isLarge = (uint8_t)(((double)dx > 2.0 * (double)u->minNodeSize) || ((double)dy > 2.0 * (double)u->minNodeSize));
-	}
-	/* pass 2, render.cu:906-933 + makeVisible :746-756 */
-	uint32_t numVisible = 0, visPoints = 0, visVoxels = 0, visInner = 0, visLeaves = 0;
-	for (uint32_t i = 0; i < stats->numNodes; i++) {
-		SimlodNode* n = &nodes[i];
-		SimlodNode* emit[8]; int ne = 0;
-		if (n->isLarge && !node_is_leaf(n)) {
-			for (int k = 0; k < 8; k++) {
-				SimlodNode* ch = n->children[k];
-				if (ch && !ch->isLarge && ch->visible) emit[ne++] = ch;
+	RenderEnv r; r.u = u; r.fb = fb; r.W = W; r.H = H; r.fbDepth = depthPlane; r.fbColor = sumPlanes;
+	const int hqs = u->useHighQualityShading != 0;
+	if (part == 0) {
+		for (size_t i = 0; i < numPixels; i++) fb[i] = SIMLOD_CLEAR_PIXEL; /* :1126-1131 */
+		/* compute_visibility_disjunct pass 1, render.cu:762-901 */
+		for (uint32_t i = 0; i < stats->numNodes; i++) {
+			SimlodNode* n = &nodes[i];
+			float nodeSize = cubeSize / ldexpf(1.0f, (int)n->level);
+			float mn[3], mx[3];
+			uint32_t XYZ[3] = {n->X, n->Y, n->Z};
+			for (int a = 0; a < 3; a++) {
+				mn[a] = cmin[a] + ((float)XYZ[a] + 0.0f) * nodeSize;
+				mx[a] = cmin[a] + ((float)XYZ[a] + 1.0f) * nodeSize;
 			}
-		} else if (n->isLarge && node_is_leaf(n) && n->visible) {
-			emit[ne++] = n;
+			float sx[8], sy[8];
+			for (int k = 0; k < 8; k++) { /* order p000,p001,p010,p011,p100,p101,p110,p111 (:783-790) */
+				float x = (k & 4) ? mx[0] : mn[0], y = (k & 2) ? mx[1] : mn[1], z = (k & 1) ? mx[2] : mn[2];
+				vec4 ndc = xform(&u->transform_updateBound, x, y, z);
+				sx[k] = ((ndc.x / ndc.w) * 0.5f + 0.5f) * u->width;
+				sy[k] = ((ndc.y / ndc.w) * 0.5f + 0.5f) * u->height;
+			}
+			float dx = max8(sx) - min8(sx), dy = max8(sy) - min8(sy);
+			int vis = intersects_frustum(&u->transform_updateBound, mn, mx) && (n->numPoints > 0 || n->numVoxels > 0);
+			n->visible = (uint8_t)vis;
+			n->isLarge = (uint8_t)(((double)dx > 2.0 * (double)u->minNodeSize) || ((double)dy > 2.0 * (double)u->minNodeSize));
 		}
-		for (int k = 0; k < ne; k++) {
-			if (numVisible >= SIMLOD_MAX_VISIBLE_NODES) { if (c) c->lastError = ORACLE_ERR_VISIBLE; break; }
-			visible[numVisible++] = *emit[k];
-			if (emit[k]->numPoints > 0) { visLeaves++; visPoints += emit[k]->numPoints; }
-			else if (emit[k]->numVoxels > 0) { visInner++; visVoxels += emit[k]->numVoxels; }
+		/* pass 2, render.cu:906-933 + makeVisible :746-756 */
+		uint32_t numVisible = 0, visPoints = 0, visVoxels = 0, visInner = 0, visLeaves = 0;
+		for (uint32_t i = 0; i < stats->numNodes; i++) {
+			SimlodNode* n = &nodes[i];
+			SimlodNode* emit[8]; int ne = 0;
+			if (n->isLarge && !node_is_leaf(n)) {
+				for (int k = 0; k < 8; k++) {
+					SimlodNode* ch = n->children[k];
+					if (ch && !ch->isLarge && ch->visible) emit[ne++] = ch;
+				}
+			} else if (n->isLarge && node_is_leaf(n) && n->visible) {
+				emit[ne++] = n;
+			}
+			for (int k = 0; k < ne; k++) {
+				if (numVisible >= SIMLOD_MAX_VISIBLE_NODES) { if (c) c->lastError = ORACLE_ERR_VISIBLE; break; }
+				visible[numVisible++] = *emit[k];
+				if (emit[k]->numPoints > 0) { visLeaves++; visPoints += emit[k]->numPoints; }
+				else if (emit[k]->numVoxels > 0) { visInner++; visVoxels += emit[k]->numVoxels; }
+			}
 		}
-	}
-
-	RenderEnv r; r.u = u; r.fb = fb; r.W = W; r.H = H; r.fbDepth = NULL; r.fbColor = NULL;
-	if (u->showPoints) {
-		if (!u->useHighQualityShading) { /* drawNodes, render.cu:161-210 */
+		stats->numVisibleNodes = numVisible; stats->numVisibleInner = visInner; stats->numVisibleLeaves = visLeaves;
+		stats->numVisiblePoints = visPoints; stats->numVisibleVoxels = visVoxels;
+		if (u->showPoints && !hqs) { /* drawNodes, render.cu:161-210 */
 			for (uint32_t i = 0; i < numVisible; i++) {
 				for_each_sample(&visible[i], visible[i].points, visible[i].numPoints, draw_point, &r);
 				for_each_sample(&visible[i], visible[i].voxelChunks, visible[i].numVoxels, draw_point, &r);
 			}
-		} else { /* drawNodesHQS, render.cu:212-635 */
-			r.fbDepth = (uint32_t*)malloc(numPixels * 4);
-			r.fbColor = (uint32_t*)calloc(numPixels * 4, 4);
-			for (size_t i = 0; i < numPixels; i++) r.fbDepth[i] = 0x7f800000u;
-			for (uint32_t i = 0; i < numVisible; i++) {
+		}
+		if (hqs) {
+			for (size_t i = 0; i < numPixels; i++) { depthPlane[i] = 0x7f800000u; sumPlanes[4 * i] = sumPlanes[4 * i + 1] = sumPlanes[4 * i + 2] = sumPlanes[4 * i + 3] = 0; }
+			if (u->showPoints) for (uint32_t i = 0; i < numVisible; i++) { /* drawNodesHQS depth pass, render.cu:212-388 */
 				for_each_sample(&visible[i], visible[i].points, visible[i].numPoints, hqs_depth, &r);
 				if (visible[i].numVoxels > 0) for_each_sample(&visible[i], visible[i].voxelChunks, visible[i].numVoxels, hqs_depth, &r);
 			}
-			for (uint32_t i = 0; i < numVisible; i++) {
-				for_each_sample(&visible[i], visible[i].points, visible[i].numPoints, hqs_color, &r);
-				if (visible[i].numVoxels > 0) for_each_sample(&visible[i], visible[i].voxelChunks, visible[i].numVoxels, hqs_color, &r);
-			}
-			for (size_t i = 0; i < numPixels; i++) { /* resolve, :607-632 */
-				uint32_t C = r.fbColor[4 * i + 3];
-				if (C == 0) continue;
-				uint32_t color = ((r.fbColor[4 * i + 0] / C) & 0xff) | (((r.fbColor[4 * i + 1] / C) & 0xff) << 8)
-				               | (((r.fbColor[4 * i + 2] / C) & 0xff) << 16) | (255u << 24);
-				fb[i] = ((uint64_t)r.fbDepth[i] << 32) | color;
-			}
-			free(r.fbDepth); free(r.fbColor);
-		}
+		} else if (u->showBoundingBox) draw_debug_lines(u, visible, numVisible, cubeSize, cmin, fb, W, H);   /* render.cu:1197-1235 */
+		return;
 	}
-	if (u->showBoundingBox) draw_debug_lines(u, visible, numVisible, cubeSize, cmin, fb, W, H);   /* render.cu:1197-1235 */
-	/* stats, render.cu:1244-1252 */
-	stats->numVisibleNodes = numVisible; stats->numVisibleInner = visInner; stats->numVisibleLeaves = visLeaves;
-	stats->numVisiblePoints = visPoints; stats->numVisibleVoxels = visVoxels;
-	stats->frameID = (uint32_t)u->frameCounter;
-
+	const uint32_t numVisible = stats->numVisibleNodes;
+	if (part == 1) {
+		if (hqs && u->showPoints) for (uint32_t i = 0; i < numVisible; i++) { /* colour pass, render.cu:447-599 */
+			for_each_sample(&visible[i], visible[i].points, visible[i].numPoints, hqs_color, &r);
+			if (visible[i].numVoxels > 0) for_each_sample(&visible[i], visible[i].voxelChunks, visible[i].numVoxels, hqs_color, &r);
+		}
+		return;
+	}
+	if (part == 2) {
+		if (!hqs) return;
+		if (u->showPoints) for (size_t i = 0; i < numPixels; i++) { /* resolve, :607-632 */
+			uint32_t C = r.fbColor[4 * i + 3];
+			if (C == 0) continue;
+			uint32_t color = ((r.fbColor[4 * i + 0] / C) & 0xff) | (((r.fbColor[4 * i + 1] / C) & 0xff) << 8)
+			               | (((r.fbColor[4 * i + 2] / C) & 0xff) << 16) | (255u << 24);
+			fb[i] = ((uint64_t)r.fbDepth[i] << 32) | color;
+		}
+		if (u->showBoundingBox) draw_debug_lines(u, visible, numVisible, cubeSize, cmin, fb, W, H);   /* render.cu:1197-1235 */
+		return;
+	}
+	stats->frameID = (uint32_t)u->frameCounter;   /* stats, render.cu:1244-1252 (the visible counters were stored by part 0) */
+	(void)c;
 	if (!colorOut) return;
 	for (size_t i = 0; i < numPixels; i++) colorOut[i] = (uint32_t)(fb[i] & 0xffffffffull);
 	if (edl) { /* render.cu:1255-1325 on every full tile; reads depth from fb (unchanged by the pass) */
@@ -868,4 +875,13 @@ void oracle_render(OracleCtx* c, const SimlodUniforms* u, SimlodNode* nodes, Sim
 			colorOut[pixelID] = R | (G << 8) | (B << 16) | (255u << 24);
 		}
 	}
+}
+
+void oracle_render(OracleCtx* c, const SimlodUniforms* u, SimlodNode* nodes, SimlodStats* stats,
+                   uint64_t* fb, uint32_t* colorOut, SimlodNode* visible, int edl) {
+	size_t numPixels = (size_t)(int)u->width * (size_t)(int)u->height;
+	uint32_t* depth = u->useHighQualityShading ? (uint32_t*)malloc(numPixels * 4) : NULL;
+	uint32_t* sums = u->useHighQualityShading ? (uint32_t*)malloc(numPixels * 16) : NULL;
+	for (int part = 0; part < 4; part++) oracle_render_part(c, u, nodes, stats, fb, colorOut, visible, edl, part, depth, sums);
+	free(depth); free(sums);
 }

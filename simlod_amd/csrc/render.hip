@@ -562,6 +562,21 @@ __global__ __launch_bounds__(TPB) void r_resolve(RenderArgs a) {
 	}
 }
 
+// ---- multi-GPU HQS: fold the packed per-pixel sums into the {R, G, B, count} plane, so that ranks can all-reduce(SUM) it ---------
+__global__ __launch_bounds__(TPB) void r_unpack(RenderArgs a) {
+	unsigned long long* packed = reinterpret_cast<unsigned long long*>(a.mom + a.offColor);
+	uint4* sums = reinterpret_cast<uint4*>(a.mom + a.offOverflow);
+	const uint32_t stride = gridDim.x * TPB;
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) {
+		const unsigned long long pk = packed[i];
+		if (pk == 0ull) continue;
+		uint4 s = sums[i];
+		s.x += (uint32_t)((pk >> 28) & 0x3fffu); s.y += (uint32_t)((pk >> 14) & 0x3fffu); s.z += (uint32_t)(pk & 0x3fffu); s.w += (uint32_t)(pk >> 42);
+		sums[i] = s;
+		packed[i] = 0ull;
+	}
+}
+
 // ---- output: Stats (render.cu:1244-1252), EDL (:1255-1325, every full 16x16 tile), surface write (:1334-1343) ---------
 __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
 	const uint64_t* fb = reinterpret_cast<const uint64_t*>(a.mom + R_OFF_FB);
@@ -652,8 +667,25 @@ int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, Siml
 	return (int)hipGetLastError();
 }
 
+static void render_plane_offsets(uint64_t numPixels, uint64_t& offWork, uint64_t& offItems, uint64_t& offDepth, uint64_t& offColor, uint64_t& offOverflow) {
+	offWork = R_OFF_FB + align16(numPixels * 8);
+	offItems = offWork + 256;
+	offDepth = offItems + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem);
+	offColor = offDepth + align16(numPixels * 4);
+	offOverflow = offColor + align16(numPixels * 8);
+}
+
+uint64_t render_depth_plane_offset(uint32_t width, uint32_t height) {
+	uint64_t w, i, d, c, o; render_plane_offsets((uint64_t)width * height, w, i, d, c, o); return d;
+}
+uint64_t render_sum_planes_offset(uint32_t width, uint32_t height) {
+	uint64_t w, i, d, c, o; render_plane_offsets((uint64_t)width * height, w, i, d, c, o); return o;
+}
+
+// parts: bit 0 = clear, visibility, draw items and the first pass (plain: the only pass, and the debug lines; HQS: depth)
+//        bit 1 = HQS colour pass, sums unpacked        bit 2 = HQS resolve, then the debug lines        bit 3 = Stats, EDL, RGBA8 output
 int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
-                  uint64_t* frameStart, hipStream_t stream) {
+                  uint64_t* frameStart, hipStream_t stream, uint32_t parts) {
 	RenderArgs a{};
 	a.mom = reinterpret_cast<uint8_t*>(buffer); a.nodes = nodes; a.stats = stats; a.colorbuffer = colorbuffer; a.frameStart = frameStart;
 	a.transform = u->transform; a.transformUpdate = u->transform_updateBound;
@@ -669,34 +701,37 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.nodeCapacity = node_capacity();
 	a.frameCounter = (uint32_t)u->frameCounter;
 	a.showPoints = u->showPoints; a.colorByNode = u->colorByNode; a.colorByLOD = u->colorByLOD; a.hqs = u->useHighQualityShading;
-	a.offWork = R_OFF_FB + align16((uint64_t)a.numPixels * 8);
-	a.offItems = a.offWork + 256;
+	render_plane_offsets(a.numPixels, a.offWork, a.offItems, a.offDepth, a.offColor, a.offOverflow);
 	a.itemCap = MAX_DRAW_ITEMS;
 	a.useTiles = (uint32_t)tune("SIMLOD_RASTER_LDS_TILES", 1);
-	a.offDepth = a.offItems + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem);
-	a.offColor = a.offDepth + align16((uint64_t)a.numPixels * 4);
-	a.offOverflow = a.offColor + align16((uint64_t)a.numPixels * 8);
 
 	const DeviceInfo& dev = device_info();
 	const uint32_t gridPixels = dev.numCUs * 8;
 	const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 	const uint32_t gridDraw = dev.numCUs * 8;
-	SIMLOD_LAUNCH(r_clear, dim3(gridPixels), dim3(TPB), stream, a);
-	SIMLOD_LAUNCH(r_vis1, dim3(gridNodes), dim3(TPB), stream, a);
-	SIMLOD_LAUNCH(r_vis2, dim3(gridNodes), dim3(TPB), stream, a);
-	SIMLOD_LAUNCH(r_items, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a);
-	if (a.hqs) {
-		SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(r_resolve, dim3(gridPixels), dim3(TPB), stream, a);
-	} else {
-		SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(TPB), stream, a);
-	}
-	if (u->showBoundingBox) {
+	const bool whole = parts == RENDER_ALL;
+	auto lines = [&]() {
+		if (!u->showBoundingBox) return;
 		SIMLOD_LAUNCH(r_lines_emit, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a, u->transformInv_updateBound);
 		SIMLOD_LAUNCH(r_lines_raster, dim3((LINE_VERTEX_CAP / 2 + TPB - 1) / TPB), dim3(TPB), stream, a);
+	};
+	if (parts & RENDER_FIRST) {
+		SIMLOD_LAUNCH(r_clear, dim3(gridPixels), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_vis1, dim3(gridNodes), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_vis2, dim3(gridNodes), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_items, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a);
+		if (a.hqs) SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(TPB), stream, a);
+		else { SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(TPB), stream, a); lines(); }
 	}
-	SIMLOD_LAUNCH(r_output, dim3(gridPixels), dim3(TPB), stream, a);
+	if (a.hqs && (parts & RENDER_COLOR)) {
+		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(TPB), stream, a);
+		if (!whole) SIMLOD_LAUNCH(r_unpack, dim3(gridPixels), dim3(TPB), stream, a);     // ranks all-reduce(SUM) the {R,G,B,count} plane
+	}
+	if (a.hqs && (parts & RENDER_RESOLVE)) {
+		SIMLOD_LAUNCH(r_resolve, dim3(gridPixels), dim3(TPB), stream, a);
+		lines();
+	}
+	if (parts & RENDER_OUTPUT) SIMLOD_LAUNCH(r_output, dim3(gridPixels), dim3(TPB), stream, a);
 	if (profile_enabled()) profile_close(stream);
 	return (int)hipGetLastError();
 }

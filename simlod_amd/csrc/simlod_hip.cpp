@@ -124,8 +124,18 @@ int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms, Simlo
                          SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
 	(void)cudaprint;
 	if (!uniforms || !buffer || !nodes || !stats || !frameStartTimestamp) return (int)hipErrorInvalidValue;
-	return launch_render(buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream);
+	return launch_render(buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, RENDER_ALL);
 }
+
+int simlod_launch_render_part(uint32_t part, uint32_t* buffer, const SimlodUniforms* uniforms, SimlodNode* nodes, uint32_t* colorbuffer,
+                              SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
+	(void)cudaprint;
+	if (!uniforms || !buffer || !nodes || !stats || !frameStartTimestamp || part > 3) return (int)hipErrorInvalidValue;
+	return launch_render(buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, 1u << part);
+}
+
+uint64_t simlod_render_depth_plane_offset(uint32_t width, uint32_t height) { return render_depth_plane_offset(width, height); }
+uint64_t simlod_render_sum_planes_offset(uint32_t width, uint32_t height) { return render_sum_planes_offset(width, height); }
 
 static bool ends_with(const std::string& s, const char* suffix) {
 	const size_t n = std::strlen(suffix);

@@ -8,6 +8,7 @@ LOD maths are those of the single-GPU octree.
   render   every rank rasterises its own visible nodes; the frame is the element-wise MIN of the uint64 framebuffers
            (depth bits << 32 | colour, exactly what atomicMin builds on one GPU, render.cu:95-100) — one all-reduce —
            and the visible-node records are all-gathered so every rank holds the merged list (stats, LOD bookkeeping).
+           HQS frames reduce the depth plane (MIN) and the colour sums (SUM) between the passes (render_frame).
 
 All functions take torch tensors living wherever the process group's backend wants them (CUDA for nccl/RCCL, CPU for
 gloo in the tests); nothing here launches kernels.
@@ -64,14 +65,43 @@ def compose_min(framebuffer_u64_as_i64, group=None):
     return framebuffer_u64_as_i64
 
 
+def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
+    """One frame over all ranks, EXACT for plain and for HQS shading: every rank rasterises its own sub-octrees
+    and the ranks reduce the planes between the parts of kernel_render (include/simlod_hip.h, simlod_launch_render_part):
+        part 0 | HQS: all-reduce(MIN) depth | part 1 | HQS: all-reduce(SUM) {R,G,B,count} | part 2 | all-reduce(MIN) framebuffer | part 3
+    so a pixel's average is taken over the samples of ALL ranks within 1 % of the GLOBAL nearest depth, exactly as one GPU holding
+    every sample would.  `renderer` is a runtime.DeviceOctree (RCCL) or, in the CPU tests, an oracle.HostOctree (gloo): anything
+    with render_part / depth_plane / sum_planes / framebuffer_words / visible_records.  Returns (visible records, counts)."""
+    u = np.ascontiguousarray(uniforms).reshape(1)
+    hqs = bool(u["useHighQualityShading"][0])
+    boxes = bool(u["showBoundingBox"][0])
+    renderer.render_part(uniforms, 0)
+    if hqs:
+        dist.all_reduce(renderer.depth_plane(), op=dist.ReduceOp.MIN, group=group)
+        renderer.render_part(uniforms, 1)
+        dist.all_reduce(renderer.sum_planes(), op=dist.ReduceOp.SUM, group=group)
+        renderer.render_part(uniforms, 2)
+    if not hqs or boxes:                       # resolved HQS frames are identical on every rank; only rank-local debug lines differ
+        compose_min(renderer.framebuffer_words(), group=group)
+    renderer.render_part(uniforms, 3)
+    vis, n = renderer.visible_records()
+    return gather_visible(vis, n, group=group, capacity=gather_capacity)
+
+
 def gather_visible(visible_bytes, count, group=None, capacity=4096):
-    """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, capacity, 152], counts)."""
+    """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, capacity, 152], counts).
+    `count` may be a host int or a one-element tensor on the records' device (then nothing synchronises with the host: the
+    first `capacity` records travel as they are and the gathered counts say how many of them are valid)."""
     world = dist.get_world_size(group)
     dev = visible_bytes.device
-    n = min(int(count), capacity)
-    buf = torch.zeros((capacity, 152), dtype=torch.uint8, device=dev)
-    buf[:n] = visible_bytes[: n * 152].view(n, 152)
-    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    if isinstance(count, torch.Tensor):
+        buf = visible_bytes[: capacity * 152].view(capacity, 152).contiguous()
+        cnt = torch.clamp(count.to(torch.int64).reshape(1), max=capacity)
+    else:
+        n = min(int(count), capacity)
+        buf = torch.zeros((capacity, 152), dtype=torch.uint8, device=dev)
+        buf[:n] = visible_bytes[: n * 152].view(n, 152)
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)

@@ -44,6 +44,11 @@ def lib():
         L.simlod_launch_reset.argtypes = [vp] * 8
         L.simlod_launch_construct.argtypes = [vp] * 11
         L.simlod_launch_render.argtypes = [vp] * 8
+        L.simlod_launch_render_part.argtypes = [ctypes.c_uint32] + [vp] * 8
+        L.simlod_render_depth_plane_offset.restype = u64
+        L.simlod_render_depth_plane_offset.argtypes = [u32, u32]
+        L.simlod_render_sum_planes_offset.restype = u64
+        L.simlod_render_sum_planes_offset.argtypes = [u32, u32]
         L.simlod_program_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
         L.simlod_program_destroy.argtypes = [vp]
@@ -62,7 +67,8 @@ EXPORTED_SYMBOLS = [
     "simlod_set_node_capacity", "simlod_render_framebuffer_offset", "simlod_render_buffer_bytes",
     "simlod_construct_buffer_min_bytes", "simlod_launch_reset", "simlod_launch_construct", "simlod_launch_render",
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
-    "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las",
+    "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
+    "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset",
 ]
 
 
@@ -214,6 +220,42 @@ class DeviceOctree:
         _check(self.L.simlod_launch_render(self._p(self.render_buffer), up, self._p(self.nodes), self._p(self.colorbuffer),
                                            self._p(self.stats), self._p(self.frame_start), None, self._stream()), "kernel_render")
         return W, H
+
+    # -- a frame in parts, for composition across GPUs (simlod_launch_render_part; driven by distributed.render_frame) ----------
+    def render_part(self, uniforms, part):
+        u, up = self._u(uniforms)
+        W, H = int(u["width"][0]), int(u["height"][0])
+        need = int(self.L.simlod_render_buffer_bytes(W, H))
+        if self.render_buffer.numel() < need:
+            self.render_buffer = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self.colorbuffer.numel() < W * H:
+            self.colorbuffer = torch.zeros(W * H, dtype=torch.int32, device=self.device)
+        _check(self.L.simlod_launch_render_part(ctypes.c_uint32(part), self._p(self.render_buffer), up, self._p(self.nodes), self._p(self.colorbuffer),
+                                                self._p(self.stats), self._p(self.frame_start), None, self._stream()), "kernel_render part")
+        self._frame_size = (W, H)
+
+    def depth_plane(self):
+        """The HQS depth plane as an int32 view (positive float bits: integer MIN == float MIN)."""
+        W, H = self._frame_size
+        off = int(self.L.simlod_render_depth_plane_offset(W, H))
+        return self.render_buffer[off: off + W * H * 4].view(torch.int32)
+
+    def sum_planes(self):
+        """{R, G, B, count} per pixel as an int32 view."""
+        W, H = self._frame_size
+        off = int(self.L.simlod_render_sum_planes_offset(W, H))
+        return self.render_buffer[off: off + W * H * 16].view(torch.int32)
+
+    def framebuffer_words(self):
+        """depth|colour words as an int64 view (the sign bit is never set)."""
+        W, H = self._frame_size
+        off = int(self.L.simlod_render_framebuffer_offset())
+        return self.render_buffer[off: off + W * H * 8].view(torch.int64)
+
+    def visible_records(self):
+        """(bytes of the visible-node array, number of visible nodes of the last frame as a device tensor — no host sync)."""
+        off = abi.stats_dtype.fields["numVisibleNodes"][1]
+        return self.render_buffer, self.stats[off: off + 4].view(torch.int32)
 
     # -- readback ------------------------------------------------------------------------------------------------
     def read_stats(self):

@@ -14,6 +14,10 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+FRAME_VARIANTS = [("plain", dict(useHighQualityShading=0)), ("hqs", dict(useHighQualityShading=1)),
+                  ("hqs_boxes", dict(useHighQualityShading=1, showBoundingBox=1)), ("hqs_ps2", dict(useHighQualityShading=1, pointSize=2))]
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -48,6 +52,15 @@ def _worker(rank, world, port, out_dir):
     recs, cnts = distributed.gather_visible(vis_bytes, len(o.visible))
     np.save(os.path.join(out_dir, f"fb_{rank}.npy"), t.numpy().view(np.uint64))
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([int(o.stats["numPoints"][0]), int(cnts.sum()), int(o.stats["numVisibleNodes"][0])]))
+    # whole frames through render_frame: plain, HQS (depth MIN / colour SUM between the passes), HQS with bounding boxes
+    for name, kw in FRAME_VARIANTS:
+        uv = u.copy()
+        for k, v in kw.items():
+            uv[k] = v
+        recs, cnts = distributed.render_frame(o, uv)
+        np.save(os.path.join(out_dir, f"frame_{name}_{rank}.npy"), o._fb.copy())
+        np.save(os.path.join(out_dir, f"color_{name}_{rank}.npy"), o._color.copy())
+        assert int(cnts.sum()) == int(np.load(os.path.join(out_dir, f"meta_{rank}.npy"))[1])
     dist.destroy_process_group()
 
 
@@ -74,6 +87,17 @@ def test_two_rank_sharded_ingest_and_min_composition(built_libs, tmp_path):
     diff = int((f0 != fb).sum())
     assert diff == 0, f"{diff} pixels of the composed frame differ from the single-process frame"
     assert int((fb != abi.CLEAR_PIXEL).sum()) > 5000
+    # render_frame: every variant must be the single-process frame, bit for bit, on both ranks
+    for name, kw in FRAME_VARIANTS:
+        uv = u.copy()
+        for k, v in kw.items():
+            uv[k] = v
+        want_fb, want_color = o.render(uv)
+        for rank in range(world):
+            got = np.load(tmp_path / f"frame_{name}_{rank}.npy")
+            bad = int((got != want_fb).sum())
+            assert bad == 0, f"{name}: {bad} pixels of rank {rank}'s composed frame differ from the single-process frame"
+            assert np.array_equal(np.load(tmp_path / f"color_{name}_{rank}.npy"), want_color), name
 
 
 def test_ownership_is_a_partition():

@@ -409,3 +409,84 @@ def test_las_file_to_octree_equals_oracle_on_decoded_points(built_libs, tmp_path
     assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "las")
     nodes, pers, nn = host_image_of(dev)
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "las")
+
+
+# ---- frames in parts / composed across ranks -------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["plain", "hqs", "hqs_boxes", "plain_boxes", "hqs_ps2"])
+def test_render_parts_equal_the_whole_frame_and_two_emulated_ranks_compose_exactly(built_libs, variant):
+    """(1) the four parts of simlod_launch_render_part, run back to back, are simlod_launch_render; (2) two sub-octrees that split the
+    points by top-level octant (distributed.owner_of), rendered in parts with the reductions of distributed.render_frame done by hand
+    on one GPU, give the frame of the single octree that holds every point — plain and HQS, bit for bit."""
+    import torch
+    from simlod_amd import distributed
+    pts, box = synthetic.uniform_cube(800_000, seed=21)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    kw = dict(hqs="hqs" in variant)
+    whole = _device(ring_slots=2)
+    u = whole.uniforms(W, H, T, box, **kw)
+    if "boxes" in variant:
+        u["showBoundingBox"] = 1
+    if "ps2" in variant:
+        u["pointSize"] = 2
+    _ingest(whole, u, [pts])
+    whole.render(u)
+    want_fb, want_color = whole.framebuffer(W, H), whole.color(W, H)
+    for part in range(4):
+        whole.render_part(u, part)
+    assert np.array_equal(whole.framebuffer(W, H), want_fb) and np.array_equal(whole.color(W, H), want_color)
+
+    own = distributed.owner_of(pts, box, 2)
+    ranks = []
+    for r in range(2):
+        d = _device(ring_slots=2)
+        _ingest(d, u, [pts[own == r]])
+        ranks.append(d)
+    for d in ranks:
+        d.render_part(u, 0)
+    if kw["hqs"]:
+        m = torch.minimum(ranks[0].depth_plane(), ranks[1].depth_plane())
+        for d in ranks:
+            d.depth_plane().copy_(m)
+            d.render_part(u, 1)
+        ssum = ranks[0].sum_planes() + ranks[1].sum_planes()
+        for d in ranks:
+            d.sum_planes().copy_(ssum)
+            d.render_part(u, 2)
+    m = torch.minimum(ranks[0].framebuffer_words(), ranks[1].framebuffer_words())
+    for d in ranks:
+        d.framebuffer_words().copy_(m)
+        d.render_part(u, 3)
+    # The two rank octrees were built in runs of their own, so their voxel colours (first writer wins, SURVEY.md H6) need not be
+    # those of `whole`: depth must match the single-octree frame everywhere, and the exact frame is what the CPU oracle composes
+    # from the SAME two octree images with the same reductions.
+    images = [host_image_of(d) for d in ranks]
+    lib_o = oracle.port_lib()
+    p = lambda arr: ctypes.c_void_p(arr.ctypes.data)
+    uu = np.ascontiguousarray(u).reshape(1)
+    state = []
+    for nodes, pers, nn in images:
+        st = np.zeros(1, dtype=abi.stats_dtype); st["numNodes"] = nn
+        state.append(dict(nodes=nodes, stats=st, fb=np.zeros(W * H, dtype=np.uint64), color=np.zeros(W * H, dtype=np.uint32),
+                          vis=np.zeros(abi.MAX_VISIBLE_NODES, dtype=abi.node_dtype), depth=np.zeros(W * H, dtype=np.uint32), sums=np.zeros(W * H * 4, dtype=np.uint32)))
+    def part(k):
+        for s_ in state:
+            lib_o.oracle_render_part(None, p(uu), p(s_["nodes"]), p(s_["stats"]), p(s_["fb"]), p(s_["color"]), p(s_["vis"]), 1, k, p(s_["depth"]), p(s_["sums"]))
+    part(0)
+    if kw["hqs"]:
+        dm = np.minimum(state[0]["depth"], state[1]["depth"])       # positive float bits: unsigned MIN
+        for s_ in state: s_["depth"][:] = dm
+        part(1)
+        sm = state[0]["sums"] + state[1]["sums"]
+        for s_ in state: s_["sums"][:] = sm
+        part(2)
+    fm = np.minimum(state[0]["fb"], state[1]["fb"])
+    for s_ in state: s_["fb"][:] = fm
+    part(3)
+    for d, s_ in zip(ranks, state):
+        got = d.framebuffer(W, H)
+        assert np.array_equal(got >> np.uint64(32), want_fb >> np.uint64(32)), f"{variant}: depth differs from the single-octree frame"
+        bad = int((got != s_["fb"]).sum())
+        assert bad == 0, f"{variant}: {bad} pixels differ from the frame the oracle composes from the same two octrees"
+        c_got, c_want = d.color(W, H).view(np.uint8).astype(np.int16), s_["color"].view(np.uint8).astype(np.int16)
+        assert np.abs(c_got - c_want).max() <= 1                                         # EDL: +-1 per channel (DESIGN.md)
+    assert sum(int(d.read_stats()["numVisiblePoints"]) for d in ranks) == int(whole.read_stats()["numVisiblePoints"])
