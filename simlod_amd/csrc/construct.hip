@@ -422,16 +422,16 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				atomicAdd(&sh_childCount[c], 1u);
 			}
 			__syncthreads();
-			if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0 && round + 1 < SIMLOD_MAX_EXPAND_ROUNDS)
+			if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0)
 				count_into(a, ctl, item.childOffset + threadIdx.x, sh_childCount[threadIdx.x], listNext, countNext);
-			else if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0)
-				atomicAdd(&a.nodes[item.childOffset + threadIdx.x].counter, sh_childCount[threadIdx.x]);
 		}
 
 		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; }
 		// -- B2: recount — only samples whose cached leaf was split in THIS round go one (or more) levels down ------------
-		// (the reference's 20th split is not followed by a count, voxels.cu:394-412)
-		if (round + 1 < SIMLOD_MAX_EXPAND_ROUNDS) {
+		// Also after the 20th split: the reference does not count again there (voxels.cu:394-412), allocates no chunks for the
+		// level-20 children and drops every point that lands in them (:599-604) — 50 001 points in one 2^-20 cell.  Here they are
+		// counted and stored; a level-20 leaf never asks for another split (count_into).
+		{
 			const uint32_t total = n + numSpilledPrev;
 			__syncthreads();
 			table_init(tbl);                           // one table for the whole scan of this workgroup, one flush

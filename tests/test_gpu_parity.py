@@ -125,6 +125,50 @@ def test_too_small_momentary_buffer_is_reported_not_silently_overrun(built_libs)
     assert int(s["dbg"]) & 0x1 and int(s["batchletIndex"]) == 0
 
 
+def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
+    """70 000 identical points force twenty split rounds inside one batch, down to level 20 where a node cannot split any more;
+    8 000 points sit exactly on the faces / corners of the bounding box (coordinate == boxMax quantises to 2^20 and, as in the
+    reference, wraps into the low child).  Tree shape, voxels, grids and counts must be the reference restatement's.  One
+    deliberate difference: the reference does not count after its 20th split, allocates no chunks for the level-20 leaf and
+    drops the points that land there (voxels.cu:394-412, 599-604 — the restatement reports NULL_CHUNK); here every point is stored."""
+    rs = np.random.RandomState(4)
+    base, box = synthetic.uniform_cube(60_000, seed=9)
+    same = np.repeat(base[:1], 70_000)
+    same["x"], same["y"], same["z"] = np.float32(0.3), np.float32(0.6), np.float32(0.2)
+    corners = np.repeat(base[:1], 8_000)
+    for k in "xyz":
+        corners[k] = rs.choice(np.array([0.0, 1.0], dtype=np.float32), 8_000)
+    pts = np.concatenate([base[:30_000], same, corners, base[30_000:]])
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    dev = _device(ring_slots=4)
+    u = dev.uniforms(W, H, T, box)
+    _ingest(dev, u, [pts[i:i + 50_000] for i in range(0, len(pts), 50_000)])
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=4)
+    ref.reset(u)
+    ref.add_points(u, pts, 50_000)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    assert_stats_equal(ds, ref.stats[0], ["numNodes", "numInner", "numLeaves", "numNonemptyLeaves", "numPoints", "numVoxels", "numChunksVoxels",
+                                          "batchletIndex", "numPointsProcessed"], "collisions")
+    nodes, pers, nn = host_image_of(dev)
+    got, want = oracle.dump_image(nodes, nn), ref.dump()
+    got, want = got[np.argsort(got["key"])], want[np.argsort(want["key"])]
+    assert int(got["level"].max()) == abi.MAX_DEPTH
+    for f in ("key", "level", "X", "Y", "Z", "isLeaf", "numPoints", "numVoxels", "numVoxelsStored", "hasGrid", "gridPopcount", "gridHash",
+              "voxelPosSum", "voxelPosXor", "voxelChunks", "childMask"):
+        assert np.array_equal(got[f], want[f]), f
+    shallow = got["level"] < abi.MAX_DEPTH                          # what the reference stores it stores identically
+    for f in ("counter", "pointChunks", "pointsSum", "pointsXor"):
+        assert np.array_equal(got[f][shallow], want[f][shallow]), f
+    tot = oracle.check_invariants(nodes, nn)
+    assert tot["points"] == len(pts)
+    hs, hx = points_multiset_hash(pts)
+    with np.errstate(over="ignore"):
+        assert hs == np.uint64(got["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(got["pointsXor"])
+    deep = int(nodes["numVoxelsStored"][:nn][nodes["level"][:nn] > 12].sum())    # one voxel per level of the collision chain
+    assert voxel_colors_are_member(nodes, nn, pts, box, max_level=12) == int(nodes["numVoxelsStored"][:nn].sum()) - deep
+
+
 def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs):
     """Scattered input makes hundreds of leaves cross the limit in the same batch.  With a momentary buffer that can hold only
     a fraction of their stored points (the reference drops points here) the splits that do not fit are deferred:

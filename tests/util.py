@@ -38,9 +38,10 @@ def host_image_of(dev):
     return nodes, pers, n
 
 
-def voxel_colors_are_member(nodes, n, points, box_size):
+def voxel_colors_are_member(nodes, n, points, box_size, max_level=20):
     """Every voxel's colour must be the colour of SOME input point that falls into the voxel's cell (first-writer-wins is
-    scheduling dependent).  Returns the number of voxels checked."""
+    scheduling dependent).  Returns the number of voxels checked.  Nodes deeper than `max_level` are skipped:
+    their cells are smaller than an fp32 position can resolve, so the cell cannot be recovered from the stored voxel position."""
     size = np.float32(max(box_size))
     X = (np.float32(2 ** 20) * points["x"] / size).astype(np.uint32)
     Y = (np.float32(2 ** 20) * points["y"] / size).astype(np.uint32)
@@ -55,6 +56,8 @@ def voxel_colors_are_member(nodes, n, points, box_size):
         if nv == 0:
             continue
         lvl = int(nd["level"])
+        if lvl > max_level:
+            continue
         vox = oracle.gather_samples(int(nd["voxelChunks"]), nv)
         sel = ((X >> (20 - lvl)) == nd["X"]) & ((Y >> (20 - lvl)) == nd["Y"]) & ((Z >> (20 - lvl)) == nd["Z"]) if lvl > 0 else np.ones(len(points), bool)
         sh = 21 - lvl
