@@ -125,6 +125,42 @@ def test_too_small_momentary_buffer_is_reported_not_silently_overrun(built_libs)
     assert int(s["dbg"]) & 0x1 and int(s["batchletIndex"]) == 0
 
 
+def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs):
+    """voxels.cu:896-912: a batch is taken only while allocator offset + 200 MB < persistentBufferCapacity; otherwise
+    Stats.memCapacityReached is raised and the launch does nothing — and neither do later launches.  Same stopping batch,
+    same octree as the restatement; nothing is written beyond the capacity the kernels were told."""
+    import torch
+    n = 6_000_000
+    pts, box = synthetic.uniform_cube(n, seed=17)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    cap = 260_000_000                                             # 60 MB of octree, then the guard
+    dev = _device(ring_slots=8, persistent_bytes=cap + 4096)
+    dev.persistent[cap:].fill_(0x3C)                              # canary behind the capacity the uniforms announce
+    u = dev.uniforms(W, H, T, box)
+    u["persistentBufferCapacity"] = cap
+    dev.persistent_bytes = cap
+    dev.reset(u)
+    for i in range(0, n, 1_000_000):
+        dev.upload(pts[i:i + 1_000_000])
+    for _ in range(4):                                            # the frame loop keeps launching; nothing may move any more
+        dev.construct(u)
+    torch.cuda.synchronize()
+    ds = dev.read_stats()
+    ref = oracle.HostOctree("port", persistent_bytes=cap, ring_slots=8)
+    uh = u.copy()
+    ref.reset(uh)
+    for i in range(0, n, 1_000_000):
+        ref.upload(pts[i:i + 1_000_000])
+    for _ in range(4):
+        ref.construct(uh)
+    assert int(ds["memCapacityReached"]) == 1 == int(ref.stats["memCapacityReached"][0])
+    assert 0 < int(ds["batchletIndex"]) < 6
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "memory guard")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "memory guard")
+    assert int(ds["allocatedBytes_persistent"]) <= cap and bool((dev.persistent[cap:] == 0x3C).all())
+
+
 def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
     """70 000 identical points force twenty split rounds inside one batch, down to level 20 where a node cannot split any more;
     8 000 points sit exactly on the faces / corners of the bounding box (coordinate == boxMax quantises to 2^20 and, as in the
@@ -256,6 +292,53 @@ def test_render_bit_exact_on_device_built_octree(built_libs, variant):
     assert int(np.abs(col_dev.view(np.uint8).astype(np.int16) - col.view(np.uint8).astype(np.int16)).max()) <= 1
     dev.render(u)                           # a frame is a pure function of (image, uniforms)
     assert np.array_equal(dev.framebuffer(Wd, Hd), fb_dev)
+
+
+@pytest.mark.parametrize("variant", ["odd_size_hqs", "odd_size_plain_boxes", "tiny_frame", "inside_the_cloud_hqs", "inside_the_cloud_plain",
+                                     "point_size_5", "fine_lod_hqs", "boxes_only", "terrain_close_hqs", "hotspot_tiles_hqs", "hotspot_tiles_plain"])
+def test_render_edge_cases_bit_exact(built_libs, variant):
+    """Frame sizes that are not multiples of the 16-pixel EDL tile (nor of the 32-pixel LDS tile), a camera inside the point cloud
+    (samples behind the eye, w <= 0), point sizes that reach over the frame border, a LOD threshold that makes thousands of nodes
+    visible, lines without points, nodes small enough on screen for the LDS-tile path: pre-EDL framebuffer bit-identical to the
+    oracle on the same octree image, RGBA8 within 1 per channel."""
+    Wd, Hd = (250, 131) if "odd_size" in variant else (40, 23) if variant == "tiny_frame" else (640, 360) if "hotspot" in variant else (384, 256)
+    if "terrain" in variant:
+        pts, box = synthetic.terrain(1_500_000, seed=3, box=(600.0, 400.0, 40.0), tile=50.0)
+    elif "hotspot" in variant:
+        pts, box = synthetic.hotspot(1_200_000, seed=11, level=4, cell=(5, 9, 6))
+    else:
+        pts, box = synthetic.uniform_cube(1_000_000, seed=77)
+    if "inside" in variant:
+        eye, target = (0.52 * box[0], 0.48 * box[1], 0.5 * box[2]), (0.9 * box[0], 0.6 * box[1], 0.45 * box[2])
+    elif "terrain" in variant:
+        eye, target = (0.5 * box[0], 0.45 * box[1], 0.9 * box[2]), (0.52 * box[0], 0.6 * box[1], 0.4 * box[2])
+    elif "hotspot" in variant:
+        c = (np.array([5, 9, 6], dtype=np.float32) + 0.5) / 16.0
+        eye, target = tuple(c + np.float32(0.09) * np.array([1.4, -1.1, 0.9], dtype=np.float32)), tuple(c)
+    else:
+        eye, target = (1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2])
+    T = camera.lookat_transform(eye, target, Wd, Hd)
+    dev = _device(ring_slots=2)
+    u = dev.uniforms(Wd, Hd, T, box)
+    _ingest(dev, u, [pts[i:i + 1_000_000] for i in range(0, len(pts), 1_000_000)])
+    u["useHighQualityShading"] = 1 if "hqs" in variant else 0
+    u["showBoundingBox"] = 1 if "boxes" in variant else 0
+    u["showPoints"] = 0 if variant == "boxes_only" else 1
+    u["pointSize"] = 5 if variant == "point_size_5" else 1
+    if variant == "fine_lod_hqs" or "odd_size" in variant:
+        u["minNodeSize"] = 8.0                                  # a node is drawn once its box spans 2 * minNodeSize pixels (render.cu:893-901)
+    if variant == "tiny_frame":
+        u["minNodeSize"] = 2.0
+    dev.render(u)
+    fb_dev, col_dev, ds = dev.framebuffer(Wd, Hd), dev.color(Wd, Hd), dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    nodes, pers, nn = host_image_of(dev)
+    fb, col, st = _oracle_render(nodes, nn, u)
+    assert_stats_equal(ds, st, STATS_RENDER_FIELDS, variant)
+    diff = np.nonzero(fb_dev != fb)[0]
+    assert len(diff) == 0, f"{variant}: {len(diff)} pixels differ, first {diff[:5]}: dev {fb_dev[diff[:5]]} oracle {fb[diff[:5]]}"
+    assert int((fb != abi.CLEAR_PIXEL).sum()) > (50 if variant in ("tiny_frame", "boxes_only") else 2000), "the case must draw something"
+    assert int(np.abs(col_dev.view(np.uint8).astype(np.int16) - col.view(np.uint8).astype(np.int16)).max()) <= 1
 
 
 # ---- the reference's launch surface ------------------------------------------------------------------------------------------
