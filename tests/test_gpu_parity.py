@@ -161,6 +161,34 @@ def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs):
     assert int(ds["allocatedBytes_persistent"]) <= cap and bool((dev.persistent[cap:] == 0x3C).all())
 
 
+def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs):
+    """The reference's node array holds 263 157 nodes (main_progressive_octree.cpp:552) and its kernel writes past the end when
+    more are needed.  Here a split that finds no eight free slots is refused: the leaf keeps growing, Stats.dbg says so."""
+    from simlod_amd.runtime import lib
+    n = 1_000_000
+    pts, box = synthetic.uniform_cube(n, seed=5)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    try:
+        dev = _device(ring_slots=4, max_nodes=41)                     # room for five splits; the data wants nine (73 nodes)
+        dev.nodes[41 * 152:].fill_(0x77) if dev.nodes.numel() > 41 * 152 else None
+        u = dev.uniforms(W, H, T, box)
+        _ingest(dev, u, [pts[i:i + 250_000] for i in range(0, n, 250_000)])
+        ds = dev.read_stats()
+        assert int(ds["dbg"]) == 0x8 and int(ds["numNodes"]) == 41
+        assert int(ds["numPoints"]) == n == int(ds["numPointsProcessed"])
+        nodes, pers, nn = host_image_of(dev)
+        tot = oracle.check_invariants(nodes, nn, allow_overfull=True)
+        assert tot["points"] == n
+        d = oracle.dump_image(nodes, nn)
+        hs, hx = points_multiset_hash(pts)
+        with np.errstate(over="ignore"):
+            assert hs == np.uint64(d["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(d["pointsXor"])
+        dev.render(u)                                                 # and the octree is still drawable
+        assert int((dev.framebuffer(W, H) != abi.CLEAR_PIXEL).sum()) > 1000
+    finally:
+        lib().simlod_set_node_capacity(263_157)
+
+
 def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
     """70 000 identical points force twenty split rounds inside one batch, down to level 20 where a node cannot split any more;
     8 000 points sit exactly on the faces / corners of the bounding box (coordinate == boxMax quantises to 2^20 and, as in the
