@@ -580,12 +580,7 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 // (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
 __device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
 
-__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= numNodes) return;
+__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i) {
 	SimlodNode* node = a.nodes + i;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -657,6 +652,14 @@ __global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
 		NodeDir& d = nodeDir[i];
 		d.voxBase = base; d.voxFirst = first; d.voxTag = tag;
 	}
+}
+
+// A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
+__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i);
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -962,7 +965,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			case 8: SIMLOD_LAUNCH(k_sample<8>, dim3(gridPoints), dim3(TPB), stream, a); break;
 			default: SIMLOD_LAUNCH(k_sample<4>, dim3(gridPoints), dim3(TPB), stream, a); break;
 			}
-			SIMLOD_LAUNCH(k_alloc, dim3(gridNodes), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
 		}
