@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=6_000_000, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
+                    help="record order of the synthetic terrain: shuffled inside 250 m tiles (default, the harder case) or scan-line order as in a LAS file")
     return ap.parse_args()
 
 
@@ -95,7 +97,8 @@ def main():
     batch = abi.MAX_BATCH_SIZE
     n_batches = (n_points + batch - 1) // batch
     assert n_batches <= abi.BATCH_STREAM_SIZE, "the workload must fit the 50-slot ring (resident input)"
-    pts, box = synthetic.terrain(n_points, seed=7 + rank)     # rank r owns tile r of the tiled terrain (pre-partitioned)
+    gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
+    pts, box = gen(n_points, seed=7 + rank)                   # rank r owns tile r of the tiled terrain (pre-partitioned)
     dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=300_000_000, max_pixels=W * H)
     L = lib()
     sizes = torch.tensor([min(batch, n_points - i * batch) for i in range(n_batches)], dtype=torch.int32, device=dev.device)
@@ -253,7 +256,7 @@ def main():
             "config": {"workload": f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M "
                                    f"ring batches resident in HBM, reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
                                    f"(<= 20 batches and <= 10 ms each, Stats read back between launches); "
-                                   f"raster 1920x1080", "points_per_gpu": n_points, "parallelism": f"spatial sub-octree per GPU x{world}"},
+                                   f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order, "parallelism": f"spatial sub-octree per GPU x{world}"},
             "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu, "loader": loader,
             "octree": {k: int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels", "allocatedBytes_persistent")},
         }
