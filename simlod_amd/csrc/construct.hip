@@ -436,19 +436,38 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			__syncthreads();
 			table_init(tbl);                           // one table for the whole scan of this workgroup, one flush
 			__syncthreads();
-			for (uint32_t t = blockIdx.x * ETPB + threadIdx.x; t < total; t += gridDim.x * ETPB) {
-				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-				uint32_t leafIdx = leafOf[idx];
-				if (splitTag[leafIdx] != tag) continue;
-				const float4 p = t < n ? pts[t] : spilled[t - n];
-				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
-				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
-				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-				SimlodNode* from = a.nodes + leafIdx;
-				leafIdx = (uint32_t)(descend(from, (int)from->level, X, Y, Z) - a.nodes);
-				leafOf[idx] = leafIdx;
-				uint32_t rank;
-				if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
+			// four samples per thread at a time, stage by stage: the four cached-leaf loads are in flight together, then the four
+			// split tags, then the points and the first child pointer of those that have to move (a 1 M-sample batch is four
+			// samples per thread: the dependent chain leaf -> tag -> point -> child is paid once, not four times)
+			constexpr uint32_t U = 4;
+			const uint32_t stride = gridDim.x * ETPB;
+			for (uint32_t t0 = blockIdx.x * ETPB + threadIdx.x; t0 < total; t0 += U * stride) {
+				uint32_t idx[U], leaf[U]; bool move[U]; float4 p[U]; uint32_t level[U];
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t t = t0 + q * stride;
+					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+					leaf[q] = t < total ? leafOf[idx[q]] : 0xffffffffu;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) move[q] = leaf[q] != 0xffffffffu && splitTag[leaf[q]] == tag;
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t t = t0 + q * stride;
+					p[q] = move[q] ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
+					level[q] = move[q] ? a.nodes[leaf[q]].level : 0u;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					if (!move[q]) continue;
+					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size);
+					const uint32_t Y = quantize(F_GRID, p[q].y, a.miny, a.size);
+					const uint32_t Z = quantize(F_GRID, p[q].z, a.minz, a.size);
+					const uint32_t leafIdx = (uint32_t)(descend(a.nodes + leaf[q], (int)level[q], X, Y, Z) - a.nodes);
+					leafOf[idx[q]] = leafIdx;
+					uint32_t rank;
+					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
+				}
 			}
 			__syncthreads();
 			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += ETPB) {
