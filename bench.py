@@ -172,8 +172,10 @@ def main():
     roofline, chain, kernels = None, None, {}
     if rank == 0 and not args.no_profile:
         L.simlod_profile_enable(1)
+        dev.momentary[208:216].zero_()                                       # control block: points moved by splits (simlod_internal.hpp)
         ingest_step()
         prof_c = collect_profile(L)
+        spilled_points = int(dev.momentary[208:216].cpu().numpy().view(np.uint64)[0])
         dev.render(u)
         prof_r = collect_profile(L)
         L.simlod_profile_enable(0)
@@ -184,12 +186,14 @@ def main():
         chain_bytes = 32.0 * n_points + 16.0 * new_voxels                  # 32 B/point + 16 B/new voxel
         chain = {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms, "what": "whole kernel_construct chain, one 36 M ingest"}
-        per_point = {"k_count": 16.0, "k_sample": 16.0, "k_insert": 32.0}   # algorithmic bytes per point per kernel
+        per_point = {"k_count": 16.0, "k_sample": 16.0, "k_insert": 32.0, "k_expand": 0.0}   # algorithmic bytes per point per kernel
         base = lambda k: k.split("<")[0]                                     # k_sample<4> -> k_sample
         dom_full = max((k for k in prof_c if base(k) in per_point), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
         active = n_batches                                                   # launches that had a batch to process
         bytes_per_launch = per_point[dom] * batch + (16.0 * new_voxels / n_batches if dom == "k_insert" else 0.0)
+        if dom == "k_expand":                                                # 32 B per stored point that a split moves (read + write), SURVEY.md §8a row a6
+            bytes_per_launch = 32.0 * spilled_points / n_batches
         avg_ms = prof_c[dom_full][1] / active
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -197,7 +201,8 @@ def main():
             traffic = json.load(open(tpath)).get(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                    "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active}
+                    "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
+                    "note": "k_expand moves %d stored points per ingest; it is bound by split rounds and grid barriers, not by bytes" % spilled_points if dom == "k_expand" else None}
 
     # ---- loader row: LAS format-2 records (26 B) -> Points (16 B) on the device, one 1 M-point batch ----
     loader = None

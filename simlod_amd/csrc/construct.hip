@@ -855,6 +855,7 @@ __global__ void k_end(BuildArgs a, uint32_t ordinal) {
 		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
 		a.stats->batchletIndex += 1;
 		a.stats->numPointsProcessed += ctl->batchSize;
+		ctl->expandNs[7] += min(ctl->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
 		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
 		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
 	}

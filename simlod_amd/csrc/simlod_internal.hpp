@@ -30,7 +30,7 @@ struct Ctl {
 	uint32_t statCounters[8];
 	unsigned long long reserve;        // k_expand: nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves both or neither
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish)
-	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls); tools/kprof.py
+	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
 };
 
 struct BuildArgs {
