@@ -245,7 +245,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	uint32_t* splitTag = at<uint32_t>(a, a.offSplitTag);
+	unsigned long long* splitInfo = at<unsigned long long>(a, a.offSplitTag);   // per node: round tag << 32 | first child << 5 | level
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				if (lane == 0) {
 					node->numPoints = 0;
 					node->points = nullptr;
-					splitTag[nodeIdx] = tag;
+					splitInfo[nodeIdx] = ((unsigned long long)tag << 32) | ((unsigned long long)childOffset << 5) | level;
 				}
 			}
 			// meanwhile the other lanes clear the occupancy grid — of EVERY spilling node, also one that already had a
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			constexpr uint32_t U = 4;
 			const uint32_t stride = gridDim.x * ETPB;
 			for (uint32_t t0 = blockIdx.x * ETPB + threadIdx.x; t0 < total; t0 += U * stride) {
-				uint32_t idx[U], leaf[U]; bool move[U]; float4 p[U]; uint32_t level[U];
+				uint32_t idx[U], leaf[U]; unsigned long long info[U]; float4 p[U];
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
 					const uint32_t t = t0 + q * stride;
@@ -450,20 +450,21 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 					leaf[q] = t < total ? leafOf[idx[q]] : 0xffffffffu;
 				}
 #pragma unroll
-				for (uint32_t q = 0; q < U; q++) move[q] = leaf[q] != 0xffffffffu && splitTag[leaf[q]] == tag;
+				for (uint32_t q = 0; q < U; q++) info[q] = leaf[q] != 0xffffffffu ? splitInfo[leaf[q]] : 0ull;
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
 					const uint32_t t = t0 + q * stride;
-					p[q] = move[q] ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
-					level[q] = move[q] ? a.nodes[leaf[q]].level : 0u;
+					p[q] = (uint32_t)(info[q] >> 32) == tag ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
 				}
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
-					if (!move[q]) continue;
+					if ((uint32_t)(info[q] >> 32) != tag) continue;
+					// the children of a leaf split in this round are leaves: the record of the split says where they are, no node is read
 					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size);
 					const uint32_t Y = quantize(F_GRID, p[q].y, a.miny, a.size);
 					const uint32_t Z = quantize(F_GRID, p[q].z, a.minz, a.size);
-					const uint32_t leafIdx = (uint32_t)(descend(a.nodes + leaf[q], (int)level[q], X, Y, Z) - a.nodes);
+					const uint32_t level = (uint32_t)info[q] & 31u, childOffset = ((uint32_t)info[q] >> 5) & 0x7ffffu;
+					const uint32_t leafIdx = childOffset + (uint32_t)child_index(X, Y, Z, (int)level);
 					leafOf[idx[q]] = leafIdx;
 					uint32_t rank;
 					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
@@ -914,7 +915,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	uint64_t off = 4096;                                                       // Ctl
 	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	off += 3 * align_up((uint64_t)nodeCapacity * 4, 256);                      // splitTag, retryTag, parentOf
+	off += 4 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
@@ -928,7 +929,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
 	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
@@ -969,7 +970,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 
 	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u);
 	if (fits) {
-		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // splitTag and retryTag
+		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
 		if (e != hipSuccess) return (int)e;
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
