@@ -2,7 +2,7 @@
 //
 // Replaces modules/progressive_octree/progressive_octree_voxels.cu:804-1010 (one persistent cooperative CUDA
 // kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
-// memory image.  Design (DESIGN.md §3):
+// memory image.  Design (DESIGN.md §3-4):
 //
 //   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, sample, alloc, insert,
 //     end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
@@ -11,12 +11,18 @@
 //   * every point is read with one coalesced 16-byte load per phase and descends the tree ONCE: the leaf found
 //     by `count` is cached (4 B/point) and only points whose leaf was split re-descend, from that leaf down
 //     (the reference re-descends from the root in three phases and re-scans the batch in every split round);
-//   * per-leaf counters, slot reservations and voxel counters are aggregated per 64-lane wave by a ballot/
-//     readlane peel loop (cg::labeled_partition has no HIP equivalent);
+//   * per-leaf counters, slot reservations and voxel counters are aggregated per WORKGROUP in LDS hash tables (one global
+//     atomic per workgroup and counter): device-scope atomics on one word retire at ~88 M/s on this chip, and a spatially
+//     compact batch sends most of its points to a few dozen leaves;
+//   * voxel sampling walks the root path BOTTOM-UP (occupancy is hierarchical: a set bit implies the covering bits of all
+//     ancestors) and reads the path from a per-node ancestor table instead of chasing parent -> node -> grid pointers;
 //   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of every
-//     list remembers its tail (8 spare bytes of Chunk), and a per-batch chunk directory gives O(1) slot->chunk;
+//     list remembers its tail (8 spare bytes of Chunk), a per-batch chunk directory gives O(1) slot->chunk, and a leaf chunk
+//     table lets a split read the whole list of a leaf with one wave;
 //   * new voxels are not copied through a 24-byte backlog record: `sample` leaves a 20-bit per-point mask of the
-//     levels the point won, `insert` regenerates the voxel from (node, cell) while the point is in registers.
+//     levels the point won, `insert` regenerates the voxel from (level, cell) while the point is in registers;
+//   * no capacity limit loses a point: a split reserves its node slots and spill space in one compare-and-swap or does not
+//     happen yet (the leaf grows and is queued again by a later batch).
 //
 // The result after every batch is the reference's: same topology, same per-node sample multisets, same occupancy
 // bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same

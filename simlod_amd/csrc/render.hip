@@ -4,7 +4,7 @@
 // Replaces modules/progressive_octree/render.cu:1084-1355 (one persistent cooperative CUDA kernel, ~25 grid.sync())
 // behind the same argument list, reading the same Node/Chunk image and leaving the same uint64 framebuffer
 // (depth bits << 32 | colour) at the same offset of the momentary buffer.  A frame is a chain of ordinary launches
-// (clear -> visibility 1 -> visibility 2 -> draw [depth, colour, resolve] -> output); the only cross-workgroup
+// (clear -> visibility 1 -> visibility 2 -> draw items -> draw [depth, colour, resolve] -> [debug lines] -> output; simlod_launch_render_part runs it in four parts for multi-GPU frames); the only cross-workgroup
 // traffic inside a launch is device-scope atomics (visible-node list, work queue, framebuffer).
 //
 // Arithmetic contract: projection = four fp32 dot products evaluated left to right, IEEE divide,
