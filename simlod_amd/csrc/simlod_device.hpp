@@ -2,8 +2,10 @@
 //
 // Hardware model these helpers are written for (MI355X / CDNA4): 64-lane wavefronts, 256 CUs in 8 XCDs with
 // private, mutually non-coherent L2s, device-scope atomics resolved at the memory side.  Hence:
-//   * wave_group_by(): 64-lane "match-any" peel loop on ballot/readlane — the replacement for CUDA's
-//     cg::labeled_partition (progressive_octree_voxels.cu:203-218), which HIP does not have;
+//   * BlockTable: an LDS open-addressing table (key -> count) per workgroup, the replacement for the per-warp
+//     cg::labeled_partition aggregation of progressive_octree_voxels.cu:203-218 — a spatially compact batch sends most of
+//     its points to a few dozen counters, and atomics on one word retire at ~88 M/s here: one global atomic per
+//     (workgroup, counter) instead of one per wave;
 //   * grid_barrier(): monotonic-counter barrier with agent-scope release/acquire (only the rarely executed
 //     expand loop uses it; every other dependency is a kernel boundary, which is cheaper on this chip);
 //   * all arithmetic that feeds a comparison with the CPU oracle is written operation by operation and the
@@ -20,42 +22,6 @@
 namespace simlod {
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-__device__ __forceinline__ uint64_t lanemask_lt() {
-	int l = lane_id();
-	return l == 0 ? 0ull : (~0ull >> (64 - l));
-}
-
-__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
-}
-
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
-	uint32_t lo = readlane_u32((uint32_t)v, lane), hi = readlane_u32((uint32_t)(v >> 32), lane);
-	return ((uint64_t)hi << 32) | lo;
-}
-
-// Partition the `active` lanes of a wave by `key` and run f(groupMask, leaderLane, rank, count) once per lane,
-// where lanes holding equal keys form a group.  MUST be called from wave-convergent code (every lane of the wave
-// reaches the call; lanes without work pass active = false).  After MAX_PEEL distinct keys the remaining lanes
-// are handed out as singleton groups — spatially coherent batches need 1-3 rounds, random ones gain nothing
-// from more.
-template <int MAX_PEEL = 6, class F>
-__device__ __forceinline__ void wave_group_by(uint32_t key, bool active, F&& f) {
-	uint64_t remaining = __ballot(active);
-	const int lane = lane_id();
-	const uint64_t lt = lanemask_lt();
-#pragma unroll 1
-	for (int it = 0; it < MAX_PEEL && remaining; ++it) {
-		const int leader = __ffsll((unsigned long long)remaining) - 1;
-		const uint32_t k = readlane_u32(key, leader);
-		const bool mine = active && key == k && ((remaining >> lane) & 1ull);
-		const uint64_t m = __ballot(mine);
-		if (mine) f(m, leader, (int)__popcll(m & lt), (int)__popcll(m));
-		remaining &= ~m;
-	}
-	if ((remaining >> lane) & 1ull) f(1ull << lane, lane, 0, 1);
-}
 
 // exact 2^level as fp32 (the reference's pow(2.0f, float(level)))
 __device__ __forceinline__ float exp2_int(uint32_t level) { return __uint_as_float((127u + level) << 23); }

@@ -10,7 +10,6 @@ namespace simlod {
 
 static constexpr uint32_t CHUNK_QUEUE_CAPACITY = 1000000u;   // progressive_octree_voxels.cu:856
 static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octree_voxels.cu:847
-static constexpr int MAX_SPILL_CHUNKS = 64;                  // a spilling leaf stores <= 50 000 points = 50 chunks
 
 // Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
 // (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
