@@ -190,6 +190,11 @@ __device__ __forceinline__ void flush_counts(const BuildArgs& a, Ctl* ctl, Block
 	}
 }
 
+// k_count takes more points per thread than k_insert (PPT): its cost is the flush of the per-workgroup counts into a few dozen
+// hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
+static constexpr uint32_t CPT = 8;
+static constexpr uint32_t CPB = TPB * CPT;
+
 __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
@@ -198,21 +203,21 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
-	const uint32_t numChunks = (n + PPB - 1) / PPB;
+	const uint32_t numChunks = (n + CPB - 1) / CPB;
 	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
 	// other's slowest descent; one flush at the end.
 	table_init(tbl);
 	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		float4 p[PPT];
+		float4 p[CPT];
 #pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t i = chunk * PPB + j * TPB + threadIdx.x;
+		for (uint32_t j = 0; j < CPT; j++) {
+			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
 			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
 		}
 #pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t i = chunk * PPB + j * TPB + threadIdx.x;
+		for (uint32_t j = 0; j < CPT; j++) {
+			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
 			if (i >= n) continue;
 			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
 			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
