@@ -74,3 +74,34 @@ def test_point_size_and_color_modes_match_reference(built_libs):
         for hqs in (0, 1):
             u["useHighQualityShading"] = hqs
             assert np.array_equal(ref.render(u)[0], port.render(u)[0]), (field, hqs)
+
+
+def test_hazard_regimes_match_reference(built_libs):
+    """Where the reference is lossy the restatement must be lossy in the same way (the HIP path documents where it is not):
+    20 split rounds down to level 20 with 70 000 identical points (the reference does not count after its 20th split, allocates no
+    chunks for the level-20 leaf, increments its numPoints and drops the points, voxels.cu:394-412, 599-604 — the restatement
+    reports that as NULL_CHUNK), and points exactly on the box faces (coordinate == boxMax quantises to 2^20, wraps into the low
+    child, voxels.cu:148-179)."""
+    from simlod_amd import abi, camera, synthetic
+    rs = np.random.RandomState(4)
+    base, box = synthetic.uniform_cube(20_000, seed=9)
+    same = np.repeat(base[:1], 70_000)
+    same["x"], same["y"], same["z"] = np.float32(0.3), np.float32(0.6), np.float32(0.2)
+    corners = np.repeat(base[:1], 4_000)
+    for k in "xyz":
+        corners[k] = rs.choice(np.array([0.0, 1.0], dtype=np.float32), 4_000)
+    pts = np.concatenate([base[:10_000], same, corners, base[10_000:]])
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), 256, 256)
+    u = uniforms_for(box, T)
+    runs = {}
+    for kind in ("ref", "port"):
+        o = oracle.HostOctree(kind, persistent_bytes=1 << 30, ring_slots=4)
+        o.reset(u)
+        o.add_points(u, pts, 50_000)
+        runs[kind] = o
+    ref, port = runs["ref"], runs["port"]
+    assert port.last_error() == 5                                   # ORACLE_ERR_NULL_CHUNK
+    assert_stats_equal(port.stats[0], ref.stats[0], STATS_BUILD_FIELDS, "hazards")
+    assert int(ref.stats["numNodes"][0]) == 1 + 8 * 20 and int(ref.nodes["level"][:161].max()) == abi.MAX_DEPTH
+    assert_dumps_equal(port.dump(), ref.dump(), "hazards")
+    assert np.array_equal(ref.render(u)[0], port.render(u)[0])
