@@ -105,3 +105,35 @@ def test_hazard_regimes_match_reference(built_libs):
     assert int(ref.stats["numNodes"][0]) == 1 + 8 * 20 and int(ref.nodes["level"][:161].max()) == abi.MAX_DEPTH
     assert_dumps_equal(port.dump(), ref.dump(), "hazards")
     assert np.array_equal(ref.render(u)[0], port.render(u)[0])
+
+
+@pytest.mark.parametrize("variant", ["odd_size_hqs", "odd_size_plain_boxes", "tiny_frame", "inside_the_cloud_hqs", "inside_the_cloud_plain",
+                                     "fine_lod_hqs", "boxes_only"])
+def test_render_edge_cases_match_reference(built_libs, variant):
+    """The render edge cases of the GPU suite (tests/test_gpu_parity.py: frame sizes off the 16-pixel grid, camera inside the cloud,
+    fine LOD threshold, lines without points), restatement against the reference's own render.cu on a reference-built octree."""
+    from simlod_amd import abi, camera, synthetic
+    Wd, Hd = (250, 131) if "odd_size" in variant else (40, 23) if variant == "tiny_frame" else (384, 256)
+    pts, box = synthetic.uniform_cube(300_000, seed=77)
+    if "inside" in variant:
+        eye, target = (0.52, 0.48, 0.5), (0.9, 0.6, 0.45)
+    else:
+        eye, target = (1.8, -1.2, 1.4), (0.5, 0.5, 0.3)
+    T = camera.lookat_transform(eye, target, Wd, Hd)
+    u = abi.make_uniforms(Wd, Hd, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000, hqs="hqs" in variant)
+    u["showBoundingBox"] = 1 if "boxes" in variant else 0
+    u["showPoints"] = 0 if variant == "boxes_only" else 1
+    if variant == "fine_lod_hqs" or "odd_size" in variant:
+        u["minNodeSize"] = 8.0
+    if variant == "tiny_frame":
+        u["minNodeSize"] = 2.0
+    frames = {}
+    for kind in ("ref", "port"):
+        o = oracle.HostOctree(kind, persistent_bytes=1 << 30, ring_slots=4)
+        o.reset(u)
+        o.add_points(u, pts, 100_000)
+        frames[kind] = (o.render(u)[0], o.stats[0].copy(), o.visible["name"].copy())
+    assert np.array_equal(frames["ref"][0], frames["port"][0]), variant
+    assert_stats_equal(frames["port"][1], frames["ref"][1], STATS_RENDER_FIELDS, variant)
+    assert np.array_equal(frames["ref"][2], frames["port"][2])
+    assert int((frames["ref"][0] != abi.CLEAR_PIXEL).sum()) > 50
