@@ -203,14 +203,39 @@ static void setCamera(double yaw, double pitch, double radius, const double targ
 }
 
 int main(int argc, char** argv) {
-	if (argc < 2) { std::printf("usage: %s <file.simlod | synthetic:N> [out.ppm] [width height]\n", argv[0]); return 2; }
+	if (argc < 2) { std::printf("usage: %s <file.simlod | file.las | synthetic:N> [out.ppm] [width height]\n", argv[0]); return 2; }
 	const std::string path = argv[1];
 	const char* outPath = argc > 2 ? argv[2] : nullptr;
 	if (argc > 4) { width = std::atoi(argv[3]); height = std::atoi(argv[4]); }
 
-	// reload(): a .simlod file is a 24-byte bounding box followed by 16-byte XYZRGBA records (main.cpp:722-745, tools/las2simlod.mjs:96-147)
+	// reload(): a .simlod file is a 24-byte bounding box followed by 16-byte XYZRGBA records (main.cpp:722-745, tools/las2simlod.mjs:96-147);
+	// a .las file is kept as raw records and decoded on the device (loadHeader LasLoader.h:21-55; simlod_decode_las replaces the
+	// loader threads' parse loop LasLoader.cpp:169-227)
 	std::vector<Point> points;
-	if (path.rfind("synthetic:", 0) == 0) {
+	std::vector<uint8_t> lasRecords;
+	uint32_t lasBytesPerPoint = 0, lasFormat = 0;
+	double lasScale[3] = {0, 0, 0}, lasOffset[3] = {0, 0, 0};
+	uint64_t lasNumPoints = 0;
+	const bool isLas = path.size() > 4 && (path.substr(path.size() - 4) == ".las" || path.substr(path.size() - 4) == ".LAS");
+	if (isLas) {
+		FILE* f = std::fopen(path.c_str(), "rb");
+		if (!f) { std::perror(path.c_str()); return 1; }
+		uint8_t h[375] = {0};
+		if (std::fread(h, 1, 375, f) < 227) { std::fprintf(stderr, "short LAS header\n"); return 1; }
+		auto rd = [&](auto& v, size_t off) { std::memcpy(&v, h + off, sizeof(v)); };
+		uint8_t vMajor = h[24], vMinor = h[25]; uint32_t offsetToPointData, legacyCount; uint16_t bpp; uint64_t count64;
+		rd(offsetToPointData, 96); lasFormat = h[104]; rd(bpp, 105); rd(legacyCount, 107); rd(count64, 247);
+		lasBytesPerPoint = bpp;
+		lasNumPoints = (vMajor == 1 && vMinor <= 3) ? legacyCount : count64;
+		double mn[3], mx[3];
+		for (int k = 0; k < 3; k++) { rd(lasScale[k], 131 + 8 * k); rd(lasOffset[k], 155 + 8 * k); rd(mx[k], 179 + 16 * k); rd(mn[k], 187 + 16 * k); }
+		for (int k = 0; k < 3; k++) lasOffset[k] += -mn[k];                                  // translation = -boxMin, main.cpp:868, LasLoader.cpp:197-199
+		boxSize = {(float)(mx[0] - mn[0]), (float)(mx[1] - mn[1]), (float)(mx[2] - mn[2])};
+		lasRecords.resize((size_t)lasNumPoints * lasBytesPerPoint);
+		std::fseek(f, (long)offsetToPointData, SEEK_SET);
+		if (std::fread(lasRecords.data(), 1, lasRecords.size(), f) != lasRecords.size()) { std::fprintf(stderr, "short LAS point data\n"); return 1; }
+		std::fclose(f);
+	} else if (path.rfind("synthetic:", 0) == 0) {
 		const size_t n = std::strtoull(path.c_str() + 10, nullptr, 10);
 		points.resize(n);
 		uint32_t s = 1234567u;
@@ -230,7 +255,7 @@ int main(int argc, char** argv) {
 		boxSize = {bbox[3] - bbox[0], bbox[4] - bbox[1], bbox[5] - bbox[2]};
 		for (auto& p : points) { p.x -= bbox[0]; p.y -= bbox[1]; p.z -= bbox[2]; }   // main.cpp:868
 	}
-	const uint64_t numPointsTotal = points.size();
+	const uint64_t numPointsTotal = isLas ? lasNumPoints : points.size();
 	const uint64_t numBatchesTotal = (numPointsTotal + MAX_BATCH_SIZE - 1) / MAX_BATCH_SIZE;
 
 	initCuda();
@@ -242,7 +267,10 @@ int main(int argc, char** argv) {
 	// pinned staging slots, as the reference's pinnedMemPool (main.cpp:141-222)
 	void* pinned[4];
 	CUevent uploadEnd[4];
-	for (int i = 0; i < 4; i++) { cuMemAllocHost(&pinned[i], MAX_BATCH_SIZE * sizeof(Point)); cuEventCreate(&uploadEnd[i], 0); cuEventRecord(uploadEnd[i], stream_upload); }
+	const size_t slotBytes = MAX_BATCH_SIZE * std::max<size_t>(sizeof(Point), lasBytesPerPoint);
+	for (int i = 0; i < 4; i++) { cuMemAllocHost(&pinned[i], slotBytes); cuEventCreate(&uploadEnd[i], 0); cuEventRecord(uploadEnd[i], stream_upload); }
+	CUdeviceptr lasStage[4] = {0, 0, 0, 0};                            // raw records of a batch on the device, one per pinned slot
+	if (isLas) for (int i = 0; i < 4; i++) cuMemAlloc(&lasStage[i], slotBytes);
 
 	// SIMLOD_HARNESS_PINNED=1: the point array itself is page-locked, as if the loader threads had already read every batch into its
 	// pinned slot (main.cpp:846-935) — the uploader then issues the H2D copy straight from it and the staging memcpy disappears.
@@ -261,10 +289,19 @@ int main(int argc, char** argv) {
 			cuEventSynchronize(uploadEnd[slot]);
 			const uint64_t first = batchStreamUploadIndex * MAX_BATCH_SIZE;
 			const uint32_t count = (uint32_t)std::min<uint64_t>(MAX_BATCH_SIZE, numPointsTotal - first);
-			const void* src = points.data() + first;
-			if (!sourcePinned) { std::memcpy(pinned[slot], src, (size_t)count * sizeof(Point)); src = pinned[slot]; }
 			const int uploadRingIndex = (int)(batchStreamUploadIndex % BATCH_STREAM_SIZE);
-			cuMemcpyHtoDAsync(cptr_points_ring[uploadRingIndex], src, (size_t)count * sizeof(Point), stream_upload);
+			if (isLas) {
+				// the loader thread's job shrinks to moving bytes: raw records -> pinned slot -> device, decoded into the ring slot there
+				const size_t bytes = (size_t)count * lasBytesPerPoint;
+				std::memcpy(pinned[slot], lasRecords.data() + first * lasBytesPerPoint, bytes);
+				cuMemcpyHtoDAsync(lasStage[slot], pinned[slot], bytes, stream_upload);
+				simlod_decode_las((const void*)(uintptr_t)lasStage[slot], count, lasBytesPerPoint, lasFormat, lasScale, lasOffset,
+				                  (SimlodPoint*)(uintptr_t)cptr_points_ring[uploadRingIndex], (void*)stream_upload);
+			} else {
+				const void* src = points.data() + first;
+				if (!sourcePinned) { std::memcpy(pinned[slot], src, (size_t)count * sizeof(Point)); src = pinned[slot]; }
+				cuMemcpyHtoDAsync(cptr_points_ring[uploadRingIndex], src, (size_t)count * sizeof(Point), stream_upload);
+			}
 			cuEventRecord(uploadEnd[slot], stream_upload);
 			cuMemsetD32Async(cptr_batchSizes + 4 * uploadRingIndex, count, 1, stream_upload);
 			cuMemsetD32Async(cptr_numBatchesUploaded, (unsigned)(batchStreamUploadIndex + 1), 1, stream_upload);

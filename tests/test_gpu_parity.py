@@ -484,6 +484,37 @@ def test_headless_cpp_host_replay(built_libs, tmp_path):
     assert (img != np.array([0x11, 0x22, 0x33], dtype=np.uint8)).any(axis=2).sum() > 5000      # something other than background was drawn
 
 
+def test_headless_cpp_host_streams_a_las_file(built_libs, tmp_path):
+    """The same C++ host fed a LAS 1.4 format-7 file (world coordinates far from the origin): the loader moves raw records, the
+    device decodes them into the ring (simlod_decode_las).  The octree must be the one the oracle builds from the oracle-decoded
+    points."""
+    import re
+    import subprocess
+    from simlod_amd import lasio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "simlod_headless")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "harness")])
+    pts0, box = synthetic.terrain(2_200_000, seed=8, box=(1500.0, 1000.0, 100.0), tile=125.0)
+    path = str(tmp_path / "terrain.las")
+    h = lasio.points_to_las(path, pts0, box, fmt=7, scale=0.001, world_min=(694000.0, 3915000.0, -3.0), version=(1, 4))
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"numNodes (\d+) numInner (\d+) numLeaves (\d+) numPoints (\d+) numVoxels (\d+) persistentBytes (\d+) chunkPoolSize (\d+) dbg (\d+)", out.stdout)
+    assert m, out.stdout
+    got = [int(v) for v in m.groups()]
+    tr = tuple(-v for v in h.min)
+    pts = oracle.decode_las_port(lasio.read_records(path, h, 0, h.numPoints), h.bytesPerPoint, h.format, h.scale, lasio.decode_offset(h, tr))
+    hbox = (np.array(h.max) - np.array(h.min)).astype(np.float32)      # what the host derives from the header
+    T = camera.lookat_transform((1.8 * hbox[0], -1.2 * hbox[1], 1.4 * max(hbox)), (0.5 * hbox[0], 0.5 * hbox[1], 0.3 * hbox[2]), W, H)
+    u = uniforms_for(hbox, T, persistent=8 << 30)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    s = ref.stats[0]
+    assert got == [int(s[k]) for k in ("numNodes", "numInner", "numLeaves", "numPoints", "numVoxels", "allocatedBytes_persistent", "chunkPoolSize")] + [0]
+
+
 # ---- loader row (SURVEY.md §8 f-2): LAS records -> Points on the device -----------------------------------------------------
 def _gpu_decode(raw, n, bpp, fmt, scale, offset):
     import torch
