@@ -230,6 +230,24 @@ def main():
                   "avg_launch_ms": msl / nl, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                                          "bytes_per_point": 42.0}}
 
+    # ---- measured denominator next to the vendor peak: a large device-to-device copy on this box ---------
+    if rank == 0 and roofline is not None:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev.device)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        copy_ms = e0.elapsed_time(e1) / 10
+        measured = {"what": "1 GiB device-to-device copy, read + write bytes per second", "GB/s": 2.0 * src.numel() / (copy_ms * 1e-3) / 1e9}
+        for r in (roofline, chain):
+            r["measured_copy_peak"] = measured
+            r["frac_of_measured_copy"] = r["achieved"] / measured["GB/s"]
+        del src, dst
+
     # ---- CPU baseline: the oracle's serial C restatement on a bounded sample of the same workload ------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
