@@ -247,7 +247,7 @@ struct SpillWork {
 	uint32_t pad0, pad1;
 };
 
-static constexpr uint32_t ETPB = 1024;             // k_expand: ONE workgroup per CU (256 barrier participants), 16 waves each
+static constexpr uint32_t ETPB = 1024;             // k_expand: at most one workgroup per CU (grid barrier participants), 16 waves each
 
 __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
@@ -986,11 +986,15 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
-		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);                            // grid-stride, 8 workgroups per CU
+		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);
+		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
+		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
+		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
+		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));                            // grid-stride, 8 workgroups per CU
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_expand, dim3(dev.numCUs), dim3(ETPB), stream, a);
+			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
 			switch (sampleSpt) {
 			case 1: SIMLOD_LAUNCH(k_sample<1>, dim3(gridPoints), dim3(TPB), stream, a); break;
 			case 2: SIMLOD_LAUNCH(k_sample<2>, dim3(gridPoints), dim3(TPB), stream, a); break;
