@@ -233,7 +233,7 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 }
 
 // ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
-// Persistent, one workgroup per CU, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
+// Persistent, one workgroup per two CUs, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
 // Per round:  A) one workgroup per spilling leaf: eight children, occupancy grid (allocated, cleared), the leaf's chunk
 //                list is walked ONCE by one lane which turns every chunk into a work item and recycles the chunks;
 //             -- barrier --
@@ -990,7 +990,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
-		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));                            // grid-stride, 8 workgroups per CU
+		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
