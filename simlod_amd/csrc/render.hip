@@ -708,7 +708,9 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	const DeviceInfo& dev = device_info();
 	const uint32_t gridPixels = dev.numCUs * 8;
 	const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
-	const uint32_t gridDraw = dev.numCUs * 8;
+	// four draw workgroups per CU: measured at 1080p on the 36 M terrain, 8 -> 4 takes the plain frame from 0.40 to 0.36 ms and the
+	// HQS frame from 1.05 to 1.01 ms (2: 0.37 / 1.05, 12: 0.40 / 1.07) — fewer waves contend for the same framebuffer lines
+	const uint32_t gridDraw = dev.numCUs * (uint32_t)tune("SIMLOD_DRAW_MULT", 4);
 	const bool whole = parts == RENDER_ALL;
 	auto lines = [&]() {
 		if (!u->showBoundingBox) return;
