@@ -50,6 +50,13 @@ def _worker(rank, world, port, out_dir):
     distributed.compose_min(t)
     vis_bytes = torch.from_numpy(np.ascontiguousarray(o.visible).view(np.uint8).reshape(-1).copy())
     recs, cnts = distributed.gather_visible(vis_bytes, len(o.visible))
+    # the count may also be a one-element tensor next to the records (what the GPU path passes: no host synchronisation)
+    padded = torch.zeros(4096 * 152, dtype=torch.uint8)
+    padded[: vis_bytes.numel()] = vis_bytes
+    recs2, cnts2 = distributed.gather_visible(padded, torch.tensor([len(o.visible)], dtype=torch.int32))
+    assert torch.equal(cnts, cnts2)
+    for r in range(world):
+        assert torch.equal(recs[r, : int(cnts[r])], recs2[r, : int(cnts2[r])])
     np.save(os.path.join(out_dir, f"fb_{rank}.npy"), t.numpy().view(np.uint64))
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([int(o.stats["numPoints"][0]), int(cnts.sum()), int(o.stats["numVisibleNodes"][0])]))
     # whole frames through render_frame: plain, HQS (depth MIN / colour SUM between the passes), HQS with bounding boxes
