@@ -170,12 +170,13 @@ def main():
 
     # ---- per-kernel attribution with HIP events on the launch stream (separate, untimed pass) --------------------
     roofline, chain, kernels = None, None, {}
+    CTL_COUNTERS = slice(168, 192)                                           # simlod_internal.hpp Ctl: spilledTotal, pendingTotal, placeVoxels
     if rank == 0 and not args.no_profile:
         L.simlod_profile_enable(1)
-        dev.momentary[208:216].zero_()                                       # control block: points moved by splits (simlod_internal.hpp)
+        dev.momentary[CTL_COUNTERS].zero_()
         ingest_step()
         prof_c = collect_profile(L)
-        spilled_points = int(dev.momentary[208:216].cpu().numpy().view(np.uint64)[0])
+        moved, placed, place_voxels = (int(v) for v in dev.momentary[CTL_COUNTERS].cpu().numpy().view(np.uint64))
         dev.render(u)
         prof_r = collect_profile(L)
         L.simlod_profile_enable(0)
@@ -186,23 +187,29 @@ def main():
         chain_bytes = 32.0 * n_points + 16.0 * new_voxels                  # 32 B/point + 16 B/new voxel
         chain = {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms, "what": "whole kernel_construct chain, one 36 M ingest"}
-        per_point = {"k_count": 16.0, "k_sample": 16.0, "k_insert": 32.0, "k_expand": 0.0}   # algorithmic bytes per point per kernel
-        base = lambda k: k.split("<")[0]                                     # k_sample<4> -> k_sample
-        dom_full = max((k for k in prof_c if base(k) in per_point), key=lambda k: prof_c[k][1])
+        # Algorithmic bytes per kernel for one whole ingest: k_ingest reads every point (16 B), stores the ones it places
+        # itself (16 B) and the voxels they create (16 B); k_place does the same for the samples of overflowing leaves and the stored
+        # points that move (read 16 B + store 16 B each); k_expand reads a moved point and writes it to the spill buffer (32 B) and
+        # reads every waiting sample once per split round (16 B, lower bound: one round).
+        per_ingest = {"k_ingest": 16.0 * n_points + 16.0 * (n_points - placed) + 16.0 * (new_voxels - place_voxels),
+                      "k_place": 32.0 * (placed + moved) + 16.0 * place_voxels,
+                      "k_expand": 32.0 * moved + 16.0 * placed}
+        base = lambda k: k.split("<")[0]                                     # k_ingest<4> -> k_ingest
+        dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
-        active = n_batches                                                   # launches that had a batch to process
-        bytes_per_launch = per_point[dom] * batch + (16.0 * new_voxels / n_batches if dom == "k_insert" else 0.0)
-        if dom == "k_expand":                                                # 32 B per stored point that a split moves (read + write), SURVEY.md §8a row a6
-            bytes_per_launch = 32.0 * spilled_points / n_batches
+        active = launches_per_step_active = n_batches                        # launches that had a batch to process
+        bytes_per_launch = per_ingest[dom] / active
         avg_ms = prof_c[dom_full][1] / active
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
+        traffic, traffic_src = None, None
+        for tname in ("traffic_r02.json", "traffic_r01.json"):               # rocprofv3 --pmc passes of THIS command, folded by tools/summarize_profile.py
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and dom in json.load(open(tpath)):
+                traffic, traffic_src = json.load(open(tpath)).get(dom), "profiles/" + tname
+                break
         roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
-                    "note": "k_expand moves %d stored points per ingest; it is bound by split rounds and grid barriers, not by bytes" % spilled_points if dom == "k_expand" else None}
+                    "moved_points": moved, "placed_by_k_place": placed, "voxels_by_k_place": place_voxels}
 
     # ---- loader row: LAS format-2 records (26 B) -> Points (16 B) on the device, one 1 M-point batch ----
     loader = None

@@ -337,5 +337,18 @@ int main(int argc, char** argv) {
 		for (int y = height - 1; y >= 0; y--) for (int x = 0; x < width; x++) { const uint32_t c = img[(size_t)y * width + x]; const unsigned char rgb[3] = {(unsigned char)c, (unsigned char)(c >> 8), (unsigned char)(c >> 16)}; std::fwrite(rgb, 1, 3, f); }
 		std::fclose(f);
 	}
+	// SIMLOD_HARNESS_DUMP=<file>: the octree image as the kernels left it — {numNodes, persistent bytes in use, device address of the
+	// node array, device address of the persistent buffer} as four uint64, the node records, the used part of the persistent buffer
+	// — so that a test can compare the replay's octree with the oracle's node by node, not by seven counters
+	if (const char* dumpPath = std::getenv("SIMLOD_HARNESS_DUMP")) {
+		const uint64_t head[4] = {stats.numNodes, stats.allocatedBytes_persistent, (uint64_t)cptr_nodes, (uint64_t)cptr_buffer_persistent};
+		std::vector<uint8_t> nodesHost((size_t)stats.numNodes * sizeof(SimlodNode)), persHost((size_t)stats.allocatedBytes_persistent);
+		cuMemcpyDtoH(nodesHost.data(), cptr_nodes, nodesHost.size());
+		cuMemcpyDtoH(persHost.data(), cptr_buffer_persistent, persHost.size());
+		FILE* f = std::fopen(dumpPath, "wb");
+		if (!f) { std::perror(dumpPath); return 1; }
+		std::fwrite(head, 8, 4, f); std::fwrite(nodesHost.data(), 1, nodesHost.size(), f); std::fwrite(persHost.data(), 1, persHost.size(), f);
+		std::fclose(f);
+	}
 	return (stats.dbg & ~0xeu) == 0 ? 0 : 3;   // 0x2 | 0x4 | 0x8: splits were deferred for lack of scratch space / node slots — nothing lost
 }

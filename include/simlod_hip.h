@@ -33,17 +33,29 @@ extern "C" {
 /* Stats.dbg bits */
 #define SIMLOD_ERR_MOMENTARY_TOO_SMALL 0x001u /* Uniforms.momentaryBufferCapacity cannot hold the scratch layout   */
 #define SIMLOD_ERR_SPILLED_OVERFLOW    0x002u /* spill space exhausted: some splits were DEFERRED to a later batch (no point lost) */
-#define SIMLOD_ERR_SPILLING_OVERFLOW   0x004u /* > 100 000 spilling nodes in one round (voxels.cu:847): the rest is deferred */
+#define SIMLOD_ERR_SPILLING_OVERFLOW   0x004u /* more leaves cross the limit at once than one split round holds (65 536; voxels.cu:847: 100 000): the rest is deferred */
 #define SIMLOD_ERR_NODES_EXHAUSTED     0x008u /* node array full (main_progressive_octree.cpp:552: 263 157 nodes): leaves stop splitting */
-#define SIMLOD_ERR_CHUNK_DIR_OVERFLOW  0x010u /* per-batch chunk directory full                                     */
+#define SIMLOD_ERR_DIRECTORY_FULL      0x010u /* FATAL: directory of the chunks allocated in a batch full (sticky until reset) */
 #define SIMLOD_ERR_NULL_CHUNK          0x020u /* insert into a leaf without storage (voxels.cu:599-604)             */
-#define SIMLOD_ERR_BARRIER_TIMEOUT     0x040u /* in-kernel grid barrier of the expand phase gave up                 */
+#define SIMLOD_ERR_BARRIER_TIMEOUT     0x040u /* FATAL: in-kernel grid barrier of the split cascade gave up (sticky until reset) */
 #define SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW 0x080u /* > 1 000 000 recycled chunks (voxels.cu:856)                        */
 #define SIMLOD_ERR_VISIBLE_OVERFLOW    0x100u /* > 100 000 visible nodes (render.cu:1108)                           */
 
 /* Number of Node records the host's node buffer holds (default 263 157 = 40 000 000 / 152,
  * main_progressive_octree.cpp:552).  Process-wide; set before the first reset if the host allocates differently. */
 int simlod_set_node_capacity(uint32_t numNodes);
+
+/* Ingest granularity of kernel_construct.  0 (default) = EXACT: one ring batch at a time, as progressive_octree_voxels.cu:883-949 does
+ * — every Node and Stats field after every batch is the reference's.  1 = COALESCED: all pending batches of a launch (<= 20, as many
+ * as the momentary buffer holds) are ingested as one batch.  Topology, per-node sample multisets, occupancy bitsets, voxel positions
+ * and counts do not depend on the granularity; the allocator / chunk-pool accounting (Stats.allocatedBytes_persistent,
+ * numAllocatedChunks, chunkPoolSize) does: fewer intermediate chunks are ever allocated.  Process-wide. */
+int simlod_set_ingest_mode(uint32_t mode);
+
+/* Optional host hint: no more than `maxBatches` (1..20, default 20) ring batches are pending when kernel_construct is launched, so
+ * no more than that many per-batch kernel groups need to be enqueued (the reference host knows its upload counter,
+ * main_progressive_octree.cpp:1012-1050).  A launch never ingests more than this many batches.  Process-wide. */
+int simlod_set_construct_batch_limit(uint32_t maxBatches);
 
 /* Byte offset of the uint64 framebuffer inside kernel_render's momentary `buffer` (identical to where the
  * reference's bump allocator places it, render.cu:1108-1123) and the minimum size of that buffer. */

@@ -20,7 +20,7 @@ import numpy as np
 from simlod_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PORT = os.path.join(_HERE, "libsimlod_oracle.so")
+_PORT = os.environ.get("SIMLOD_ORACLE_LIB") or os.path.join(_HERE, "libsimlod_oracle.so")   # override: a -march=native build made by bench.py
 _REF = {k: os.path.join(_HERE, "_ref", f"libref_{k}.so") for k in ("reset", "update", "render")}
 
 REF_MOMENTARY_BYTES = 408_800_192   # what kernel_construct bump-allocates; the host only gives 300 MB

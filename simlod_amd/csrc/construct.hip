@@ -4,30 +4,35 @@
 // kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
 // memory image.  Design:
 //
-//   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, sample, alloc, insert,
-//     end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
-//     over 256 CUs / 8 XCDs costs 4-26 us; control flow stays on the device (a control block at byte 0 of the
-//     momentary buffer), inactive kernels exit at once, so the call is fully asynchronous like the reference's;
-//   * every point is read with one coalesced 16-byte load per phase and descends the tree ONCE: the leaf found
-//     by `count` is cached (4 B/point) and only points whose leaf was split re-descend, from that leaf down
-//     (the reference re-descends from the root in three phases and re-scans the batch in every split round);
-//   * per-leaf counters, slot reservations and voxel counters are aggregated per WORKGROUP in LDS hash tables (one global
-//     atomic per workgroup and counter): device-scope atomics on one word retire at ~88 M/s on this chip, and a spatially
-//     compact batch sends most of its points to a few dozen leaves;
+//   * per batch a short CHAIN of launches on the caller's stream — ingest, expand, place, link, nodes, end — because a
+//     dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier over 256 CUs / 8 XCDs costs 4-26 us;
+//     control flow stays on the device (a control block at byte 0 of the momentary buffer), inactive kernels exit at once, so the
+//     call is fully asynchronous like the reference's;
+//   * `k_ingest` reads every point ONCE (one coalesced 16-byte load) and, for a sample whose leaf does not overflow — the common
+//     case — does everything the reference spreads over three passes and three tree descents: descent, arrival count, slot
+//     reservation, the 16-byte store into the leaf's chunk, voxel sampling of the root path, and the stores of the voxels it won;
+//   * counters are aggregated per WORKGROUP in LDS hash tables (one global atomic per workgroup and counter): device-scope atomics
+//     on one word retire at ~88 M/s on this chip and a spatially compact batch sends most of its points to a few dozen leaves;
+//   * chunks are allocated ON DEMAND by whoever reserves the first slot of a chunk (slot % 1000 == 0) and published through a
+//     directory (the leaf chunk table for point lists, a hash directory for voxel lists); everybody else looks the chunk up.
+//     Allocators never wait, so lookups always terminate.  The O(list length) walks of voxels.cu:500-503 / 606-610 / 688-692 are gone;
+//   * samples of an overflowing leaf (and the leaf's stored points) take the slow path: `k_expand` builds, per round, a 512-bin
+//     histogram of them three octree levels below the leaf, decides up to three generations of the split cascade from it in one
+//     step (one grid barrier per round instead of the reference's ~8 grid.sync() per level), and `k_place` inserts and samples
+//     them in their final leaves;
 //   * voxel sampling walks the root path BOTTOM-UP (occupancy is hierarchical: a set bit implies the covering bits of all
 //     ancestors) and reads the path from a per-node ancestor table instead of chasing parent -> node -> grid pointers;
-//   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of every
-//     list remembers its tail (8 spare bytes of Chunk), a per-batch chunk directory gives O(1) slot->chunk, and a leaf chunk
-//     table lets a split read the whole list of a leaf with one wave;
-//   * new voxels are not copied through a 24-byte backlog record: `sample` leaves a 20-bit per-point mask of the
-//     levels the point won, `insert` regenerates the voxel from (level, cell) while the point is in registers;
-//   * no capacity limit loses a point: a split reserves its node slots and spill space in one compare-and-swap or does not
+//   * no capacity limit loses a point: a split reserves its node slots and spill space before anything is modified, or it does not
 //     happen yet (the leaf grows and is queued again by a later batch).
 //
 // The result after every batch is the reference's: same topology, same per-node sample multisets, same occupancy
 // bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
 // chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
 // (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
+//
+// Opt-in COALESCED mode (simlod_set_ingest_mode(1)): all pending batches of a launch (<= 20, as many as the momentary buffer
+// holds) are ingested as one group.  Topology, multisets, bitsets and voxel positions do not depend on the batch granularity;
+// the allocator / chunk-pool counters of Stats do (fewer intermediate chunks are ever allocated), so the default stays exact.
 #include "simlod_device.hpp"
 #include "simlod_hip.h"
 #include "simlod_internal.hpp"
@@ -37,23 +42,24 @@ namespace simlod {
 static constexpr uint32_t TPB = 256;
 static constexpr float F_GRID = 1048576.0f;      // 2^MAX_DEPTH, progressive_octree_voxels.cu:139
 static constexpr float F_FULL = 268435456.0f;    // MAX_DEPTH_GRIDSIZE, structures.cuh:26
-
-struct NodeDir {          // per node, valid for the batch whose tag it carries
-	uint32_t ptBase, ptFirst, ptTag, voxBase, voxFirst, voxTag, pad0, pad1;
-};
+static constexpr uint32_t MAXPTS = SIMLOD_MAX_POINTS_PER_NODE;
+static constexpr uint32_t CHUNK = SIMLOD_POINTS_PER_CHUNK;
+static constexpr uint32_t NONE = 0xffffffffu;
+static constexpr uint32_t STORED = 0xfffffffeu;
 
 // Leaf chunk table: slot k of leaf i's point list -> chunk, LEAF_SLOTS entries per node.  A leaf that can still split stores
-// at most MAX_POINTS_PER_NODE points between batches (= 50 chunks), so the split reads its whole list from here with all
-// lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by k_alloc; survives between
-// launches like the recycle stack does, and is refilled by k_parents whenever k_begin finds its stamp stale.
-static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
-static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
+// at most MAX_POINTS_PER_NODE points (= 50 chunks).  It is the DIRECTORY of the on-demand allocation (whoever reserves slot
+// k * 1000 of a leaf allocates chunk k and publishes it here; everybody else polls the entry) and it lets a split read a leaf's
+// whole list with all lanes at once instead of chasing 50 `next` pointers with one.  Entries behind the end of a list are null.
+// Survives between launches like the recycle stack does; refilled by k_parents whenever k_begin finds its stamp stale.
+static constexpr uint32_t LEAF_SLOTS = MAXPTS / CHUNK;
+static constexpr uint32_t TABLE_MAGIC = 0x51ab1e06u;
 
 // Ancestor paths: PATH_WORDS 64-bit entries per node, entry k = the k-th ancestor (parent first), zero-terminated.
-// An entry packs everything `sample` and `insert` need to know about that ancestor — its occupancy grid (offset into the
-// persistent buffer), level and node index — so a sample reads its whole root path with independent loads instead of chasing
-// parent -> node -> grid pointers level by level (the chain of dependent L2 round trips that bounded k_sample).
-// Rebuilt for every node at the start of a launch (k_paths), extended for the eight children at a split (k_expand).
+// An entry packs everything sampling needs to know about that ancestor — its occupancy grid (offset into the persistent
+// buffer), level and node index — so a sample reads its whole root path with independent loads instead of chasing
+// parent -> node -> grid pointers level by level.  Rebuilt for every node at the start of a launch (k_paths), extended for new
+// nodes at a split (k_expand).
 static constexpr uint32_t PATH_WORDS = SIMLOD_MAX_DEPTH + 1;
 static constexpr unsigned long long PATH_VALID = 1ull << 63;
 
@@ -71,43 +77,84 @@ __device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_
 template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
 
 __device__ __forceinline__ void raise(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); }
+// conditions after which the octree image cannot be trusted: everything stops, pollers bail out, Stats.dbg keeps the bit until a reset
+__device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) {
+	atomicOr(&ctl->errors, bit);
+	__hip_atomic_store(&ctl->panic, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	ctl->abortBatch = 1; ctl->stop = 1;
+}
+__device__ __forceinline__ bool panicked(Ctl* ctl) { return __hip_atomic_load(&ctl->panic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 
-// Make batch #ordinal of this launch current, or deactivate (progressive_octree_voxels.cu:890-912).
-__device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
+__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
+
+// ---- the group of batches that is being ingested ----------------------------------------------------------------------------
+// A group is ONE batch in exact mode and all pending batches of the launch in coalesced mode.  Its samples live in the ring slots
+// batchSlot[0..groupBatches); the virtual index of sample i of batch b is b * MAX_BATCH_SIZE + i.
+__device__ __forceinline__ const float4* ring_slot(const BuildArgs& a, uint32_t slot) {
+	return reinterpret_cast<const float4*>(a.ring + (size_t)slot * SIMLOD_MAX_BATCH_SIZE);
+}
+__device__ __forceinline__ float4 point_of(const BuildArgs& a, const Ctl* ctl, uint32_t v) {
+	const uint32_t b = v / SIMLOD_MAX_BATCH_SIZE;
+	return ring_slot(a, ctl->batchSlot[b])[v - b * SIMLOD_MAX_BATCH_SIZE];
+}
+// tile #t of `tileSize` samples -> (batch, first sample inside the batch); false behind the last tile
+__device__ __forceinline__ bool tile_lookup(const Ctl* ctl, uint32_t tileSize, uint32_t t, uint32_t& b, uint32_t& first) {
+	const uint32_t nb = ctl->groupBatches;
+	for (b = 0; b < nb; b++) {
+		const uint32_t nt = (ctl->batchSize[b] + tileSize - 1) / tileSize;
+		if (t < nt) { first = t * tileSize; return true; }
+		t -= nt;
+	}
+	return false;
+}
+
+__device__ __forceinline__ uint32_t spilled_end(const Ctl* ctl) { return (uint32_t)__hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Make group #ordinal of this launch current, or deactivate (progressive_octree_voxels.cu:890-912).
+__device__ void prepare_group(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->active = 0;
-	if (ordinal >= ctl->numBatches || ctl->stop) return;
+	if (ctl->consumed >= ctl->numBatches || ctl->stop) return;
 	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
 	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
 	a.stats->memCapacityReached = full ? 1 : 0;
 	if (full) { ctl->stop = 1; return; }
 	const uint32_t batchIndex = a.stats->batchletIndex;
-	const uint32_t slot = batchIndex % SIMLOD_BATCH_STREAM_SIZE;
-	uint32_t size = a.batchSizes[slot];
-	if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
+	const uint32_t g = ctl->coalesce ? min(ctl->numBatches - ctl->consumed, a.groupMax) : 1u;
+	uint32_t total = 0;
+	for (uint32_t b = 0; b < g; b++) {
+		const uint32_t slot = (batchIndex + b) % SIMLOD_BATCH_STREAM_SIZE;
+		uint32_t size = a.batchSizes[slot];
+		if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
+		ctl->batchSize[b] = size; ctl->batchSlot[b] = slot;
+		total += size;
+	}
 	ctl->batchIndex = batchIndex;
-	ctl->ringSlot = slot;
-	ctl->batchSize = size;
+	ctl->groupBatches = g;
+	ctl->groupPoints = total;
 	ctl->ordinal = ordinal;
+	ctl->numPending = 0;
 	ctl->numSpilling = 0;
-	ctl->roundSpill[0] = 0;
-	ctl->roundSpill[1] = 0;
-	ctl->numWork = 0;
-	ctl->spilledSnap[0] = ctl->spilledSnap[1] = 0;
-	ctl->workSnap[0] = ctl->workSnap[1] = 0;
-	ctl->numSpilled = 0;
+	ctl->roundSpill[0] = 0; ctl->roundSpill[1] = 0;
+	ctl->dirUsed = 0;
 	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
-	ctl->dirCount = 0;
+	ctl->nodesAtStart = a.stats->numNodes;
+	ctl->treeModified = 0;
 	ctl->abortBatch = 0;
 	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
 	ctl->active = 1;
 }
 
 // ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
-__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall) {
+__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t coalesce, uint32_t batchLimit, uint32_t debugFlags) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
+	const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
 	ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
-	ctl->stop = momentaryTooSmall ? 1u : 0u;
+	ctl->stop = (momentaryTooSmall || fatal) ? 1u : 0u;
+	ctl->panic = 0;
+	ctl->abortBatch = 0;
+	ctl->coalesce = coalesce;
+	ctl->debugFlags = debugFlags;
 	ctl->startNs = wall_ns();
 	*a.frameStart = ctl->startNs;
 	// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
@@ -116,34 +163,52 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall) {
 	uint32_t n = uploaded - first;
 	if ((int32_t)n < 0) n = 0;
 	if (n > SIMLOD_MAX_BATCHES_PER_LAUNCH) n = SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	if (n > batchLimit) n = batchLimit;
 	ctl->uploaded = uploaded;
 	ctl->firstBatch = first;
 	ctl->numBatches = n;
+	ctl->consumed = 0;
 	ctl->barrierCount = 0;
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
-	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first) ? 1u : 0u;
+	const bool valid = ctl->tableMagic == TABLE_MAGIC && ctl->tableBatch == first && ctl->tableNodes == (uint64_t)a.nodes && ctl->tablePers == (uint64_t)a.pers;
+	ctl->rebuildLeafChunks = valid ? 0u : 1u;
 	ctl->tableMagic = 0;                        // valid again once k_finish has run
-	prepare_batch(a, ctl, 0);
+	prepare_group(a, ctl, 0);
 }
 
-// ---- parents: node index -> parent index, rebuilt at the start of every launch from the children pointers -----------
-// (a momentary table: nothing but the octree image itself and the recycle stack has to survive between launches)
+// ---- parents: node index -> parent index, rebuilt at the start of every launch from the children pointers; snapshots of the
+// list lengths; the leaf chunk table and the tail pointers when the table's stamp is stale -----------------------------------------
 __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= numNodes) return;
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
-	if (i == 0) parentOf[0] = 0xffffffffu;
-	const SimlodNode* n = a.nodes + i;
+	if (i == 0) parentOf[0] = NONE;
+	SimlodNode* n = a.nodes + i;
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
 		const SimlodNode* c = n->children[k];
 		if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
 	}
-	if (ctl_of(a)->rebuildLeafChunks && node_is_leaf(n)) {
+	at<uint32_t>(a, a.offPtStart)[i] = n->numPoints;
+	at<uint32_t>(a, a.offVoxStart)[i] = n->numVoxelsStored;
+	if (ctl_of(a)->rebuildLeafChunks) {
 		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
-		const SimlodChunk* c = n->points;
-		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
+		const bool leaf = node_is_leaf(n);
+		SimlodChunk* c = leaf ? n->points : nullptr;
+		SimlodChunk* last = nullptr;
+		for (uint32_t k = 0; k < LEAF_SLOTS; k++) {
+			slots[k] = c;
+			if (c != nullptr) { last = c; c = c->next; }
+		}
+		// the tail pointers (8 spare bytes of a head chunk) are this implementation's own: an image built elsewhere has none
+		while (c != nullptr) { last = c; c = c->next; }
+		if (leaf && n->points != nullptr) tail_of(n->points) = last;
+		if (n->voxelChunks != nullptr) {
+			SimlodChunk* t = n->voxelChunks;
+			while (t->next != nullptr) t = t->next;
+			tail_of(n->voxelChunks) = t;
+		}
 	}
 }
 
@@ -155,361 +220,277 @@ __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
 	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
 	unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
 	uint32_t k = 0;
-	for (uint32_t cur = parentOf[i]; cur != 0xffffffffu && k < PATH_WORDS - 1; cur = parentOf[cur]) {
+	for (uint32_t cur = parentOf[i]; cur != NONE && k < PATH_WORDS - 1; cur = parentOf[cur]) {
 		const SimlodNode* n = a.nodes + cur;
 		rec[k++] = path_pack(a.pers, cur, n->level, n->grid);
 	}
 	rec[k] = 0;
 }
 
-// ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
-static constexpr uint32_t PPT = 4;                 // points per thread per chunk
-static constexpr uint32_t PPB = TPB * PPT;         // points per workgroup chunk
+// ---- on-demand chunk allocation -------------------------------------------------------------------------------------------------
+// Point chunks come from the recycle stack first (voxels.cu:505-516).  Free chunks are chunkQueue[numAllocatedChunks ..
+// chunkPoolSize); chunkPoolSize is constant while a kernel pops (k_ingest, k_place) and is raised to the high-water mark of
+// numAllocatedChunks before anything is pushed back (k_expand) and at the end of the batch (k_end) — the same totals as the
+// reference's "recycle, then allocate, then max" (:346-357, :535-537), because the chunks in use never exceed their end-of-batch number.
+__device__ __forceinline__ SimlodChunk* take_point_chunk(const BuildArgs& a) {
+	const unsigned long long idx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), 1ull);
+	SimlodChunk* c = idx < a.stats->chunkPoolSize ? at<SimlodChunk*>(a, a.offQueue)[idx]
+	                                              : reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), 1));
+	c->next = nullptr;
+	return c;
+}
 
-// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  A leaf is queued for splitting by whoever sees its counter
-// cross the limit — or, if it is already over the limit because an earlier batch could not split it (spill space, node array or
-// spill list exhausted: the split is deferred, nothing is lost), by whoever touches it first in this batch.  The exchange on the
-// per-node tag makes that exactly one caller per leaf and batch.
-__device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt, uint32_t* spillList, uint32_t* spillCount) {
+// Hash directory of the chunks allocated in the current group: (kind, node, chunk index) -> chunk.  Cleared by the host-enqueued
+// memset of every launch; entries of earlier groups of the launch carry another tag and count as free.
+struct DirEntry {
+	unsigned long long key;
+	SimlodChunk* ptr;
+};
+static constexpr unsigned long long DIR_BUSY = 1ull << 62;
+enum : uint32_t { KIND_PT = 0, KIND_VOX = 1 };
+__device__ __forceinline__ unsigned long long dir_key(uint32_t tag, uint32_t kind, uint32_t node, uint32_t k) {
+	return (1ull << 63) | ((unsigned long long)(tag & 0xfffffu) << 42) | ((unsigned long long)kind << 41) | ((unsigned long long)node << 22) | (k & 0x3fffffu);
+}
+__device__ __forceinline__ uint32_t dir_tag(unsigned long long key) { return (uint32_t)(key >> 42) & 0xfffffu; }
+__device__ __forceinline__ uint32_t dir_hash(const BuildArgs& a, unsigned long long key) {
+	key ^= key >> 29; key *= 0x9e3779b97f4a7c15ull; key ^= key >> 32;
+	return (uint32_t)key & (a.dirCap - 1u);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ void dir_insert(const BuildArgs& a, Ctl* ctl, uint32_t kind, uint32_t node, uint32_t k, SimlodChunk* c) {
+	DirEntry* dir = at<DirEntry>(a, a.offDir);
+	const uint32_t tag = ctl->ordinal + 1u;
+	const unsigned long long key = dir_key(tag, kind, node, k);
+	atomicAdd(&ctl->dirUsed, 1u);
+	uint32_t h = dir_hash(a, key);
+	for (uint32_t probe = 0; probe < a.dirCap; probe++, h = (h + 1u) & (a.dirCap - 1u)) {
+		unsigned long long cur = ld_agent(&dir[h].key);
+		while (cur == 0ull || ((cur >> 63) != 0ull && dir_tag(cur) != tag)) {           // free, or left over from an earlier group
+			const unsigned long long prev = atomicCAS(&dir[h].key, cur, DIR_BUSY);
+			if (prev == cur) {
+				// pointer first, key second: a reader that sees the key must see the pointer (write-through stores, drained in between)
+				__hip_atomic_store(reinterpret_cast<unsigned long long*>(&dir[h].ptr), (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(&dir[h].key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			cur = prev;
+		}
+	}
+	panic(ctl, SIMLOD_ERR_DIRECTORY_FULL);
+}
+
+// non-blocking lookup; nullptr when the entry is not (yet) there
+__device__ SimlodChunk* dir_find(const BuildArgs& a, const Ctl* ctl, uint32_t kind, uint32_t node, uint32_t k) {
+	const DirEntry* dir = at<const DirEntry>(a, a.offDir);
+	const uint32_t tag = ctl->ordinal + 1u;
+	const unsigned long long key = dir_key(tag, kind, node, k);
+	uint32_t h = dir_hash(a, key);
+	for (uint32_t probe = 0; probe < a.dirCap; probe++, h = (h + 1u) & (a.dirCap - 1u)) {
+		const unsigned long long cur = ld_agent(&dir[h].key);
+		if (cur == key) return reinterpret_cast<SimlodChunk*>(ld_agent(reinterpret_cast<const unsigned long long*>(&dir[h].ptr)));
+		if (cur == 0ull) return nullptr;
+		if ((cur >> 63) != 0ull && dir_tag(cur) != tag) return nullptr;
+	}
+	return nullptr;
+}
+
+// blocking lookup: the allocator of the chunk has already reserved its slot range (its atomicAdd precedes the caller's) and it
+// never waits for anything, so this terminates; the bound is a guard against a broken device
+__device__ SimlodChunk* dir_wait(const BuildArgs& a, Ctl* ctl, uint32_t kind, uint32_t node, uint32_t k) {
+	for (uint32_t spin = 0;; spin++) {
+		SimlodChunk* c = dir_find(a, ctl, kind, node, k);
+		if (c != nullptr) return c;
+		__builtin_amdgcn_s_sleep(2);
+		if ((spin & 255u) == 255u && panicked(ctl)) return nullptr;
+		if (spin > (1u << 22)) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return nullptr; }
+	}
+}
+
+// chunk k of a node's point list: allocate (the caller reserved slot k * 1000) ...
+__device__ void make_point_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, uint32_t k) {
+	SimlodChunk* c = take_point_chunk(a);
+	if (k == 0u) { a.nodes[node].points = c; tail_of(c) = c; }
+	if (k < LEAF_SLOTS) {
+		unsigned long long* slot = reinterpret_cast<unsigned long long*>(at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)node * LEAF_SLOTS + k);
+		__hip_atomic_store(slot, (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else dir_insert(a, ctl, KIND_PT, node, k, c);
+}
+// ... or look up (the caller holds some other slot of the chunk)
+__device__ SimlodChunk* wait_point_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, uint32_t k) {
+	if (k < LEAF_SLOTS) {
+		const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)node * LEAF_SLOTS + k);
+		for (uint32_t spin = 0;; spin++) {
+			const unsigned long long c = ld_agent(slot);
+			if (c != 0ull) return reinterpret_cast<SimlodChunk*>(c);
+			__builtin_amdgcn_s_sleep(2);
+			if ((spin & 255u) == 255u && panicked(ctl)) return nullptr;
+			if (spin > (1u << 22)) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return nullptr; }
+		}
+	}
+	// an over-full leaf (its split was deferred, or it sits at MAX_DEPTH): the only older chunk anyone can still write to is the tail
+	if (k * CHUNK < at<const uint32_t>(a, a.offPtStart)[node]) return tail_of(a.nodes[node].points);
+	return dir_wait(a, ctl, KIND_PT, node, k);
+}
+__device__ void make_voxel_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, uint32_t k) {
+	SimlodChunk* c = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), 1));   // voxel chunks never come from the pool (voxels.cu:656-659)
+	c->next = nullptr;
+	if (k == 0u) { a.nodes[node].voxelChunks = c; tail_of(c) = c; }
+	dir_insert(a, ctl, KIND_VOX, node, k, c);
+}
+__device__ SimlodChunk* wait_voxel_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, uint32_t k) {
+	if (k * CHUNK < at<const uint32_t>(a, a.offVoxStart)[node]) return tail_of(a.nodes[node].voxelChunks);   // the partially filled tail of earlier batches
+	return dir_wait(a, ctl, KIND_VOX, node, k);
+}
+
+// ---- split bookkeeping ---------------------------------------------------------------------------------------------------------------
+// Reserve `nodes` node slots and `spill` points of spill space TOGETHER (one 64-bit word), before anything is modified: a leaf that
+// cannot be served now stays a leaf — too full, but intact — and is queued again by a later batch.
+__device__ bool reserve(const BuildArgs& a, Ctl* ctl, uint32_t nodes, uint32_t spill, uint32_t& nodeBase, uint32_t& spillBase) {
+	unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for (;;) {
+		nodeBase = (uint32_t)(cur >> 32); spillBase = (uint32_t)cur;
+		if (nodeBase + nodes > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); return false; }
+		if ((unsigned long long)spillBase + spill > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); return false; }
+		const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + ((unsigned long long)nodes << 32) + spill);
+		if (prev == cur) { atomicAdd(&a.stats->numNodes, nodes); return true; }   // voxels.cu:317
+		cur = prev;
+	}
+}
+
+__device__ __forceinline__ uint32_t round_tag(const Ctl* ctl, uint32_t round) { return ctl->ordinal * 64u + round + 1u; }
+
+// Queue `leafIdx` for splitting in round `round` of the current group (round 0: by k_ingest, with room for `stored` points to move;
+// later rounds: by k_expand for freshly created, empty nodes).  Everything the split needs is reserved here, by ONE thread per leaf:
+// a place in the round's work list (and with it a histogram), eight node slots, the spill space, the occupancy grid.
+__device__ void queue_split(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t stored, uint32_t round, SpillEntry* list, uint32_t* count) {
+	const uint32_t s = atomicAdd(count, 1u);
+	if (s >= a.histCap) { raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); return; }            // more leaves cross the limit at once than a round can hold: deferred
+	uint32_t nodeBase, spillBase;
+	if (!reserve(a, ctl, 8u, stored, nodeBase, spillBase)) { list[s] = SpillEntry{NONE, 0u, 0u, 0u}; return; }
+	SimlodNode* leaf = a.nodes + leafIdx;
+	if (leaf->grid == nullptr)                              // voxels.cu:363-365
+		leaf->grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+	list[s] = SpillEntry{leafIdx, nodeBase, spillBase, stored};
+	at<unsigned long long>(a, a.offSplitTag)[leafIdx] = ((unsigned long long)round_tag(ctl, round) << 32) | s;
+}
+
+// One arrival-counter update for `cnt` samples (voxels.cu:203-218); returns the counter's previous value.  A leaf is queued for
+// splitting by the arrival that crosses the limit — everything that arrived before it was stored directly, so `old` bounds the
+// stored points that will have to move — or, if the leaf is already over the limit because an earlier batch could not split it
+// (spill space, node array or work list exhausted: the split was deferred, nothing was lost), by whoever touches it first in this
+// group.  A node at MAX_DEPTH cannot be subdivided (the descent stops there): it keeps growing instead.
+__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt) {
 	SimlodNode* leaf = a.nodes + leafIdx;
 	const uint32_t old = atomicAdd(&leaf->counter, cnt);
-	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
-	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
-		const uint32_t tag = ctl->batchIndex + 1u;
-		if (atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag) {
-			const uint32_t s = atomicAdd(spillCount, 1u);
-			if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
+	if (old + cnt > MAXPTS && leaf->level < SIMLOD_MAX_DEPTH) {
+		SpillEntry* list = at<SpillEntry>(a, a.offSpillA);
+		if (old <= MAXPTS) queue_split(a, ctl, leafIdx, old, 0u, list, &ctl->numSpilling);
+		else {
+			const uint32_t start = at<const uint32_t>(a, a.offPtStart)[leafIdx];
+			const uint32_t tag = ctl->ordinal + 1u;
+			if (start > MAXPTS && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag) queue_split(a, ctl, leafIdx, start, 0u, list, &ctl->numSpilling);
 		}
 	}
+	return old;
 }
 
-__device__ __forceinline__ void flush_counts(const BuildArgs& a, Ctl* ctl, BlockTable& tbl, uint32_t* spillList, uint32_t* spillCount) {
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], spillList, spillCount);
-	}
-}
+// ---- one tile of samples: slots, stores, voxel sampling -----------------------------------------------------------------------------
+static constexpr int LT_BITS = 9, VT_BITS = 8, SET_BITS = 11;
+static constexpr uint32_t LT_CAP = 1u << LT_BITS, VT_CAP = 1u << VT_BITS, SET_CAP = 1u << SET_BITS;
 
-// k_count takes more points per thread than k_insert (PPT): its cost is the flush of the per-workgroup counts into a few dozen
-// hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
-static constexpr uint32_t CPT = 8;
-static constexpr uint32_t CPB = TPB * CPT;
-
-__global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active) return;
-	__shared__ BlockTable tbl;
-	const uint32_t n = ctl->batchSize;
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
-	const uint32_t numChunks = (n + CPB - 1) / CPB;
-	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
-	// other's slowest descent; one flush at the end.
-	table_init(tbl);
-	__syncthreads();
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		float4 p[CPT];
-#pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) {
-			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
-			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) {
-			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
-			if (i >= n) continue;
-			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
-			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
-			const uint32_t Z = quantize(F_GRID, p[j].z, a.minz, a.size);
-			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
-			leafOf[i] = leafIdx;
-			uint32_t rank;
-			if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, spillList, &ctl->numSpilling);
-		}
-	}
-	__syncthreads();
-	flush_counts(a, ctl, tbl, spillList, &ctl->numSpilling);
-}
-
-// ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
-// Persistent, one workgroup per two CUs, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
-// Per round:  A) one workgroup per spilling leaf: eight children, occupancy grid (allocated, cleared), the leaf's chunk
-//                list is walked ONCE by one lane which turns every chunk into a work item and recycles the chunks;
-//             -- barrier --
-//             B) all workgroups: spill-copy work items (1000 stored points each, routed to the child they belong to)
-//                and the recount of the batch samples whose cached leaf was split; both feed the children's arrival
-//                counters, whoever sees a counter cross the limit appends the child to the next round's list;
-//             -- barrier --
-struct SpillWork {
-	const SimlodChunk* chunk;
-	uint32_t childOffset, dstBase, count, level;
-	uint32_t pad0, pad1;
+struct TileShared {
+	Tab<LT_BITS> lt;                       // leaf -> samples of this workgroup (count; the old value of the count is a sample's rank)
+	uint32_t ltBase[LT_CAP];               // first slot of the range this workgroup reserved in the leaf, or NONE (samples wait for k_place)
+	SimlodChunk* ltPtr[LT_CAP][2];         // the chunk that holds slot ltBase and the one behind it
+	Tab<VT_BITS> vt;                       // inner node -> voxels created by this workgroup (count, later the store cursor)
+	uint32_t vtBase[VT_CAP];
+	SimlodChunk* vtPtr[VT_CAP][2];
+	uint32_t claimed[SET_CAP];             // (node, cell) pairs this workgroup already claimed
+	uint32_t pendCount, pendBase;
 };
 
-static constexpr uint32_t ETPB = 1024;             // k_expand: at most one workgroup per CU (grid barrier participants), 16 waves each
+__device__ __forceinline__ void tile_reset(TileShared& sh) {
+	tab_init(sh.lt);
+	tab_init(sh.vt);
+	for (uint32_t i = threadIdx.x; i < SET_CAP; i += blockDim.x) sh.claimed[i] = TBL_EMPTY;
+	if (threadIdx.x == 0) { sh.pendCount = 0; sh.pendBase = 0; }
+}
 
-__global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active) return;
-	if (ctl->numSpilling == 0) return;          // written by k_count, never modified here: a stable early-exit test
-
-	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	unsigned long long* splitInfo = at<unsigned long long>(a, a.offSplitTag);   // per node: round tag << 32 | first child << 5 | level
-	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
-	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
-	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
-	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
-	SpillWork* work = at<SpillWork>(a, a.offWork);
-	float4* spilled = at<float4>(a, a.offSpilled);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const uint32_t n = ctl->batchSize;
-	uint32_t generation = 0;
-
-	__shared__ BlockTable tbl;
-	__shared__ uint32_t sh_childOffset, sh_ok, sh_spillBase;
-	__shared__ uint32_t sh_childCount[8];
-	__shared__ SimlodOccupancyGrid* sh_grid;
-
-	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS; ++round) {
-		uint32_t* listCur = at<uint32_t>(a, (round & 1) ? a.offSpillB : a.offSpillA);
-		uint32_t* listNext = at<uint32_t>(a, (round & 1) ? a.offSpillA : a.offSpillB);
-		uint32_t* countCur = round == 0 ? &ctl->numSpilling : &ctl->roundSpill[(round - 1) & 1];
-		uint32_t* countNext = &ctl->roundSpill[round & 1];
-		uint32_t numSpilling = *countCur;
-		if (numSpilling > SPILLING_CAPACITY) numSpilling = SPILLING_CAPACITY;
-		if (numSpilling == 0) break;
-		const uint32_t tag = ctl->ordinal * 32u + round + 1u;
-		const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
-		uint64_t t0 = timer ? wall_ns() : 0, t1;
-		if (timer && round == 0) ctl->expandNs[6] += 1;
-		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;   // last read one round ago, appended to only after the barrier below
-
-		// -- A: split ---------------------------------------------------------------------------------------------
-		for (uint32_t s = blockIdx.x; s < numSpilling; s += gridDim.x) {
-			const uint32_t nodeIdx = listCur[s];
-			SimlodNode* node = a.nodes + nodeIdx;
-			__syncthreads();
-			if (threadIdx.x == 0) {
-				// Reserve eight node slots and the spill space for the stored points TOGETHER (one 64-bit word), before anything is
-				// modified: a leaf that cannot be served now stays a leaf — too full, but intact — and is queued again by a later batch.
-				const uint32_t stored = node->numPoints;
-				uint32_t ok = 1, off = 0, base = 0;
-				unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				for (;;) {
-					off = (uint32_t)(cur >> 32); base = (uint32_t)cur;
-					if (off + 8u > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ok = 0; break; }
-					if ((unsigned long long)base + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ok = 0; break; }
-					const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + (8ull << 32) + stored);
-					if (prev == cur) break;
-					cur = prev;
-				}
-				SimlodOccupancyGrid* grid = node->grid;
-				if (ok) {
-					atomicAdd(&a.stats->numNodes, 8u);         // voxels.cu:317
-					atomicAdd(&ctl->numSpilled, stored);
-					if (grid == nullptr) {                     // voxels.cu:363-365
-						grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
-						node->grid = grid;
-					}
-				}
-				sh_childOffset = off; sh_ok = ok; sh_grid = grid; sh_spillBase = base;
-			}
-			__syncthreads();
-			if (!sh_ok) continue;
-			const uint32_t childOffset = sh_childOffset;
-			const uint32_t level = node->level;
-			if (threadIdx.x < 8) {                          // the eight children, voxels.cu:318-343
-				const uint32_t i = threadIdx.x;
-				// written field by field straight to the node array (a 152-byte local would live in scratch memory)
-				SimlodNode& c = a.nodes[childOffset + i];
-				for (int k = 0; k < 8; k++) c.children[k] = nullptr;
-				c.counter = 0; c.numPoints = 0;
-				c.level = level + 1;
-				c.X = 2 * node->X + ((i >> 2) & 1u);
-				c.Y = 2 * node->Y + ((i >> 1) & 1u);
-				c.Z = 2 * node->Z + (i & 1u);
-				c.countIteration = 0; c.countFlag = 0;
-				for (int k = 0; k < 20; k++) c.name[k] = node->name[k];
-				if (level + 1 < 20) c.name[level + 1] = (uint8_t)('0' + i);
-				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
-				c.grid = nullptr; c.points = nullptr; c.voxelChunks = nullptr;
-				c.numVoxels = 0; c.numVoxelsStored = 0;
-				node->children[i] = a.nodes + childOffset + i;
-				parentOf[childOffset + i] = nodeIdx;
-				// the child's ancestors: this node (its grid is final now), then this node's own ancestors
-				const unsigned long long* mine = paths + (uint64_t)nodeIdx * PATH_WORDS;
-				unsigned long long* theirs = paths + (uint64_t)(childOffset + i) * PATH_WORDS;
-				theirs[0] = path_pack(a.pers, nodeIdx, level, sh_grid);
-				for (uint32_t k = 0; k + 1 < PATH_WORDS; k++) {
-					const unsigned long long e = k + 2 < PATH_WORDS ? mine[k] : 0ull;
-					theirs[k + 1] = e;
-					if (e == 0ull) break;
-				}
-			}
-			if (threadIdx.x >= 64 && threadIdx.x < 128) {
-				// Wave 1 turns every chunk of the leaf into a work item and hands the chunks back to the recycle stack
-				// (voxels.cu:346-357; nothing pops before k_alloc).  Chunk k comes from the leaf chunk table, not from a walk.
-				const uint32_t lane = threadIdx.x - 64;
-				const uint32_t stored = node->numPoints;
-				SimlodChunk* const head = node->points;
-				// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
-				const uint32_t numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
-				const uint32_t spillBase = sh_spillBase;
-				uint32_t w0 = 0;
-				unsigned long long top = 0;
-				if (lane == 0 && numChunks > 0) {
-					w0 = atomicAdd(&ctl->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
-					top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
-				}
-				w0 = __shfl(w0, 0);
-				top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
-				SimlodChunk* const* slots = leafChunks + (uint64_t)nodeIdx * LEAF_SLOTS;
-				auto emit = [&](uint32_t ci, SimlodChunk* chunk) {
-					if (w0 + ci < a.workCap) {
-						SpillWork w;
-						w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
-						w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
-						work[w0 + ci] = w;
-					} else raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW);
-					const unsigned long long q = top - numChunks + ci;
-					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
-				};
-				SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
-				if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
-				for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
-					SimlodChunk* chunk = slots[ci];
-					emit(ci, chunk);
-					chunk->next = nullptr;
-				}
-				if (lane == 0) for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
-					SimlodChunk* next = beyond->next;
-					emit(ci, beyond);
-					beyond->next = nullptr;
-					beyond = next;
-				}
-				if (lane == 0) {
-					node->numPoints = 0;
-					node->points = nullptr;
-					splitInfo[nodeIdx] = ((unsigned long long)tag << 32) | ((unsigned long long)childOffset << 5) | level;
-				}
-			}
-			// meanwhile the other lanes clear the occupancy grid — of EVERY spilling node, also one that already had a
-			// grid (the root), voxels.cu:371-382
-			{
-				uint4* g = reinterpret_cast<uint4*>(sh_grid->values);
-				const uint4 z = make_uint4(0, 0, 0, 0);
-				if (threadIdx.x >= 128) for (uint32_t w = threadIdx.x - 128; w < SIMLOD_GRID_NUM_WORDS / 4; w += ETPB - 128) g[w] = z;
-			}
-		}
-
-		if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-		if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
-		// numSpilled / numWork are stable between this barrier and the next round's split phase: snapshot them for round+1
-		const uint32_t workEnd = min(ctl->numWork, a.workCap);
-		const uint32_t workBegin = ctl->workSnap[round & 1];
-		const uint32_t numSpilledPrev = ctl->spilledSnap[round & 1];
-		if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->workSnap[(round + 1) & 1] = workEnd; ctl->spilledSnap[(round + 1) & 1] = min(ctl->numSpilled, a.spilledCap); }
-
-		// -- B1: move the stored points of the split leaves into the spill buffer, routed to their child (voxels.cu:253-289)
-		for (uint32_t w = workBegin + blockIdx.x; w < workEnd; w += gridDim.x) {
-			const SpillWork item = work[w];
-			__syncthreads();
-			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
-			__syncthreads();
-			const float4* src = reinterpret_cast<const float4*>(item.chunk->points);
-			for (uint32_t j = threadIdx.x; j < item.count; j += ETPB) {
-				const float4 p = src[j];
-				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
-				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
-				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-				const int c = child_index(X, Y, Z, (int)item.level);
-				const uint32_t dst = item.dstBase + j;
-				spilled[dst] = p;
-				leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = item.childOffset + (uint32_t)c;
-				winMask[SIMLOD_MAX_BATCH_SIZE + dst] = item.level << 24;     // `sample` starts at the spilling node's level
-				atomicAdd(&sh_childCount[c], 1u);
-			}
-			__syncthreads();
-			if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0)
-				count_into(a, ctl, item.childOffset + threadIdx.x, sh_childCount[threadIdx.x], listNext, countNext);
-		}
-
-		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; }
-		// -- B2: recount — only samples whose cached leaf was split in THIS round go one (or more) levels down ------------
-		// Also after the 20th split: the reference does not count again there (voxels.cu:394-412), allocates no chunks for the
-		// level-20 children and drops every point that lands in them (:599-604) — 50 001 points in one 2^-20 cell.  Here they are
-		// counted and stored; a level-20 leaf never asks for another split (count_into).
-		{
-			const uint32_t total = n + numSpilledPrev;
-			__syncthreads();
-			table_init(tbl);                           // one table for the whole scan of this workgroup, one flush
-			__syncthreads();
-			// four samples per thread at a time, stage by stage: the four cached-leaf loads are in flight together, then the four
-			// split tags, then the points and the first child pointer of those that have to move (a 1 M-sample batch is four
-			// samples per thread: the dependent chain leaf -> tag -> point -> child is paid once, not four times)
-			constexpr uint32_t U = 4;
-			const uint32_t stride = gridDim.x * ETPB;
-			for (uint32_t t0 = blockIdx.x * ETPB + threadIdx.x; t0 < total; t0 += U * stride) {
-				uint32_t idx[U], leaf[U]; unsigned long long info[U]; float4 p[U];
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					const uint32_t t = t0 + q * stride;
-					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-					leaf[q] = t < total ? leafOf[idx[q]] : 0xffffffffu;
-				}
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) info[q] = leaf[q] != 0xffffffffu ? splitInfo[leaf[q]] : 0ull;
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					const uint32_t t = t0 + q * stride;
-					p[q] = (uint32_t)(info[q] >> 32) == tag ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
-				}
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					if ((uint32_t)(info[q] >> 32) != tag) continue;
-					// the children of a leaf split in this round are leaves: the record of the split says where they are, no node is read
-					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size);
-					const uint32_t Y = quantize(F_GRID, p[q].y, a.miny, a.size);
-					const uint32_t Z = quantize(F_GRID, p[q].z, a.minz, a.size);
-					const uint32_t level = (uint32_t)info[q] & 31u, childOffset = ((uint32_t)info[q] >> 5) & 0x7ffffu;
-					const uint32_t leafIdx = childOffset + (uint32_t)child_index(X, Y, Z, (int)level);
-					leafOf[idx[q]] = leafIdx;
-					uint32_t rank;
-					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
-				}
-			}
-			__syncthreads();
-			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += ETPB) {
-				const uint32_t key = tbl.keys[e];
-				if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], listNext, countNext);
-			}
-		}
-		if (timer) { t1 = wall_ns(); ctl->expandNs[3] += t1 - t0; t0 = t1; }
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) raise(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-		if (timer) { t1 = wall_ns(); ctl->expandNs[4] += t1 - t0; ctl->expandNs[5] += 1; }
+// Reserve the slot ranges of this workgroup's samples, one global atomic per (workgroup, leaf), allocate the chunks whose first slot
+// falls into a range, then look up the others.  ALL allocations of a thread come before its first lookup: allocators never wait.
+// INGEST: ranges come from the arrival counter and are only taken while the leaf stays within its limit (and is not a root that
+// is still a leaf: whether its grid survives the batch is not known yet) — otherwise the samples are left to k_place.
+template <bool INGEST>
+__device__ void flush_points(const BuildArgs& a, Ctl* ctl, TileShared& sh) {
+	for (uint32_t e = threadIdx.x; e < LT_CAP; e += blockDim.x) {
+		const uint32_t key = sh.lt.keys[e];
+		if (key == TBL_EMPTY) continue;
+		const uint32_t cnt = sh.lt.vals[e];
+		uint32_t old;
+		bool direct = true;
+		if (INGEST) {
+			old = count_into(a, ctl, key, cnt);
+			direct = key != 0u && old + cnt <= MAXPTS;
+			if (direct) atomicAdd(&a.nodes[key].numPoints, cnt);                      // voxels.cu:593
+		} else old = atomicAdd(&a.nodes[key].numPoints, cnt);
+		if (direct) for (uint32_t k = (old + CHUNK - 1) / CHUNK; k * CHUNK < old + cnt; k++) make_point_chunk(a, ctl, key, k);
+		sh.ltBase[e] = direct ? old : NONE;
+	}
+	for (uint32_t e = threadIdx.x; e < LT_CAP; e += blockDim.x) {
+		const uint32_t key = sh.lt.keys[e];
+		if (key == TBL_EMPTY || sh.ltBase[e] == NONE) continue;
+		const uint32_t old = sh.ltBase[e], cnt = sh.lt.vals[e], k0 = old / CHUNK;
+		sh.ltPtr[e][0] = wait_point_chunk(a, ctl, key, k0);
+		sh.ltPtr[e][1] = (old + cnt - 1) / CHUNK > k0 ? wait_point_chunk(a, ctl, key, k0 + 1) : nullptr;
 	}
 }
 
-// ---- sample: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
-// The reference tests the sample's cell in EVERY node of the path, root first.  Occupancy is hierarchical, though: a
-// cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit in a node
-// had, in the same pass, been offered to all its ancestors — so "bit set in node N" implies "covering bit set in every
-// ancestor of N".  This kernel therefore walks the path BOTTOM-UP and stops at the first level whose bit is already
-// set, or where its own atomicOr lost the race (the winner keeps climbing).  Same bitsets, same voxel counts, one
-// winner per cell as in the reference; what it removes is the contention: measured on MI355X, a top-down pass issued
-// 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
-// (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
-// NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
-// Per-workgroup set of (node, cell) claims.  While the octree is still shallow the deepest grid of a sample is coarse: on the
-// terrain workload the 1 M points of an early batch fall into 4 nodes and ~1000 occupancy words, 890 k of them see a clear
-// bit (tools/analyze_candidates.py), and thousands of atomicOr per word serialise at ~11 ns each.  So only the FIRST sample of
-// a workgroup that sees a clear cell issues the global atomicOr; the others know the cell is being taken care of and stop,
-// exactly as if they had lost the race.  key = table entry of the node (10 bits) << 21 | cell (21 bits).
-static constexpr int SET_BITS = 12;
-static constexpr int SET_CAP = 1 << SET_BITS;
+__device__ __forceinline__ void store_point(const BuildArgs& a, Ctl* ctl, TileShared& sh, uint32_t e, uint32_t rank, const float4& p) {
+	const uint32_t base = sh.ltBase[e], slot = base + rank, k = slot / CHUNK, d = k - base / CHUNK;
+	SimlodChunk* c = d == 0u ? sh.ltPtr[e][0] : d == 1u ? sh.ltPtr[e][1] : wait_point_chunk(a, ctl, sh.lt.keys[e], k);
+	if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % CHUNK] = p;
+}
+
+// a sample whose leaf found no room in the LDS table (k_place only): its own slot, its own chunk bookkeeping
+__device__ void store_point_direct(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, const float4& p) {
+	const uint32_t slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u), k = slot / CHUNK;
+	if (slot % CHUNK == 0u) make_point_chunk(a, ctl, leafIdx, k);
+	SimlodChunk* c = wait_point_chunk(a, ctl, leafIdx, k);
+	if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % CHUNK] = p;
+}
+
+// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
+__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
+	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
+	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize),
+	// masked to `level` bits: a coordinate exactly on the max face quantises to 2^20 (2^28 here) and the reference's descent, which
+	// looks at bits 19..0 only, files it under node coordinate 0 on that axis (voxels.cu:171-179) — the voxel sits at the LOW face
+	const uint32_t nsh = 28u - (uint32_t)level;
+	const uint32_t nmask = (1u << (uint32_t)level) - 1u;
+	const uint32_t nX = (pX >> nsh) & nmask, nY = (pY >> nsh) & nmask, nZ = (pZ >> nsh) & nmask;
+	const float nodeSize = a.size / exp2_int((uint32_t)level);
+	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
+	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
+	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
+	float4 v;
+	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
+	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
+	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
+	v.w = colorBits;                       // colour of the claiming point
+	return v;
+}
+
+// a voxel whose node found no room in the LDS table: its own slot, its own chunk bookkeeping
+__device__ void store_voxel_direct(const BuildArgs& a, Ctl* ctl, uint32_t nodeIdx, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const uint32_t slot = atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u), k = slot / CHUNK;          // voxels.cu:101
+	if (slot % CHUNK == 0u) make_voxel_chunk(a, ctl, nodeIdx, k);
+	SimlodChunk* c = wait_voxel_chunk(a, ctl, nodeIdx, k);
+	if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % CHUNK] = voxel_of(a, level, pX, pY, pZ, colorBits);
+}
 
 // true: the caller is the first of its workgroup to claim `key` (or the set has no room: claim anyway, merely redundant)
 __device__ __forceinline__ bool set_insert(uint32_t* set, uint32_t key) {
@@ -525,353 +506,655 @@ __device__ __forceinline__ bool set_insert(uint32_t* set, uint32_t key) {
 	return true;
 }
 
-template <uint32_t SPT>
-__global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
-	constexpr uint32_t SPB = TPB * SPT;
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
-	__shared__ uint32_t claimed[SET_CAP];              // (node, cell) pairs this workgroup already claimed
-	const uint32_t n = ctl->batchSize;
-	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const float4* spilled = at<const float4>(a, a.offSpilled);
-	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
-	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
-	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	const uint32_t numChunks = (total + SPB - 1) / SPB;
-	table_init(tbl);                                   // lives for the whole workgroup: no barrier inside the chunk loop
-	for (uint32_t i = threadIdx.x; i < (uint32_t)SET_CAP; i += TPB) claimed[i] = TBL_EMPTY;
-	__syncthreads();
+// the k-th ancestor entry of a leaf; a root that is still a leaf samples itself (voxels.cu:449-463: every node of the path that
+// has a grid is sampled, and the root has one from the reset on)
+__device__ __forceinline__ unsigned long long path_entry(const BuildArgs& a, const unsigned long long* rec, uint32_t leafIdx, uint32_t k) {
+	if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; return (k == 0u && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
+	return k < PATH_WORDS - 1 ? rec[k] : 0ull;
+}
+
+// 128^3 occupancy test-and-set on the inner nodes of the root-to-leaf path (voxels.cu:50-121, 417-483), BOTTOM-UP.
+// The reference tests the sample's cell in EVERY node of the path, root first.  Occupancy is hierarchical, though: a cell of a node
+// covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit in a node had, in the same pass, been
+// offered to all its ancestors — so "bit set in node N" implies "covering bit set in every ancestor of N".  The walk therefore
+// starts at the deepest inner node and stops at the first level whose bit is already set, or where its own atomicOr lost the race
+// (the winner keeps climbing).  Same bitsets, same voxel counts, one winner per cell as in the reference; what it removes is the
+// contention: a top-down pass issues 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly
+// entered territory; bottom-up issues about one per NEW voxel, and steady-state samples cost one 4-byte probe.
+// Only the FIRST sample of a workgroup that sees a clear cell issues the global atomicOr (per-workgroup claim set in LDS): the
+// others know the cell is being taken care of and stop, exactly as if they had lost the race.
+// Returns the mask of levels this sample won; the voxels are stored later (store_voxels) behind ranges reserved per workgroup.
+// `startLevel`: stored points that move because their leaf splits were offered to the levels above it when they first arrived.
+__device__ uint32_t sample_path(const BuildArgs& a, Ctl* ctl, TileShared& sh, uint32_t leafIdx, uint32_t startLevel, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
 	constexpr int WIN = 3;                             // ancestors fetched and probed together
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+	const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)leafIdx * PATH_WORDS;
+	uint32_t wins = 0;
+	bool go = true;
 #pragma unroll 1
-		for (uint32_t j = 0; j < SPT; j++) {
-			const uint32_t t = chunk * SPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			uint32_t idx, startLevel = 0;
-			float4 p;
-			if (t < n) { idx = t; p = pts[t]; }
-			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
-			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-			// the leaf was cached by count/expand; grids live in the inner nodes above it (and in a root that is still a leaf)
-			const uint32_t leafIdx = leafOf[idx];
-			const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
-			uint32_t wins = 0;
-			bool go = true;
-#pragma unroll 1
-			for (uint32_t k0 = 0; go && k0 < PATH_WORDS - 1; k0 += WIN) {
-				unsigned long long ent[WIN];
-				uint32_t* word[WIN];
-				uint32_t seen[WIN], cell[WIN];
+	for (uint32_t k0 = 0; go && k0 < PATH_WORDS - 1; k0 += WIN) {
+		unsigned long long ent[WIN];
+		uint32_t* word[WIN];
+		uint32_t seen[WIN], cell[WIN];
 #pragma unroll
-				for (int w = 0; w < WIN; w++) {              // independent loads: the entries ...
-					if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; ent[w] = (k0 + w == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
-					else ent[w] = k0 + w < PATH_WORDS - 1 ? rec[k0 + w] : 0ull;
-				}
+		for (int w = 0; w < WIN; w++) ent[w] = path_entry(a, rec, leafIdx, k0 + w);           // independent loads: the entries ...
 #pragma unroll
-				for (int w = 1; w < WIN; w++) if (ent[w - 1] == 0ull) ent[w] = 0ull;   // what lies behind the terminator was never written
+		for (int w = 1; w < WIN; w++) if (ent[w - 1] == 0ull) ent[w] = 0ull;                   // what lies behind the terminator was never written
 #pragma unroll
-				for (int w = 0; w < WIN; w++) {              // ... then the occupancy words of all of them
-					const uint32_t level = path_level(ent[w]);
-					const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
-					const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
-					cell[w] = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-					word[w] = &path_grid(a.pers, ent[w])->values[cell[w] >> 5];
-					// voxels.cu:449: the traverse loop samples levels 0..19 only; spilled samples start at the spilling node's level
-					if (ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { ent[w] = 0ull; seen[w] = 0u; }
-					else seen[w] = *word[w];        // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
-				}
-#pragma unroll
-				for (int w = 0; w < WIN; w++) {              // bottom-up: claim while winning
-					if (!go) break;
-					if (ent[w] == 0ull) { go = false; break; }
-					const uint32_t bit = cell[w] & 31u;
-					if (((seen[w] >> bit) & 1u) != 0u) { go = false; break; }               // voxels.cu:93-94; the ancestors are set as well
-					const uint32_t nodeIdx = path_node(ent[w]);
-					uint32_t rank;
-					const int e = table_add(tbl, nodeIdx, 0u, &rank);
-					if (e >= 0 && !set_insert(claimed, ((uint32_t)e << 21) | cell[w])) { go = false; break; }   // a sample of this workgroup already claims the cell
-					if (((atomicOr(word[w], 1u << bit) >> bit) & 1u) != 0u) { go = false; break; }              // voxels.cu:96; lost: the winner climbs on
-					wins |= 1u << path_level(ent[w]);                                       // first point in the cell, voxels.cu:99
-					if (e >= 0) atomicAdd(&tbl.vals[e], 1u); else atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u);   // voxels.cu:101
-				}
-			}
-			winMask[idx] = wins;
+		for (int w = 0; w < WIN; w++) {              // ... then the occupancy words of all of them
+			const uint32_t level = path_level(ent[w]);
+			const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
+			const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
+			cell[w] = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+			word[w] = &path_grid(a.pers, ent[w])->values[cell[w] >> 5];
+			// voxels.cu:449: the traverse loop samples levels 0..19 only
+			if (ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { ent[w] = 0ull; seen[w] = 0u; }
+			else seen[w] = *word[w];        // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
 		}
-	}
-	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY && tbl.vals[e] != 0u) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
-	}
-}
-
-// ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
-// (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
-__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
-
-__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i) {
-	SimlodNode* node = a.nodes + i;
-	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
-	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
-	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
-	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
-	const uint32_t tag = ctl->batchIndex + 1u;
-	node->countIteration = tag;
-
-	// -- points of leaves -------------------------------------------------------------------------------------
-	const uint32_t counter = node->counter, stored = node->numPoints;
-	if (stored < counter && node_is_leaf(node)) {
-		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
-		const uint32_t entries = required - first;
-		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
-		if (base + entries > a.dirCap) { raise(ctl, SIMLOD_ERR_CHUNK_DIR_OVERFLOW); return; }
-		SimlodChunk* head = node->points;
-		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
-		uint32_t e = 0;
-		if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
-		const uint32_t additional = required - existing;
-		if (additional > 0) {
-			// pop from the recycle stack, allocate what the stack cannot serve (voxels.cu:505-516): one atomic each
-			const unsigned long long firstIdx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional);
-			const unsigned long long pool = a.stats->chunkPoolSize;     // raised only by k_end
-			const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
-			uint8_t* fresh = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
-			for (uint32_t k = 0; k < additional; k++) {
-				SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
-				                              : reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-				c->next = nullptr;
-				if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
-				tail = c;
-				chunkDir[base + e++] = c;
-				if (existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;
-			}
-			tail_of(head) = tail;
-		}
-		NodeDir& d = nodeDir[i];
-		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
-	}
-
-	// -- voxels of inner nodes (and of the root while it is still a leaf) --------------------------------------
-	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
-	if (numVoxels > voxStored) {
-		const uint32_t required = (numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		SimlodChunk* head = node->voxelChunks;
-		const uint32_t existing = head == nullptr ? 0u : max(1u, (voxStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK);
-		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t entries = required - first;
-		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
-		if (base + entries > a.dirCap) { raise(ctl, SIMLOD_ERR_CHUNK_DIR_OVERFLOW); return; }
-		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
-		uint32_t e = 0;
-		if (first < existing) chunkDir[base + e++] = tail;
-		if (required > existing) {
-			const uint32_t additional = required - existing;
-			uint8_t* fresh = persistent_alloc(a.pers, sizeof(SimlodChunk), additional);   // voxel chunks never come from the pool
-			for (uint32_t k = 0; k < additional; k++) {
-				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-				c->next = nullptr;
-				if (tail == nullptr) { node->voxelChunks = c; head = c; } else tail->next = c;
-				tail = c;
-				chunkDir[base + e++] = c;
-			}
-			tail_of(head) = tail;
-		}
-		NodeDir& d = nodeDir[i];
-		d.voxBase = base; d.voxFirst = first; d.voxTag = tag;
-	}
-}
-
-// A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
-__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i);
-}
-
-// ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
-struct InsertShared {
-	BlockTable tbl;                       // node -> count (step 1), then node -> running cursor (step 3)
-	uint32_t base[TBL_CAP];               // first slot of the range this workgroup reserved in the node
-	uint32_t dirBase[TBL_CAP];            // chunk-directory base of the node for this batch, or 0xffffffff
-	uint32_t dirFirst[TBL_CAP];
-};
-
-// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
-__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
-	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
-	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
-	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
-	const uint32_t nsh = 28u - (uint32_t)level;
-	const uint32_t nX = level == 0 ? 0u : pX >> nsh, nY = level == 0 ? 0u : pY >> nsh, nZ = level == 0 ? 0u : pZ >> nsh;
-	const float nodeSize = a.size / exp2_int((uint32_t)level);
-	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
-	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
-	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
-	float4 v;
-	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
-	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
-	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
-	v.w = colorBits;                       // colour of the claiming point
-	return v;
-}
-
-__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
-	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	__shared__ InsertShared sh;
-	const uint32_t n = ctl->batchSize;
-	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const float4* spilled = at<const float4>(a, a.offSpilled);
-	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
-	const uint32_t* winMask = at<const uint32_t>(a, a.offWin);
-	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
-	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
-	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
-	const uint32_t tag = ctl->batchIndex + 1u;
-	const uint32_t numChunks = (total + PPB - 1) / PPB;
-	// Three workgroup-wide steps, each over ALL chunks this workgroup owns, so that barriers are paid per workgroup and not
-	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
-	// global atomic each, (3) store — the slot inside the range comes from an LDS cursor.
-
-	// ======== points ========
-	table_init(sh.tbl);
-	__syncthreads();
-	bool anyWins = false;
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 #pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-			anyWins |= (winMask[idx] & 0xfffffu) != 0u;
+		for (int w = 0; w < WIN; w++) {              // bottom-up: claim while winning
+			if (!go) break;
+			if (ent[w] == 0ull) { go = false; break; }
+			const uint32_t bit = cell[w] & 31u;
+			if (((seen[w] >> bit) & 1u) != 0u) { go = false; break; }               // voxels.cu:93-94; the ancestors are set as well
+			const uint32_t nodeIdx = path_node(ent[w]);
 			uint32_t rank;
-			(void)table_add(sh.tbl, leafOf[idx], 1u, &rank);
+			const int e = tab_add(sh.vt, nodeIdx, 0u, &rank);
+			if (e >= 0 && !set_insert(sh.claimed, ((uint32_t)e << 21) | cell[w])) { go = false; break; }   // a sample of this workgroup already claims the cell
+			if (((atomicOr(word[w], 1u << bit) >> bit) & 1u) != 0u) { go = false; break; }              // voxels.cu:96; lost: the winner climbs on
+			if (e >= 0) { wins |= 1u << path_level(ent[w]); atomicAdd(&sh.vt.vals[e], 1u); }            // first point in the cell, voxels.cu:99
+			else store_voxel_direct(a, ctl, nodeIdx, (int)path_level(ent[w]), pX, pY, pZ, colorBits);
 		}
 	}
-	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-		const uint32_t key = sh.tbl.keys[e];
-		if (key == TBL_EMPTY) continue;
-		const NodeDir d = nodeDir[key];
-		sh.base[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);                      // voxels.cu:593
-		sh.tbl.vals[e] = 0;                                                                    // becomes the cursor
-		sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
-		sh.dirFirst[e] = d.ptFirst;
-	}
-	__syncthreads();
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		float4 p[PPT];
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? pts[t] : spilled[t - n]);
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
-			const int e = table_find(sh.tbl, leafIdx);
-			uint32_t slot, base, first;
-			if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
-			else {                                                                                // table had no room for this leaf
-				const NodeDir d = nodeDir[leafIdx];
-				slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u); base = d.ptTag == tag ? d.ptBase : 0xffffffffu; first = d.ptFirst;
-			}
-			if (base == 0xffffffffu) { raise(ctl, SIMLOD_ERR_NULL_CHUNK); continue; }           // voxels.cu:599-604
-			SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
-			reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p[j];
-		}
-	}
+	return wins;
+}
 
-	// ======== voxels: the samples that won a cell in `sample` regenerate their voxel(s) ========
-	if (!__syncthreads_or(anyWins ? 1 : 0)) return;
-	table_init(sh.tbl);
-	__syncthreads();
-	for (int pass = 0; pass < 2; pass++) {
-		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
-		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+// voxel slot ranges of this workgroup, one global atomic per (workgroup, node): numVoxels is counter and cursor in one
+// (voxels.cu:101 and :685; numVoxelsStored catches up in k_nodes)
+__device__ void flush_voxels(const BuildArgs& a, Ctl* ctl, TileShared& sh, unsigned long long* tally = nullptr) {
+	for (uint32_t e = threadIdx.x; e < VT_CAP; e += blockDim.x) {
+		const uint32_t key = sh.vt.keys[e];
+		if (key == TBL_EMPTY) continue;
+		const uint32_t cnt = sh.vt.vals[e];
+		if (cnt == 0u) { sh.vtBase[e] = NONE; continue; }
+		const uint32_t old = atomicAdd(&a.nodes[key].numVoxels, cnt);
+		for (uint32_t k = (old + CHUNK - 1) / CHUNK; k * CHUNK < old + cnt; k++) make_voxel_chunk(a, ctl, key, k);
+		sh.vtBase[e] = old;
+		if (tally != nullptr) atomicAdd(tally, (unsigned long long)cnt);
+	}
+	for (uint32_t e = threadIdx.x; e < VT_CAP; e += blockDim.x) {
+		const uint32_t key = sh.vt.keys[e];
+		if (key == TBL_EMPTY || sh.vtBase[e] == NONE) continue;
+		const uint32_t old = sh.vtBase[e], cnt = sh.vt.vals[e], k0 = old / CHUNK;
+		sh.vtPtr[e][0] = wait_voxel_chunk(a, ctl, key, k0);
+		sh.vtPtr[e][1] = (old + cnt - 1) / CHUNK > k0 ? wait_voxel_chunk(a, ctl, key, k0 + 1) : nullptr;
+		sh.vt.vals[e] = 0;                  // becomes the store cursor
+	}
+}
+
+// the samples that won cells regenerate their voxel(s) from (level, cell) and store them behind the reserved bases
+__device__ void store_voxels(const BuildArgs& a, Ctl* ctl, TileShared& sh, uint32_t leafIdx, uint32_t wins, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)leafIdx * PATH_WORDS;
 #pragma unroll 1
-			for (uint32_t j = 0; j < PPT; j++) {
-				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-				if (t >= total) continue;
-				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-				uint32_t left = winMask[idx] & 0xfffffu;
-				if (left == 0u) continue;
-				// the won levels are among the deepest ancestors of the cached leaf: read them off its path
-				const uint32_t leafIdx = leafOf[idx];
-				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
-				float4 p = make_float4(0, 0, 0, 0);
-				uint32_t pX = 0, pY = 0, pZ = 0;
-				if (pass == 1) {
-					p = t < n ? pts[t] : spilled[t - n];
-					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
-				}
-#pragma unroll 1
-				for (uint32_t k = 0; left != 0u && k < PATH_WORDS - 1; k++) {
-					const unsigned long long ent = leafIdx == 0u ? (k == 0 ? PATH_VALID : 0ull) : rec[k];   // a root that is still a leaf samples itself
-					if (ent == 0ull) break;
-					const uint32_t curIdx = path_node(ent);
-					const int level = (int)path_level(ent);
-					if (((left >> level) & 1u) == 0u) continue;
-					left &= ~(1u << level);
-					if (pass == 0) {
-						uint32_t rank;
-						(void)table_add(sh.tbl, curIdx, 1u, &rank);
-					} else {
-						const int e = table_find(sh.tbl, curIdx);
-						uint32_t slot, base, first;
-						if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
-						else {
-							const NodeDir d = nodeDir[curIdx];
-							slot = atomicAdd(&a.nodes[curIdx].numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
-						}
-						if (base == 0xffffffffu) raise(ctl, SIMLOD_ERR_NULL_CHUNK);
-						else {
-							SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
-							reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, level, pX, pY, pZ, p.w);
-						}
-					}
+	for (uint32_t k = 0; wins != 0u && k < PATH_WORDS - 1; k++) {
+		const unsigned long long ent = path_entry(a, rec, leafIdx, k);
+		if (ent == 0ull) break;
+		const int level = (int)path_level(ent);
+		if (((wins >> level) & 1u) == 0u) continue;
+		wins &= ~(1u << level);
+		const uint32_t nodeIdx = path_node(ent);
+		const int e = tab_find(sh.vt, nodeIdx);
+		if (e < 0) continue;                               // cannot happen: a win bit is only set for a node that has an entry
+		const uint32_t base = sh.vtBase[e], slot = base + atomicAdd(&sh.vt.vals[e], 1u), kk = slot / CHUNK, d = kk - base / CHUNK;
+		SimlodChunk* c = d == 0u ? sh.vtPtr[e][0] : d == 1u ? sh.vtPtr[e][1] : wait_voxel_chunk(a, ctl, nodeIdx, kk);
+		if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % CHUNK] = voxel_of(a, level, pX, pY, pZ, colorBits);
+	}
+}
+
+// ---- ingest: the whole job for samples whose leaf stays within its limit (voxels.cu:124-229, 417-483, 485-639, 674-698) ----------
+template <int P>
+__global__ __launch_bounds__(TPB) void k_ingest(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	__shared__ TileShared sh;
+	constexpr uint32_t TILE = TPB * P;
+	uint32_t* pendIdx = at<uint32_t>(a, a.offPendIdx);
+	uint32_t* pendLeaf = at<uint32_t>(a, a.offPendLeaf);
+	for (uint32_t tile = blockIdx.x;; tile += gridDim.x) {
+		uint32_t b, first;
+		if (!tile_lookup(ctl, TILE, tile, b, first)) break;
+		const uint32_t cnt = min(TILE, ctl->batchSize[b] - first);
+		const float4* pts = ring_slot(a, ctl->batchSlot[b]) + first;
+		const uint32_t vbase = b * SIMLOD_MAX_BATCH_SIZE + first;
+		__syncthreads();
+		tile_reset(sh);
+		__syncthreads();
+
+		// 1: one coalesced 16-byte load per sample, ONE root -> leaf descent, count per (workgroup, leaf) in LDS
+		float4 p[P];
+		uint32_t leafOf[P], er[P];                     // er: table entry << 16 | rank inside the workgroup, NONE without an entry
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			const uint32_t i = j * TPB + threadIdx.x;
+			p[j] = i < cnt ? pts[i] : make_float4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			const uint32_t i = j * TPB + threadIdx.x;
+			leafOf[j] = NONE; er[j] = NONE;
+			if (i >= cnt) continue;
+			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
+			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
+			const uint32_t Z = quantize(F_GRID, p[j].z, a.minz, a.size);
+			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
+			leafOf[j] = leafIdx;
+			uint32_t rank;
+			const int e = tab_add(sh.lt, leafIdx, 1u, &rank);
+			if (e >= 0) er[j] = ((uint32_t)e << 16) | rank;
+			else {
+				// no room in the table: this sample is its own (workgroup, leaf) entry.  Its slot comes from the arrival counter like
+				// everybody's, so the leaf's storage stays gap-free; whoever allocates its chunk reserved an earlier slot and never waits
+				const uint32_t old = count_into(a, ctl, leafIdx, 1u);
+				if (leafIdx != 0u && old + 1u <= MAXPTS) {
+					atomicAdd(&a.nodes[leafIdx].numPoints, 1u);
+					if (old % CHUNK == 0u) make_point_chunk(a, ctl, leafIdx, old / CHUNK);
+					SimlodChunk* c = wait_point_chunk(a, ctl, leafIdx, old / CHUNK);
+					if (c != nullptr) reinterpret_cast<float4*>(c->points)[old % CHUNK] = p[j];
+					er[j] = STORED;
 				}
 			}
 		}
 		__syncthreads();
-		if (pass == 0) {
-			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-				const uint32_t key = sh.tbl.keys[e];
-				if (key == TBL_EMPTY) continue;
-				const NodeDir d = nodeDir[key];
-				sh.base[e] = atomicAdd(&a.nodes[key].numVoxelsStored, sh.tbl.vals[e]);            // voxels.cu:685
-				sh.tbl.vals[e] = 0;
-				sh.dirBase[e] = d.voxTag == tag ? d.voxBase : 0xffffffffu;
-				sh.dirFirst[e] = d.voxFirst;
+
+		// 2: arrival counters, slot ranges, chunks
+		flush_points<true>(a, ctl, sh);
+		__syncthreads();
+
+		// 3: store, sample; what cannot be placed yet is queued for k_place
+		uint32_t wins[P], pend[P];
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			wins[j] = 0; pend[j] = NONE;
+			if (leafOf[j] == NONE) continue;
+			const uint32_t e = er[j] >> 16;
+			if (er[j] == STORED || (er[j] != NONE && sh.ltBase[e] != NONE)) {
+				if (er[j] != STORED) store_point(a, ctl, sh, e, er[j] & 0xffffu, p[j]);
+				const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
+				wins[j] = sample_path(a, ctl, sh, leafOf[j], 0u, pX, pY, pZ, p[j].w);
+			} else pend[j] = atomicAdd(&sh.pendCount, 1u);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0 && sh.pendCount != 0u) sh.pendBase = atomicAdd(&ctl->numPending, sh.pendCount);
+
+		// 4: voxel slot ranges and chunks
+		flush_voxels(a, ctl, sh);
+		__syncthreads();
+
+		// 5: voxel stores; the queue entries of the samples left to k_place
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			if (wins[j] != 0u) {
+				const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
+				store_voxels(a, ctl, sh, leafOf[j], wins[j], pX, pY, pZ, p[j].w);
 			}
-			__syncthreads();
+			if (pend[j] != NONE) {
+				const uint32_t q = sh.pendBase + pend[j];
+				if (q < a.pendCap) { pendIdx[q] = vbase + j * TPB + threadIdx.x; pendLeaf[q] = leafOf[j]; }
+			}
 		}
 	}
 }
 
-// ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
+// ---- expand: the split cascade (voxels.cu:385-415, 245-289, 308-383) ------------------------------------------------------------
+// Persistent, one workgroup per two CUs, launched cooperatively (all workgroups resident), hand-rolled grid barrier.
+// Per round, for the leaves of the round's work list (round 0: the leaves k_ingest saw overflow; later: nodes created by the
+// previous round that are still too full):
+//   H) histogram, per listed leaf, of everything that has to go below it — its stored points (moved to the spill buffer on the
+//      way, round 0) and the samples waiting for k_place — over the 8^nl cells nl = 3 levels further down (2 when the list is
+//      longer than the histogram space at 512 bins each);
+//   -- barrier --
+//   D) one workgroup per (leaf, child): from the histogram alone it creates the child, and while a descendant holds more than
+//      MAX_POINTS_PER_NODE samples, that one's children too, down to nl generations, arrival counters filled in, occupancy grids
+//      allocated and cleared, ancestor paths written; descendants of the last generation that are still too full go on the next
+//      round's list.  The leaf's chunks return to the recycle stack.
+// Nothing waits for a barrier while the tree is half modified, and k_ingest reserved everything a round-0 split needs, so a round
+// either happens completely or — a barrier that gives up — not at all.
+static constexpr uint32_t ETPB = 1024;             // at most one workgroup per CU (grid barrier participants), 16 waves each
+static constexpr int HT_BITS = 12;
+
+struct ExpandShared {
+	Tab<HT_BITS> ht;                               // (list entry << 9 | bin) -> count, for the scan of the waiting samples
+	uint32_t dense[512];                           // one stored chunk's histogram
+	uint32_t hc[64];                               // D: bins below one child
+	uint32_t childSplit, gcBase, split2Mask, ggBase[8], queueMask2, queueMask3[8];
+	SimlodOccupancyGrid* gridC;
+	SimlodOccupancyGrid* gridG[8];
+};
+
+__device__ __forceinline__ int child_at(uint32_t X, uint32_t Y, uint32_t Z, uint32_t level) {
+	return level < (uint32_t)SIMLOD_MAX_DEPTH ? child_index(X, Y, Z, (int)level) : 0;
+}
+// histogram bin of a sample below a node of `level`: its child, grand-child (and great-grand-child) octant
+__device__ __forceinline__ uint32_t bin_of(const BuildArgs& a, const float4& p, uint32_t level, uint32_t nl) {
+	const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+	uint32_t bin = (uint32_t)child_at(X, Y, Z, level) * 8u + (uint32_t)child_at(X, Y, Z, level + 1);
+	if (nl == 3u) bin = bin * 8u + (uint32_t)child_at(X, Y, Z, level + 2);
+	return bin;
+}
+
+__device__ __forceinline__ const SimlodChunk* leaf_chunk(const BuildArgs& a, uint32_t leafIdx, uint32_t k) {
+	SimlodChunk* const* slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)leafIdx * LEAF_SLOTS;
+	if (k < LEAF_SLOTS) return slots[k];
+	const SimlodChunk* c = slots[LEAF_SLOTS - 1];                  // a leaf whose split was deferred and that kept growing: walk
+	for (uint32_t i = LEAF_SLOTS - 1; i < k && c != nullptr; i++) c = c->next;
+	return c;
+}
+
+// write one freshly created node, field by field straight to the node array (a 152-byte local would live in scratch memory)
+__device__ void write_node(const BuildArgs& a, uint32_t idx, uint32_t parentIdx, uint32_t octant, uint32_t counter, SimlodNode* firstChild, SimlodOccupancyGrid* grid) {
+	SimlodNode& c = a.nodes[idx];
+	const SimlodNode& par = a.nodes[parentIdx];
+	const uint32_t level = par.level + 1u;
+	for (int k = 0; k < 8; k++) c.children[k] = firstChild != nullptr ? firstChild + k : nullptr;
+	c.counter = counter; c.numPoints = 0;
+	c.level = level;
+	c.X = 2 * par.X + ((octant >> 2) & 1u);
+	c.Y = 2 * par.Y + ((octant >> 1) & 1u);
+	c.Z = 2 * par.Z + (octant & 1u);
+	c.countIteration = 0; c.countFlag = 0;
+	for (int k = 0; k < 20; k++) c.name[k] = par.name[k];
+	if (level < 20u) c.name[level] = (uint8_t)('0' + octant);
+	c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
+	c.grid = grid; c.points = nullptr; c.voxelChunks = nullptr;
+	c.numVoxels = 0; c.numVoxelsStored = 0;
+	at<uint32_t>(a, a.offParent)[idx] = parentIdx;
+	at<uint32_t>(a, a.offPtStart)[idx] = 0;
+	at<uint32_t>(a, a.offVoxStart)[idx] = 0;
+	// its ancestors: the parent (whose grid is final), then the parent's own ancestors
+	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
+	const unsigned long long* mine = paths + (uint64_t)parentIdx * PATH_WORDS;
+	unsigned long long* theirs = paths + (uint64_t)idx * PATH_WORDS;
+	theirs[0] = path_pack(a.pers, parentIdx, par.level, par.grid);
+	for (uint32_t k = 0; k + 1 < PATH_WORDS; k++) {
+		const unsigned long long e = k + 2 < PATH_WORDS ? mine[k] : 0ull;
+		theirs[k + 1] = e;
+		if (e == 0ull) break;
+	}
+	SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)idx * LEAF_SLOTS;
+	for (uint32_t k = 0; k < LEAF_SLOTS; k++) slots[k] = nullptr;
+}
+
+__device__ __forceinline__ void clear_grid(SimlodOccupancyGrid* g, uint32_t firstWord4, uint32_t numWords4) {
+	uint4* w = reinterpret_cast<uint4*>(g->values) + firstWord4;
+	const uint4 z = make_uint4(0, 0, 0, 0);
+	for (uint32_t i = threadIdx.x; i < numWords4; i += ETPB) w[i] = z;
+}
+
+// roundFirst == 0: round 0 only (the common case is a cascade that ends within three levels: one barrier, then the kernel boundary
+// does the rest).  roundFirst == 1: the remaining rounds, until a round leaves no node over the limit.
+__global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t roundFirst) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	if (roundFirst == 0u ? ctl->numSpilling == 0u : ctl->roundSpill[0] == 0u) return;      // stable: written before this launch, never modified by it (roundSpill[0]: see the zeroing below)
+
+	__shared__ ExpandShared sh;
+	uint32_t* hist = at<uint32_t>(a, a.offHist);
+	uint32_t* pendIdx = at<uint32_t>(a, a.offPendIdx);
+	uint32_t* pendLeaf = at<uint32_t>(a, a.offPendLeaf);
+	uint32_t* spMeta = at<uint32_t>(a, a.offSpMeta);
+	float4* spilled = at<float4>(a, a.offSpilled);
+	const unsigned long long* splitInfo = at<const unsigned long long>(a, a.offSplitTag);
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	const uint32_t numPending = min(ctl->numPending, a.pendCap);
+	const uint32_t spEnd = spilled_end(ctl);
+	uint32_t generation = 0;
+	const bool forceTimeout = (ctl->debugFlags & 1u) != 0u;
+
+	// before anything returns to the recycle stack: free chunks are chunkQueue[numAllocatedChunks .. chunkPoolSize)
+	if (roundFirst == 0u && blockIdx.x == 0 && threadIdx.x == 0) {
+		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
+		ctl->expandNs[5] += 1;
+	}
+
+	for (uint32_t round = roundFirst;; ++round) {
+		SpillEntry* listCur = at<SpillEntry>(a, (round & 1u) ? a.offSpillB : a.offSpillA);
+		SpillEntry* listNext = at<SpillEntry>(a, (round & 1u) ? a.offSpillA : a.offSpillB);
+		uint32_t* countCur = round == 0u ? &ctl->numSpilling : &ctl->roundSpill[(round - 1u) & 1u];
+		uint32_t* countNext = &ctl->roundSpill[round & 1u];
+		const uint32_t n = min(*countCur, a.histCap);
+		if (n == 0u) break;
+		const uint32_t nl = n * 512u <= a.histCap * 64u ? 3u : 2u;     // the histogram space holds histCap entries at 64 bins
+		const uint32_t bins = nl == 3u ? 512u : 64u;
+		const uint32_t tag = round_tag(ctl, round);
+		if (blockIdx.x == 0 && threadIdx.x == 0) { if (round >= 2u) *countNext = 0; ctl->expandNs[4] += 1; }   // last read one round ago, appended to only after the barrier below
+
+		// -- H1: stored points of the listed leaves -> spill buffer, histogram per chunk (entries of later rounds are empty nodes)
+		if (round == 0u) for (uint32_t s = 0; s < n; s++) {
+			const SpillEntry en = listCur[s];
+			if (en.leaf == NONE || en.stored == 0u) continue;
+			const SimlodNode* L = a.nodes + en.leaf;
+			const uint32_t actual = min(L->numPoints, en.stored), lvl = L->level;
+			const uint32_t numChunks = (en.stored + CHUNK - 1) / CHUNK;
+			for (uint32_t k = blockIdx.x; k < numChunks; k += gridDim.x) {
+				__syncthreads();
+				for (uint32_t i = threadIdx.x; i < 512u; i += ETPB) sh.dense[i] = 0;
+				__syncthreads();
+				const SimlodChunk* c = k * CHUNK < actual ? leaf_chunk(a, en.leaf, k) : nullptr;
+				const uint32_t j = threadIdx.x, idx = k * CHUNK + j;
+				if (j < CHUNK && idx < en.stored) {
+					const uint32_t dst = en.spillBase + idx;
+					if (idx < actual && c != nullptr) {
+						const float4 p = reinterpret_cast<const float4*>(c->points)[j];
+						spilled[dst] = p;
+						spMeta[dst] = en.leaf | (lvl << 19);           // sampling restarts at the spilling node's level
+						atomicAdd(&sh.dense[bin_of(a, p, lvl, nl)], 1u);
+					} else spMeta[dst] = NONE;                        // reserved for arrivals that were not stored after all
+				}
+				__syncthreads();
+				for (uint32_t i = threadIdx.x; i < bins; i += ETPB) if (sh.dense[i] != 0u) atomicAdd(&hist[(uint64_t)s * bins + i], sh.dense[i]);
+			}
+		}
+
+		// -- H2: the samples waiting for k_place (and, from round 1 on, the moved points): follow the tree as far as it goes now,
+		//        count those that end in a listed leaf
+		{
+			__syncthreads();
+			tab_init(sh.ht);
+			__syncthreads();
+			const uint32_t total = numPending + (round == 0u ? 0u : spEnd);
+			for (uint32_t q = blockIdx.x * ETPB + threadIdx.x; q < total; q += gridDim.x * ETPB) {
+				const bool isPend = q < numPending;
+				const uint32_t meta = isPend ? pendLeaf[q] : spMeta[q - numPending];
+				if (meta == NONE) continue;
+				uint32_t cur = meta & 0x7ffffu;
+				float4 p = make_float4(0, 0, 0, 0);
+				bool have = false;
+				if (round != 0u && !node_is_leaf(a.nodes + cur)) {
+					p = isPend ? point_of(a, ctl, pendIdx[q]) : spilled[q - numPending]; have = true;
+					const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+					cur = (uint32_t)(descend(a.nodes + cur, (int)a.nodes[cur].level, X, Y, Z) - a.nodes);
+					if (isPend) pendLeaf[q] = cur; else spMeta[q - numPending] = cur | (meta & ~0x7ffffu);
+				}
+				const unsigned long long info = splitInfo[cur];
+				if ((uint32_t)(info >> 32) != tag) continue;
+				const uint32_t s = (uint32_t)info;
+				if (s >= n) continue;
+				if (!have) p = isPend ? point_of(a, ctl, pendIdx[q]) : spilled[q - numPending];
+				const uint32_t key = s * bins + bin_of(a, p, a.nodes[cur].level, nl);
+				uint32_t rank;
+				if (tab_add(sh.ht, key, 1u, &rank) < 0) atomicAdd(&hist[key], 1u);
+			}
+			__syncthreads();
+			for (uint32_t e = threadIdx.x; e < (uint32_t)Tab<HT_BITS>::CAP; e += ETPB) {
+				const uint32_t key = sh.ht.keys[e];
+				if (key != TBL_EMPTY) atomicAdd(&hist[key], sh.ht.vals[e]);
+			}
+		}
+
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x, forceTimeout)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+
+		// -- D: decide and build, one workgroup per (listed leaf, child octant)
+		const uint32_t sub = bins / 8u;
+		if (threadIdx.x == 0) ctl->treeModified = 1;
+		for (uint32_t item = blockIdx.x; item < n * 8u; item += gridDim.x) {
+			const uint32_t s = item >> 3, c1 = item & 7u;
+			const SpillEntry en = listCur[s];
+			if (en.leaf == NONE) continue;
+			SimlodNode* L = a.nodes + en.leaf;
+			const uint32_t lvl = L->level;
+			const uint32_t childIdx = en.childBase + c1;
+			__syncthreads();
+			if (threadIdx.x < 64u) {
+				uint32_t* h = hist + (uint64_t)s * bins + c1 * sub;
+				sh.hc[threadIdx.x] = threadIdx.x < sub ? h[threadIdx.x] : 0u;
+				if (threadIdx.x < sub) h[threadIdx.x] = 0;           // the histogram space is clean again for the next round / batch
+			}
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				// which descendants exist: a node splits while it holds more than MAX_POINTS_PER_NODE samples and is above MAX_DEPTH
+				// (voxels.cu:203-218) and eight node slots can still be had — otherwise it stays a leaf, over-full, and is queued
+				// again by a later batch
+				uint32_t count1 = 0;
+				for (uint32_t i = 0; i < sub; i++) count1 += sh.hc[i];
+				sh.childSplit = 0; sh.gcBase = 0; sh.split2Mask = 0; sh.queueMask2 = 0; sh.gridC = nullptr;
+				for (int i = 0; i < 8; i++) { sh.ggBase[i] = 0; sh.queueMask3[i] = 0; sh.gridG[i] = nullptr; }
+				uint32_t nb, sb;
+				if (count1 > MAXPTS && lvl + 1u < (uint32_t)SIMLOD_MAX_DEPTH && reserve(a, ctl, 8u, 0u, nb, sb)) {
+					sh.childSplit = 1; sh.gcBase = nb;
+					sh.gridC = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+					for (uint32_t c2 = 0; c2 < 8u; c2++) {
+						uint32_t count2 = 0;
+						if (nl == 3u) for (uint32_t i = 0; i < 8u; i++) count2 += sh.hc[c2 * 8u + i]; else count2 = sh.hc[c2];
+						if (count2 <= MAXPTS || lvl + 2u >= (uint32_t)SIMLOD_MAX_DEPTH) continue;
+						if (nl == 2u) { sh.queueMask2 |= 1u << c2; continue; }     // its histogram is the next round's business
+						if (!reserve(a, ctl, 8u, 0u, nb, sb)) continue;
+						sh.split2Mask |= 1u << c2; sh.ggBase[c2] = nb;
+						sh.gridG[c2] = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+						for (uint32_t c3 = 0; c3 < 8u; c3++)
+							if (sh.hc[c2 * 8u + c3] > MAXPTS && lvl + 3u < (uint32_t)SIMLOD_MAX_DEPTH) sh.queueMask3[c2] |= 1u << c3;
+					}
+				}
+				L->children[c1] = a.nodes + childIdx;
+			}
+			__syncthreads();
+			// the nodes: thread 0 the child, 1..8 its children, 9..72 theirs — parents first (a node copies its parent's record)
+			if (threadIdx.x == 0) {
+				uint32_t count1 = 0;
+				for (uint32_t i = 0; i < sub; i++) count1 += sh.hc[i];
+				write_node(a, childIdx, en.leaf, c1, count1, sh.childSplit ? a.nodes + sh.gcBase : nullptr, sh.gridC);
+			}
+			__syncthreads();
+			if (sh.childSplit && threadIdx.x >= 1u && threadIdx.x < 9u) {
+				const uint32_t c2 = threadIdx.x - 1u;
+				uint32_t count2 = 0;
+				if (nl == 3u) for (uint32_t i = 0; i < 8u; i++) count2 += sh.hc[c2 * 8u + i]; else count2 = sh.hc[c2];
+				const bool split = ((sh.split2Mask >> c2) & 1u) != 0u;
+				write_node(a, sh.gcBase + c2, childIdx, c2, count2, split ? a.nodes + sh.ggBase[c2] : nullptr, sh.gridG[c2]);
+			}
+			__syncthreads();
+			if (threadIdx.x >= 9u && threadIdx.x < 73u) {
+				const uint32_t c2 = (threadIdx.x - 9u) >> 3, c3 = (threadIdx.x - 9u) & 7u;
+				if (((sh.split2Mask >> c2) & 1u) != 0u) write_node(a, sh.ggBase[c2] + c3, sh.gcBase + c2, c3, sh.hc[c2 * 8u + c3], nullptr, nullptr);
+			}
+			// the occupancy grids: this workgroup's eighth of the leaf's own — of EVERY split node, also one that already had a grid
+			// (the root), voxels.cu:371-382 — and the whole grid of every descendant it split
+			clear_grid(L->grid, c1 * (SIMLOD_GRID_NUM_WORDS / 32u), SIMLOD_GRID_NUM_WORDS / 32u);
+			if (sh.childSplit) clear_grid(sh.gridC, 0u, SIMLOD_GRID_NUM_WORDS / 4u);
+			for (uint32_t c2 = 0; c2 < 8u; c2++) if (((sh.split2Mask >> c2) & 1u) != 0u) clear_grid(sh.gridG[c2], 0u, SIMLOD_GRID_NUM_WORDS / 4u);
+			if (c1 == 0u && threadIdx.x >= 64u && threadIdx.x < 128u) {
+				// Wave 1 hands the leaf's chunks back to the recycle stack (voxels.cu:346-357; nothing pops before k_place).  Chunk k
+				// comes from the leaf chunk table, not from a walk.
+				const uint32_t lane = threadIdx.x - 64u;
+				const uint32_t stored = L->numPoints;
+				const uint32_t numChunks = L->points != nullptr ? (stored + CHUNK - 1) / CHUNK : 0u;
+				unsigned long long top = 0;
+				if (lane == 0 && numChunks > 0) top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
+				top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
+				SimlodChunk** slots = leafChunks + (uint64_t)en.leaf * LEAF_SLOTS;
+				SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
+				if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
+				for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
+					SimlodChunk* chunk = slots[ci];
+					const unsigned long long q = top - numChunks + ci;
+					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+					chunk->next = nullptr;
+				}
+				if (lane == 0) for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
+					SimlodChunk* next = beyond->next;
+					const unsigned long long q = top - numChunks + ci;
+					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = beyond; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+					beyond->next = nullptr;
+					beyond = next;
+				}
+				for (uint32_t ci = lane; ci < LEAF_SLOTS; ci += 64) slots[ci] = nullptr;
+				if (lane == 0) {
+					atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->spilledTotal), (unsigned long long)stored);
+					L->numPoints = 0;
+					L->points = nullptr;
+				}
+			}
+			__syncthreads();
+			// descendants of the last generation that are still too full: next round (reserves their slots and grids now)
+			if (threadIdx.x == 0) {
+				for (uint32_t c2 = 0; c2 < 8u; c2++) {
+					if (((sh.queueMask2 >> c2) & 1u) != 0u) queue_split(a, ctl, sh.gcBase + c2, 0u, round + 1u, listNext, countNext);
+					for (uint32_t c3 = 0; c3 < 8u; c3++)
+						if (((sh.queueMask3[c2] >> c3) & 1u) != 0u) queue_split(a, ctl, sh.ggBase[c2] + c3, 0u, round + 1u, listNext, countNext);
+				}
+			}
+		}
+		if (roundFirst == 0u) break;                            // the kernel boundary is the barrier
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x, false)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+	}
+}
+
+// ---- place: samples that k_ingest could not place — their leaf overflowed — and the stored points of the split leaves go into
+// the leaves that exist now: slots, stores, voxel sampling, as in k_ingest (voxels.cu:540-639 for the spilled points) -------------
+template <int P>
+__global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t numPending = min(ctl->numPending, a.pendCap);
+	const uint32_t total = numPending + spilled_end(ctl);
+	if (total == 0u) return;
+	__shared__ TileShared sh;
+	constexpr uint32_t TILE = TPB * P;
+	const uint32_t* pendIdx = at<const uint32_t>(a, a.offPendIdx);
+	const uint32_t* pendLeaf = at<const uint32_t>(a, a.offPendLeaf);
+	const uint32_t* spMeta = at<const uint32_t>(a, a.offSpMeta);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
+	const uint32_t numTiles = (total + TILE - 1) / TILE;
+	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+		__syncthreads();
+		tile_reset(sh);
+		__syncthreads();
+		float4 p[P];
+		uint32_t leafOf[P], er[P], startLevel[P];
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			const uint32_t q = tile * TILE + j * TPB + threadIdx.x;
+			leafOf[j] = NONE; er[j] = NONE; startLevel[j] = 0; p[j] = make_float4(0, 0, 0, 0);
+			if (q >= total) continue;
+			const uint32_t meta = q < numPending ? pendLeaf[q] : spMeta[q - numPending];
+			if (meta == NONE) continue;
+			p[j] = q < numPending ? point_of(a, ctl, pendIdx[q]) : spilled[q - numPending];
+			leafOf[j] = meta & 0x7ffffu;
+			startLevel[j] = q < numPending ? 0u : meta >> 19;
+		}
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			if (leafOf[j] == NONE) continue;
+			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
+			const uint32_t cached = leafOf[j];
+			leafOf[j] = (uint32_t)(descend(a.nodes + cached, (int)a.nodes[cached].level, X, Y, Z) - a.nodes);
+			uint32_t rank;
+			const int e = tab_add(sh.lt, leafOf[j], 1u, &rank);
+			if (e >= 0) er[j] = ((uint32_t)e << 16) | rank;
+		}
+		__syncthreads();
+		flush_points<false>(a, ctl, sh);
+		__syncthreads();
+		uint32_t wins[P];
+#pragma unroll
+		for (int j = 0; j < P; j++) {                       // every allocation before any lookup: first the samples that own their slot bookkeeping
+			if (leafOf[j] != NONE && er[j] == NONE) store_point_direct(a, ctl, leafOf[j], p[j]);
+		}
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			wins[j] = 0;
+			if (leafOf[j] == NONE) continue;
+			if (er[j] != NONE) store_point(a, ctl, sh, er[j] >> 16, er[j] & 0xffffu, p[j]);
+			const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
+			wins[j] = sample_path(a, ctl, sh, leafOf[j], startLevel[j], pX, pY, pZ, p[j].w);
+		}
+		__syncthreads();
+		flush_voxels(a, ctl, sh, reinterpret_cast<unsigned long long*>(&ctl->placeVoxels));
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			if (wins[j] == 0u) continue;
+			const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
+			store_voxels(a, ctl, sh, leafOf[j], wins[j], pX, pY, pZ, p[j].w);
+		}
+	}
+}
+
+// ---- link: chunks allocated in this group hang behind their predecessors (the `next` pointers the reference sets while it walks,
+// voxels.cu:517-531, 660-669) — one thread per directory slot; the leaf lists below LEAF_SLOTS are linked by k_nodes ------------------
+__global__ __launch_bounds__(TPB) void k_link(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->dirUsed == 0u) return;       // also after an aborted batch: the lists must stay walkable
+	const DirEntry* dir = at<const DirEntry>(a, a.offDir);
+	const uint32_t tag = ctl->ordinal + 1u;
+	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	for (uint32_t h = blockIdx.x * TPB + threadIdx.x; h < a.dirCap; h += gridDim.x * TPB) {
+		const unsigned long long key = dir[h].key;
+		if ((key >> 63) == 0ull || dir_tag(key) != tag) continue;
+		const uint32_t kind = (uint32_t)(key >> 41) & 1u, node = (uint32_t)(key >> 22) & 0x7ffffu, k = (uint32_t)key & 0x3fffffu;
+		if (k == 0u) continue;
+		SimlodChunk* prev;
+		if (kind == KIND_VOX) prev = (k - 1u) * CHUNK < at<const uint32_t>(a, a.offVoxStart)[node] ? tail_of(a.nodes[node].voxelChunks) : dir_find(a, ctl, KIND_VOX, node, k - 1u);
+		else if (k - 1u < LEAF_SLOTS) prev = leafChunks[(uint64_t)node * LEAF_SLOTS + k - 1u];
+		else prev = (k - 1u) * CHUNK < at<const uint32_t>(a, a.offPtStart)[node] ? tail_of(a.nodes[node].points) : dir_find(a, ctl, KIND_PT, node, k - 1u);
+		if (prev != nullptr) prev->next = dir[h].ptr;
+	}
+}
+
+// ---- nodes: per node, what the batch leaves behind — countIteration stamp (voxels.cu:298-300), numVoxelsStored (:685), the links
+// of a leaf's new chunks, tail pointers, and the list lengths the next batch starts from --------------------------------------------
+__global__ __launch_bounds__(TPB) void k_nodes(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || (ctl->abortBatch && ctl->treeModified)) return;   // a cascade that gave up half way: node slots without nodes
+	const uint32_t numNodes = min(ctl->abortBatch ? ctl->nodesAtStart : a.stats->numNodes, a.nodeCapacity);
+	uint32_t* ptStart = at<uint32_t>(a, a.offPtStart);
+	uint32_t* voxStart = at<uint32_t>(a, a.offVoxStart);
+	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	const uint32_t stamp = ctl->batchIndex + ctl->groupBatches;
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
+		SimlodNode* node = a.nodes + i;
+		node->countIteration = stamp;
+		const uint32_t np = node->numPoints, ps = ptStart[i];
+		if (np > ps) {
+			const uint32_t kOld = (ps + CHUNK - 1) / CHUNK, kNew = (np + CHUNK - 1) / CHUNK;
+			SimlodChunk* const* slots = leafChunks + (uint64_t)i * LEAF_SLOTS;
+			for (uint32_t k = max(kOld, 1u); k < min(kNew, LEAF_SLOTS); k++) slots[k - 1]->next = slots[k];
+			if (kNew > kOld) {
+				SimlodChunk* t = kNew - 1u < LEAF_SLOTS ? slots[kNew - 1u] : dir_find(a, ctl, KIND_PT, i, kNew - 1u);
+				if (t != nullptr) tail_of(node->points) = t;
+			}
+		}
+		ptStart[i] = np;
+		const uint32_t nv = node->numVoxels, vs = voxStart[i];
+		if (nv > vs) {
+			node->numVoxelsStored = nv;
+			const uint32_t kOld = (vs + CHUNK - 1) / CHUNK, kNew = (nv + CHUNK - 1) / CHUNK;
+			if (kNew > kOld) {
+				SimlodChunk* t = dir_find(a, ctl, KIND_VOX, i, kNew - 1u);
+				if (t != nullptr) tail_of(node->voxelChunks) = t;
+			}
+			voxStart[i] = nv;
+		}
+	}
+}
+
+// ---- end of group: bookkeeping (voxels.cu:535-537, 925-949), then make the next group current ------------------
 __global__ void k_end(BuildArgs a, uint32_t ordinal) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
-	if (ctl->active && ctl->abortBatch) ctl->stop = 1;       // scratch overflow: this batch is lost, report through Stats.dbg
+	if (ctl->active && ctl->abortBatch) {                    // this batch is lost: report through Stats.dbg (fatal, sticky until a reset)
+		ctl->stop = 1;
+		if (!ctl->treeModified) a.stats->numNodes = ctl->nodesAtStart;   // node slots reserved for splits that never began
+	}
 	if (ctl->active && !ctl->abortBatch) {
 		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
-		a.stats->batchletIndex += 1;
-		a.stats->numPointsProcessed += ctl->batchSize;
-		ctl->expandNs[7] += min(ctl->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
+		a.stats->batchletIndex += ctl->groupBatches;
+		a.stats->numPointsProcessed += ctl->groupPoints;
+		ctl->consumed += ctl->groupBatches;
+		ctl->pendingTotal += min(ctl->numPending, a.pendCap);
 		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
 		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
 	}
-	prepare_batch(a, ctl, ordinal + 1);
+	prepare_group(a, ctl, ordinal + 1);
 }
 
 // ---- stats pass (voxels.cu:957-1009) -------------------------------------------------------------------------------
@@ -888,10 +1171,10 @@ __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 	if (i < numNodes) {
 		const SimlodNode* n = a.nodes + i;
 		if (node_is_leaf(n)) {
-			v[1] = 1; v[3] = n->numPoints; v[5] = (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			v[1] = 1; v[3] = n->numPoints; v[5] = (n->numPoints + CHUNK - 1) / CHUNK;
 			v[2] = n->numPoints > 0 ? 1u : 0u;
 		} else {
-			v[0] = 1; v[4] = n->numVoxels; v[6] = (n->numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			v[0] = 1; v[4] = n->numVoxels; v[6] = (n->numVoxels + CHUNK - 1) / CHUNK;
 		}
 	}
 	for (int k = 0; k < 7; k++) {
@@ -900,69 +1183,78 @@ __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 	}
 }
 
-__global__ void k_finish(BuildArgs a) {
+__global__ void k_finish(BuildArgs a, uint32_t fits) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
 	SimlodStats* s = a.stats;
-	s->numInner = ctl->statCounters[0];
-	s->numLeaves = ctl->statCounters[1];
-	s->numNonemptyLeaves = ctl->statCounters[2];
-	s->numPoints = ctl->statCounters[3];
-	s->numVoxels = ctl->statCounters[4];
-	s->numChunksPoints = ctl->statCounters[5];
-	s->numChunksVoxels = ctl->statCounters[6];
+	if (fits) {
+		s->numInner = ctl->statCounters[0];
+		s->numLeaves = ctl->statCounters[1];
+		s->numNonemptyLeaves = ctl->statCounters[2];
+		s->numPoints = ctl->statCounters[3];
+		s->numVoxels = ctl->statCounters[4];
+		s->numChunksPoints = ctl->statCounters[5];
+		s->numChunksVoxels = ctl->statCounters[6];
+	}
 	s->allocatedBytes_momentary = a.scratchBytes;
 	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
 	s->frameID = (uint32_t)a.frameCounter;
 	s->dbg |= ctl->errors;
-	ctl->tableBatch = s->batchletIndex;
-	ctl->tableMagic = TABLE_MAGIC;
+	if (fits && !panicked(ctl)) {               // the side tables describe THIS octree as it is after THIS batch
+		ctl->tableBatch = s->batchletIndex;
+		ctl->tableNodes = (uint64_t)a.nodes;
+		ctl->tablePers = (uint64_t)a.pers;
+		ctl->tableMagic = TABLE_MAGIC;
+	}
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
-
-uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
-	uint64_t off = 4096;                                                       // Ctl
-	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
-	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	off += 4 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf
-	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
-	off += align_up((uint64_t)dirCap * 8, 256);
-	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
-	off += align_up((uint64_t)nodeCapacity * PATH_WORDS * 8, 256);
-	return off;
-}
+static constexpr uint64_t HIST_BYTES = 16ull << 20;        // 8192 leaves per round at 512 bins, 65536 at 64
+static constexpr uint32_t DIR_CAP = 1u << 17;
 
 bool layout_construct(BuildArgs& a, uint64_t capacity) {
-	a.dirCap = 2 * a.nodeCapacity + 65536;
 	uint64_t off = 4096;
+	a.histCap = (uint32_t)std::min<uint64_t>(SPILLING_CAPACITY, HIST_BYTES / (64 * 4));
+	a.dirCap = DIR_CAP;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
-	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	a.offSpillA = off;   off += align_up((uint64_t)a.histCap * sizeof(SpillEntry), 256);
+	a.offSpillB = off;   off += align_up((uint64_t)a.histCap * sizeof(SpillEntry), 256);
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
-	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
-	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
+	a.offPtStart = off;  off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offVoxStart = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
-	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
-	const uint64_t fixedEnd = off;
-	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
+	a.offPaths = off;    off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
+	a.offHist = off;     off += HIST_BYTES;
+	a.offDir = off;      off += align_up((uint64_t)a.dirCap * sizeof(DirEntry), 256);
+	// what is left is shared by the per-sample arrays: 8 B per sample of a group that may have to wait for k_place, 20 B per moved point
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
-	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
-	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
-	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (24 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
-	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
+	const uint64_t minSpill = 100000ull * 20;                                     // two leaves' worth of moved points
+	if (capacity < off + perBatch + minSpill + 4096) { a.spilledCap = 0; a.pendCap = 0; a.groupMax = 1; a.scratchBytes = off + perBatch + minSpill + 4096; return false; }
+	const uint64_t left = capacity - off - 4096;
+	// coalesced mode: as many batches per group as fit beside a quarter of the space kept for moved points; exact mode: one
+	uint32_t groupMax = ingest_mode() ? (uint32_t)std::min<uint64_t>(SIMLOD_MAX_BATCHES_PER_LAUNCH, std::max<uint64_t>(1, (left - std::max<uint64_t>(minSpill, left / 4)) / perBatch)) : 1u;
+	a.groupMax = groupMax;
+	a.pendCap = groupMax * SIMLOD_MAX_BATCH_SIZE;
+	a.offPendIdx = off;  off += align_up((uint64_t)a.pendCap * 4, 256);
+	a.offPendLeaf = off; off += align_up((uint64_t)a.pendCap * 4, 256);
+	uint64_t cap = (capacity - off - 1024) / 20;
+	if (cap > 0x7fffffffull) cap = 0x7fffffffull;
 	a.spilledCap = (uint32_t)cap;
-	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 spilled points + one partial chunk per split
-	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
-	(void)fixedEnd;
-	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
-	a.offWin = off;      off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offSpMeta = off;   off += align_up((uint64_t)a.spilledCap * 4, 256);
 	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
 	a.scratchBytes = off;
 	return off <= capacity;
+}
+
+static int launch_expand(const BuildArgs& a, uint32_t roundFirst, uint32_t wgs, bool cooperative, hipStream_t stream) {
+	if (profile_enabled()) profile_mark(roundFirst ? "k_expand_more" : "k_expand", stream);
+	if (!cooperative) { hipLaunchKernelGGL(k_expand, dim3(wgs), dim3(ETPB), 0, stream, a, roundFirst); return (int)hipGetLastError(); }
+	BuildArgs args = a;
+	void* params[] = {&args, &roundFirst};
+	return (int)hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_expand), dim3(wgs), dim3(ETPB), params, 0, stream);
 }
 
 int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
@@ -978,36 +1270,39 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.nodeCapacity = node_capacity();
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
 	const DeviceInfo& dev = device_info();
+	const uint32_t coalesce = ingest_mode();
+	const uint32_t limit = std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH);
+	const uint32_t debugFlags = (uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u;
 
-	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u);
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, coalesce, limit, debugFlags);
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
+		if (e == hipSuccess) e = hipMemsetAsync(a.mom + a.offHist, 0, (size_t)(HIST_BYTES + (uint64_t)a.dirCap * sizeof(DirEntry)), stream);
 		if (e != hipSuccess) return (int)e;
-		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
-		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
-		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);
-		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
-		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
-		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
-		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
-		for (uint32_t b = 0; b < SIMLOD_MAX_BATCHES_PER_LAUNCH; b++) {
-			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
-			switch (sampleSpt) {
-			case 1: SIMLOD_LAUNCH(k_sample<1>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			case 2: SIMLOD_LAUNCH(k_sample<2>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			case 8: SIMLOD_LAUNCH(k_sample<8>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			default: SIMLOD_LAUNCH(k_sample<4>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			}
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
+		SIMLOD_LAUNCH(k_parents, dim3(gridNodes), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(k_paths, dim3(gridNodes), dim3(TPB), stream, a);
+		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
+		const int ingestP = tune("SIMLOD_INGEST_P", 4);
+		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
+		// measured optimum on MI355X: the barrier's agent-scope release / acquire and the polling cost grow with the participants
+		const uint32_t expandWgs = (uint32_t)std::max(1, std::min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
+		const bool cooperative = tune("SIMLOD_EXPAND_COOPERATIVE", 1) != 0;
+		const uint32_t groups = coalesce ? (limit + a.groupMax - 1) / a.groupMax : limit;
+		for (uint32_t g = 0; g < groups; g++) {
+			if (ingestP == 4) SIMLOD_LAUNCH(k_ingest<4>, dim3(gridPoints), dim3(TPB), stream, a);
+			else SIMLOD_LAUNCH(k_ingest<8>, dim3(gridPoints), dim3(TPB), stream, a);
+			int rc = launch_expand(a, 0u, expandWgs, cooperative, stream);
+			if (rc == 0) rc = launch_expand(a, 1u, expandWgs, cooperative, stream);
+			if (rc != 0) return rc;
+			SIMLOD_LAUNCH(k_place<4>, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_link, dim3(std::min<uint32_t>(dev.numCUs, a.dirCap / TPB)), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_nodes, dim3(std::min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, g);
 		}
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
-	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a);
+	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
 	if (profile_enabled()) profile_close(stream);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return (int)e;

@@ -71,45 +71,49 @@ __device__ __forceinline__ uint8_t* persistent_alloc(uint8_t* pers, uint64_t siz
 // A device-scope atomic on ONE address retires at ~88 M/s on this chip (MI355X_MICROARCH.md, rows fanin / dequeue), and a
 // spatially compact 1 M-point batch funnels most of its points into a few dozen leaves: per-wave aggregation still
 // leaves ~16 k atomics per hot counter per batch.  So every counter update of the build (leaf arrival counters, slot
-// reservations, voxel counters) is first combined per WORKGROUP in an open-addressing LDS table and flushed with one
-// global atomic per (workgroup, node).  table_add returns the entry and the value the entry's counter had before
+// reservations, voxel counters, split histograms) is first combined per WORKGROUP in an open-addressing LDS table and flushed
+// with one global atomic per (workgroup, key).  tab_add returns the entry and the value the entry's counter had before
 // (= rank of this caller inside the workgroup), or -1 when 16 probes found no room; a key that failed once keeps
-// failing (entries are never removed), so callers can fall back to a direct global atomic consistently.
+// failing (entries are never removed), so callers can fall back consistently.
 static constexpr uint32_t TBL_EMPTY = 0xffffffffu;
-static constexpr int TBL_BITS = 10;
-static constexpr int TBL_CAP = 1 << TBL_BITS;
 
-struct BlockTable {
-	uint32_t keys[TBL_CAP];
-	uint32_t vals[TBL_CAP];
+template <int BITS>
+struct Tab {
+	static constexpr int CAP = 1 << BITS;
+	uint32_t keys[CAP];
+	uint32_t vals[CAP];
 };
 
-__device__ __forceinline__ void table_init(BlockTable& t) {
-	for (uint32_t i = threadIdx.x; i < (uint32_t)TBL_CAP; i += blockDim.x) { t.keys[i] = TBL_EMPTY; t.vals[i] = 0u; }
+template <int BITS>
+__device__ __forceinline__ void tab_init(Tab<BITS>& t) {
+	for (uint32_t i = threadIdx.x; i < (uint32_t)Tab<BITS>::CAP; i += blockDim.x) { t.keys[i] = TBL_EMPTY; t.vals[i] = 0u; }
 }
 
-__device__ __forceinline__ uint32_t table_hash(uint32_t key) { return (key * 2654435761u) >> (32 - TBL_BITS); }
+template <int BITS>
+__device__ __forceinline__ uint32_t tab_hash(uint32_t key) { return (key * 2654435761u) >> (32 - BITS); }
 
-__device__ __forceinline__ int table_add(BlockTable& t, uint32_t key, uint32_t inc, uint32_t* rank) {
-	uint32_t h = table_hash(key);
+template <int BITS>
+__device__ __forceinline__ int tab_add(Tab<BITS>& t, uint32_t key, uint32_t inc, uint32_t* rank) {
+	uint32_t h = tab_hash<BITS>(key);
 #pragma unroll 1
 	for (int probe = 0; probe < 16; ++probe) {
 		uint32_t k = t.keys[h];
 		if (k == TBL_EMPTY) { k = atomicCAS(&t.keys[h], TBL_EMPTY, key); if (k == TBL_EMPTY) k = key; }
 		if (k == key) { *rank = atomicAdd(&t.vals[h], inc); return (int)h; }
-		h = (h + 1) & (TBL_CAP - 1);
+		h = (h + 1) & (Tab<BITS>::CAP - 1);
 	}
 	return -1;
 }
 
-__device__ __forceinline__ int table_find(const BlockTable& t, uint32_t key) {
-	uint32_t h = table_hash(key);
+template <int BITS>
+__device__ __forceinline__ int tab_find(const Tab<BITS>& t, uint32_t key) {
+	uint32_t h = tab_hash<BITS>(key);
 #pragma unroll 1
 	for (int probe = 0; probe < 16; ++probe) {
 		const uint32_t k = t.keys[h];
 		if (k == key) return (int)h;
 		if (k == TBL_EMPTY) return -1;
-		h = (h + 1) & (TBL_CAP - 1);
+		h = (h + 1) & (Tab<BITS>::CAP - 1);
 	}
 	return -1;
 }
@@ -117,8 +121,9 @@ __device__ __forceinline__ int table_find(const BlockTable& t, uint32_t key) {
 // ---- grid barrier (expand loop only) --------------------------------------------------------------------------
 // One monotonic device-scope counter, zeroed by the host-enqueued prologue of every launch.  Producer side: every
 // wave drains its stores, the block syncs, lane 0 issues the agent-scope release (L2 write-back), arrives, polls
-// relaxed, then ONE agent-scope acquire (L1 invalidate) and a block sync.  Returns false after ~0.2 s of polling.
-__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& generation, uint32_t numBlocks) {
+// relaxed, then ONE agent-scope acquire (L1 invalidate) and a block sync.  The kernel that uses it is launched cooperatively
+// (all workgroups resident), so the 2 s bound on the poll is a guard against a broken device, not a scheduling hazard.
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& generation, uint32_t numBlocks, bool forceTimeout = false) {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	__shared__ int ok;
@@ -128,11 +133,11 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& genera
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const uint32_t target = generation * numBlocks;
-		int good = 1;
+		int good = forceTimeout ? 0 : 1;
 		uint64_t t0 = wall_clock64();
-		while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+		while (good && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
 			__builtin_amdgcn_s_sleep(8);
-			if (wall_clock64() - t0 > 20000000ull) { good = 0; break; }
+			if (wall_clock64() - t0 > 200000000ull) { good = 0; break; }   // 2 s at 100 MHz
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		ok = good;

@@ -14,7 +14,12 @@ namespace simlod {
 
 static std::atomic<uint32_t> g_nodeCapacity{263157u};   // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
 
+static std::atomic<uint32_t> g_ingestMode{0u};
+static std::atomic<uint32_t> g_batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};
+
 uint32_t node_capacity() { return g_nodeCapacity.load(); }
+uint32_t ingest_mode() { return g_ingestMode.load(); }
+uint32_t batch_limit() { return g_batchLimit.load(); }
 
 int tune(const char* envName, int dflt) {
 	const char* v = std::getenv(envName);
@@ -80,7 +85,8 @@ using namespace simlod;
 extern "C" {
 
 int simlod_set_node_capacity(uint32_t numNodes) {
-	if (numNodes < 9) return (int)hipErrorInvalidValue;
+	// node indices travel in 19-bit fields (ancestor path entries, split records, claim-set keys: construct.hip)
+	if (numNodes < 9 || numNodes > (1u << 19)) return (int)hipErrorInvalidValue;
 	g_nodeCapacity.store(numNodes);
 	return 0;
 }
@@ -95,7 +101,19 @@ uint64_t simlod_construct_buffer_min_bytes(void) {
 	BuildArgs a{};
 	a.nodeCapacity = node_capacity();
 	layout_construct(a, 0);
-	return a.scratchBytes + 4096 + 26ull * 65536;   // the smallest capacity layout_construct accepts, plus a page of slack
+	return a.scratchBytes + 4096;   // the smallest capacity layout_construct accepts, plus a page of slack
+}
+
+int simlod_set_ingest_mode(uint32_t mode) {
+	if (mode > 1u) return (int)hipErrorInvalidValue;
+	g_ingestMode.store(mode);
+	return 0;
+}
+
+int simlod_set_construct_batch_limit(uint32_t maxBatches) {
+	if (maxBatches == 0u) return (int)hipErrorInvalidValue;
+	g_batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
+	return 0;
 }
 
 int simlod_launch_reset(const SimlodUniforms* uniforms, uint8_t* buffer_octree, SimlodNode* nodes, SimlodStats* stats,

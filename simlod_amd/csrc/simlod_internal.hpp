@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "simlod_abi.h"
@@ -11,26 +12,45 @@ namespace simlod {
 static constexpr uint32_t CHUNK_QUEUE_CAPACITY = 1000000u;   // progressive_octree_voxels.cu:856
 static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octree_voxels.cu:847
 
+// One entry of a split round's work list: the leaf that has to split, the eight node slots reserved for its children and — for
+// leaves that hold stored points (round 0 only: nodes created inside a cascade are empty) — where those points go in the spill buffer.
+struct SpillEntry {
+	uint32_t leaf, childBase, spillBase, stored;
+};
+
 // Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
-// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
+// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches; so does the leaf chunk table).
 struct Ctl {
-	uint32_t uploaded, firstBatch, numBatches, stop;
-	uint32_t active, batchSize, ringSlot, batchIndex;
-	uint32_t numSpilling;        // spilling leaves found by k_count; NOT modified by k_expand (its early-exit test must be stable)
-	uint32_t numSpilled, dirCount, errors;
-	uint32_t ordinal, abortBatch, barrierCount;
-	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
-	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]
-	uint32_t numWork;            // spill-copy work items appended so far in this batch (monotonic)
-	uint32_t pad1;
-	uint32_t spilledSnap[2];     // numSpilled / numWork as they were BEFORE round r's split phase: slot [r & 1]
-	uint32_t workSnap[2];
+	uint32_t uploaded, firstBatch, numBatches, stop;      // launch: snapshot of the upload counter, first batch, batches to take
+	uint32_t consumed;           // batches of this launch already ingested
+	uint32_t active;             // the current group exists
+	uint32_t ordinal;            // group number inside this launch (tags)
+	uint32_t batchIndex;         // Stats.batchletIndex of the group's first batch
+	uint32_t groupBatches;       // 1 in exact mode, up to 20 in coalesced mode
+	uint32_t groupPoints;
+	uint32_t numPending;         // samples waiting for the place pass (their leaf overflowed, or is the root, or the LDS table was full)
+	uint32_t numSpilling;        // round-0 list length (written by k_ingest, never modified by k_expand: stable early-exit test)
+	uint32_t dirUsed;            // chunks published in the hash directory by this group
+	uint32_t errors, abortBatch, panic;
+	uint32_t barrierCount;
+	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer)
+	uint32_t roundSpill[2];      // list length of rounds >= 1: round r appends to roundSpill[r & 1]
+	uint32_t coalesce, debugFlags;
+	uint32_t nodesAtStart;       // Stats.numNodes when the group began
+	uint32_t treeModified;       // k_expand has started to build nodes in this group
 	uint64_t startNs;
 	uint32_t statCounters[8];
-	unsigned long long reserve;        // k_expand: nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves both or neither
-	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish)
-	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
+	unsigned long long reserve;  // nodes in use << 32 | spill space in use — ONE word, so a split reserves both or neither
+	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
+	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
+	uint64_t spilledTotal;       // byte 168: measurement aid — stored points moved by splits since the host last cleared it (bench.py)
+	uint64_t pendingTotal;       // byte 176: samples that went through k_place (their leaf overflowed) ...
+	uint64_t placeVoxels;        // byte 184: ... and the voxels k_place created, since the host last cleared them
+	uint64_t expandNs[8];        // byte 192: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
+	uint32_t batchSize[SIMLOD_MAX_BATCHES_PER_LAUNCH], batchSlot[SIMLOD_MAX_BATCHES_PER_LAUNCH];
 };
+static_assert(offsetof(Ctl, spilledTotal) == 168, "bench.py reads Ctl.spilledTotal at byte 168");
+static_assert(sizeof(Ctl) <= 4096, "control block");
 
 struct BuildArgs {
 	SimlodPoint* ring;
@@ -43,8 +63,9 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offWin, offSpilled;
-	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offPtStart, offVoxStart, offLeafChunks, offPaths, offHist, offDir,
+	             offPendIdx, offPendLeaf, offSpMeta, offSpilled;
+	uint32_t     nodeCapacity, spilledCap, pendCap, histCap, dirCap, groupMax;
 };
 
 struct DeviceInfo {
@@ -66,6 +87,8 @@ void profile_close(hipStream_t stream);                           // records the
 		hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);          \
 	} while (0)
 uint32_t node_capacity();
+uint32_t ingest_mode();                      // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
+uint32_t batch_limit();                      // host hint: at most this many batches are pending (<= 20)
 int tune(const char* envName, int dflt);     // integer tuning knob from the environment (read once per call site)
 
 bool layout_construct(BuildArgs& a, uint64_t capacity);

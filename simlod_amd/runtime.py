@@ -37,6 +37,8 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
         L.simlod_set_node_capacity.argtypes = [u32]
+        L.simlod_set_ingest_mode.argtypes = [u32]
+        L.simlod_set_construct_batch_limit.argtypes = [u32]
         L.simlod_render_framebuffer_offset.restype = u64
         L.simlod_render_buffer_bytes.restype = u64
         L.simlod_render_buffer_bytes.argtypes = [u32, u32]
@@ -68,7 +70,8 @@ EXPORTED_SYMBOLS = [
     "simlod_construct_buffer_min_bytes", "simlod_launch_reset", "simlod_launch_construct", "simlod_launch_render",
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
     "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
-    "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset",
+    "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
+    "simlod_profile_enable", "simlod_profile_collect",
 ]
 
 
@@ -98,7 +101,7 @@ class DeviceOctree:
     """Device buffers of initCudaProgram() + the three launches, on one GPU."""
 
     def __init__(self, device="cuda:0", *, persistent_bytes=4 << 30, momentary_bytes=300_000_000, max_nodes=263_157,
-                 ring_slots=abi.BATCH_STREAM_SIZE, max_pixels=1920 * 1080):
+                 ring_slots=abi.BATCH_STREAM_SIZE, max_pixels=1920 * 1080, coalesce=False):
         if not torch.cuda.is_available():
             raise SimlodError("no GPU visible: the SimLOD hot paths only exist as gfx950 kernels")
         self.L = lib()
@@ -106,6 +109,10 @@ class DeviceOctree:
         torch.cuda.set_device(self.device)
         self.max_nodes = max_nodes
         _check(self.L.simlod_set_node_capacity(max_nodes), "simlod_set_node_capacity")
+        # ingest granularity (process-wide, like the node capacity): exact = the reference's batch-by-batch bookkeeping; coalesced = all
+        # pending batches of a launch as one (same octree content, different allocator / chunk-pool counters, include/simlod_hip.h)
+        _check(self.L.simlod_set_ingest_mode(1 if coalesce else 0), "simlod_set_ingest_mode")
+        _check(self.L.simlod_set_construct_batch_limit(abi.MAX_BATCHES_PER_LAUNCH), "simlod_set_construct_batch_limit")
         z = dict(dtype=torch.uint8, device=self.device)
         # H11: the reference renders before any reset and relies on fresh VRAM reading as zero
         self.nodes = torch.zeros(max_nodes * 152, **z)

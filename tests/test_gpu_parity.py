@@ -426,6 +426,15 @@ def test_full_size_36m_properties(built_libs):
     s = dev.read_stats()
     assert int(s["dbg"]) == 0 and int(s["numPointsProcessed"]) == n and int(s["numPoints"]) == n and int(s["batchletIndex"]) == 36
     nodes, pers, nn = host_image_of(dev)
+    # the same 36 batches through the CPU oracle (a few seconds): every Stats counter incl. allocator offset and chunk pool, and every
+    # node — topology, counters, point multisets, occupancy bitsets, voxel positions — must be identical at full size too
+    ref = oracle.HostOctree("port", persistent_bytes=4 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    assert ref.last_error() == 0
+    assert_stats_equal(s, ref.stats[0], STATS_BUILD_FIELDS, "36M")
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "36M")
+    del ref
     inv = oracle.check_invariants(nodes, nn)
     assert inv["points"] == n and inv["voxels"] >= int(s["numVoxels"])        # Stats.numVoxels counts inner nodes only
     assert int(s["numNodes"]) == nn == 1 + 8 * int(s["numInner"]) and int(s["numLeaves"]) == nn - int(s["numInner"])
@@ -676,3 +685,200 @@ def test_render_parts_equal_the_whole_frame_and_two_emulated_ranks_compose_exact
         c_got, c_want = d.color(W, H).view(np.uint8).astype(np.int16), s_["color"].view(np.uint8).astype(np.int16)
         assert np.abs(c_got - c_want).max() <= 1                                         # EDL: +-1 per channel
     assert sum(int(d.read_stats()["numVisiblePoints"]) for d in ranks) == int(whole.read_stats()["numVisiblePoints"])
+
+
+# ---- BASELINE configs 3 and 5 at a size the oracle still finishes in seconds; the ring; ingest granularity ---------------------------
+def test_ring_wraps_around_more_than_twice(built_libs):
+    """Config 3's mechanism: batches stream through the 50-slot ring (slot = batchletIndex % 50, voxels.cu:883-925) with the host's
+    back-pressure rule.  130 batches of 50 000 points wrap the ring 2.6 times; the octree must be the oracle's after the same 130 batches."""
+    pts, box = synthetic.terrain(6_500_000, seed=21, box=(2400.0, 1600.0, 160.0), tile=100.0)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(ring_slots=abi.BATCH_STREAM_SIZE)
+    u = dev.uniforms(W, H, T, box)
+    _ingest(dev, u, [pts[i:i + 50_000] for i in range(0, len(pts), 50_000)])
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0 and int(ds["batchletIndex"]) == 130 and int(ds["numPointsProcessed"]) == len(pts)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+    ref.reset(u)
+    ref.add_points(u, pts, 50_000)
+    assert ref.last_error() == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "ring")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "ring")
+    oracle.check_invariants(nodes, nn)
+
+
+def test_config5_hotspot_20m_octree_and_frames_match_oracle_with_and_without_lds_tiles(built_libs):
+    """BASELINE config 5 at 20 M points: every point in one level-6 cell (the first batch cascades six levels down and keeps splitting),
+    camera on the cell.  Octree == oracle; plain and HQS frames bit-exact against the oracle's rasteriser on the same image, with the
+    LDS-tile path of the rasteriser on and off."""
+    n = 20_000_000
+    pts, box = synthetic.hotspot(n, seed=11)
+    Wd, Hd = 1920, 1080
+    cell = np.array([21, 40, 13], dtype=np.float64) / 64 + 1 / 128
+    dist = (1 / 64) * (Hd / 128.0) / (2 * np.tan(np.radians(30)))
+    T = camera.lookat_transform(cell + np.array([0.6, -0.7, 0.4]) / np.linalg.norm([0.6, -0.7, 0.4]) * dist, cell, Wd, Hd)
+    dev = _device(persistent_bytes=4 << 30, ring_slots=20)
+    u = dev.uniforms(Wd, Hd, T, box, min_node_size=8.0)
+    _ingest(dev, u, [pts[i:i + abi.MAX_BATCH_SIZE] for i in range(0, n, abi.MAX_BATCH_SIZE)])
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0 and int(ds["numPoints"]) == n
+    ref = oracle.HostOctree("port", persistent_bytes=4 << 30, ring_slots=20)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    assert ref.last_error() == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "config 5")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "config 5")
+    del ref
+    want = {}
+    try:
+        for tiles in ("1", "0"):
+            os.environ["SIMLOD_RASTER_LDS_TILES"] = tiles
+            for hqs in (0, 1):
+                u["useHighQualityShading"] = hqs
+                dev.render(u)
+                fb, st = dev.framebuffer(Wd, Hd), dev.read_stats()
+                if hqs not in want:
+                    want[hqs] = _oracle_render(nodes, nn, u)
+                fo, _, so = want[hqs]
+                assert_stats_equal(st, so, STATS_RENDER_FIELDS, f"config 5 tiles={tiles} hqs={hqs}")
+                assert np.array_equal(fb, fo), f"tiles={tiles} hqs={hqs}: {int((fb != fo).sum())} pixels differ from the oracle"
+    finally:
+        os.environ.pop("SIMLOD_RASTER_LDS_TILES", None)
+
+
+def test_headless_cpp_host_replay_octree_dump_equals_oracle(built_libs, tmp_path):
+    """The C++ replay of the reference host writes the octree image it built (SIMLOD_HARNESS_DUMP); node by node it must be the
+    oracle's octree of the same file — not just the same seven counters."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "simlod_headless")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "harness")])
+    pts, box = synthetic.terrain(3_300_000, seed=15, box=(1500.0, 1000.0, 100.0), tile=125.0)
+    path, dump = str(tmp_path / "terrain.simlod"), str(tmp_path / "octree.bin")
+    synthetic.write_simlod(path, pts, box)
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300, env=dict(os.environ, SIMLOD_HARNESS_DUMP=dump))
+    assert out.returncode == 0, out.stdout + out.stderr
+    head = np.fromfile(dump, dtype=np.uint64, count=4)
+    nn, used, nodes_base, pers_base = (int(v) for v in head)
+    nodes = np.fromfile(dump, dtype=abi.node_dtype, count=nn, offset=32)
+    pers = np.fromfile(dump, dtype=np.uint8, count=used, offset=32 + nn * 152)
+    oracle.rebase_image(nodes, nn, pers, nodes_base, pers_base)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    u = uniforms_for(box, T, persistent=8 << 30)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "harness dump")
+    oracle.check_invariants(nodes, nn)
+
+
+def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs):
+    """A coordinate equal to boxMax quantises to 2^20; the reference's descent looks at bits 19..0 and files the point (and the voxels
+    it creates) under node coordinate 0 of that axis.  Only such points here, so they are the ones that win the cells."""
+    rs = np.random.RandomState(8)
+    base, box = synthetic.uniform_cube(120_000, seed=3)
+    faces = base[:60_000].copy()
+    for k in "xyz":
+        on = rs.rand(len(faces)) < 0.5
+        faces[k][on] = np.float32(1.0)
+    pts = np.concatenate([faces, base[60_000:]])
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    dev = _device(ring_slots=4)
+    u = dev.uniforms(W, H, T, box)
+    _ingest(dev, u, [pts[i:i + 40_000] for i in range(0, len(pts), 40_000)])
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=4)
+    ref.reset(u)
+    ref.add_points(u, pts, 40_000)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "faces")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "faces")
+
+
+def test_node_capacity_beyond_the_packed_index_width_is_rejected(built_libs):
+    from simlod_amd.runtime import lib
+    L = lib()
+    try:
+        assert L.simlod_set_node_capacity((1 << 19) + 1) != 0 and L.simlod_set_node_capacity(8) != 0
+        assert L.simlod_set_node_capacity(1 << 19) == 0
+    finally:
+        L.simlod_set_node_capacity(263_157)
+
+
+def test_forced_barrier_timeout_aborts_the_batch_and_stays_fatal_until_reset(built_libs):
+    """The split cascade's grid barrier giving up (here: forced) must not let the rest of the chain run on a half-built state: the batch
+    is not counted, Stats.dbg carries the fatal bit, later launches refuse to touch the octree, and a reset brings everything back."""
+    from simlod_amd.runtime import SimlodError
+    pts, box = synthetic.uniform_cube(300_000, seed=12)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    dev = _device(ring_slots=4)
+    u = dev.uniforms(W, H, T, box)
+    dev.reset(u)
+    dev.upload(pts[:40_000])
+    dev.drain(u)                                       # 40 000 points: no split yet
+    os.environ["SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT"] = "1"
+    try:
+        dev.upload(pts[40_000:])                       # crosses the limit: k_expand runs and its barrier "gives up"
+        with pytest.raises(SimlodError):
+            dev.drain(u)
+    finally:
+        os.environ.pop("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", None)
+    s = dev.read_stats()
+    assert int(s["dbg"]) & 0x40 and int(s["batchletIndex"]) == 1 and int(s["numNodes"]) == 1
+    with pytest.raises(SimlodError):
+        dev.drain(u)                                   # still refused: the bit is sticky
+    assert int(dev.read_stats()["batchletIndex"]) == 1
+    _ingest(dev, u, [pts[:40_000], pts[40_000:]])      # reset + the same two batches
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=4)
+    ref.reset(u)
+    ref.upload(pts[:40_000]); ref.construct(u); ref.upload(pts[40_000:]); ref.construct(u)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "after reset")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "after reset")
+
+
+# what does not depend on the ingest granularity: topology, per-node counters and multisets, bitsets, voxel positions and counts
+GRANULARITY_FREE_FIELDS = ["key", "level", "X", "Y", "Z", "isLeaf", "childMask", "numPoints", "numVoxels", "numVoxelsStored", "hasGrid",
+                           "gridPopcount", "gridHash", "pointsSum", "pointsXor", "voxelPosSum", "voxelPosXor", "pointChunks", "voxelChunks", "name"]
+GRANULARITY_FREE_STATS = ["numNodes", "numInner", "numLeaves", "numNonemptyLeaves", "numPoints", "numVoxels", "numChunksPoints", "numChunksVoxels",
+                          "batchletIndex", "numPointsProcessed", "numAllocatedChunks", "memCapacityReached"]
+
+
+@pytest.mark.parametrize("kind,n", [("terrain", 7_300_000), ("hotspot", 5_000_000), ("uniform", 3_000_000)])
+def test_coalesced_ingest_builds_the_same_octree_content(built_libs, kind, n):
+    """Opt-in coalesced mode (simlod_set_ingest_mode(1)): all pending batches of a launch as ONE batch.  Everything that does not depend
+    on the batch granularity must equal the oracle's batch-by-batch octree; the frame of that image must equal the oracle's rasteriser."""
+    from simlod_amd.runtime import lib
+    pts, box = {"uniform": lambda: synthetic.uniform_cube(n, seed=31), "terrain": lambda: synthetic.terrain(n, seed=9, box=(3000.0, 2000.0, 200.0), tile=125.0),
+                "hotspot": lambda: synthetic.hotspot(n, seed=13, level=4, cell=(5, 9, 6))}[kind]()
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    try:
+        dev = _device(ring_slots=8, coalesce=True, momentary_bytes=400_000_000)
+        u = dev.uniforms(W, H, T, box)
+        _ingest(dev, u, [pts[i:i + abi.MAX_BATCH_SIZE] for i in range(0, n, abi.MAX_BATCH_SIZE)])
+        ds = dev.read_stats()
+        assert int(ds["dbg"]) == 0
+        ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+        ref.reset(u)
+        ref.add_points(u, pts)
+        assert_stats_equal(ds, ref.stats[0], GRANULARITY_FREE_STATS, kind)
+        nodes, pers, nn = host_image_of(dev)
+        got, want = oracle.dump_image(nodes, nn), ref.dump()
+        assert len(got) == len(want)
+        for f in GRANULARITY_FREE_FIELDS:
+            assert np.array_equal(got[f], want[f]), f
+        oracle.check_invariants(nodes, nn)
+        assert voxel_colors_are_member(nodes, nn, pts, box) == int(nodes["numVoxelsStored"][:nn].sum())
+        u["useHighQualityShading"] = 1
+        dev.render(u)
+        fo, _, so = _oracle_render(nodes, nn, u)
+        assert np.array_equal(dev.framebuffer(W, H), fo)
+        assert_stats_equal(dev.read_stats(), so, STATS_RENDER_FIELDS, kind)
+    finally:
+        lib().simlod_set_ingest_mode(0)

@@ -17,7 +17,7 @@ for rep in range(2):
     dev.reset(u)
     if rep == 1:
         L.simlod_profile_enable(1)
-        dev.momentary[152:216].zero_()
+        dev.momentary[168:256].zero_()
     dev.add_points(u, pts)
     torch.cuda.synchronize()
 prof = bench.collect_profile(L)
@@ -25,9 +25,8 @@ st = dev.read_stats()
 nb = (n + 999999) // 1000000
 print("variant", os.environ.get("SIMLOD_VARIANT", "0"), "pts", int(st["numPoints"]), "voxels", int(st["numVoxels"]), "dbg", int(st["dbg"]))
 print({k: (c, round(ms, 2), "%.0f us/batch" % (ms * 1e3 / nb)) for k, (c, ms) in prof.items() if "k_" in k})
-ex = dev.momentary[152:216].cpu().numpy().view(np.uint64)
-print("k_expand workgroup 0, us per batch: split %.1f barrier %.1f copy %.1f recount %.1f barrier %.1f | rounds %d in %d calls with spills" % (
-    ex[0] / 1e3 / nb, ex[1] / 1e3 / nb, ex[2] / 1e3 / nb, ex[3] / 1e3 / nb, ex[4] / 1e3 / nb, ex[5], ex[6]))
+c = dev.momentary[168:256].cpu().numpy().view(np.uint64)
+print("moved points %d, samples through k_place %d, voxels by k_place %d | k_expand: %d rounds in %d calls with spills" % (c[0], c[1], c[2], c[3 + 4], c[3 + 5]))
 for hq in (1, 0):
     u["useHighQualityShading"] = hq
     dev.render(u); torch.cuda.synchronize()
