@@ -170,7 +170,7 @@ def main():
 
     # ---- per-kernel attribution with HIP events on the launch stream (separate, untimed pass) --------------------
     roofline, chain, kernels = None, None, {}
-    CTL_COUNTERS = slice(168, 192)                                           # simlod_internal.hpp Ctl: spilledTotal, pendingTotal, placeVoxels
+    CTL_COUNTERS = slice(176, 200)                                           # simlod_internal.hpp Ctl: spilledTotal, pendingTotal, placeVoxels
     if rank == 0 and not args.no_profile:
         L.simlod_profile_enable(1)
         dev.momentary[CTL_COUNTERS].zero_()

@@ -140,7 +140,7 @@ __device__ void prepare_group(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->nodesAtStart = a.stats->numNodes;
 	ctl->treeModified = 0;
 	ctl->abortBatch = 0;
-	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
+	ctl->barrierCount[0] = 0; ctl->barrierCount[1] = 0;      // every k_expand launch counts its barrier generations from zero
 	ctl->active = 1;
 }
 
@@ -168,7 +168,6 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t coales
 	ctl->firstBatch = first;
 	ctl->numBatches = n;
 	ctl->consumed = 0;
-	ctl->barrierCount = 0;
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
 	const bool valid = ctl->tableMagic == TABLE_MAGIC && ctl->tableBatch == first && ctl->tableNodes == (uint64_t)a.nodes && ctl->tablePers == (uint64_t)a.pers;
 	ctl->rebuildLeafChunks = valid ? 0u : 1u;
@@ -891,7 +890,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t roundFirs
 			}
 		}
 
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x, forceTimeout)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (!grid_barrier(&ctl->barrierCount[roundFirst], generation, gridDim.x, forceTimeout)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 
 		// -- D: decide and build, one workgroup per (listed leaf, child octant)
 		const uint32_t sub = bins / 8u;
@@ -1004,7 +1003,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t roundFirs
 			}
 		}
 		if (roundFirst == 0u) break;                            // the kernel boundary is the barrier
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x, false)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (!grid_barrier(&ctl->barrierCount[roundFirst], generation, gridDim.x, false)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 	}
 }
 

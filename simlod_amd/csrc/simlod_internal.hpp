@@ -32,7 +32,7 @@ struct Ctl {
 	uint32_t numSpilling;        // round-0 list length (written by k_ingest, never modified by k_expand: stable early-exit test)
 	uint32_t dirUsed;            // chunks published in the hash directory by this group
 	uint32_t errors, abortBatch, panic;
-	uint32_t barrierCount;
+	uint32_t barrierCount[2];    // one monotonic counter per k_expand launch of a group (round 0 | the later rounds)
 	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer)
 	uint32_t roundSpill[2];      // list length of rounds >= 1: round r appends to roundSpill[r & 1]
 	uint32_t coalesce, debugFlags;
@@ -43,13 +43,13 @@ struct Ctl {
 	unsigned long long reserve;  // nodes in use << 32 | spill space in use — ONE word, so a split reserves both or neither
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
-	uint64_t spilledTotal;       // byte 168: measurement aid — stored points moved by splits since the host last cleared it (bench.py)
-	uint64_t pendingTotal;       // byte 176: samples that went through k_place (their leaf overflowed) ...
-	uint64_t placeVoxels;        // byte 184: ... and the voxels k_place created, since the host last cleared them
-	uint64_t expandNs[8];        // byte 192: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
+	uint64_t spilledTotal;       // byte 176: measurement aid — stored points moved by splits since the host last cleared it (bench.py)
+	uint64_t pendingTotal;       // byte 184: samples that went through k_place (their leaf overflowed) ...
+	uint64_t placeVoxels;        // byte 192: ... and the voxels k_place created, since the host last cleared them
+	uint64_t expandNs[8];        // byte 200: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
 	uint32_t batchSize[SIMLOD_MAX_BATCHES_PER_LAUNCH], batchSlot[SIMLOD_MAX_BATCHES_PER_LAUNCH];
 };
-static_assert(offsetof(Ctl, spilledTotal) == 168, "bench.py reads Ctl.spilledTotal at byte 168");
+static_assert(offsetof(Ctl, spilledTotal) == 176, "bench.py reads Ctl.spilledTotal at byte 176");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
 struct BuildArgs {
