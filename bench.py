@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=6_000_000, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--coalesce", action="store_true", help="opt-in coalesced ingest (simlod_set_ingest_mode(1)): all pending batches of a launch as one")
+    ap.add_argument("--momentary-mb", type=int, default=300, help="size of kernel_construct's momentary buffer (the reference host gives 300 MB)")
     ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
                     help="record order of the synthetic terrain: shuffled inside 250 m tiles (default, the harder case) or scan-line order as in a LAS file")
     return ap.parse_args()
@@ -99,7 +101,7 @@ def main():
     assert n_batches <= abi.BATCH_STREAM_SIZE, "the workload must fit the 50-slot ring (resident input)"
     gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
     pts, box = gen(n_points, seed=7 + rank)                   # rank r owns tile r of the tiled terrain (pre-partitioned)
-    dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=300_000_000, max_pixels=W * H)
+    dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
     L = lib()
     sizes = torch.tensor([min(batch, n_points - i * batch) for i in range(n_batches)], dtype=torch.int32, device=dev.device)
     ring_view = dev.ring.view(torch.uint8)
@@ -283,6 +285,7 @@ def main():
             "value": value, "unit": "M points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+u32 (fp32 quantise/project, fp64 pixel coordinate, integer octree/atomics)", "data": "synthetic",
+            "ingest_mode": "coalesced" if args.coalesce else "exact",
             "config": {"workload": f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M "
                                    f"ring batches resident in HBM, reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
                                    f"(<= 20 batches and <= 10 ms each, Stats read back between launches); "

@@ -136,6 +136,7 @@ __device__ void prepare_group(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->numSpilling = 0;
 	ctl->roundSpill[0] = 0; ctl->roundSpill[1] = 0;
 	ctl->dirUsed = 0;
+	ctl->numVoxLeaves = 0;
 	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
 	ctl->nodesAtStart = a.stats->numNodes;
 	ctl->treeModified = 0;
@@ -309,6 +310,7 @@ __device__ SimlodChunk* dir_wait(const BuildArgs& a, Ctl* ctl, uint32_t kind, ui
 
 // chunk k of a node's point list: allocate (the caller reserved slot k * 1000) ...
 __device__ void make_point_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, uint32_t k) {
+	if (k < LEAF_SLOTS && at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)node * LEAF_SLOTS + k] != nullptr) return;   // k_prealloc was here
 	SimlodChunk* c = take_point_chunk(a);
 	if (k == 0u) { a.nodes[node].points = c; tail_of(c) = c; }
 	if (k < LEAF_SLOTS) {
@@ -380,9 +382,14 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint
 // stored points that will have to move — or, if the leaf is already over the limit because an earlier batch could not split it
 // (spill space, node array or work list exhausted: the split was deferred, nothing was lost), by whoever touches it first in this
 // group.  A node at MAX_DEPTH cannot be subdivided (the descent stops there): it keeps growing instead.
-__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt) {
+// `withPoints`: counter and numPoints sit side by side in Node (byte 64 / 68): ONE 64-bit atomic advances both — the caller takes the
+// numPoints part back if the range turns out not to fit (device-scope atomics on one word retire at ~88 M/s: every hot leaf sees one
+// atomic per workgroup instead of two).
+__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt, bool withPoints) {
 	SimlodNode* leaf = a.nodes + leafIdx;
-	const uint32_t old = atomicAdd(&leaf->counter, cnt);
+	uint32_t old;
+	if (withPoints) old = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&leaf->counter), (unsigned long long)cnt | ((unsigned long long)cnt << 32));
+	else old = atomicAdd(&leaf->counter, cnt);
 	if (old + cnt > MAXPTS && leaf->level < SIMLOD_MAX_DEPTH) {
 		SpillEntry* list = at<SpillEntry>(a, a.offSpillA);
 		if (old <= MAXPTS) queue_split(a, ctl, leafIdx, old, 0u, list, &ctl->numSpilling);
@@ -393,6 +400,22 @@ __device__ __forceinline__ uint32_t count_into(const BuildArgs& a, Ctl* ctl, uin
 		}
 	}
 	return old;
+}
+
+// k_peek counted every PEEK-th sample of the group per leaf.  A leaf that is on course to overflow in this group takes no direct
+// inserts: its samples would be stored only to be moved again by the split (a prediction — wrong either way it only shifts work
+// between k_ingest and k_place).  The root as a leaf never does: whether its grid survives the batch is not known yet.
+static constexpr uint32_t PEEK = 8;
+__device__ __forceinline__ bool leaf_is_hot(const BuildArgs& a, uint32_t leafIdx) {
+	if (leafIdx == 0u) return true;
+	const uint32_t start = at<const uint32_t>(a, a.offPtStart)[leafIdx], est = at<const uint32_t>(a, a.offEst)[leafIdx];
+	return start + PEEK * est > MAXPTS - MAXPTS / 16u;
+}
+
+// k_place stores samples in `leafIdx`: the first to do so in this group puts the leaf on k_voxelize's work list
+__device__ __forceinline__ void note_placed(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx) {
+	const uint32_t tag = ctl->ordinal + 1u;
+	if (atomicExch(at<uint32_t>(a, a.offPlacedTag) + leafIdx, tag) != tag) at<uint32_t>(a, a.offVoxList)[atomicAdd(&ctl->numVoxLeaves, 1u)] = leafIdx;
 }
 
 // ---- one tile of samples: slots, stores, voxel sampling -----------------------------------------------------------------------------
@@ -430,10 +453,11 @@ __device__ void flush_points(const BuildArgs& a, Ctl* ctl, TileShared& sh) {
 		uint32_t old;
 		bool direct = true;
 		if (INGEST) {
-			old = count_into(a, ctl, key, cnt);
-			direct = key != 0u && old + cnt <= MAXPTS;
-			if (direct) atomicAdd(&a.nodes[key].numPoints, cnt);                      // voxels.cu:593
-		} else old = atomicAdd(&a.nodes[key].numPoints, cnt);
+			const bool hot = leaf_is_hot(a, key);
+			old = count_into(a, ctl, key, cnt, !hot);                                  // arrivals and, speculatively, stored points (voxels.cu:203-218, :593)
+			direct = !hot && old + cnt <= MAXPTS;
+			if (!hot && !direct) atomicSub(&a.nodes[key].numPoints, cnt);
+		} else { old = atomicAdd(&a.nodes[key].numPoints, cnt); note_placed(a, ctl, key); }
 		if (direct) for (uint32_t k = (old + CHUNK - 1) / CHUNK; k * CHUNK < old + cnt; k++) make_point_chunk(a, ctl, key, k);
 		sh.ltBase[e] = direct ? old : NONE;
 	}
@@ -455,6 +479,7 @@ __device__ __forceinline__ void store_point(const BuildArgs& a, Ctl* ctl, TileSh
 // a sample whose leaf found no room in the LDS table (k_place only): its own slot, its own chunk bookkeeping
 __device__ void store_point_direct(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, const float4& p) {
 	const uint32_t slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u), k = slot / CHUNK;
+	note_placed(a, ctl, leafIdx);
 	if (slot % CHUNK == 0u) make_point_chunk(a, ctl, leafIdx, k);
 	SimlodChunk* c = wait_point_chunk(a, ctl, leafIdx, k);
 	if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % CHUNK] = p;
@@ -524,45 +549,62 @@ __device__ __forceinline__ unsigned long long path_entry(const BuildArgs& a, con
 // others know the cell is being taken care of and stop, exactly as if they had lost the race.
 // Returns the mask of levels this sample won; the voxels are stored later (store_voxels) behind ranges reserved per workgroup.
 // `startLevel`: stored points that move because their leaf splits were offered to the levels above it when they first arrived.
-__device__ uint32_t sample_path(const BuildArgs& a, Ctl* ctl, TileShared& sh, uint32_t leafIdx, uint32_t startLevel, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
-	constexpr int WIN = 3;                             // ancestors fetched and probed together
+static constexpr int WIN = 3;                         // ancestors fetched and probed together
+struct Probe {
+	unsigned long long ent[WIN];                      // path entries, 0 = nothing (more) to do
+	uint32_t seen[WIN];                               // their occupancy words as read
+};
+
+__device__ __forceinline__ uint32_t cell_of(uint32_t level, uint32_t pX, uint32_t pY, uint32_t pZ) {
+	const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
+	const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
+	return cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+}
+
+// ancestors k0 .. k0+WIN-1 of the leaf and the sample's occupancy word in each: independent loads, no side effects — a thread issues
+// them for ALL its samples before it starts claiming for the first (the claims are dependent chains of LDS and global atomics)
+__device__ __forceinline__ void probe_load(const BuildArgs& a, uint32_t leafIdx, uint32_t startLevel, uint32_t pX, uint32_t pY, uint32_t pZ, uint32_t k0, Probe& pr) {
 	const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)leafIdx * PATH_WORDS;
+#pragma unroll
+	for (int w = 0; w < WIN; w++) pr.ent[w] = path_entry(a, rec, leafIdx, k0 + w);
+#pragma unroll
+	for (int w = 1; w < WIN; w++) if (pr.ent[w - 1] == 0ull) pr.ent[w] = 0ull;                   // what lies behind the terminator was never written
+#pragma unroll
+	for (int w = 0; w < WIN; w++) {
+		const uint32_t level = path_level(pr.ent[w]);
+		// voxels.cu:449: the traverse loop samples levels 0..19 only
+		if (pr.ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { pr.ent[w] = 0ull; pr.seen[w] = 0u; }
+		else pr.seen[w] = path_grid(a.pers, pr.ent[w])->values[cell_of(level, pX, pY, pZ) >> 5];   // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
+	}
+}
+
+// bottom-up over one window: claim while winning; false = the walk ends here
+__device__ __forceinline__ bool probe_claim(const BuildArgs& a, Ctl* ctl, TileShared& sh, const Probe& pr, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits, uint32_t& wins) {
+#pragma unroll
+	for (int w = 0; w < WIN; w++) {
+		if (pr.ent[w] == 0ull) return false;
+		const uint32_t level = path_level(pr.ent[w]), cell = cell_of(level, pX, pY, pZ), bit = cell & 31u;
+		if (((pr.seen[w] >> bit) & 1u) != 0u) return false;                      // voxels.cu:93-94; the ancestors are set as well
+		const uint32_t nodeIdx = path_node(pr.ent[w]);
+		uint32_t rank;
+		const int e = tab_add(sh.vt, nodeIdx, 0u, &rank);
+		if (e >= 0 && !set_insert(sh.claimed, ((uint32_t)e << 21) | cell)) return false;          // a sample of this workgroup already claims the cell
+		uint32_t* word = &path_grid(a.pers, pr.ent[w])->values[cell >> 5];
+		if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) return false;                         // voxels.cu:96; lost: the winner climbs on
+		if (e >= 0) { wins |= 1u << level; atomicAdd(&sh.vt.vals[e], 1u); }                        // first point in the cell, voxels.cu:99
+		else store_voxel_direct(a, ctl, nodeIdx, (int)level, pX, pY, pZ, colorBits);
+	}
+	return true;
+}
+
+__device__ __forceinline__ uint32_t sample_path(const BuildArgs& a, Ctl* ctl, TileShared& sh, uint32_t leafIdx, uint32_t startLevel, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits, const Probe& first) {
 	uint32_t wins = 0;
-	bool go = true;
+	bool go = probe_claim(a, ctl, sh, first, pX, pY, pZ, colorBits, wins);
 #pragma unroll 1
-	for (uint32_t k0 = 0; go && k0 < PATH_WORDS - 1; k0 += WIN) {
-		unsigned long long ent[WIN];
-		uint32_t* word[WIN];
-		uint32_t seen[WIN], cell[WIN];
-#pragma unroll
-		for (int w = 0; w < WIN; w++) ent[w] = path_entry(a, rec, leafIdx, k0 + w);           // independent loads: the entries ...
-#pragma unroll
-		for (int w = 1; w < WIN; w++) if (ent[w - 1] == 0ull) ent[w] = 0ull;                   // what lies behind the terminator was never written
-#pragma unroll
-		for (int w = 0; w < WIN; w++) {              // ... then the occupancy words of all of them
-			const uint32_t level = path_level(ent[w]);
-			const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
-			const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
-			cell[w] = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-			word[w] = &path_grid(a.pers, ent[w])->values[cell[w] >> 5];
-			// voxels.cu:449: the traverse loop samples levels 0..19 only
-			if (ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { ent[w] = 0ull; seen[w] = 0u; }
-			else seen[w] = *word[w];        // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
-		}
-#pragma unroll
-		for (int w = 0; w < WIN; w++) {              // bottom-up: claim while winning
-			if (!go) break;
-			if (ent[w] == 0ull) { go = false; break; }
-			const uint32_t bit = cell[w] & 31u;
-			if (((seen[w] >> bit) & 1u) != 0u) { go = false; break; }               // voxels.cu:93-94; the ancestors are set as well
-			const uint32_t nodeIdx = path_node(ent[w]);
-			uint32_t rank;
-			const int e = tab_add(sh.vt, nodeIdx, 0u, &rank);
-			if (e >= 0 && !set_insert(sh.claimed, ((uint32_t)e << 21) | cell[w])) { go = false; break; }   // a sample of this workgroup already claims the cell
-			if (((atomicOr(word[w], 1u << bit) >> bit) & 1u) != 0u) { go = false; break; }              // voxels.cu:96; lost: the winner climbs on
-			if (e >= 0) { wins |= 1u << path_level(ent[w]); atomicAdd(&sh.vt.vals[e], 1u); }            // first point in the cell, voxels.cu:99
-			else store_voxel_direct(a, ctl, nodeIdx, (int)path_level(ent[w]), pX, pY, pZ, colorBits);
-		}
+	for (uint32_t k0 = WIN; go && k0 < PATH_WORDS - 1; k0 += WIN) {
+		Probe pr;
+		probe_load(a, leafIdx, startLevel, pX, pY, pZ, k0, pr);
+		go = probe_claim(a, ctl, sh, pr, pX, pY, pZ, colorBits, wins);
 	}
 	return wins;
 }
@@ -609,9 +651,40 @@ __device__ void store_voxels(const BuildArgs& a, Ctl* ctl, TileShared& sh, uint3
 	}
 }
 
+// ---- peek: every PEEK-th sample of the group, counted per leaf — k_ingest's forecast of which leaves will overflow ------------------
+__global__ __launch_bounds__(TPB) void k_peek(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	__shared__ Tab<LT_BITS> tab;
+	tab_init(tab);
+	__syncthreads();
+	uint32_t* est = at<uint32_t>(a, a.offEst);
+	const uint32_t nb = ctl->groupBatches;
+	for (uint32_t b = 0; b < nb; b++) {
+		const uint32_t n = ctl->batchSize[b];
+		const float4* pts = ring_slot(a, ctl->batchSlot[b]);
+		for (uint32_t i = (blockIdx.x * TPB + threadIdx.x) * PEEK; i < n; i += gridDim.x * TPB * PEEK) {
+			const float4 p = pts[i];
+			const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
+			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
+			uint32_t rank;
+			if (tab_add(tab, leafIdx, 1u, &rank) < 0) atomicAdd(&est[leafIdx], 1u);
+		}
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < LT_CAP; e += TPB) if (tab.keys[e] != TBL_EMPTY) atomicAdd(&est[tab.keys[e]], tab.vals[e]);
+}
+
+// SIMLOD_PHASE_TIMERS=1: thread 0 of every workgroup adds the wall time of each phase to Ctl.phaseNs (tools/kprof.py prints them)
+struct PhaseTimer {
+	uint64_t t; unsigned long long* slots; bool on;
+	__device__ PhaseTimer(Ctl* ctl, uint32_t first) : t(0), slots(reinterpret_cast<unsigned long long*>(ctl->phaseNs) + first), on((ctl->debugFlags & 2u) != 0u && threadIdx.x == 0) { if (on) t = wall_ns(); }
+	__device__ void lap(uint32_t k) { if (on) { const uint64_t n = wall_ns(); atomicAdd(&slots[k], (unsigned long long)(n - t)); t = n; } }
+};
+
 // ---- ingest: the whole job for samples whose leaf stays within its limit (voxels.cu:124-229, 417-483, 485-639, 674-698) ----------
 template <int P>
-__global__ __launch_bounds__(TPB) void k_ingest(BuildArgs a) {
+__global__ __launch_bounds__(TPB, 4) void k_ingest(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
 	__shared__ TileShared sh;
@@ -624,6 +697,7 @@ __global__ __launch_bounds__(TPB) void k_ingest(BuildArgs a) {
 		const uint32_t cnt = min(TILE, ctl->batchSize[b] - first);
 		const float4* pts = ring_slot(a, ctl->batchSlot[b]) + first;
 		const uint32_t vbase = b * SIMLOD_MAX_BATCH_SIZE + first;
+		PhaseTimer timer(ctl, 0);
 		__syncthreads();
 		tile_reset(sh);
 		__syncthreads();
@@ -652,9 +726,10 @@ __global__ __launch_bounds__(TPB) void k_ingest(BuildArgs a) {
 			else {
 				// no room in the table: this sample is its own (workgroup, leaf) entry.  Its slot comes from the arrival counter like
 				// everybody's, so the leaf's storage stays gap-free; whoever allocates its chunk reserved an earlier slot and never waits
-				const uint32_t old = count_into(a, ctl, leafIdx, 1u);
-				if (leafIdx != 0u && old + 1u <= MAXPTS) {
-					atomicAdd(&a.nodes[leafIdx].numPoints, 1u);
+				const bool hot = leaf_is_hot(a, leafIdx);
+				const uint32_t old = count_into(a, ctl, leafIdx, 1u, !hot);
+				if (!hot && old + 1u > MAXPTS) atomicSub(&a.nodes[leafIdx].numPoints, 1u);
+				if (!hot && old + 1u <= MAXPTS) {
 					if (old % CHUNK == 0u) make_point_chunk(a, ctl, leafIdx, old / CHUNK);
 					SimlodChunk* c = wait_point_chunk(a, ctl, leafIdx, old / CHUNK);
 					if (c != nullptr) reinterpret_cast<float4*>(c->points)[old % CHUNK] = p[j];
@@ -663,43 +738,56 @@ __global__ __launch_bounds__(TPB) void k_ingest(BuildArgs a) {
 			}
 		}
 		__syncthreads();
+		timer.lap(0);
 
 		// 2: arrival counters, slot ranges, chunks
 		flush_points<true>(a, ctl, sh);
 		__syncthreads();
+		timer.lap(1);
 
 		// 3: store, sample; what cannot be placed yet is queued for k_place
-		uint32_t wins[P], pend[P];
+		constexpr uint32_t WAITS = 0x80000000u;             // wins[j]: levels won (bits 0..19), or WAITS | index in the workgroup's share of the k_place queue
+		uint32_t wins[P];
+		Probe pr[P];
+#pragma unroll
+		for (int j = 0; j < P; j++) {                       // the probes of all samples of the thread are in flight together
+			wins[j] = 0;
+			if (leafOf[j] == NONE) continue;
+			const bool placed = er[j] == STORED || (er[j] != NONE && sh.ltBase[er[j] >> 16] != NONE);
+			if (!placed) { wins[j] = WAITS; continue; }
+			probe_load(a, leafOf[j], 0u, quantize(F_FULL, p[j].x, a.minx, a.size), quantize(F_FULL, p[j].y, a.miny, a.size), quantize(F_FULL, p[j].z, a.minz, a.size), 0u, pr[j]);
+		}
 #pragma unroll
 		for (int j = 0; j < P; j++) {
-			wins[j] = 0; pend[j] = NONE;
 			if (leafOf[j] == NONE) continue;
-			const uint32_t e = er[j] >> 16;
-			if (er[j] == STORED || (er[j] != NONE && sh.ltBase[e] != NONE)) {
-				if (er[j] != STORED) store_point(a, ctl, sh, e, er[j] & 0xffffu, p[j]);
+			if (wins[j] == 0u) {
+				if (er[j] != STORED) store_point(a, ctl, sh, er[j] >> 16, er[j] & 0xffffu, p[j]);
 				const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
-				wins[j] = sample_path(a, ctl, sh, leafOf[j], 0u, pX, pY, pZ, p[j].w);
-			} else pend[j] = atomicAdd(&sh.pendCount, 1u);
+				wins[j] = sample_path(a, ctl, sh, leafOf[j], 0u, pX, pY, pZ, p[j].w, pr[j]);
+			} else wins[j] = WAITS | atomicAdd(&sh.pendCount, 1u);
 		}
 		__syncthreads();
+		timer.lap(2);
 		if (threadIdx.x == 0 && sh.pendCount != 0u) sh.pendBase = atomicAdd(&ctl->numPending, sh.pendCount);
 
 		// 4: voxel slot ranges and chunks
 		flush_voxels(a, ctl, sh);
 		__syncthreads();
+		timer.lap(3);
 
 		// 5: voxel stores; the queue entries of the samples left to k_place
 #pragma unroll
 		for (int j = 0; j < P; j++) {
-			if (wins[j] != 0u) {
+			if (wins[j] != 0u && (wins[j] & WAITS) == 0u) {
 				const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
 				store_voxels(a, ctl, sh, leafOf[j], wins[j], pX, pY, pZ, p[j].w);
 			}
-			if (pend[j] != NONE) {
-				const uint32_t q = sh.pendBase + pend[j];
+			if ((wins[j] & WAITS) != 0u) {
+				const uint32_t q = sh.pendBase + (wins[j] & ~WAITS);
 				if (q < a.pendCap) { pendIdx[q] = vbase + j * TPB + threadIdx.x; pendLeaf[q] = leafOf[j]; }
 			}
 		}
+		timer.lap(4);
 	}
 }
 
@@ -1007,8 +1095,41 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t roundFirs
 	}
 }
 
-// ---- place: samples that k_ingest could not place — their leaf overflowed — and the stored points of the split leaves go into
-// the leaves that exist now: slots, stores, voxel sampling, as in k_ingest (voxels.cu:540-639 for the spilled points) -------------
+// ---- prealloc: the leaves the cascade created know how many samples k_place will bring them: all their chunks with ONE pop of the
+// recycle stack and ONE allocation per leaf (voxels.cu:485-538), instead of a thousand on-demand allocations on two hot words while
+// every workgroup waits -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_prealloc(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t last = min(a.stats->numNodes, a.nodeCapacity);
+	SimlodChunk** queue = at<SimlodChunk*>(a, a.offQueue);
+	for (uint32_t i = ctl->nodesAtStart + blockIdx.x * TPB + threadIdx.x; i < last; i += gridDim.x * TPB) {
+		SimlodNode* node = a.nodes + i;
+		const uint32_t cnt = node->counter;
+		if (cnt == 0u || !node_is_leaf(node)) continue;
+		const uint32_t n = min((cnt + CHUNK - 1) / CHUNK, LEAF_SLOTS);           // an over-full new leaf gets the rest on demand
+		const unsigned long long idx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)n);
+		const unsigned long long pool = a.stats->chunkPoolSize;
+		const uint32_t fromPool = idx >= pool ? 0u : (uint32_t)min((unsigned long long)n, pool - idx);
+		uint8_t* fresh = n > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), n - fromPool) : nullptr;
+		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
+		SimlodChunk* prev = nullptr;
+		SimlodChunk* head = nullptr;
+		for (uint32_t k = 0; k < n; k++) {
+			SimlodChunk* c = k < fromPool ? queue[idx + k] : reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+			c->next = nullptr;
+			if (prev != nullptr) prev->next = c; else head = c;
+			slots[k] = c;
+			prev = c;
+		}
+		node->points = head;
+		tail_of(head) = prev;
+	}
+}
+
+// ---- place: samples that k_ingest could not place — their leaf overflowed, or was forecast to — and the stored points of the split
+// leaves go into the leaves that exist now: slot ranges per (workgroup, leaf), 16-byte stores (voxels.cu:540-639).  Their voxel
+// sampling is k_voxelize's job --------------------------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
@@ -1024,21 +1145,21 @@ __global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	const uint32_t numTiles = (total + TILE - 1) / TILE;
 	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+		PhaseTimer timer(ctl, 8);
 		__syncthreads();
-		tile_reset(sh);
+		tab_init(sh.lt);
 		__syncthreads();
 		float4 p[P];
-		uint32_t leafOf[P], er[P], startLevel[P];
+		uint32_t leafOf[P], er[P];
 #pragma unroll
 		for (int j = 0; j < P; j++) {
 			const uint32_t q = tile * TILE + j * TPB + threadIdx.x;
-			leafOf[j] = NONE; er[j] = NONE; startLevel[j] = 0; p[j] = make_float4(0, 0, 0, 0);
+			leafOf[j] = NONE; er[j] = NONE; p[j] = make_float4(0, 0, 0, 0);
 			if (q >= total) continue;
 			const uint32_t meta = q < numPending ? pendLeaf[q] : spMeta[q - numPending];
 			if (meta == NONE) continue;
 			p[j] = q < numPending ? point_of(a, ctl, pendIdx[q]) : spilled[q - numPending];
 			leafOf[j] = meta & 0x7ffffu;
-			startLevel[j] = q < numPending ? 0u : meta >> 19;
 		}
 #pragma unroll
 		for (int j = 0; j < P; j++) {
@@ -1051,29 +1172,208 @@ __global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
 			if (e >= 0) er[j] = ((uint32_t)e << 16) | rank;
 		}
 		__syncthreads();
+		timer.lap(0);
 		flush_points<false>(a, ctl, sh);
 		__syncthreads();
-		uint32_t wins[P];
+		timer.lap(1);
 #pragma unroll
 		for (int j = 0; j < P; j++) {                       // every allocation before any lookup: first the samples that own their slot bookkeeping
 			if (leafOf[j] != NONE && er[j] == NONE) store_point_direct(a, ctl, leafOf[j], p[j]);
 		}
 #pragma unroll
-		for (int j = 0; j < P; j++) {
-			wins[j] = 0;
-			if (leafOf[j] == NONE) continue;
-			if (er[j] != NONE) store_point(a, ctl, sh, er[j] >> 16, er[j] & 0xffffu, p[j]);
-			const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
-			wins[j] = sample_path(a, ctl, sh, leafOf[j], startLevel[j], pX, pY, pZ, p[j].w);
+		for (int j = 0; j < P; j++) if (leafOf[j] != NONE && er[j] != NONE) store_point(a, ctl, sh, er[j] >> 16, er[j] & 0xffffu, p[j]);
+		timer.lap(2);
+	}
+}
+
+// ---- voxelize: 128^3 occupancy sampling of what k_place stored (voxels.cu:50-121, 417-483), ONE workgroup per leaf ---------------------
+// k_place's samples are the contended ones: a batch that enters new territory puts its points into a few dozen fresh leaves under a
+// handful of fresh inner nodes whose grids are empty — a million test-and-set attempts on a few hundred 128-byte lines, twelve
+// candidates per cell from twelve different workgroups when samples are taken in arrival order.  But placed, the samples of a leaf
+// sit side by side in the leaf's chunks, and a leaf owns a CUBE of every ancestor's grid: 64^3 cells of its parent's (32 KB of
+// bits), 32^3 of the grand-parent's, ... down to one cell seven levels up — cubes of different leaves are disjoint.  So the
+// workgroup that owns a leaf copies those cubes into LDS, runs the whole test-and-set cascade of the leaf's new samples there
+// (bottom-up, climbing while a cell is new, as everywhere in this file), and writes the cubes back: no global atomic per sample, none
+// contended at all.  Only above the seventh ancestor, where several leaves share a cell, the global atomicOr decides.
+// Pass A marks the new cells; their number per ancestor reserves a voxel slot range with ONE atomic per (leaf, ancestor); pass B
+// walks the samples again and whoever finds its cell still marked new takes the mark and stores the voxel with its own colour (which
+// point of a cell colours the voxel is scheduling dependent in the reference too).
+// Leaves with few new samples (and a root that is still a leaf: its cube is the whole grid) take the per-sample path with global
+// atomics; there is nothing to contend for.
+static constexpr uint32_t VTPB = 512;
+static constexpr uint32_t BULK_MIN = 768;
+static constexpr uint32_t LDS_LEVELS = 7;           // ancestors whose cube of this leaf has at least one whole cell: side 128 >> d
+struct VoxShared {
+	uint32_t occ[8192 + 1024 + 256 + 64 + 16 + 4 + 4];   // cubes d = 1..7: rows of (128 >> d) x-bits, one row per word from d = 2 on
+	uint32_t fresh[8192 + 1024 + 256 + 64 + 16 + 4 + 4]; // cells this pass set
+	unsigned long long anc[PATH_WORDS];
+	uint32_t cnt[PATH_WORDS], base[PATH_WORDS], cursor[PATH_WORDS];
+	SimlodChunk* ptr[PATH_WORDS][2];
+};
+__device__ __forceinline__ uint32_t cube_offset(uint32_t d) {          // word offset of cube d in VoxShared::occ / fresh
+	return d == 1u ? 0u : d == 2u ? 8192u : d == 3u ? 9216u : d == 4u ? 9472u : d == 5u ? 9536u : d == 6u ? 9552u : 9556u;
+}
+// word and bit of cell (lx, ly, lz) of cube d (side = 128 >> d)
+__device__ __forceinline__ void cube_cell(uint32_t d, uint32_t lx, uint32_t ly, uint32_t lz, uint32_t& word, uint32_t& bit) {
+	const uint32_t side = 128u >> d, row = ly + side * lz;
+	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
+	else { word = cube_offset(d) + row; bit = lx; }
+}
+
+__device__ __forceinline__ const SimlodChunk* placed_chunk(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t k, uint32_t start) {
+	if (k < LEAF_SLOTS) return at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)leafIdx * LEAF_SLOTS + k];
+	if (k * CHUNK < start) return tail_of(a.nodes[leafIdx].points);       // an over-full leaf: the tail it had when the batch began
+	return dir_find(a, ctl, KIND_PT, leafIdx, k);
+}
+
+__device__ __forceinline__ float4 voxel_at(const BuildArgs& a, uint32_t level, uint32_t nX, uint32_t nY, uint32_t nZ, uint32_t cell, float colorBits) {
+	const uint32_t cx = cell & 127u, cy = (cell >> 7) & 127u, cz = cell >> 14;
+	const float nodeSize = a.size / exp2_int(level);                        // voxels.cu:103-114, operation by operation
+	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
+	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
+	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
+	float4 v;
+	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
+	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
+	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
+	v.w = colorBits;
+	return v;
+}
+
+__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t numLeaves = ctl->numVoxLeaves;
+	if (numLeaves == 0u) return;
+	__shared__ VoxShared sh;
+	const uint32_t* list = at<const uint32_t>(a, a.offVoxList);
+	const uint32_t* ptStart = at<const uint32_t>(a, a.offPtStart);
+	for (uint32_t item = blockIdx.x; item < numLeaves; item += gridDim.x) {
+		const uint32_t leafIdx = list[item];
+		const SimlodNode* leaf = a.nodes + leafIdx;
+		const uint32_t s0 = ptStart[leafIdx], s1 = leaf->numPoints;
+		if (s1 <= s0 || !node_is_leaf(leaf)) continue;
+		const uint32_t lvl = leaf->level, LX = leaf->X, LY = leaf->Y, LZ = leaf->Z;
+		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)leafIdx * PATH_WORDS;
+		__syncthreads();
+		if (threadIdx.x < PATH_WORDS) { sh.anc[threadIdx.x] = path_entry(a, rec, leafIdx, threadIdx.x); sh.cnt[threadIdx.x] = 0; sh.cursor[threadIdx.x] = 0; sh.base[threadIdx.x] = NONE; }
+		__syncthreads();
+		// ancestor d (1 = parent) is sh.anc[d - 1]; a root that is still a leaf has itself as "ancestor 1" and no cube
+		uint32_t depth = 0;
+		while (depth < PATH_WORDS - 1 && sh.anc[depth] != 0ull) depth++;
+		const bool bulk = leafIdx != 0u && s1 - s0 >= BULK_MIN;
+		const uint32_t ldsDepth = bulk ? min(depth, LDS_LEVELS) : 0u;
+
+		if (bulk) {
+			// the leaf's cubes, as the grids hold them now
+			for (uint32_t d = 1; d <= ldsDepth; d++) {
+				const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
+				const uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
+				const uint32_t rows = side * side;
+				if (d == 1u) for (uint32_t w = threadIdx.x; w < rows * 2u; w += VTPB) {
+					const uint32_t row = w >> 1, ly = row % side, lz = row / side;
+					sh.occ[w] = grid[((ox + 128u * (oy + ly) + 16384u * (oz + lz)) >> 5) + (w & 1u)];
+					sh.fresh[w] = 0;
+				} else for (uint32_t row = threadIdx.x; row < rows; row += VTPB) {
+					const uint32_t ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
+					const uint32_t mask = side >= 32u ? 0xffffffffu : (1u << side) - 1u;
+					sh.occ[cube_offset(d) + row] = (grid[cell >> 5] >> (cell & 31u)) & mask;
+					sh.fresh[cube_offset(d) + row] = 0;
+				}
+			}
+			__syncthreads();
+		}
+
+		// pass A: test-and-set, bottom-up, climbing while the cell is new
+		for (uint32_t i = s0 + threadIdx.x; i < s1; i += VTPB) {
+			const SimlodChunk* c = placed_chunk(a, ctl, leafIdx, i / CHUNK, s0);
+			if (c == nullptr) continue;
+			const float4 p = reinterpret_cast<const float4*>(c->points)[i % CHUNK];
+			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+			for (uint32_t d = 1; d <= depth; d++) {
+				const unsigned long long ent = sh.anc[d - 1];
+				const uint32_t level = path_level(ent);
+				if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;                 // voxels.cu:449: levels 0..19 only
+				const uint32_t cell = cell_of(level, pX, pY, pZ);
+				if (d <= ldsDepth) {
+					const uint32_t side = 128u >> d;
+					uint32_t word, bit;
+					cube_cell(d, (cell & 127u) & (side - 1u), ((cell >> 7) & 127u) & (side - 1u), (cell >> 14) & (side - 1u), word, bit);
+					if (((sh.occ[word] >> bit) & 1u) != 0u) break;
+					if (((atomicOr(&sh.occ[word], 1u << bit) >> bit) & 1u) != 0u) break;
+					atomicOr(&sh.fresh[word], 1u << bit);
+				} else {
+					uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
+					const uint32_t bit = cell & 31u;
+					if (((*word >> bit) & 1u) != 0u) break;                         // voxels.cu:93-94
+					if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) break;     // voxels.cu:96
+					// a cell that several leaves share, or a leaf with few samples: the voxel is stored right away
+					const uint32_t sd = lvl - level;
+					const uint32_t nodeIdx = path_node(ent);
+					const uint32_t slot = atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u), k = slot / CHUNK;
+					if (slot % CHUNK == 0u) make_voxel_chunk(a, ctl, nodeIdx, k);
+					SimlodChunk* vc = wait_voxel_chunk(a, ctl, nodeIdx, k);
+					if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> sd, LY >> sd, LZ >> sd, cell, p.w);
+				}
+			}
+		}
+		if (!bulk) continue;
+		__syncthreads();
+
+		// new cells per cube; the cubes go back to the grids (d = 1, 2: whole words that belong to this leaf alone; above: shared words)
+		for (uint32_t d = 1; d <= ldsDepth; d++) {
+			const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
+			uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
+			const uint32_t rows = side * side, words = d == 1u ? rows * 2u : rows;
+			uint32_t mine = 0;
+			for (uint32_t w = threadIdx.x; w < words; w += VTPB) {
+				const uint32_t f = sh.fresh[cube_offset(d) + w];
+				if (f == 0u) continue;
+				mine += __popc(f);
+				const uint32_t row = d == 1u ? w >> 1 : w, ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
+				if (d == 1u) grid[(cell >> 5) + (w & 1u)] = sh.occ[w];
+				else if (d == 2u) grid[cell >> 5] = sh.occ[cube_offset(d) + w];
+				else atomicOr(&grid[cell >> 5], f << (cell & 31u));
+			}
+			if (mine != 0u) atomicAdd(&sh.cnt[d], mine);
 		}
 		__syncthreads();
-		flush_voxels(a, ctl, sh, reinterpret_cast<unsigned long long*>(&ctl->placeVoxels));
+		// voxel slot ranges: one atomic per (leaf, ancestor); chunks whose first slot falls into a range; then the lookups
+		if (threadIdx.x >= 1u && threadIdx.x <= ldsDepth && sh.cnt[threadIdx.x] != 0u) {
+			const uint32_t d = threadIdx.x, nodeIdx = path_node(sh.anc[d - 1]), cnt = sh.cnt[d];
+			const uint32_t old = atomicAdd(&a.nodes[nodeIdx].numVoxels, cnt);                  // voxels.cu:101
+			for (uint32_t k = (old + CHUNK - 1) / CHUNK; k * CHUNK < old + cnt; k++) make_voxel_chunk(a, ctl, nodeIdx, k);
+			sh.base[d] = old;
+		}
 		__syncthreads();
-#pragma unroll
-		for (int j = 0; j < P; j++) {
-			if (wins[j] == 0u) continue;
-			const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
-			store_voxels(a, ctl, sh, leafOf[j], wins[j], pX, pY, pZ, p[j].w);
+		if (threadIdx.x >= 1u && threadIdx.x <= ldsDepth && sh.base[threadIdx.x] != NONE) {
+			const uint32_t d = threadIdx.x, nodeIdx = path_node(sh.anc[d - 1]), old = sh.base[d], cnt = sh.cnt[d], k0 = old / CHUNK;
+			sh.ptr[d][0] = wait_voxel_chunk(a, ctl, nodeIdx, k0);
+			sh.ptr[d][1] = (old + cnt - 1) / CHUNK > k0 ? wait_voxel_chunk(a, ctl, nodeIdx, k0 + 1) : nullptr;
+		}
+		__syncthreads();
+
+		// pass B: every new cell becomes a voxel, coloured by whichever of its samples gets there first
+		for (uint32_t i = s0 + threadIdx.x; i < s1; i += VTPB) {
+			const SimlodChunk* c = placed_chunk(a, ctl, leafIdx, i / CHUNK, s0);
+			if (c == nullptr) continue;
+			const float4 p = reinterpret_cast<const float4*>(c->points)[i % CHUNK];
+			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+			for (uint32_t d = 1; d <= ldsDepth; d++) {
+				if (sh.cnt[d] == 0u) continue;
+				const unsigned long long ent = sh.anc[d - 1];
+				const uint32_t level = path_level(ent);
+				if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;
+				const uint32_t cell = cell_of(level, pX, pY, pZ), side = 128u >> d;
+				uint32_t word, bit;
+				cube_cell(d, (cell & 127u) & (side - 1u), ((cell >> 7) & 127u) & (side - 1u), (cell >> 14) & (side - 1u), word, bit);
+				if (((sh.fresh[word] >> bit) & 1u) == 0u) continue;
+				if (((atomicAnd(&sh.fresh[word], ~(1u << bit)) >> bit) & 1u) == 0u) continue;     // somebody else took the mark
+				const uint32_t base = sh.base[d], slot = base + atomicAdd(&sh.cursor[d], 1u), kk = slot / CHUNK, dk = kk - base / CHUNK;
+				const uint32_t nodeIdx = path_node(ent);
+				SimlodChunk* vc = dk == 0u ? sh.ptr[d][0] : dk == 1u ? sh.ptr[d][1] : wait_voxel_chunk(a, ctl, nodeIdx, kk);
+				if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> d, LY >> d, LZ >> d, cell, p.w);
+			}
 		}
 	}
 }
@@ -1108,10 +1408,12 @@ __global__ __launch_bounds__(TPB) void k_nodes(BuildArgs a) {
 	uint32_t* ptStart = at<uint32_t>(a, a.offPtStart);
 	uint32_t* voxStart = at<uint32_t>(a, a.offVoxStart);
 	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	uint32_t* est = at<uint32_t>(a, a.offEst);
 	const uint32_t stamp = ctl->batchIndex + ctl->groupBatches;
 	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
 		SimlodNode* node = a.nodes + i;
 		node->countIteration = stamp;
+		est[i] = 0;
 		const uint32_t np = node->numPoints, ps = ptStart[i];
 		if (np > ps) {
 			const uint32_t kOld = (ps + CHUNK - 1) / CHUNK, kNew = (np + CHUNK - 1) / CHUNK;
@@ -1221,11 +1523,14 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offSpillB = off;   off += align_up((uint64_t)a.histCap * sizeof(SpillEntry), 256);
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offEst = off;      off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offPlacedTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offPtStart = off;  off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offVoxStart = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off;    off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
+	a.offVoxList = off;  off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offHist = off;     off += HIST_BYTES;
 	a.offDir = off;      off += align_up((uint64_t)a.dirCap * sizeof(DirEntry), 256);
 	// what is left is shared by the per-sample arrays: 8 B per sample of a group that may have to wait for k_place, 20 B per moved point
@@ -1271,30 +1576,32 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	const DeviceInfo& dev = device_info();
 	const uint32_t coalesce = ingest_mode();
 	const uint32_t limit = std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH);
-	const uint32_t debugFlags = (uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u;
+	const uint32_t debugFlags = ((uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u) | (tune("SIMLOD_PHASE_TIMERS", 0) ? 2u : 0u);
 
 	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, coalesce, limit, debugFlags);
 	if (fits) {
-		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
+		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records, retry tags, arrival estimates
 		if (e == hipSuccess) e = hipMemsetAsync(a.mom + a.offHist, 0, (size_t)(HIST_BYTES + (uint64_t)a.dirCap * sizeof(DirEntry)), stream);
 		if (e != hipSuccess) return (int)e;
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		SIMLOD_LAUNCH(k_parents, dim3(gridNodes), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(k_paths, dim3(gridNodes), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
-		const int ingestP = tune("SIMLOD_INGEST_P", 4);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X: the barrier's agent-scope release / acquire and the polling cost grow with the participants
 		const uint32_t expandWgs = (uint32_t)std::max(1, std::min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
-		const bool cooperative = tune("SIMLOD_EXPAND_COOPERATIVE", 1) != 0;
+		const bool cooperative = tune("SIMLOD_EXPAND_COOPERATIVE", 0) != 0;
+		const bool peek = tune("SIMLOD_PEEK", 1) != 0;
 		const uint32_t groups = coalesce ? (limit + a.groupMax - 1) / a.groupMax : limit;
 		for (uint32_t g = 0; g < groups; g++) {
-			if (ingestP == 4) SIMLOD_LAUNCH(k_ingest<4>, dim3(gridPoints), dim3(TPB), stream, a);
-			else SIMLOD_LAUNCH(k_ingest<8>, dim3(gridPoints), dim3(TPB), stream, a);
+			if (peek) SIMLOD_LAUNCH(k_peek, dim3(dev.numCUs * 2), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_ingest<4>, dim3(gridPoints), dim3(TPB), stream, a);
 			int rc = launch_expand(a, 0u, expandWgs, cooperative, stream);
 			if (rc == 0) rc = launch_expand(a, 1u, expandWgs, cooperative, stream);
 			if (rc != 0) return rc;
+			SIMLOD_LAUNCH(k_prealloc, dim3(dev.numCUs), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_place<4>, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a);
 			SIMLOD_LAUNCH(k_link, dim3(std::min<uint32_t>(dev.numCUs, a.dirCap / TPB)), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_nodes, dim3(std::min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, g);

@@ -31,6 +31,7 @@ struct Ctl {
 	uint32_t numPending;         // samples waiting for the place pass (their leaf overflowed, or is the root, or the LDS table was full)
 	uint32_t numSpilling;        // round-0 list length (written by k_ingest, never modified by k_expand: stable early-exit test)
 	uint32_t dirUsed;            // chunks published in the hash directory by this group
+	uint32_t numVoxLeaves;       // leaves that k_place stored samples in: k_voxelize's work list
 	uint32_t errors, abortBatch, panic;
 	uint32_t barrierCount[2];    // one monotonic counter per k_expand launch of a group (round 0 | the later rounds)
 	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer)
@@ -48,6 +49,7 @@ struct Ctl {
 	uint64_t placeVoxels;        // byte 192: ... and the voxels k_place created, since the host last cleared them
 	uint64_t expandNs[8];        // byte 200: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
 	uint32_t batchSize[SIMLOD_MAX_BATCHES_PER_LAUNCH], batchSlot[SIMLOD_MAX_BATCHES_PER_LAUNCH];
+	uint64_t phaseNs[16];        // byte 424: SIMLOD_PHASE_TIMERS=1 — wall time per phase summed over workgroups: k_ingest [0..7], k_place [8..15]
 };
 static_assert(offsetof(Ctl, spilledTotal) == 176, "bench.py reads Ctl.spilledTotal at byte 176");
 static_assert(sizeof(Ctl) <= 4096, "control block");
@@ -63,8 +65,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offPtStart, offVoxStart, offLeafChunks, offPaths, offHist, offDir,
-	             offPendIdx, offPendLeaf, offSpMeta, offSpilled;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offEst, offPlacedTag, offParent, offPtStart, offVoxStart, offLeafChunks, offPaths, offHist, offDir,
+	             offPendIdx, offPendLeaf, offSpMeta, offSpilled, offVoxList;
 	uint32_t     nodeCapacity, spilledCap, pendCap, histCap, dirCap, groupMax;
 };
 
