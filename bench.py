@@ -52,6 +52,13 @@ def parse():
     return ap.parse_args()
 
 
+def launches_idle(launches, n_batches, coalesced):
+    """kernel_construct enqueues one kernel group per possible batch (20 per launch); the groups beyond the pending batches exit at once."""
+    if coalesced:
+        return 0 if launches <= 4 else launches - 2
+    return max(0, launches - n_batches)
+
+
 def collect_profile(L):
     from simlod_amd.runtime import lib  # noqa: F401
 
@@ -172,13 +179,18 @@ def main():
 
     # ---- per-kernel attribution with HIP events on the launch stream (separate, untimed pass) --------------------
     roofline, chain, kernels = None, None, {}
-    CTL_COUNTERS = slice(176, 200)                                           # simlod_internal.hpp Ctl: spilledTotal, pendingTotal, placeVoxels
+    bulk_chain = args.coalesce or os.environ.get("SIMLOD_EXACT_CHAIN") == "bulk"
+    # measurement aids in the control block at byte 0 of the momentary buffer: construct_bulk.hip Ctl {spilledTotal, pendingTotal,
+    # placeVoxels} at byte 176; construct_batch.hip Ctl.expandNs[7] (stored points moved by splits) at byte 208
+    CTL_COUNTERS = slice(176, 200) if bulk_chain else slice(208, 216)
     if rank == 0 and not args.no_profile:
         L.simlod_profile_enable(1)
         dev.momentary[CTL_COUNTERS].zero_()
         ingest_step()
         prof_c = collect_profile(L)
-        moved, placed, place_voxels = (int(v) for v in dev.momentary[CTL_COUNTERS].cpu().numpy().view(np.uint64))
+        counters = [int(v) for v in dev.momentary[CTL_COUNTERS].cpu().numpy().view(np.uint64)]
+        moved = counters[0]
+        placed, place_voxels = (counters[1], counters[2]) if bulk_chain else (0, 0)
         dev.render(u)
         prof_r = collect_profile(L)
         L.simlod_profile_enable(0)
@@ -189,17 +201,21 @@ def main():
         chain_bytes = 32.0 * n_points + 16.0 * new_voxels                  # 32 B/point + 16 B/new voxel
         chain = {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms, "what": "whole kernel_construct chain, one 36 M ingest"}
-        # Algorithmic bytes per kernel for one whole ingest: k_ingest reads every point (16 B), stores the ones it places
-        # itself (16 B) and the voxels they create (16 B); k_place does the same for the samples of overflowing leaves and the stored
-        # points that move (read 16 B + store 16 B each); k_expand reads a moved point and writes it to the spill buffer (32 B) and
-        # reads every waiting sample once per split round (16 B, lower bound: one round).
-        per_ingest = {"k_ingest": 16.0 * n_points + 16.0 * (n_points - placed) + 16.0 * (new_voxels - place_voxels),
-                      "k_place": 32.0 * (placed + moved) + 16.0 * place_voxels,
-                      "k_expand": 32.0 * moved + 16.0 * placed}
-        base = lambda k: k.split("<")[0]                                     # k_ingest<4> -> k_ingest
+        # Algorithmic bytes per kernel for one whole ingest.
+        #  batch chain: k_count reads every point (16 B), k_sample reads it again (16 B), k_insert reads and stores it (32 B) and stores the
+        #    new voxels (16 B each), k_expand reads a moved point and writes it to the spill buffer (32 B);
+        #  bulk chain: k_ingest reads every point, stores the ones it places itself and their voxels; k_place reads and stores the samples of
+        #    overflowing leaves and the moved points; k_voxelize reads them back twice and stores their voxels; k_expand as above plus one
+        #    read of every waiting sample per split round (lower bound: one round).
+        if bulk_chain:
+            per_ingest = {"k_ingest": 16.0 * n_points + 16.0 * (n_points - placed) + 16.0 * (new_voxels - place_voxels), "k_place": 32.0 * (placed + moved),
+                          "k_voxelize": 32.0 * (placed + moved) + 16.0 * place_voxels, "k_expand": 32.0 * moved + 16.0 * placed}
+        else:
+            per_ingest = {"k_count": 16.0 * n_points, "k_sample": 16.0 * (n_points + moved), "k_insert": 32.0 * (n_points + moved) + 16.0 * new_voxels, "k_expand": 32.0 * moved}
+        base = lambda k: k.split("<")[0]                                     # k_sample<4> -> k_sample
         dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
-        active = launches_per_step_active = n_batches                        # launches that had a batch to process
+        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, bulk_chain and args.coalesce)))
         bytes_per_launch = per_ingest[dom] / active
         avg_ms = prof_c[dom_full][1] / active
         traffic, traffic_src = None, None

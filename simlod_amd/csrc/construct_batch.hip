@@ -1,0 +1,1130 @@
+// construct_batch.hip — incremental octree/LOD builder for MI355X (gfx950): `kernel_construct` in EXACT mode (one ring batch at a time,
+// the reference's granularity; the default).  construct_bulk.hip is the chain of the opt-in coalesced mode.
+//
+// Replaces modules/progressive_octree/progressive_octree_voxels.cu:804-1010 (one persistent cooperative CUDA
+// kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
+// memory image.  Design:
+//
+//   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, sample, alloc, insert,
+//     end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
+//     over 256 CUs / 8 XCDs costs 4-26 us; control flow stays on the device (a control block at byte 0 of the
+//     momentary buffer), inactive kernels exit at once, so the call is fully asynchronous like the reference's;
+//   * every point is read with one coalesced 16-byte load per phase and descends the tree ONCE: the leaf found
+//     by `count` is cached (4 B/point) and only points whose leaf was split re-descend, from that leaf down
+//     (the reference re-descends from the root in three phases and re-scans the batch in every split round);
+//   * per-leaf counters, slot reservations and voxel counters are aggregated per WORKGROUP in LDS hash tables (one global
+//     atomic per workgroup and counter): device-scope atomics on one word retire at ~88 M/s on this chip, and a spatially
+//     compact batch sends most of its points to a few dozen leaves;
+//   * voxel sampling walks the root path BOTTOM-UP (occupancy is hierarchical: a set bit implies the covering bits of all
+//     ancestors) and reads the path from a per-node ancestor table instead of chasing parent -> node -> grid pointers;
+//   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of every
+//     list remembers its tail (8 spare bytes of Chunk), a per-batch chunk directory gives O(1) slot->chunk, and a leaf chunk
+//     table lets a split read the whole list of a leaf with one wave;
+//   * new voxels are not copied through a 24-byte backlog record: `sample` leaves a 20-bit per-point mask of the
+//     levels the point won, `insert` regenerates the voxel from (level, cell) while the point is in registers;
+//   * no capacity limit loses a point: a split reserves its node slots and spill space in one compare-and-swap or does not
+//     happen yet (the leaf grows and is queued again by a later batch).
+//
+// The result after every batch is the reference's: same topology, same per-node sample multisets, same occupancy
+// bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
+// chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
+// (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
+#include "simlod_device.hpp"
+#include "simlod_hip.h"
+#include "simlod_internal.hpp"
+
+namespace simlod {
+namespace batch {
+
+// Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
+// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
+struct Ctl {
+	uint32_t uploaded, firstBatch, numBatches, stop;
+	uint32_t active, batchSize, ringSlot, batchIndex;
+	uint32_t numSpilling;        // spilling leaves found by k_count; NOT modified by k_expand (its early-exit test must be stable)
+	uint32_t numSpilled, dirCount, errors;
+	uint32_t ordinal, abortBatch, barrierCount;
+	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
+	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]
+	uint32_t numWork;            // spill-copy work items appended so far in this batch (monotonic)
+	uint32_t pad1;
+	uint32_t spilledSnap[2];     // numSpilled / numWork as they were BEFORE round r's split phase: slot [r & 1]
+	uint32_t workSnap[2];
+	uint64_t startNs;
+	uint32_t statCounters[8];
+	unsigned long long reserve;        // k_expand: nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves both or neither
+	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
+	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
+	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
+};
+
+struct BuildArgs {
+	SimlodPoint* ring;
+	uint8_t*     mom;
+	uint8_t*     pers;
+	SimlodNode*  nodes;
+	SimlodStats* stats;
+	uint64_t*    frameStart;
+	uint32_t*    numBatchesUploaded;
+	uint32_t*    batchSizes;
+	float        minx, miny, minz, size;
+	uint64_t     persCapacity, frameCounter, scratchBytes;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offWin, offSpilled;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
+};
+
+
+// ---- workgroup-level key -> count aggregation in LDS ------------------------------------------------------------------
+// A device-scope atomic on ONE address retires at ~88 M/s on this chip (MI355X_MICROARCH.md, rows fanin / dequeue), and a
+// spatially compact 1 M-point batch funnels most of its points into a few dozen leaves: per-wave aggregation still
+// leaves ~16 k atomics per hot counter per batch.  So every counter update of the build (leaf arrival counters, slot
+// reservations, voxel counters) is first combined per WORKGROUP in an open-addressing LDS table and flushed with one
+// global atomic per (workgroup, node).  table_add returns the entry and the value the entry's counter had before
+// (= rank of this caller inside the workgroup), or -1 when 16 probes found no room; a key that failed once keeps
+// failing (entries are never removed), so callers can fall back to a direct global atomic consistently.
+static constexpr uint32_t TBL_EMPTY = 0xffffffffu;
+static constexpr int TBL_BITS = 10;
+static constexpr int TBL_CAP = 1 << TBL_BITS;
+
+struct BlockTable {
+	uint32_t keys[TBL_CAP];
+	uint32_t vals[TBL_CAP];
+};
+
+__device__ __forceinline__ void table_init(BlockTable& t) {
+	for (uint32_t i = threadIdx.x; i < (uint32_t)TBL_CAP; i += blockDim.x) { t.keys[i] = TBL_EMPTY; t.vals[i] = 0u; }
+}
+
+__device__ __forceinline__ uint32_t table_hash(uint32_t key) { return (key * 2654435761u) >> (32 - TBL_BITS); }
+
+__device__ __forceinline__ int table_add(BlockTable& t, uint32_t key, uint32_t inc, uint32_t* rank) {
+	uint32_t h = table_hash(key);
+#pragma unroll 1
+	for (int probe = 0; probe < 16; ++probe) {
+		uint32_t k = t.keys[h];
+		if (k == TBL_EMPTY) { k = atomicCAS(&t.keys[h], TBL_EMPTY, key); if (k == TBL_EMPTY) k = key; }
+		if (k == key) { *rank = atomicAdd(&t.vals[h], inc); return (int)h; }
+		h = (h + 1) & (TBL_CAP - 1);
+	}
+	return -1;
+}
+
+__device__ __forceinline__ int table_find(const BlockTable& t, uint32_t key) {
+	uint32_t h = table_hash(key);
+#pragma unroll 1
+	for (int probe = 0; probe < 16; ++probe) {
+		const uint32_t k = t.keys[h];
+		if (k == key) return (int)h;
+		if (k == TBL_EMPTY) return -1;
+		h = (h + 1) & (TBL_CAP - 1);
+	}
+	return -1;
+}
+
+
+
+static constexpr uint32_t TPB = 256;
+static constexpr float F_GRID = 1048576.0f;      // 2^MAX_DEPTH, progressive_octree_voxels.cu:139
+static constexpr float F_FULL = 268435456.0f;    // MAX_DEPTH_GRIDSIZE, structures.cuh:26
+
+struct NodeDir {          // per node, valid for the batch whose tag it carries
+	uint32_t ptBase, ptFirst, ptTag, voxBase, voxFirst, voxTag, pad0, pad1;
+};
+
+// Leaf chunk table: slot k of leaf i's point list -> chunk, LEAF_SLOTS entries per node.  A leaf that can still split stores
+// at most MAX_POINTS_PER_NODE points between batches (= 50 chunks), so the split reads its whole list from here with all
+// lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by k_alloc; survives between
+// launches like the recycle stack does, and is refilled by k_parents whenever k_begin finds its stamp stale.
+static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
+static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
+
+// Ancestor paths: PATH_WORDS 64-bit entries per node, entry k = the k-th ancestor (parent first), zero-terminated.
+// An entry packs everything `sample` and `insert` need to know about that ancestor — its occupancy grid (offset into the
+// persistent buffer), level and node index — so a sample reads its whole root path with independent loads instead of chasing
+// parent -> node -> grid pointers level by level (the chain of dependent L2 round trips that bounded k_sample).
+// Rebuilt for every node at the start of a launch (k_paths), extended for the eight children at a split (k_expand).
+static constexpr uint32_t PATH_WORDS = SIMLOD_MAX_DEPTH + 1;
+static constexpr unsigned long long PATH_VALID = 1ull << 63;
+
+__device__ __forceinline__ unsigned long long path_pack(const uint8_t* pers, uint32_t nodeIdx, uint32_t level, const SimlodOccupancyGrid* grid) {
+	const unsigned long long off = (unsigned long long)(reinterpret_cast<const uint8_t*>(grid) - pers) >> 4;     // grids are 16-byte aligned allocations
+	return PATH_VALID | ((unsigned long long)nodeIdx << 41) | ((unsigned long long)level << 36) | off;
+}
+__device__ __forceinline__ uint32_t path_node(unsigned long long e) { return (uint32_t)(e >> 41) & 0x7ffffu; }
+__device__ __forceinline__ uint32_t path_level(unsigned long long e) { return (uint32_t)(e >> 36) & 31u; }
+__device__ __forceinline__ SimlodOccupancyGrid* path_grid(uint8_t* pers, unsigned long long e) {
+	return reinterpret_cast<SimlodOccupancyGrid*>(pers + ((e & 0xfffffffffull) << 4));
+}
+
+__device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
+template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
+
+__device__ __forceinline__ void raise(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); }
+// conditions after which the batch cannot be completed: the rest of the chain does nothing, Stats.dbg keeps the bit until a reset
+__device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); ctl->abortBatch = 1; ctl->stop = 1; }
+
+// Make batch #ordinal of this launch current, or deactivate (progressive_octree_voxels.cu:890-912).
+__device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
+	ctl->active = 0;
+	if (ordinal >= ctl->numBatches || ctl->stop) return;
+	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
+	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
+	a.stats->memCapacityReached = full ? 1 : 0;
+	if (full) { ctl->stop = 1; return; }
+	const uint32_t batchIndex = a.stats->batchletIndex;
+	const uint32_t slot = batchIndex % SIMLOD_BATCH_STREAM_SIZE;
+	uint32_t size = a.batchSizes[slot];
+	if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
+	ctl->batchIndex = batchIndex;
+	ctl->ringSlot = slot;
+	ctl->batchSize = size;
+	ctl->ordinal = ordinal;
+	ctl->numSpilling = 0;
+	ctl->roundSpill[0] = 0;
+	ctl->roundSpill[1] = 0;
+	ctl->numWork = 0;
+	ctl->spilledSnap[0] = ctl->spilledSnap[1] = 0;
+	ctl->workSnap[0] = ctl->workSnap[1] = 0;
+	ctl->numSpilled = 0;
+	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
+	ctl->dirCount = 0;
+	ctl->abortBatch = 0;
+	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
+	ctl->active = 1;
+}
+
+// ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
+__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	Ctl* ctl = ctl_of(a);
+	const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
+	ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
+	ctl->stop = (momentaryTooSmall || fatal) ? 1u : 0u;
+	ctl->pad1 = debugFlags;
+	ctl->startNs = wall_ns();
+	*a.frameStart = ctl->startNs;
+	// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
+	const uint32_t uploaded = __hip_atomic_load(a.numBatchesUploaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const uint32_t first = a.stats->batchletIndex;
+	uint32_t n = uploaded - first;
+	if ((int32_t)n < 0) n = 0;
+	if (n > SIMLOD_MAX_BATCHES_PER_LAUNCH) n = SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	if (n > batchLimit) n = batchLimit;
+	ctl->uploaded = uploaded;
+	ctl->firstBatch = first;
+	ctl->numBatches = n;
+	ctl->barrierCount = 0;
+	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
+	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers) ? 1u : 0u;
+	ctl->tableMagic = 0;                        // valid again once k_finish has run
+	prepare_batch(a, ctl, 0);
+}
+
+// ---- parents: node index -> parent index, rebuilt at the start of every launch from the children pointers -----------
+// (a momentary table: nothing but the octree image itself and the recycle stack has to survive between launches)
+__global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= numNodes) return;
+	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
+	if (i == 0) parentOf[0] = 0xffffffffu;
+	const SimlodNode* n = a.nodes + i;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const SimlodNode* c = n->children[k];
+		if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
+	}
+	if (ctl_of(a)->rebuildLeafChunks && node_is_leaf(n)) {
+		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
+		const SimlodChunk* c = n->points;
+		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
+	}
+}
+
+// ---- paths: every node's ancestor list, from the parent table (one thread per node, depth <= 20 steps) ---------------------
+__global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= numNodes) return;
+	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
+	unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
+	uint32_t k = 0;
+	for (uint32_t cur = parentOf[i]; cur != 0xffffffffu && k < PATH_WORDS - 1; cur = parentOf[cur]) {
+		const SimlodNode* n = a.nodes + cur;
+		rec[k++] = path_pack(a.pers, cur, n->level, n->grid);
+	}
+	rec[k] = 0;
+}
+
+// ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
+static constexpr uint32_t PPT = 4;                 // points per thread per chunk
+static constexpr uint32_t PPB = TPB * PPT;         // points per workgroup chunk
+
+// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  A leaf is queued for splitting by whoever sees its counter
+// cross the limit — or, if it is already over the limit because an earlier batch could not split it (spill space, node array or
+// spill list exhausted: the split is deferred, nothing is lost), by whoever touches it first in this batch.  The exchange on the
+// per-node tag makes that exactly one caller per leaf and batch.
+__device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt, uint32_t* spillList, uint32_t* spillCount) {
+	SimlodNode* leaf = a.nodes + leafIdx;
+	const uint32_t old = atomicAdd(&leaf->counter, cnt);
+	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
+	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
+		const uint32_t tag = ctl->batchIndex + 1u;
+		if (atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag) {
+			const uint32_t s = atomicAdd(spillCount, 1u);
+			if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
+		}
+	}
+}
+
+__device__ __forceinline__ void flush_counts(const BuildArgs& a, Ctl* ctl, BlockTable& tbl, uint32_t* spillList, uint32_t* spillCount) {
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = tbl.keys[e];
+		if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], spillList, spillCount);
+	}
+}
+
+// k_count takes more points per thread than k_insert (PPT): its cost is the flush of the per-workgroup counts into a few dozen
+// hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
+static constexpr uint32_t CPT = 8;
+static constexpr uint32_t CPB = TPB * CPT;
+
+__global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	__shared__ BlockTable tbl;
+	const uint32_t n = ctl->batchSize;
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
+	const uint32_t numChunks = (n + CPB - 1) / CPB;
+	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
+	// other's slowest descent; one flush at the end.
+	table_init(tbl);
+	__syncthreads();
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		float4 p[CPT];
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
+			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
+			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
+			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
+			if (i >= n) continue;
+			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
+			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
+			const uint32_t Z = quantize(F_GRID, p[j].z, a.minz, a.size);
+			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
+			leafOf[i] = leafIdx;
+			uint32_t rank;
+			if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, spillList, &ctl->numSpilling);
+		}
+	}
+	__syncthreads();
+	flush_counts(a, ctl, tbl, spillList, &ctl->numSpilling);
+}
+
+// ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
+// Persistent, one workgroup per two CUs, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
+// Per round:  A) one workgroup per spilling leaf: eight children, occupancy grid (allocated, cleared), the leaf's chunk
+//                list is walked ONCE by one lane which turns every chunk into a work item and recycles the chunks;
+//             -- barrier --
+//             B) all workgroups: spill-copy work items (1000 stored points each, routed to the child they belong to)
+//                and the recount of the batch samples whose cached leaf was split; both feed the children's arrival
+//                counters, whoever sees a counter cross the limit appends the child to the next round's list;
+//             -- barrier --
+struct SpillWork {
+	const SimlodChunk* chunk;
+	uint32_t childOffset, dstBase, count, level;
+	uint32_t pad0, pad1;
+};
+
+static constexpr uint32_t ETPB = 1024;             // k_expand: at most one workgroup per CU (grid barrier participants), 16 waves each
+
+__global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	if (ctl->numSpilling == 0) return;          // written by k_count, never modified here: a stable early-exit test
+	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if the grid barrier had given up (tests the abort path); a real give-up comes after
+	// the split phase has begun — either way the octree is not to be trusted any more: fatal, sticky until a reset
+	if ((ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+
+	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	uint32_t* winMask = at<uint32_t>(a, a.offWin);
+	unsigned long long* splitInfo = at<unsigned long long>(a, a.offSplitTag);   // per node: round tag << 32 | first child << 5 | level
+	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
+	SpillWork* work = at<SpillWork>(a, a.offWork);
+	float4* spilled = at<float4>(a, a.offSpilled);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const uint32_t n = ctl->batchSize;
+	uint32_t generation = 0;
+
+	__shared__ BlockTable tbl;
+	__shared__ uint32_t sh_childOffset, sh_ok, sh_spillBase;
+	__shared__ uint32_t sh_childCount[8];
+	__shared__ SimlodOccupancyGrid* sh_grid;
+
+	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS; ++round) {
+		uint32_t* listCur = at<uint32_t>(a, (round & 1) ? a.offSpillB : a.offSpillA);
+		uint32_t* listNext = at<uint32_t>(a, (round & 1) ? a.offSpillA : a.offSpillB);
+		uint32_t* countCur = round == 0 ? &ctl->numSpilling : &ctl->roundSpill[(round - 1) & 1];
+		uint32_t* countNext = &ctl->roundSpill[round & 1];
+		uint32_t numSpilling = *countCur;
+		if (numSpilling > SPILLING_CAPACITY) numSpilling = SPILLING_CAPACITY;
+		if (numSpilling == 0) break;
+		const uint32_t tag = ctl->ordinal * 32u + round + 1u;
+		const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
+		uint64_t t0 = timer ? wall_ns() : 0, t1;
+		if (timer && round == 0) ctl->expandNs[6] += 1;
+		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;   // last read one round ago, appended to only after the barrier below
+
+		// -- A: split ---------------------------------------------------------------------------------------------
+		for (uint32_t s = blockIdx.x; s < numSpilling; s += gridDim.x) {
+			const uint32_t nodeIdx = listCur[s];
+			SimlodNode* node = a.nodes + nodeIdx;
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				// Reserve eight node slots and the spill space for the stored points TOGETHER (one 64-bit word), before anything is
+				// modified: a leaf that cannot be served now stays a leaf — too full, but intact — and is queued again by a later batch.
+				const uint32_t stored = node->numPoints;
+				uint32_t ok = 1, off = 0, base = 0;
+				unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				for (;;) {
+					off = (uint32_t)(cur >> 32); base = (uint32_t)cur;
+					if (off + 8u > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ok = 0; break; }
+					if ((unsigned long long)base + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ok = 0; break; }
+					const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + (8ull << 32) + stored);
+					if (prev == cur) break;
+					cur = prev;
+				}
+				SimlodOccupancyGrid* grid = node->grid;
+				if (ok) {
+					atomicAdd(&a.stats->numNodes, 8u);         // voxels.cu:317
+					atomicAdd(&ctl->numSpilled, stored);
+					if (grid == nullptr) {                     // voxels.cu:363-365
+						grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+						node->grid = grid;
+					}
+				}
+				sh_childOffset = off; sh_ok = ok; sh_grid = grid; sh_spillBase = base;
+			}
+			__syncthreads();
+			if (!sh_ok) continue;
+			const uint32_t childOffset = sh_childOffset;
+			const uint32_t level = node->level;
+			if (threadIdx.x < 8) {                          // the eight children, voxels.cu:318-343
+				const uint32_t i = threadIdx.x;
+				// written field by field straight to the node array (a 152-byte local would live in scratch memory)
+				SimlodNode& c = a.nodes[childOffset + i];
+				for (int k = 0; k < 8; k++) c.children[k] = nullptr;
+				c.counter = 0; c.numPoints = 0;
+				c.level = level + 1;
+				c.X = 2 * node->X + ((i >> 2) & 1u);
+				c.Y = 2 * node->Y + ((i >> 1) & 1u);
+				c.Z = 2 * node->Z + (i & 1u);
+				c.countIteration = 0; c.countFlag = 0;
+				for (int k = 0; k < 20; k++) c.name[k] = node->name[k];
+				if (level + 1 < 20) c.name[level + 1] = (uint8_t)('0' + i);
+				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
+				c.grid = nullptr; c.points = nullptr; c.voxelChunks = nullptr;
+				c.numVoxels = 0; c.numVoxelsStored = 0;
+				node->children[i] = a.nodes + childOffset + i;
+				parentOf[childOffset + i] = nodeIdx;
+				// the child's ancestors: this node (its grid is final now), then this node's own ancestors
+				const unsigned long long* mine = paths + (uint64_t)nodeIdx * PATH_WORDS;
+				unsigned long long* theirs = paths + (uint64_t)(childOffset + i) * PATH_WORDS;
+				theirs[0] = path_pack(a.pers, nodeIdx, level, sh_grid);
+				for (uint32_t k = 0; k + 1 < PATH_WORDS; k++) {
+					const unsigned long long e = k + 2 < PATH_WORDS ? mine[k] : 0ull;
+					theirs[k + 1] = e;
+					if (e == 0ull) break;
+				}
+			}
+			if (threadIdx.x >= 64 && threadIdx.x < 128) {
+				// Wave 1 turns every chunk of the leaf into a work item and hands the chunks back to the recycle stack
+				// (voxels.cu:346-357; nothing pops before k_alloc).  Chunk k comes from the leaf chunk table, not from a walk.
+				const uint32_t lane = threadIdx.x - 64;
+				const uint32_t stored = node->numPoints;
+				SimlodChunk* const head = node->points;
+				// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
+				const uint32_t numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+				const uint32_t spillBase = sh_spillBase;
+				uint32_t w0 = 0;
+				unsigned long long top = 0;
+				if (lane == 0 && numChunks > 0) {
+					w0 = atomicAdd(&ctl->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
+					top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
+				}
+				w0 = __shfl(w0, 0);
+				top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
+				SimlodChunk* const* slots = leafChunks + (uint64_t)nodeIdx * LEAF_SLOTS;
+				auto emit = [&](uint32_t ci, SimlodChunk* chunk) {
+					if (w0 + ci < a.workCap) {
+						SpillWork w;
+						w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
+						w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
+						work[w0 + ci] = w;
+					} else raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW);
+					const unsigned long long q = top - numChunks + ci;
+					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+				};
+				SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
+				if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
+				for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
+					SimlodChunk* chunk = slots[ci];
+					emit(ci, chunk);
+					chunk->next = nullptr;
+				}
+				if (lane == 0) for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
+					SimlodChunk* next = beyond->next;
+					emit(ci, beyond);
+					beyond->next = nullptr;
+					beyond = next;
+				}
+				if (lane == 0) {
+					node->numPoints = 0;
+					node->points = nullptr;
+					splitInfo[nodeIdx] = ((unsigned long long)tag << 32) | ((unsigned long long)childOffset << 5) | level;
+				}
+			}
+			// meanwhile the other lanes clear the occupancy grid — of EVERY spilling node, also one that already had a
+			// grid (the root), voxels.cu:371-382
+			{
+				uint4* g = reinterpret_cast<uint4*>(sh_grid->values);
+				const uint4 z = make_uint4(0, 0, 0, 0);
+				if (threadIdx.x >= 128) for (uint32_t w = threadIdx.x - 128; w < SIMLOD_GRID_NUM_WORDS / 4; w += ETPB - 128) g[w] = z;
+			}
+		}
+
+		if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
+		// numSpilled / numWork are stable between this barrier and the next round's split phase: snapshot them for round+1
+		const uint32_t workEnd = min(ctl->numWork, a.workCap);
+		const uint32_t workBegin = ctl->workSnap[round & 1];
+		const uint32_t numSpilledPrev = ctl->spilledSnap[round & 1];
+		if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->workSnap[(round + 1) & 1] = workEnd; ctl->spilledSnap[(round + 1) & 1] = min(ctl->numSpilled, a.spilledCap); }
+
+		// -- B1: move the stored points of the split leaves into the spill buffer, routed to their child (voxels.cu:253-289)
+		for (uint32_t w = workBegin + blockIdx.x; w < workEnd; w += gridDim.x) {
+			const SpillWork item = work[w];
+			__syncthreads();
+			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
+			__syncthreads();
+			const float4* src = reinterpret_cast<const float4*>(item.chunk->points);
+			for (uint32_t j = threadIdx.x; j < item.count; j += ETPB) {
+				const float4 p = src[j];
+				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
+				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
+				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
+				const int c = child_index(X, Y, Z, (int)item.level);
+				const uint32_t dst = item.dstBase + j;
+				spilled[dst] = p;
+				leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = item.childOffset + (uint32_t)c;
+				winMask[SIMLOD_MAX_BATCH_SIZE + dst] = item.level << 24;     // `sample` starts at the spilling node's level
+				atomicAdd(&sh_childCount[c], 1u);
+			}
+			__syncthreads();
+			if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0)
+				count_into(a, ctl, item.childOffset + threadIdx.x, sh_childCount[threadIdx.x], listNext, countNext);
+		}
+
+		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; }
+		// -- B2: recount — only samples whose cached leaf was split in THIS round go one (or more) levels down ------------
+		// Also after the 20th split: the reference does not count again there (voxels.cu:394-412), allocates no chunks for the
+		// level-20 children and drops every point that lands in them (:599-604) — 50 001 points in one 2^-20 cell.  Here they are
+		// counted and stored; a level-20 leaf never asks for another split (count_into).
+		{
+			const uint32_t total = n + numSpilledPrev;
+			__syncthreads();
+			table_init(tbl);                           // one table for the whole scan of this workgroup, one flush
+			__syncthreads();
+			// four samples per thread at a time, stage by stage: the four cached-leaf loads are in flight together, then the four
+			// split tags, then the points and the first child pointer of those that have to move (a 1 M-sample batch is four
+			// samples per thread: the dependent chain leaf -> tag -> point -> child is paid once, not four times)
+			constexpr uint32_t U = 4;
+			const uint32_t stride = gridDim.x * ETPB;
+			for (uint32_t t0 = blockIdx.x * ETPB + threadIdx.x; t0 < total; t0 += U * stride) {
+				uint32_t idx[U], leaf[U]; unsigned long long info[U]; float4 p[U];
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t t = t0 + q * stride;
+					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+					leaf[q] = t < total ? leafOf[idx[q]] : 0xffffffffu;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) info[q] = leaf[q] != 0xffffffffu ? splitInfo[leaf[q]] : 0ull;
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t t = t0 + q * stride;
+					p[q] = (uint32_t)(info[q] >> 32) == tag ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					if ((uint32_t)(info[q] >> 32) != tag) continue;
+					// the children of a leaf split in this round are leaves: the record of the split says where they are, no node is read
+					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size);
+					const uint32_t Y = quantize(F_GRID, p[q].y, a.miny, a.size);
+					const uint32_t Z = quantize(F_GRID, p[q].z, a.minz, a.size);
+					const uint32_t level = (uint32_t)info[q] & 31u, childOffset = ((uint32_t)info[q] >> 5) & 0x7ffffu;
+					const uint32_t leafIdx = childOffset + (uint32_t)child_index(X, Y, Z, (int)level);
+					leafOf[idx[q]] = leafIdx;
+					uint32_t rank;
+					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
+				}
+			}
+			__syncthreads();
+			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += ETPB) {
+				const uint32_t key = tbl.keys[e];
+				if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], listNext, countNext);
+			}
+		}
+		if (timer) { t1 = wall_ns(); ctl->expandNs[3] += t1 - t0; t0 = t1; }
+		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (timer) { t1 = wall_ns(); ctl->expandNs[4] += t1 - t0; ctl->expandNs[5] += 1; }
+	}
+}
+
+// ---- sample: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
+// The reference tests the sample's cell in EVERY node of the path, root first.  Occupancy is hierarchical, though: a
+// cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit in a node
+// had, in the same pass, been offered to all its ancestors — so "bit set in node N" implies "covering bit set in every
+// ancestor of N".  This kernel therefore walks the path BOTTOM-UP and stops at the first level whose bit is already
+// set, or where its own atomicOr lost the race (the winner keeps climbing).  Same bitsets, same voxel counts, one
+// winner per cell as in the reference; what it removes is the contention: measured on MI355X, a top-down pass issued
+// 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
+// (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
+// NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
+// Per-workgroup set of (node, cell) claims.  While the octree is still shallow the deepest grid of a sample is coarse: on the
+// terrain workload the 1 M points of an early batch fall into 4 nodes and ~1000 occupancy words, 890 k of them see a clear
+// bit (tools/analyze_candidates.py), and thousands of atomicOr per word serialise at ~11 ns each.  So only the FIRST sample of
+// a workgroup that sees a clear cell issues the global atomicOr; the others know the cell is being taken care of and stop,
+// exactly as if they had lost the race.  key = table entry of the node (10 bits) << 21 | cell (21 bits).
+static constexpr int SET_BITS = 12;
+static constexpr int SET_CAP = 1 << SET_BITS;
+
+// true: the caller is the first of its workgroup to claim `key` (or the set has no room: claim anyway, merely redundant)
+__device__ __forceinline__ bool set_insert(uint32_t* set, uint32_t key) {
+	uint32_t h = (key * 2654435761u) >> (32 - SET_BITS);
+#pragma unroll 1
+	for (int probe = 0; probe < 8; ++probe) {
+		uint32_t k = set[h];
+		if (k == TBL_EMPTY) k = atomicCAS(&set[h], TBL_EMPTY, key);
+		if (k == TBL_EMPTY) return true;
+		if (k == key) return false;
+		h = (h + 1) & (SET_CAP - 1);
+	}
+	return true;
+}
+
+template <uint32_t SPT>
+__global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
+	constexpr uint32_t SPB = TPB * SPT;
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
+	__shared__ uint32_t claimed[SET_CAP];              // (node, cell) pairs this workgroup already claimed
+	const uint32_t n = ctl->batchSize;
+	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
+	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
+	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
+	uint32_t* winMask = at<uint32_t>(a, a.offWin);
+	const uint32_t numChunks = (total + SPB - 1) / SPB;
+	table_init(tbl);                                   // lives for the whole workgroup: no barrier inside the chunk loop
+	for (uint32_t i = threadIdx.x; i < (uint32_t)SET_CAP; i += TPB) claimed[i] = TBL_EMPTY;
+	__syncthreads();
+	constexpr int WIN = 3;                             // ancestors fetched and probed together
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+#pragma unroll 1
+		for (uint32_t j = 0; j < SPT; j++) {
+			const uint32_t t = chunk * SPB + j * TPB + threadIdx.x;
+			if (t >= total) continue;
+			uint32_t idx, startLevel = 0;
+			float4 p;
+			if (t < n) { idx = t; p = pts[t]; }
+			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
+			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+			// the leaf was cached by count/expand; grids live in the inner nodes above it (and in a root that is still a leaf)
+			const uint32_t leafIdx = leafOf[idx];
+			const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
+			uint32_t wins = 0;
+			bool go = true;
+#pragma unroll 1
+			for (uint32_t k0 = 0; go && k0 < PATH_WORDS - 1; k0 += WIN) {
+				unsigned long long ent[WIN];
+				uint32_t* word[WIN];
+				uint32_t seen[WIN], cell[WIN];
+#pragma unroll
+				for (int w = 0; w < WIN; w++) {              // independent loads: the entries ...
+					if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; ent[w] = (k0 + w == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
+					else ent[w] = k0 + w < PATH_WORDS - 1 ? rec[k0 + w] : 0ull;
+				}
+#pragma unroll
+				for (int w = 1; w < WIN; w++) if (ent[w - 1] == 0ull) ent[w] = 0ull;   // what lies behind the terminator was never written
+#pragma unroll
+				for (int w = 0; w < WIN; w++) {              // ... then the occupancy words of all of them
+					const uint32_t level = path_level(ent[w]);
+					const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
+					const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
+					cell[w] = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+					word[w] = &path_grid(a.pers, ent[w])->values[cell[w] >> 5];
+					// voxels.cu:449: the traverse loop samples levels 0..19 only; spilled samples start at the spilling node's level
+					if (ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { ent[w] = 0ull; seen[w] = 0u; }
+					else seen[w] = *word[w];        // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
+				}
+#pragma unroll
+				for (int w = 0; w < WIN; w++) {              // bottom-up: claim while winning
+					if (!go) break;
+					if (ent[w] == 0ull) { go = false; break; }
+					const uint32_t bit = cell[w] & 31u;
+					if (((seen[w] >> bit) & 1u) != 0u) { go = false; break; }               // voxels.cu:93-94; the ancestors are set as well
+					const uint32_t nodeIdx = path_node(ent[w]);
+					uint32_t rank;
+					const int e = table_add(tbl, nodeIdx, 0u, &rank);
+					if (e >= 0 && !set_insert(claimed, ((uint32_t)e << 21) | cell[w])) { go = false; break; }   // a sample of this workgroup already claims the cell
+					if (((atomicOr(word[w], 1u << bit) >> bit) & 1u) != 0u) { go = false; break; }              // voxels.cu:96; lost: the winner climbs on
+					wins |= 1u << path_level(ent[w]);                                       // first point in the cell, voxels.cu:99
+					if (e >= 0) atomicAdd(&tbl.vals[e], 1u); else atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u);   // voxels.cu:101
+				}
+			}
+			winMask[idx] = wins;
+		}
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = tbl.keys[e];
+		if (key != TBL_EMPTY && tbl.vals[e] != 0u) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
+	}
+}
+
+// ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
+// (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
+__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
+
+__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i) {
+	SimlodNode* node = a.nodes + i;
+	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
+	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	const uint32_t tag = ctl->batchIndex + 1u;
+	node->countIteration = tag;
+
+	// -- points of leaves -------------------------------------------------------------------------------------
+	const uint32_t counter = node->counter, stored = node->numPoints;
+	if (stored < counter && node_is_leaf(node)) {
+		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
+		const uint32_t entries = required - first;
+		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
+		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+		SimlodChunk* head = node->points;
+		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+		uint32_t e = 0;
+		if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
+		const uint32_t additional = required - existing;
+		if (additional > 0) {
+			// pop from the recycle stack, allocate what the stack cannot serve (voxels.cu:505-516): one atomic each
+			const unsigned long long firstIdx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional);
+			const unsigned long long pool = a.stats->chunkPoolSize;     // raised only by k_end
+			const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
+			uint8_t* fresh = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
+			for (uint32_t k = 0; k < additional; k++) {
+				SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
+				                              : reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				c->next = nullptr;
+				if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
+				tail = c;
+				chunkDir[base + e++] = c;
+				if (existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;
+			}
+			tail_of(head) = tail;
+		}
+		NodeDir& d = nodeDir[i];
+		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
+	}
+
+	// -- voxels of inner nodes (and of the root while it is still a leaf) --------------------------------------
+	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
+	if (numVoxels > voxStored) {
+		const uint32_t required = (numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		SimlodChunk* head = node->voxelChunks;
+		const uint32_t existing = head == nullptr ? 0u : max(1u, (voxStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK);
+		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t entries = required - first;
+		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
+		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+		uint32_t e = 0;
+		if (first < existing) chunkDir[base + e++] = tail;
+		if (required > existing) {
+			const uint32_t additional = required - existing;
+			uint8_t* fresh = persistent_alloc(a.pers, sizeof(SimlodChunk), additional);   // voxel chunks never come from the pool
+			for (uint32_t k = 0; k < additional; k++) {
+				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				c->next = nullptr;
+				if (tail == nullptr) { node->voxelChunks = c; head = c; } else tail->next = c;
+				tail = c;
+				chunkDir[base + e++] = c;
+			}
+			tail_of(head) = tail;
+		}
+		NodeDir& d = nodeDir[i];
+		d.voxBase = base; d.voxFirst = first; d.voxTag = tag;
+	}
+}
+
+// A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
+__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i);
+}
+
+// ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
+struct InsertShared {
+	BlockTable tbl;                       // node -> count (step 1), then node -> running cursor (step 3)
+	uint32_t base[TBL_CAP];               // first slot of the range this workgroup reserved in the node
+	uint32_t dirBase[TBL_CAP];            // chunk-directory base of the node for this batch, or 0xffffffff
+	uint32_t dirFirst[TBL_CAP];
+};
+
+// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
+__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
+	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
+	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
+	const uint32_t nsh = 28u - (uint32_t)level;
+	// masked to `level` bits: a coordinate exactly on the max face quantises to 2^20 (2^28 here) and the reference's descent, which
+	// looks at bits 19..0 only, files it under node coordinate 0 on that axis (voxels.cu:171-179) — the voxel sits at the LOW face
+	const uint32_t nmask = (1u << (uint32_t)level) - 1u;
+	const uint32_t nX = (pX >> nsh) & nmask, nY = (pY >> nsh) & nmask, nZ = (pZ >> nsh) & nmask;
+	const float nodeSize = a.size / exp2_int((uint32_t)level);
+	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
+	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
+	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
+	float4 v;
+	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
+	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
+	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
+	v.w = colorBits;                       // colour of the claiming point
+	return v;
+}
+
+__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active || ctl->abortBatch) return;
+	__shared__ InsertShared sh;
+	const uint32_t n = ctl->batchSize;
+	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
+	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
+	const uint32_t* winMask = at<const uint32_t>(a, a.offWin);
+	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
+	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
+	const uint32_t tag = ctl->batchIndex + 1u;
+	const uint32_t numChunks = (total + PPB - 1) / PPB;
+	// Three workgroup-wide steps, each over ALL chunks this workgroup owns, so that barriers are paid per workgroup and not
+	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
+	// global atomic each, (3) store — the slot inside the range comes from an LDS cursor.
+
+	// ======== points ========
+	table_init(sh.tbl);
+	__syncthreads();
+	bool anyWins = false;
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			if (t >= total) continue;
+			const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+			anyWins |= (winMask[idx] & 0xfffffu) != 0u;
+			uint32_t rank;
+			(void)table_add(sh.tbl, leafOf[idx], 1u, &rank);
+		}
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = sh.tbl.keys[e];
+		if (key == TBL_EMPTY) continue;
+		const NodeDir d = nodeDir[key];
+		sh.base[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);                      // voxels.cu:593
+		sh.tbl.vals[e] = 0;                                                                    // becomes the cursor
+		sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
+		sh.dirFirst[e] = d.ptFirst;
+	}
+	__syncthreads();
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		float4 p[PPT];
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? pts[t] : spilled[t - n]);
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			if (t >= total) continue;
+			const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+			const int e = table_find(sh.tbl, leafIdx);
+			uint32_t slot, base, first;
+			if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+			else {                                                                                // table had no room for this leaf
+				const NodeDir d = nodeDir[leafIdx];
+				slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u); base = d.ptTag == tag ? d.ptBase : 0xffffffffu; first = d.ptFirst;
+			}
+			if (base == 0xffffffffu) { raise(ctl, SIMLOD_ERR_NULL_CHUNK); continue; }           // voxels.cu:599-604
+			SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
+			reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p[j];
+		}
+	}
+
+	// ======== voxels: the samples that won a cell in `sample` regenerate their voxel(s) ========
+	if (!__syncthreads_or(anyWins ? 1 : 0)) return;
+	table_init(sh.tbl);
+	__syncthreads();
+	for (int pass = 0; pass < 2; pass++) {
+		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
+		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+#pragma unroll 1
+			for (uint32_t j = 0; j < PPT; j++) {
+				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+				if (t >= total) continue;
+				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+				uint32_t left = winMask[idx] & 0xfffffu;
+				if (left == 0u) continue;
+				// the won levels are among the deepest ancestors of the cached leaf: read them off its path
+				const uint32_t leafIdx = leafOf[idx];
+				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
+				float4 p = make_float4(0, 0, 0, 0);
+				uint32_t pX = 0, pY = 0, pZ = 0;
+				if (pass == 1) {
+					p = t < n ? pts[t] : spilled[t - n];
+					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
+				}
+#pragma unroll 1
+				for (uint32_t k = 0; left != 0u && k < PATH_WORDS - 1; k++) {
+					const unsigned long long ent = leafIdx == 0u ? (k == 0 ? PATH_VALID : 0ull) : rec[k];   // a root that is still a leaf samples itself
+					if (ent == 0ull) break;
+					const uint32_t curIdx = path_node(ent);
+					const int level = (int)path_level(ent);
+					if (((left >> level) & 1u) == 0u) continue;
+					left &= ~(1u << level);
+					if (pass == 0) {
+						uint32_t rank;
+						(void)table_add(sh.tbl, curIdx, 1u, &rank);
+					} else {
+						const int e = table_find(sh.tbl, curIdx);
+						uint32_t slot, base, first;
+						if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+						else {
+							const NodeDir d = nodeDir[curIdx];
+							slot = atomicAdd(&a.nodes[curIdx].numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
+						}
+						if (base == 0xffffffffu) raise(ctl, SIMLOD_ERR_NULL_CHUNK);
+						else {
+							SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
+							reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, level, pX, pY, pZ, p.w);
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (pass == 0) {
+			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+				const uint32_t key = sh.tbl.keys[e];
+				if (key == TBL_EMPTY) continue;
+				const NodeDir d = nodeDir[key];
+				sh.base[e] = atomicAdd(&a.nodes[key].numVoxelsStored, sh.tbl.vals[e]);            // voxels.cu:685
+				sh.tbl.vals[e] = 0;
+				sh.dirBase[e] = d.voxTag == tag ? d.voxBase : 0xffffffffu;
+				sh.dirFirst[e] = d.voxFirst;
+			}
+			__syncthreads();
+		}
+	}
+}
+
+// ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
+__global__ void k_end(BuildArgs a, uint32_t ordinal) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	Ctl* ctl = ctl_of(a);
+	if (ctl->active && ctl->abortBatch) ctl->stop = 1;       // scratch overflow: this batch is lost, report through Stats.dbg
+	if (ctl->active && !ctl->abortBatch) {
+		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
+		a.stats->batchletIndex += 1;
+		a.stats->numPointsProcessed += ctl->batchSize;
+		ctl->expandNs[7] += min(ctl->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
+		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
+		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
+	}
+	prepare_batch(a, ctl, ordinal + 1);
+}
+
+// ---- stats pass (voxels.cu:957-1009) -------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
+__global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};   // inner, leaves, nonempty, points, voxels, chunksP, chunksV
+	if (i < numNodes) {
+		const SimlodNode* n = a.nodes + i;
+		if (node_is_leaf(n)) {
+			v[1] = 1; v[3] = n->numPoints; v[5] = (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			v[2] = n->numPoints > 0 ? 1u : 0u;
+		} else {
+			v[0] = 1; v[4] = n->numVoxels; v[6] = (n->numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		}
+	}
+	for (int k = 0; k < 7; k++) {
+		const uint32_t s = wave_sum(v[k]);
+		if (lane_id() == 0 && s != 0u) atomicAdd(&ctl->statCounters[k], s);
+	}
+}
+
+__global__ void k_finish(BuildArgs a, uint32_t fits) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	Ctl* ctl = ctl_of(a);
+	SimlodStats* s = a.stats;
+	s->numInner = ctl->statCounters[0];
+	s->numLeaves = ctl->statCounters[1];
+	s->numNonemptyLeaves = ctl->statCounters[2];
+	s->numPoints = ctl->statCounters[3];
+	s->numVoxels = ctl->statCounters[4];
+	s->numChunksPoints = ctl->statCounters[5];
+	s->numChunksVoxels = ctl->statCounters[6];
+	s->allocatedBytes_momentary = a.scratchBytes;
+	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
+	s->frameID = (uint32_t)a.frameCounter;
+	s->dbg |= ctl->errors;
+	if (fits && !ctl->abortBatch) {              // the side tables describe THIS octree as it is after THIS batch
+		ctl->tableBatch = s->batchletIndex;
+		ctl->tableNodes = (uint64_t)a.nodes;
+		ctl->tablePers = (uint64_t)a.pers;
+		ctl->tableMagic = TABLE_MAGIC;
+	}
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
+	uint64_t off = 4096;                                                       // Ctl
+	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
+	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	off += 4 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf
+	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
+	off += align_up((uint64_t)dirCap * 8, 256);
+	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
+	off += align_up((uint64_t)nodeCapacity * PATH_WORDS * 8, 256);
+	return off;
+}
+
+bool layout_construct(BuildArgs& a, uint64_t capacity) {
+	a.dirCap = 2 * a.nodeCapacity + 65536;
+	uint64_t off = 4096;
+	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
+	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
+	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
+	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
+	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
+	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
+	const uint64_t fixedEnd = off;
+	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
+	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
+	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
+	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
+	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (24 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
+	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
+	a.spilledCap = (uint32_t)cap;
+	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 spilled points + one partial chunk per split
+	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
+	(void)fixedEnd;
+	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offWin = off;      off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
+	a.scratchBytes = off;
+	return off <= capacity;
+}
+
+int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream) {
+	BuildArgs a{};
+	a.ring = points; a.mom = reinterpret_cast<uint8_t*>(buffer); a.pers = pers; a.nodes = nodes; a.stats = stats;
+	a.frameStart = frameStart; a.numBatchesUploaded = numBatchesUploaded; a.batchSizes = batchSizes;
+	const float bx = u->boxMax.x - u->boxMin.x, by = u->boxMax.y - u->boxMin.y, bz = u->boxMax.z - u->boxMin.z;
+	a.size = fmaxf(fmaxf(bx, by), bz);                                         // voxels.cu:860-863
+	a.minx = u->boxMin.x; a.miny = u->boxMin.y; a.minz = u->boxMin.z;
+	a.persCapacity = u->persistentBufferCapacity;
+	a.frameCounter = u->frameCounter;
+	a.nodeCapacity = node_capacity();
+	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
+	const DeviceInfo& dev = device_info();
+
+	const uint32_t limit = std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH);
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, (uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u);
+	if (fits) {
+		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
+		if (e != hipSuccess) return (int)e;
+		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
+		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
+		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);
+		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
+		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
+		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
+		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
+		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
+		for (uint32_t b = 0; b < limit; b++) {
+			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
+			switch (sampleSpt) {
+			case 1: SIMLOD_LAUNCH(k_sample<1>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			case 2: SIMLOD_LAUNCH(k_sample<2>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			case 8: SIMLOD_LAUNCH(k_sample<8>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			default: SIMLOD_LAUNCH(k_sample<4>, dim3(gridPoints), dim3(TPB), stream, a); break;
+			}
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
+		}
+		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
+	}
+	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
+	if (profile_enabled()) profile_close(stream);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return (int)e;
+	return fits ? 0 : (int)hipErrorInvalidValue;
+}
+
+uint64_t construct_min_bytes() {
+	BuildArgs a{};
+	a.nodeCapacity = node_capacity();
+	layout_construct(a, 0);
+	return a.scratchBytes + 4096 + 26ull * 65536;   // the smallest capacity layout_construct accepts, plus a page of slack
+}
+
+}  // namespace batch
+}  // namespace simlod

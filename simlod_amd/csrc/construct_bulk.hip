@@ -1,4 +1,6 @@
-// construct.hip — incremental octree/LOD builder for MI355X (gfx950): the `kernel_construct` entry point.
+// construct_bulk.hip — incremental octree/LOD builder for MI355X (gfx950): `kernel_construct` in the opt-in COALESCED mode
+// (simlod_set_ingest_mode(1)); construct_batch.hip is the chain of the default exact mode.  This chain is exact as well when it is given
+// one batch at a time (SIMLOD_EXACT_CHAIN=bulk, used by the parity tests), it is built for many.
 //
 // Replaces modules/progressive_octree/progressive_octree_voxels.cu:804-1010 (one persistent cooperative CUDA
 // kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
@@ -38,6 +40,7 @@
 #include "simlod_internal.hpp"
 
 namespace simlod {
+namespace bulk {
 
 static constexpr uint32_t TPB = 256;
 static constexpr float F_GRID = 1048576.0f;      // 2^MAX_DEPTH, progressive_octree_voxels.cu:139
@@ -1615,4 +1618,12 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	return fits ? 0 : (int)hipErrorInvalidValue;
 }
 
+uint64_t construct_min_bytes() {
+	BuildArgs a{};
+	a.nodeCapacity = node_capacity();
+	layout_construct(a, 0);
+	return a.scratchBytes + 4096;
+}
+
+}  // namespace bulk
 }  // namespace simlod

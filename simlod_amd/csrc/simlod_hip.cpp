@@ -97,12 +97,14 @@ uint64_t simlod_render_framebuffer_offset(void) {
 
 uint64_t simlod_render_buffer_bytes(uint32_t width, uint32_t height) { return render_buffer_bytes(width, height); }
 
-uint64_t simlod_construct_buffer_min_bytes(void) {
-	BuildArgs a{};
-	a.nodeCapacity = node_capacity();
-	layout_construct(a, 0);
-	return a.scratchBytes + 4096;   // the smallest capacity layout_construct accepts, plus a page of slack
+// exact mode runs the batch chain (construct_batch.hip) unless SIMLOD_EXACT_CHAIN=bulk asks for the bulk chain one batch at a time
+static bool use_bulk_chain() {
+	if (ingest_mode() != 0u) return true;
+	const char* v = std::getenv("SIMLOD_EXACT_CHAIN");
+	return v != nullptr && std::strcmp(v, "bulk") == 0;
 }
+
+uint64_t simlod_construct_buffer_min_bytes(void) { return use_bulk_chain() ? bulk::construct_min_bytes() : batch::construct_min_bytes(); }
 
 int simlod_set_ingest_mode(uint32_t mode) {
 	if (mode > 1u) return (int)hipErrorInvalidValue;
@@ -129,8 +131,10 @@ int simlod_launch_construct(const SimlodUniforms* uniforms, SimlodPoint* points,
 	(void)cudaprint;
 	if (!uniforms || !points || !buffer || !buffer_persistent || !nodes || !stats || !frameStartTimestamp ||
 	    !numBatchesUploaded_volatile || !batchSizes) return (int)hipErrorInvalidValue;
-	return launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp,
-	                        numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
+	return use_bulk_chain() ? bulk::launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp,
+	                                                 numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream)
+	                        : batch::launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp,
+	                                                  numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
 }
 
 int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double scale[3],

@@ -12,6 +12,8 @@ namespace simlod {
 static constexpr uint32_t CHUNK_QUEUE_CAPACITY = 1000000u;   // progressive_octree_voxels.cu:856
 static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octree_voxels.cu:847
 
+namespace bulk {   // construct_bulk.hip: the chain of the coalesced ingest mode
+
 // One entry of a split round's work list: the leaf that has to split, the eight node slots reserved for its children and — for
 // leaves that hold stored points (round 0 only: nodes created inside a cascade are empty) — where those points go in the spill buffer.
 struct SpillEntry {
@@ -70,6 +72,21 @@ struct BuildArgs {
 	uint32_t     nodeCapacity, spilledCap, pendCap, histCap, dirCap, groupMax;
 };
 
+bool layout_construct(BuildArgs& a, uint64_t capacity);
+int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
+uint64_t construct_min_bytes();
+
+}  // namespace bulk
+
+namespace batch {  // construct_batch.hip: exact mode, one ring batch at a time
+
+int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
+uint64_t construct_min_bytes();
+
+}  // namespace batch
+
 struct DeviceInfo {
 	int      device;
 	uint32_t numCUs;
@@ -93,9 +110,6 @@ uint32_t ingest_mode();                      // 0 = exact (one batch at a time, 
 uint32_t batch_limit();                      // host hint: at most this many batches are pending (<= 20)
 int tune(const char* envName, int dflt);     // integer tuning knob from the environment (read once per call site)
 
-bool layout_construct(BuildArgs& a, uint64_t capacity);
-int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
-                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream);
 int launch_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double* scale,

@@ -56,9 +56,19 @@ def _oracle_render(nodes, nn, u):
     return fb, col, stats[0]
 
 
+@pytest.fixture(params=["batch", "bulk"])
+def chain(request):
+    """Exact mode runs the batch chain (construct_batch.hip); SIMLOD_EXACT_CHAIN=bulk runs the chain of the coalesced mode
+    (construct_bulk.hip) one batch at a time instead — it must be exactly as exact."""
+    if request.param == "bulk":
+        os.environ["SIMLOD_EXACT_CHAIN"] = "bulk"
+    yield request.param
+    os.environ.pop("SIMLOD_EXACT_CHAIN", None)
+
+
 # ---- construct ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", CASES)
-def test_construct_matches_golden_and_oracle(built_libs, name):
+def test_construct_matches_golden_and_oracle(built_libs, name, chain):
     g = load_golden(name)
     pts, box, batch, T = case(name)
     dev = _device(ring_slots=8)
@@ -75,7 +85,7 @@ def test_construct_matches_golden_and_oracle(built_libs, name):
 
 @pytest.mark.parametrize("kind,n,batch", [("uniform", 1_000_000, 1_000_000), ("uniform", 3_000_000, 1_000_000),
                                           ("terrain", 4_000_000, 1_000_000), ("hotspot", 3_000_000, 1_000_000)])
-def test_construct_full_batches_match_oracle(built_libs, kind, n, batch):
+def test_construct_full_batches_match_oracle(built_libs, kind, n, batch, chain):
     pts, box = {"uniform": lambda: synthetic.uniform_cube(n, seed=1234), "terrain": lambda: synthetic.terrain(n, seed=7),
                 "hotspot": lambda: synthetic.hotspot(n, seed=11)}[kind]()
     T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
@@ -125,7 +135,7 @@ def test_too_small_momentary_buffer_is_reported_not_silently_overrun(built_libs)
     assert int(s["dbg"]) & 0x1 and int(s["batchletIndex"]) == 0
 
 
-def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs):
+def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs, chain):
     """voxels.cu:896-912: a batch is taken only while allocator offset + 200 MB < persistentBufferCapacity; otherwise
     Stats.memCapacityReached is raised and the launch does nothing — and neither do later launches.  Same stopping batch,
     same octree as the restatement; nothing is written beyond the capacity the kernels were told."""
@@ -161,7 +171,7 @@ def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs):
     assert int(ds["allocatedBytes_persistent"]) <= cap and bool((dev.persistent[cap:] == 0x3C).all())
 
 
-def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs):
+def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs, chain):
     """The reference's node array holds 263 157 nodes (main_progressive_octree.cpp:552) and its kernel writes past the end when
     more are needed.  Here a split that finds no eight free slots is refused: the leaf keeps growing, Stats.dbg says so."""
     from simlod_amd.runtime import lib
@@ -189,7 +199,7 @@ def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs):
         lib().simlod_set_node_capacity(263_157)
 
 
-def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
+def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs, chain):
     """70 000 identical points force twenty split rounds inside one batch, down to level 20 where a node cannot split any more;
     8 000 points sit exactly on the faces / corners of the bounding box (coordinate == boxMax quantises to 2^20 and, as in the
     reference, wraps into the low child).  Tree shape, voxels, grids and counts must be the reference restatement's.  One
@@ -233,7 +243,7 @@ def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
     assert voxel_colors_are_member(nodes, nn, pts, box, max_level=12) == int(nodes["numVoxelsStored"][:nn].sum()) - deep
 
 
-def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs):
+def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs, chain):
     """Scattered input makes hundreds of leaves cross the limit in the same batch.  With a momentary buffer that can hold only
     a fraction of their stored points (the reference drops points here) the splits that do not fit are deferred:
     the leaves stay intact, grow past 50 000, and split in a later batch.  Every point must be in the octree, the image must
@@ -688,7 +698,7 @@ def test_render_parts_equal_the_whole_frame_and_two_emulated_ranks_compose_exact
 
 
 # ---- BASELINE configs 3 and 5 at a size the oracle still finishes in seconds; the ring; ingest granularity ---------------------------
-def test_ring_wraps_around_more_than_twice(built_libs):
+def test_ring_wraps_around_more_than_twice(built_libs, chain):
     """Config 3's mechanism: batches stream through the 50-slot ring (slot = batchletIndex % 50, voxels.cu:883-925) with the host's
     back-pressure rule.  130 batches of 50 000 points wrap the ring 2.6 times; the octree must be the oracle's after the same 130 batches."""
     pts, box = synthetic.terrain(6_500_000, seed=21, box=(2400.0, 1600.0, 160.0), tile=100.0)
@@ -775,7 +785,7 @@ def test_headless_cpp_host_replay_octree_dump_equals_oracle(built_libs, tmp_path
     oracle.check_invariants(nodes, nn)
 
 
-def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs):
+def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs, chain):
     """A coordinate equal to boxMax quantises to 2^20; the reference's descent looks at bits 19..0 and files the point (and the voxels
     it creates) under node coordinate 0 of that axis.  Only such points here, so they are the ones that win the cells."""
     rs = np.random.RandomState(8)
@@ -809,7 +819,7 @@ def test_node_capacity_beyond_the_packed_index_width_is_rejected(built_libs):
         L.simlod_set_node_capacity(263_157)
 
 
-def test_forced_barrier_timeout_aborts_the_batch_and_stays_fatal_until_reset(built_libs):
+def test_forced_barrier_timeout_aborts_the_batch_and_stays_fatal_until_reset(built_libs, chain):
     """The split cascade's grid barrier giving up (here: forced) must not let the rest of the chain run on a half-built state: the batch
     is not counted, Stats.dbg carries the fatal bit, later launches refuse to touch the octree, and a reset brings everything back."""
     from simlod_amd.runtime import SimlodError
