@@ -767,7 +767,15 @@ __global__ __launch_bounds__(TPB, 4) void k_ingest(BuildArgs a) {
 				if (er[j] != STORED) store_point(a, ctl, sh, er[j] >> 16, er[j] & 0xffffu, p[j]);
 				const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
 				wins[j] = sample_path(a, ctl, sh, leafOf[j], 0u, pX, pY, pZ, p[j].w, pr[j]);
-			} else wins[j] = WAITS | atomicAdd(&sh.pendCount, 1u);
+			} else {
+				// one LDS atomic per wave: the lanes that wait are numbered by their rank among the waiting lanes
+				const unsigned long long waiting = __ballot(1);
+				const uint32_t lane = (uint32_t)lane_id(), leader = (uint32_t)__ffsll((long long)waiting) - 1u;
+				uint32_t first = 0;
+				if (lane == leader) first = atomicAdd(&sh.pendCount, (uint32_t)__popcll(waiting));
+				first = __shfl(first, (int)leader);
+				wins[j] = WAITS | (first + (uint32_t)__popcll(waiting & ((1ull << lane) - 1ull)));
+			}
 		}
 		__syncthreads();
 		timer.lap(2);
@@ -959,7 +967,9 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t roundFirs
 				uint32_t cur = meta & 0x7ffffu;
 				float4 p = make_float4(0, 0, 0, 0);
 				bool have = false;
-				if (round != 0u && !node_is_leaf(a.nodes + cur)) {
+				// a cached node that an earlier round of this group split has a record with that round's tag: one 8-byte load tells
+				const uint32_t cachedTag = (uint32_t)(splitInfo[cur] >> 32);
+				if (round != 0u && cachedTag >= round_tag(ctl, 0u) && cachedTag < tag) {
 					p = isPend ? point_of(a, ctl, pendIdx[q]) : spilled[q - numPending]; have = true;
 					const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size), Y = quantize(F_GRID, p.y, a.miny, a.size), Z = quantize(F_GRID, p.z, a.minz, a.size);
 					cur = (uint32_t)(descend(a.nodes + cur, (int)a.nodes[cur].level, X, Y, Z) - a.nodes);
@@ -1203,7 +1213,8 @@ __global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
 // point of a cell colours the voxel is scheduling dependent in the reference too).
 // Leaves with few new samples (and a root that is still a leaf: its cube is the whole grid) take the per-sample path with global
 // atomics; there is nothing to contend for.
-static constexpr uint32_t VTPB = 512;
+static constexpr uint32_t VTPB = 1024;
+static constexpr uint32_t VCHUNKS = 64;           // chunk pointers of the leaf's new range kept in LDS (a leaf below its limit has at most 50 chunks)
 static constexpr uint32_t BULK_MIN = 768;
 static constexpr uint32_t LDS_LEVELS = 7;           // ancestors whose cube of this leaf has at least one whole cell: side 128 >> d
 struct VoxShared {
@@ -1212,6 +1223,7 @@ struct VoxShared {
 	unsigned long long anc[PATH_WORDS];
 	uint32_t cnt[PATH_WORDS], base[PATH_WORDS], cursor[PATH_WORDS];
 	SimlodChunk* ptr[PATH_WORDS][2];
+	const SimlodChunk* chunks[VCHUNKS];
 };
 __device__ __forceinline__ uint32_t cube_offset(uint32_t d) {          // word offset of cube d in VoxShared::occ / fresh
 	return d == 1u ? 0u : d == 2u ? 8192u : d == 3u ? 9216u : d == 4u ? 9472u : d == 5u ? 9536u : d == 6u ? 9552u : 9556u;
@@ -1243,6 +1255,13 @@ __device__ __forceinline__ float4 voxel_at(const BuildArgs& a, uint32_t level, u
 	return v;
 }
 
+// sample #i of the leaf's storage; the chunk pointers of the first VCHUNKS chunks of the new range come from LDS
+__device__ __forceinline__ const float4* sample_addr(const BuildArgs& a, Ctl* ctl, const VoxShared& sh, uint32_t leafIdx, uint32_t i, uint32_t s0) {
+	const uint32_t k = i / CHUNK, rel = k - s0 / CHUNK;
+	const SimlodChunk* c = rel < VCHUNKS ? sh.chunks[rel] : placed_chunk(a, ctl, leafIdx, k, s0);
+	return c != nullptr ? reinterpret_cast<const float4*>(c->points) + i % CHUNK : nullptr;
+}
+
 __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
@@ -1258,8 +1277,14 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 		if (s1 <= s0 || !node_is_leaf(leaf)) continue;
 		const uint32_t lvl = leaf->level, LX = leaf->X, LY = leaf->Y, LZ = leaf->Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)leafIdx * PATH_WORDS;
+		PhaseTimer timer(ctl, 16);
 		__syncthreads();
 		if (threadIdx.x < PATH_WORDS) { sh.anc[threadIdx.x] = path_entry(a, rec, leafIdx, threadIdx.x); sh.cnt[threadIdx.x] = 0; sh.cursor[threadIdx.x] = 0; sh.base[threadIdx.x] = NONE; }
+		const uint32_t kFirst = s0 / CHUNK;
+		if (threadIdx.x >= 64u && threadIdx.x < 64u + VCHUNKS) {
+			const uint32_t k = kFirst + threadIdx.x - 64u;
+			sh.chunks[threadIdx.x - 64u] = k * CHUNK < s1 ? placed_chunk(a, ctl, leafIdx, k, s0) : nullptr;
+		}
 		__syncthreads();
 		// ancestor d (1 = parent) is sh.anc[d - 1]; a root that is still a leaf has itself as "ancestor 1" and no cube
 		uint32_t depth = 0;
@@ -1286,12 +1311,24 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 			}
 			__syncthreads();
 		}
+		timer.lap(0);
 
 		// pass A: test-and-set, bottom-up, climbing while the cell is new
-		for (uint32_t i = s0 + threadIdx.x; i < s1; i += VTPB) {
-			const SimlodChunk* c = placed_chunk(a, ctl, leafIdx, i / CHUNK, s0);
-			if (c == nullptr) continue;
-			const float4 p = reinterpret_cast<const float4*>(c->points)[i % CHUNK];
+		constexpr uint32_t VU = 4;                          // samples whose loads a thread has in flight together
+		for (uint32_t i0 = s0 + threadIdx.x; i0 < s1; i0 += VTPB * VU) {
+		float4 pv[VU];
+		bool ok[VU];
+#pragma unroll
+		for (uint32_t uu = 0; uu < VU; uu++) {
+			const uint32_t i = i0 + uu * VTPB;
+			const float4* src = i < s1 ? sample_addr(a, ctl, sh, leafIdx, i, s0) : nullptr;
+			ok[uu] = src != nullptr;
+			pv[uu] = src != nullptr ? *src : make_float4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (uint32_t uu = 0; uu < VU; uu++) {
+			if (!ok[uu]) continue;
+			const float4 p = pv[uu];
 			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
 			for (uint32_t d = 1; d <= depth; d++) {
 				const unsigned long long ent = sh.anc[d - 1];
@@ -1320,8 +1357,10 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 				}
 			}
 		}
-		if (!bulk) continue;
+		}
+		if (!bulk) { timer.lap(5); continue; }
 		__syncthreads();
+		timer.lap(1);
 
 		// new cells per cube; the cubes go back to the grids (d = 1, 2: whole words that belong to this leaf alone; above: shared words)
 		for (uint32_t d = 1; d <= ldsDepth; d++) {
@@ -1341,6 +1380,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 			if (mine != 0u) atomicAdd(&sh.cnt[d], mine);
 		}
 		__syncthreads();
+		timer.lap(2);
 		// voxel slot ranges: one atomic per (leaf, ancestor); chunks whose first slot falls into a range; then the lookups
 		if (threadIdx.x >= 1u && threadIdx.x <= ldsDepth && sh.cnt[threadIdx.x] != 0u) {
 			const uint32_t d = threadIdx.x, nodeIdx = path_node(sh.anc[d - 1]), cnt = sh.cnt[d];
@@ -1355,15 +1395,29 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 			sh.ptr[d][1] = (old + cnt - 1) / CHUNK > k0 ? wait_voxel_chunk(a, ctl, nodeIdx, k0 + 1) : nullptr;
 		}
 		__syncthreads();
+		timer.lap(3);
 
 		// pass B: every new cell becomes a voxel, coloured by whichever of its samples gets there first
-		for (uint32_t i = s0 + threadIdx.x; i < s1; i += VTPB) {
-			const SimlodChunk* c = placed_chunk(a, ctl, leafIdx, i / CHUNK, s0);
-			if (c == nullptr) continue;
-			const float4 p = reinterpret_cast<const float4*>(c->points)[i % CHUNK];
+		uint32_t levelsWithNew = 0;
+		for (uint32_t d = 1; d <= ldsDepth; d++) if (sh.cnt[d] != 0u) levelsWithNew |= 1u << d;
+		if (levelsWithNew == 0u) { timer.lap(4); continue; }
+		for (uint32_t i0 = s0 + threadIdx.x; i0 < s1; i0 += VTPB * VU) {
+		float4 pv[VU];
+		bool ok[VU];
+#pragma unroll
+		for (uint32_t uu = 0; uu < VU; uu++) {
+			const uint32_t i = i0 + uu * VTPB;
+			const float4* src = i < s1 ? sample_addr(a, ctl, sh, leafIdx, i, s0) : nullptr;
+			ok[uu] = src != nullptr;
+			pv[uu] = src != nullptr ? *src : make_float4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (uint32_t uu = 0; uu < VU; uu++) {
+			if (!ok[uu]) continue;
+			const float4 p = pv[uu];
 			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-			for (uint32_t d = 1; d <= ldsDepth; d++) {
-				if (sh.cnt[d] == 0u) continue;
+			for (uint32_t left = levelsWithNew; left != 0u; left &= left - 1u) {       // only the cubes that gained cells
+				const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
 				const unsigned long long ent = sh.anc[d - 1];
 				const uint32_t level = path_level(ent);
 				if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;
@@ -1378,6 +1432,8 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 				if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> d, LY >> d, LZ >> d, cell, p.w);
 			}
 		}
+		}
+		timer.lap(4);
 	}
 }
 

@@ -51,7 +51,7 @@ struct Ctl {
 	uint64_t placeVoxels;        // byte 192: ... and the voxels k_place created, since the host last cleared them
 	uint64_t expandNs[8];        // byte 200: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
 	uint32_t batchSize[SIMLOD_MAX_BATCHES_PER_LAUNCH], batchSlot[SIMLOD_MAX_BATCHES_PER_LAUNCH];
-	uint64_t phaseNs[16];        // byte 424: SIMLOD_PHASE_TIMERS=1 — wall time per phase summed over workgroups: k_ingest [0..7], k_place [8..15]
+	uint64_t phaseNs[24];        // SIMLOD_PHASE_TIMERS=1 — wall time per phase summed over workgroups: k_ingest [0..7], k_place [8..15], k_voxelize [16..23]
 };
 static_assert(offsetof(Ctl, spilledTotal) == 176, "bench.py reads Ctl.spilledTotal at byte 176");
 static_assert(sizeof(Ctl) <= 4096, "control block");

@@ -14,12 +14,15 @@ dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, momentary_bytes=700_000_0
 u = dev.uniforms(W, H, T, box)
 for rep in range(2):
     dev.reset(u)
-    dev.momentary[424:424 + 128].zero_()
+    dev.momentary[424:424 + 192].zero_()
     dev.add_points(u, pts)
     torch.cuda.synchronize()
-ph = dev.momentary[424:424 + 128].cpu().numpy().view(np.uint64).astype(np.float64) / 1e3
+ph = dev.momentary[424:424 + 192].cpu().numpy().view(np.uint64).astype(np.float64) / 1e3
 nb = (n + 999999) // 1000000
 names = ["load+descend+count", "flush points (atomics, chunk alloc, lookups)", "store + sample", "flush voxels", "store voxels (+ queue entries)"]
+vn = ["cube load", "pass A", "write-back", "slot ranges + chunks", "pass B", "light path (whole)"]
+tot = ph[16:22].sum()
+print("k_voxelize sum over workgroups %.0f us per batch" % (tot / nb), {vn[i]: "%.0f us (%.0f%%)" % (ph[16 + i] / nb, 100 * ph[16 + i] / max(tot, 1)) for i in range(6)})
 for base, k in ((0, "k_ingest"), (8, "k_place")):
     tot = ph[base:base + 5].sum()
     print(k, "sum over workgroups %.0f us per batch" % (tot / nb), {names[i]: "%.0f us (%.0f%%)" % (ph[base + i] / nb, 100 * ph[base + i] / max(tot, 1)) for i in range(5)})
