@@ -13,10 +13,19 @@
 //   renderCUDA()        main.cpp:465-546     `kernel_render`, occupancy x numSMs workgroups; linear RGBA8 instead of a GL surface
 //   frame loop          main.cpp:1159-1226   render, update, async Stats copy, until numPointsProcessed == numPointsTotal
 //
+// Built a second time as harness/_ref/ref_host_replay (make ref_host, only where /root/reference exists): resetCUDA, updateOctree,
+// renderCUDA and initCudaProgram are then the REFERENCE'S OWN TEXT, cut by line range out of main_progressive_octree.cpp at build
+// time (-DSIMLOD_REF_HOST_EXTRACT=...; nothing of it is stored in this repository) and compiled against shim/cuda.h — the proof that
+// the unchanged host functions drive libsimlod_hip.so.
+//
 // Usage: simlod_headless <file.simlod | synthetic:N> [out.ppm] [width height]
 // Prints the Stats the reference shows in its UI and the update/render kernel timings of "benchmark mode" (main.cpp:411-422).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,9 +37,17 @@
 #include "cuda.h"
 #include "simlod_abi.h"
 
+using namespace std;
 using Point = SimlodPoint;
 using Uniforms = SimlodUniforms;
 using Stats = SimlodStats;
+
+// what the host functions see of the GL renderer (src/GLRenderer.h): the colour attachment they hand to CUDA
+struct GLTexture { GLuint handle = 1; };
+struct GLFramebuffer { vector<shared_ptr<GLTexture>> colorAttachments; };
+struct GLView { shared_ptr<GLFramebuffer> framebuffer; };
+struct GLRenderer { GLView view; int width = 0, height = 0, frameCount = 0; };
+template <class... A> static void printfmt(const char*, A&&...) {}      // the reference's fmt-style log lines are dropped
 
 constexpr uint64_t BATCH_STREAM_SIZE = SIMLOD_BATCH_STREAM_SIZE;
 constexpr uint64_t MAX_BATCH_SIZE = SIMLOD_MAX_BATCH_SIZE;
@@ -40,16 +57,18 @@ static CUcontext context;
 static int numSMs;
 static CUstream stream_upload;
 static CUdeviceptr cptr_buffer, cptr_buffer_persistent, cptr_nodes, cptr_renderbuffer, cptr_stats, cptr_numBatchesUploaded, cptr_batchSizes,
-    cptr_frameStart, cptr_colorbuffer, cptr_cudaprint = 0;
+    cptr_frameStart, cptr_colorbuffer;
+static struct { CUdeviceptr cptr = 0; } cudaprint;      // CudaPrint's device side is a no-op (modules/CudaPrint/CudaPrint.cuh:49-51)
+static CUgraphicsResource cugl_colorbuffer;
 static CUdeviceptr cptr_points_ring[BATCH_STREAM_SIZE];
 static CUevent ce_render_start, ce_render_end, ce_update_start, ce_update_end;
 static CudaModularProgram *cuda_program_update, *cuda_program_render, *cuda_program_reset;
 static uint64_t momentaryBufferCapacity, persistentBufferCapacity, frameCounter = 0;
 static Stats stats;
-static void* h_stats_pinned;
+static Stats* h_stats_pinned;
 static simlod_float3 boxSize;
 static int width = 1920, height = 1080;
-static float transform[16];   // row-major world-view-projection (what glm::transpose leaves in Uniforms.transform)
+static float viewProj[16];   // row-major world-view-projection (what glm::transpose leaves in Uniforms.transform)
 
 struct {
 	bool useHighQualityShading = true;
@@ -57,7 +76,13 @@ struct {
 	bool showPoints = true;
 	float minNodeSize = 64.0f;
 	int pointSize = 1;
+	bool benchmarkRendering = false;
 } settings;   // main.cpp:123-139
+static bool requestBenchmark = true, requestStep = false;      // "benchmark mode": kernel durations are accumulated (main.cpp:411-422)
+static double kernelUpdateDuration = 0, minKernelUpdateDuration = 1e30, maxKernelUpdateDuration = 0, avgKernelUpdateDuration = 0, cntKernelUpdateDuration = 0;
+static double kernelRenderDuration = 0, minKernelRenderDuration = 1e30, maxKernelRenderDuration = 0, avgKernelRenderDuration = 0, cntKernelRenderDuration = 0;
+static float renderingDuration = 0;
+static int numBatchesProcessed = 0;
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -70,7 +95,12 @@ static void initCuda() {   // main.cpp:272-281
 	cuDeviceGetAttribute(&numSMs, CU_DEVICE_ATTRIBUTE_MULTIPROCESSOR_COUNT, device);
 }
 
-static void initCudaProgram() {   // main.cpp:549-642
+static Uniforms getUniforms(shared_ptr<GLRenderer> renderer);
+
+#ifdef SIMLOD_REF_HOST_EXTRACT
+#include SIMLOD_REF_HOST_EXTRACT      // resetCUDA, updateOctree, renderCUDA, initCudaProgram: the reference's own lines
+#else
+static void initCudaProgram(shared_ptr<GLRenderer> renderer) {   // main.cpp:549-642
 	uint64_t nodesCapacity = 200000, estimatedNodeSize = 200;
 	uint64_t cptr_buffer_bytes = 300000000, cptr_nodes_bytes = nodesCapacity * estimatedNodeSize, cptr_renderbuffer_bytes = 200000000;
 	momentaryBufferCapacity = cptr_buffer_bytes;
@@ -81,8 +111,7 @@ static void initCudaProgram() {   // main.cpp:549-642
 	cuMemAlloc(&cptr_numBatchesUploaded, 4);
 	cuMemAlloc(&cptr_batchSizes, 4 * BATCH_STREAM_SIZE);
 	cuMemAlloc(&cptr_frameStart, 8);
-	cuMemAllocHost(&h_stats_pinned, sizeof(Stats));
-	cuMemAlloc(&cptr_colorbuffer, (size_t)width * height * 4);      // stands for the GL colour attachment
+	cuMemAllocHost((void**)&h_stats_pinned, sizeof(Stats));
 	uint64_t cptr_points_bytes = MAX_BATCH_SIZE * sizeof(Point);
 	CUdeviceptr devicemem = 0;
 	cuMemAlloc(&devicemem, BATCH_STREAM_SIZE * cptr_points_bytes);
@@ -103,15 +132,17 @@ static void initCudaProgram() {   // main.cpp:549-642
 	                                             .kernels = {"kernel"}});
 	cuEventCreate(&ce_render_start, 0); cuEventCreate(&ce_render_end, 0);
 	cuEventCreate(&ce_update_start, 0); cuEventCreate(&ce_update_end, 0);
+	cuGraphicsGLRegisterImage(&cugl_colorbuffer, renderer->view.framebuffer->colorAttachments[0]->handle, GL_TEXTURE_2D, CU_GRAPHICS_REGISTER_FLAGS_WRITE_DISCARD);
 }
+#endif
 
-static Uniforms getUniforms() {   // main.cpp:283-331
+static Uniforms getUniforms(shared_ptr<GLRenderer>) {   // main.cpp:283-331
 	Uniforms u;
 	std::memset(&u, 0, sizeof(u));
 	const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 	std::memcpy(&u.world, ident, 64); std::memcpy(&u.view, ident, 64); std::memcpy(&u.proj, ident, 64);
-	std::memcpy(&u.transform, transform, 64);
-	std::memcpy(&u.transform_updateBound, transform, 64);
+	std::memcpy(&u.transform, viewProj, 64);
+	std::memcpy(&u.transform_updateBound, viewProj, 64);
 	std::memcpy(&u.transformInv_updateBound, ident, 64);
 	u.width = (float)width; u.height = (float)height;
 	u.fovy_rad = 3.1415f * 60.0f / 180.0f;
@@ -132,22 +163,20 @@ static Uniforms getUniforms() {   // main.cpp:283-331
 	return u;
 }
 
-static void resetCUDA() {   // main.cpp:333-361
-	Uniforms uniforms = getUniforms();
-	void* args[] = {&uniforms, &cptr_buffer_persistent, &cptr_nodes, &cptr_stats, &cptr_cudaprint, &cptr_numBatchesUploaded, &cptr_batchSizes};
+#ifndef SIMLOD_REF_HOST_EXTRACT
+static void resetCUDA(shared_ptr<GLRenderer> renderer) {   // main.cpp:333-361
+	Uniforms uniforms = getUniforms(renderer);
+	void* args[] = {&uniforms, &cptr_buffer_persistent, &cptr_nodes, &cptr_stats, &cudaprint.cptr, &cptr_numBatchesUploaded, &cptr_batchSizes};
 	auto res_launch = cuLaunchCooperativeKernel(cuda_program_reset->kernels["kernel"], 1, 1, 1, 1, 1, 1, 0, 0, args);
 	if (res_launch != CUDA_SUCCESS) std::printf("CUDA kernel 'reset' failed.\n");
 	cuCtxSynchronize();
 }
 
-static double kernelUpdateDuration = 0, kernelRenderDuration = 0;
-static int numUpdateLaunches = 0, numFrames = 0;
-
-static void updateOctree() {   // main.cpp:364-428
-	Uniforms uniforms = getUniforms();
+static void updateOctree(shared_ptr<GLRenderer> renderer) {   // main.cpp:364-428
+	Uniforms uniforms = getUniforms(renderer);
 	int workgroupSize = 256, numGroups = 1 * numSMs;
 	auto ptrPoints = cptr_points_ring[0];
-	void* args[] = {&uniforms, &ptrPoints, &cptr_buffer, &cptr_buffer_persistent, &cptr_nodes, &cptr_stats, &cptr_frameStart, &cptr_cudaprint,
+	void* args[] = {&uniforms, &ptrPoints, &cptr_buffer, &cptr_buffer_persistent, &cptr_nodes, &cptr_stats, &cptr_frameStart, &cudaprint.cptr,
 	                &cptr_numBatchesUploaded, &cptr_batchSizes};
 	cuEventRecord(ce_update_start, 0);
 	auto res_launch = cuLaunchCooperativeKernel(cuda_program_update->kernels["kernel_construct"], numGroups, 1, 1, workgroupSize, 1, 1, 0, 0, args);
@@ -157,15 +186,23 @@ static void updateOctree() {   // main.cpp:364-428
 	float duration;
 	cuEventElapsedTime(&duration, ce_update_start, ce_update_end);
 	kernelUpdateDuration += duration;
-	numUpdateLaunches++;
+	cntKernelUpdateDuration += 1.0;
 }
 
-static void renderCUDA() {   // main.cpp:465-546
-	Uniforms uniforms = getUniforms();
+static void renderCUDA(shared_ptr<GLRenderer> renderer) {   // main.cpp:465-546
+	Uniforms uniforms = getUniforms(renderer);
+	// the colour attachment, through the interop calls the reference makes per frame (main.cpp:472-486)
+	vector<CUgraphicsResource> dynamic_resources = {cugl_colorbuffer};
+	cuGraphicsMapResources((unsigned)dynamic_resources.size(), dynamic_resources.data(), (CUstream)CU_STREAM_DEFAULT);
+	CUDA_RESOURCE_DESC res_desc = {};
+	res_desc.resType = CU_RESOURCE_TYPE_ARRAY;
+	cuGraphicsSubResourceGetMappedArray(&res_desc.res.array.hArray, cugl_colorbuffer, 0, 0);
+	CUsurfObject output_surf;
+	cuSurfObjectCreate(&output_surf, &res_desc);
 	int workgroupSize = 256, numGroups;
 	cuOccupancyMaxActiveBlocksPerMultiprocessor(&numGroups, cuda_program_render->kernels["kernel_render"], workgroupSize, 0);
 	numGroups *= numSMs;
-	void* args[] = {&cptr_renderbuffer, &uniforms, &cptr_nodes, &cptr_colorbuffer, &cptr_stats, &cptr_frameStart, &cptr_cudaprint};
+	void* args[] = {&cptr_renderbuffer, &uniforms, &cptr_nodes, &output_surf, &cptr_stats, &cptr_frameStart, &cudaprint.cptr};
 	cuEventRecord(ce_render_start, 0);
 	auto res_launch = cuLaunchCooperativeKernel(cuda_program_render->kernels["kernel_render"], numGroups, 1, 1, workgroupSize, 1, 1, 0, 0, args);
 	if (res_launch != CUDA_SUCCESS) { const char* str; cuGetErrorString(res_launch, &str); std::printf("error: %s \n", str); }
@@ -174,8 +211,11 @@ static void renderCUDA() {   // main.cpp:465-546
 	float duration;
 	cuEventElapsedTime(&duration, ce_render_start, ce_render_end);
 	kernelRenderDuration += duration;
-	numFrames++;
+	cntKernelRenderDuration += 1.0;
+	cuSurfObjectDestroy(output_surf);
+	cuGraphicsUnmapResources((unsigned)dynamic_resources.size(), dynamic_resources.data(), (CUstream)CU_STREAM_DEFAULT);
 }
+#endif
 
 // ---- camera: OrbitControls::update (include/OrbitControls.h:140-159) + glm::perspective + main.cpp:286-298 ------------------
 static void mul4(const double a[16], const double b[16], double out[16]) {
@@ -199,7 +239,7 @@ static void setCamera(double yaw, double pitch, double radius, const double targ
 	proj[0] = 1 / (aspect * t); proj[5] = 1 / t; proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2 * zf * zn) / (zf - zn); proj[14] = -1;
 	float v32[16], p32[16];
 	for (int i = 0; i < 16; i++) { v32[i] = (float)view[i]; p32[i] = (float)proj[i]; }
-	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0; for (int k = 0; k < 4; k++) s += p32[4 * i + k] * v32[4 * k + j]; transform[4 * i + j] = s; }
+	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0; for (int k = 0; k < 4; k++) s += p32[4 * i + k] * v32[4 * k + j]; viewProj[4 * i + j] = s; }
 }
 
 int main(int argc, char** argv) {
@@ -259,10 +299,16 @@ int main(int argc, char** argv) {
 	const uint64_t numBatchesTotal = (numPointsTotal + MAX_BATCH_SIZE - 1) / MAX_BATCH_SIZE;
 
 	initCuda();
-	initCudaProgram();
+	auto renderer = make_shared<GLRenderer>();               // headless: a colour attachment that is a linear RGBA8 image on the device
+	renderer->width = width; renderer->height = height;
+	renderer->view.framebuffer = make_shared<GLFramebuffer>();
+	renderer->view.framebuffer->colorAttachments.push_back(make_shared<GLTexture>());
+	cuMemAlloc(&cptr_colorbuffer, (size_t)width * height * 4);
+	simlod_shim_register_surface(renderer->view.framebuffer->colorAttachments[0]->handle, cptr_colorbuffer, (size_t)width * height * 4);
+	initCudaProgram(renderer);
 	const double target[3] = {boxSize.x * 0.5, boxSize.y * 0.5, boxSize.z * 0.3};
 	setCamera(-0.207, -0.797, 1.1 * std::max(boxSize.x, std::max(boxSize.y, boxSize.z)), target);
-	resetCUDA();
+	resetCUDA(renderer);
 
 	// pinned staging slots, as the reference's pinnedMemPool (main.cpp:141-222)
 	void* pinned[4];
@@ -276,20 +322,28 @@ int main(int argc, char** argv) {
 	// pinned slot (main.cpp:846-935) — the uploader then issues the H2D copy straight from it and the staging memcpy disappears.
 	const bool sourcePinned = std::getenv("SIMLOD_HARNESS_PINNED") != nullptr && points.size() > 0 &&
 	                          hipHostRegister(points.data(), points.size() * sizeof(Point), hipHostRegisterDefault) == hipSuccess;
-	uint64_t batchStreamUploadIndex = 0, numPointsUploaded = 0;
-	bool lastBatchFinishedDevice = false;
-	const double loadStart = now();
-	while (!lastBatchFinishedDevice) {
-		// ---- uploader (main.cpp:1003-1056); here on the frame thread, same stream protocol
-		for (int k = 0; k < 4; k++) {
-			const bool everythingIsDone = batchStreamUploadIndex == numBatchesTotal;
-			const bool processingLagsBehind = numPointsUploaded > stats.numPointsProcessed + BATCH_STREAM_SIZE * MAX_BATCH_SIZE;
-			if (everythingIsDone || processingLagsBehind) break;
-			const int slot = (int)(batchStreamUploadIndex % 4);
+
+	// ---- spawnUploader (main.cpp:963-1063): ITS OWN THREAD, its own stream.  It publishes batchSizes[slot] and numBatchesUploaded
+	// with stream-ordered memsets WHILE kernel_construct launches run on the frame thread's stream; the frame thread
+	// publishes its Stats read-back through an atomic the back-pressure rule reads (main.cpp:1012).
+	std::atomic<uint64_t> numPointsProcessedSeen{0};
+	std::atomic<bool> quitUploader{false};
+	std::atomic<uint64_t> batchStreamUploadIndex{0};
+	const int device_ = device;
+	std::thread uploader([&]() {
+		(void)hipSetDevice(device_);
+		uint64_t numPointsUploaded = 0;
+		while (!quitUploader.load()) {
+			const bool everythingIsDone = batchStreamUploadIndex.load() == numBatchesTotal;
+			const bool processingLagsBehind = numPointsUploaded > numPointsProcessedSeen.load() + BATCH_STREAM_SIZE * MAX_BATCH_SIZE;
+			if (everythingIsDone) break;
+			if (processingLagsBehind) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
+			const uint64_t index = batchStreamUploadIndex.load();
+			const int slot = (int)(index % 4);
 			cuEventSynchronize(uploadEnd[slot]);
-			const uint64_t first = batchStreamUploadIndex * MAX_BATCH_SIZE;
+			const uint64_t first = index * MAX_BATCH_SIZE;
 			const uint32_t count = (uint32_t)std::min<uint64_t>(MAX_BATCH_SIZE, numPointsTotal - first);
-			const int uploadRingIndex = (int)(batchStreamUploadIndex % BATCH_STREAM_SIZE);
+			const int uploadRingIndex = (int)(index % BATCH_STREAM_SIZE);
 			if (isLas) {
 				// the loader thread's job shrinks to moving bytes: raw records -> pinned slot -> device, decoded into the ring slot there
 				const size_t bytes = (size_t)count * lasBytesPerPoint;
@@ -304,31 +358,39 @@ int main(int argc, char** argv) {
 			}
 			cuEventRecord(uploadEnd[slot], stream_upload);
 			cuMemsetD32Async(cptr_batchSizes + 4 * uploadRingIndex, count, 1, stream_upload);
-			cuMemsetD32Async(cptr_numBatchesUploaded, (unsigned)(batchStreamUploadIndex + 1), 1, stream_upload);
-			batchStreamUploadIndex++;
+			cuMemsetD32Async(cptr_numBatchesUploaded, (unsigned)(index + 1), 1, stream_upload);
+			batchStreamUploadIndex.store(index + 1);
 			numPointsUploaded += count;
 		}
+	});
+
+	bool lastBatchFinishedDevice = false;
+	const double loadStart = now();
+	while (!lastBatchFinishedDevice) {
 		// ---- frame (main.cpp:1159-1226): render first, then update, then the Stats copy
-		renderCUDA();
-		updateOctree();
+		renderCUDA(renderer);
+		updateOctree(renderer);
 		cuMemcpyDtoHAsync(h_stats_pinned, cptr_stats, sizeof(Stats), 0);
 		cuCtxSynchronize();
 		std::memcpy(&stats, h_stats_pinned, sizeof(Stats));
-		lastBatchFinishedDevice = stats.numPointsProcessed == numPointsTotal || stats.memCapacityReached;
+		numPointsProcessedSeen.store(stats.numPointsProcessed);
+		lastBatchFinishedDevice = stats.numPointsProcessed == numPointsTotal || stats.memCapacityReached || (stats.dbg & 0x50u) != 0u;
 		frameCounter++;
-		if (frameCounter > 100000) { std::fprintf(stderr, "no progress\n"); return 1; }
+		if (frameCounter > 2000000) { std::fprintf(stderr, "no progress\n"); quitUploader.store(true); uploader.join(); return 1; }
 	}
+	quitUploader.store(true);
+	uploader.join();
 	const double totalUpdateDuration = 1000.0 * (now() - loadStart);
-	renderCUDA();   // the frame that shows the finished octree
+	renderCUDA(renderer);   // the frame that shows the finished octree
 	cuMemcpyDtoH(&stats, cptr_stats, sizeof(Stats));
 
-	std::printf("points %llu batches %llu frames %d\n", (unsigned long long)numPointsTotal, (unsigned long long)numBatchesTotal, numFrames);
+	std::printf("points %llu batches %llu frames %d\n", (unsigned long long)numPointsTotal, (unsigned long long)numBatchesTotal, (int)cntKernelRenderDuration);
 	std::printf("numNodes %u numInner %u numLeaves %u numPoints %u numVoxels %u persistentBytes %llu chunkPoolSize %llu dbg %u\n", stats.numNodes, stats.numInner,
 	            stats.numLeaves, stats.numPoints, stats.numVoxels, (unsigned long long)stats.allocatedBytes_persistent, (unsigned long long)stats.chunkPoolSize, stats.dbg);
 	std::printf("visible nodes %u points %u voxels %u\n", stats.numVisibleNodes, stats.numVisiblePoints, stats.numVisibleVoxels);
 	std::printf("%s", sourcePinned ? "source array page-locked: no staging memcpy\n" : "");
 	std::printf("load+build wall %.1f ms (incl. H2D), update kernel %.2f ms total over %d launches = %.1f M points/s, render kernel %.3f ms/frame\n", totalUpdateDuration,
-	            kernelUpdateDuration, numUpdateLaunches, numPointsTotal / (kernelUpdateDuration * 1e-3) / 1e6, kernelRenderDuration / numFrames);
+	            kernelUpdateDuration, (int)cntKernelUpdateDuration, numPointsTotal / (kernelUpdateDuration * 1e-3) / 1e6, kernelRenderDuration / std::max(1.0, cntKernelRenderDuration));
 	if (outPath) {
 		std::vector<uint32_t> img((size_t)width * height);
 		cuMemcpyDtoH(img.data(), cptr_colorbuffer, img.size() * 4);

@@ -6,12 +6,20 @@
 //   launch surface     cuLaunchCooperativeKernel, cuOccupancyMaxActiveBlocksPerMultiprocessor  -> simlod_launch_cooperative, ...
 //   memory / streams   cuMemAlloc (zero-filled: the reference relies on fresh VRAM reading 0), cuMemAllocHost,
 //                      cuMemcpyHtoDAsync, cuMemcpyDtoHAsync, cuMemsetD32(Async), cuMemGetInfo, cuStreamCreate, cuEvent*
-//   not provided       NVRTC / nvJitLink (kernels are precompiled for gfx950), GL interop (the colour buffer is a linear image)
+//   GL interop         cuGraphicsGLRegisterImage / MapResources / SubResourceGetMappedArray / UnmapResources / UnregisterResource,
+//                      cuSurfObjectCreate / Destroy (main.cpp:472-486, 542-545, 641): headless — a GL texture handle stands for a
+//                      linear RGBA8 device image (simlod_shim_register_surface, or allocated on first use); the "surface object"
+//                      handed to kernel_render is that image's device address
+//   module loading     cuModuleLoadData / cuModuleGetFunction (include/CudaModularProgram.h:245-249): the "image" is ignored, a
+//                      function is looked up by name among the three precompiled kernels
+//   not provided       NVRTC / nvJitLink (kernels are precompiled for gfx950)
 #pragma once
 
 #include <hip/hip_runtime_api.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <unordered_map>
 
 #include "simlod_hip.h"
 
@@ -69,3 +77,76 @@ inline CUresult cuLaunchCooperativeKernel(CUfunction f, unsigned gx, unsigned gy
                                           unsigned sharedMemBytes, CUstream stream, void** kernelParams) {
 	return simlod_launch_cooperative(f, gx, gy, gz, bx, by, bz, sharedMemBytes, (void*)stream, kernelParams);
 }
+inline CUresult cuMemFree(CUdeviceptr p) { return (CUresult)hipFree((void*)(uintptr_t)p); }
+inline CUresult cuMemFreeHost(void* p) { return (CUresult)hipHostFree(p); }
+inline CUresult cuStreamDestroy(CUstream s) { return (CUresult)hipStreamDestroy(s); }
+inline CUresult cuEventDestroy(CUevent e) { return (CUresult)hipEventDestroy(e); }
+constexpr CUresult cudaSuccess = 0;                      // the reference compares a driver result with the runtime constant (main.cpp:1004)
+
+// ---- GL interop, headless ------------------------------------------------------------------------------------------------------------
+using GLuint = unsigned;
+using GLenum = unsigned;
+#ifndef GL_TEXTURE_2D
+constexpr GLenum GL_TEXTURE_2D = 0x0DE1;
+#endif
+constexpr unsigned CU_GRAPHICS_REGISTER_FLAGS_WRITE_DISCARD = 2;
+constexpr unsigned CU_GRAPHICS_REGISTER_FLAGS_SURFACE_LDST = 4;
+#define CU_STREAM_DEFAULT 0
+struct SimlodShimSurface { CUdeviceptr image; size_t bytes; int mapped; };
+using CUgraphicsResource = SimlodShimSurface*;
+using CUarray = SimlodShimSurface*;
+using CUsurfObject = unsigned long long;
+enum CUresourcetype { CU_RESOURCE_TYPE_ARRAY = 0, CU_RESOURCE_TYPE_MIPMAPPED_ARRAY = 1, CU_RESOURCE_TYPE_LINEAR = 2, CU_RESOURCE_TYPE_PITCH2D = 3 };
+struct CUDA_RESOURCE_DESC {
+	CUresourcetype resType;
+	union { struct { CUarray hArray; } array; struct { int reserved[32]; } reserved; } res;
+	unsigned flags;
+};
+inline std::unordered_map<GLuint, SimlodShimSurface>& simlod_shim_surfaces() { static std::unordered_map<GLuint, SimlodShimSurface> m; return m; }
+// what the GL texture `handle` stands for: width * height RGBA8 pixels in device memory (row 0 first)
+inline void simlod_shim_register_surface(GLuint handle, CUdeviceptr image, size_t bytes) { simlod_shim_surfaces()[handle] = SimlodShimSurface{image, bytes, 0}; }
+inline CUresult cuGraphicsGLRegisterImage(CUgraphicsResource* resource, GLuint image, GLenum, unsigned) {
+	auto& m = simlod_shim_surfaces();
+	auto it = m.find(image);
+	if (it == m.end()) {                                 // nobody said what the texture is: a 4K image of its own
+		CUdeviceptr p = 0;
+		const size_t bytes = (size_t)3840 * 2160 * 4;
+		CUresult r = cuMemAlloc(&p, bytes);
+		if (r != CUDA_SUCCESS) return r;
+		it = m.emplace(image, SimlodShimSurface{p, bytes, 0}).first;
+	}
+	*resource = &it->second;
+	return CUDA_SUCCESS;
+}
+inline CUresult cuGraphicsMapResources(unsigned count, CUgraphicsResource* resources, CUstream) { for (unsigned i = 0; i < count; i++) resources[i]->mapped++; return CUDA_SUCCESS; }
+inline CUresult cuGraphicsUnmapResources(unsigned count, CUgraphicsResource* resources, CUstream) { for (unsigned i = 0; i < count; i++) resources[i]->mapped--; return CUDA_SUCCESS; }
+inline CUresult cuGraphicsSubResourceGetMappedArray(CUarray* array, CUgraphicsResource resource, unsigned, unsigned) { *array = resource; return resource->mapped > 0 ? CUDA_SUCCESS : (CUresult)hipErrorNotMapped; }
+inline CUresult cuGraphicsUnregisterResource(CUgraphicsResource) { return CUDA_SUCCESS; }
+inline CUresult cuSurfObjectCreate(CUsurfObject* surf, const CUDA_RESOURCE_DESC* desc) {
+	if (desc->resType != CU_RESOURCE_TYPE_ARRAY || desc->res.array.hArray == nullptr) return (CUresult)hipErrorInvalidValue;
+	*surf = desc->res.array.hArray->image;               // kernel_render's `gl_colorbuffer` argument: the linear image
+	return CUDA_SUCCESS;
+}
+inline CUresult cuSurfObjectDestroy(CUsurfObject) { return CUDA_SUCCESS; }
+
+// ---- module loading (CudaModularProgram::link, include/CudaModularProgram.h:227-256) ----------------------------------------------------
+struct SimlodShimModule { SimlodProgram* program; };
+using CUmodule = SimlodShimModule*;
+// `image` would be the cubin nvJitLink produced; here every module holds the three precompiled kernels
+inline CUresult cuModuleLoadData(CUmodule* module, const void*) {
+	static const char* mods[] = {"reset.cu", "progressive_octree_voxels.cu", "render.cu", "utils.cu"};
+	*module = new SimlodShimModule{nullptr};
+	(void)mods;
+	return CUDA_SUCCESS;
+}
+inline CUresult cuModuleGetFunction(CUfunction* fn, CUmodule module, const char* name) {
+	// "kernel" -> reset.cu, "kernel_construct" -> progressive_octree_voxels.cu, "kernel_render" -> render.cu
+	const char* mod = std::strcmp(name, "kernel") == 0 ? "reset.cu" : std::strcmp(name, "kernel_construct") == 0 ? "progressive_octree_voxels.cu" : "render.cu";
+	const char* mods[] = {mod, "utils.cu"};
+	const char* kernels[] = {name};
+	CUresult r = simlod_program_create(&module->program, mods, 2, kernels, 1);
+	if (r != CUDA_SUCCESS) return r;
+	*fn = simlod_program_kernel(module->program, name);
+	return *fn != nullptr ? CUDA_SUCCESS : (CUresult)hipErrorNotFound;
+}
+inline CUresult cuModuleUnload(CUmodule) { return CUDA_SUCCESS; }   // functions handed out stay valid

@@ -785,6 +785,46 @@ def test_headless_cpp_host_replay_octree_dump_equals_oracle(built_libs, tmp_path
     oracle.check_invariants(nodes, nn)
 
 
+@pytest.mark.parametrize("kind", ["simlod", "las"])
+def test_reference_host_functions_drive_the_library(built_libs, tmp_path, kind):
+    """harness/_ref/ref_host_replay = the headless host with the REFERENCE'S OWN resetCUDA / updateOctree / renderCUDA / initCudaProgram
+    (cut out of main_progressive_octree.cpp at build time where the reference exists; the binary travels with the snapshot).  Uploader on
+    its own thread and stream while kernel_construct runs.  The octree it leaves must be the oracle's, node by node."""
+    import subprocess
+    from simlod_amd import lasio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "harness", "_ref", "ref_host_replay")
+    if not os.path.exists(exe):
+        pytest.skip("harness/_ref/ref_host_replay was not built (no reference checkout where the snapshot was made)")
+    pts0, box = synthetic.terrain(2_700_000, seed=19, box=(1500.0, 1000.0, 100.0), tile=125.0)
+    dump = str(tmp_path / "octree.bin")
+    if kind == "simlod":
+        path = str(tmp_path / "terrain.simlod")
+        synthetic.write_simlod(path, pts0, box)
+        pts, hbox = pts0, box
+    else:
+        path = str(tmp_path / "terrain.las")
+        h = lasio.points_to_las(path, pts0, box, fmt=7, scale=0.001, world_min=(694000.0, 3915000.0, -3.0), version=(1, 4))
+        tr = tuple(-v for v in h.min)
+        pts = oracle.decode_las_port(lasio.read_records(path, h, 0, h.numPoints), h.bytesPerPoint, h.format, h.scale, lasio.decode_offset(h, tr))
+        hbox = (np.array(h.max) - np.array(h.min)).astype(np.float32)
+    out = subprocess.run([exe, path, str(tmp_path / "f.ppm"), "640", "360"], capture_output=True, text=True, timeout=600, env=dict(os.environ, SIMLOD_HARNESS_DUMP=dump))
+    assert out.returncode == 0, out.stdout + out.stderr
+    head = np.fromfile(dump, dtype=np.uint64, count=4)
+    nn, used, nodes_base, pers_base = (int(v) for v in head)
+    nodes = np.fromfile(dump, dtype=abi.node_dtype, count=nn, offset=32)
+    pers = np.fromfile(dump, dtype=np.uint8, count=used, offset=32 + nn * 152)
+    oracle.rebase_image(nodes, nn, pers, nodes_base, pers_base)
+    T = camera.lookat_transform((1.8 * hbox[0], -1.2 * hbox[1], 1.4 * max(hbox)), (0.5 * hbox[0], 0.5 * hbox[1], 0.3 * hbox[2]), W, H)
+    u = uniforms_for(hbox, T, persistent=8 << 30)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "reference host functions")
+    img = np.fromfile(str(tmp_path / "f.ppm"), dtype=np.uint8, offset=15).reshape(360, 640, 3)
+    assert (img != np.array([0x11, 0x22, 0x33], dtype=np.uint8)).any(axis=2).sum() > 5000
+
+
 def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs, chain):
     """A coordinate equal to boxMax quantises to 2^20; the reference's descent looks at bits 19..0 and files the point (and the voxels
     it creates) under node coordinate 0 of that axis.  Only such points here, so they are the ones that win the cells."""
