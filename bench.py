@@ -15,9 +15,13 @@ progressive_octree_voxels.cu:883).  value = points inserted per second over exac
 The raster half of the metric is measured right after, on the octree of the last step: K frames of `kernel_render` at
 1920x1080 (HQS, the reference's default, and plain) and reported under "raster".
 
-N>1 (weak scaling): every rank owns a spatial sub-octree (its own 36 M-point terrain tile) — no data-path collective
-for ingest; a frame is composed exactly (distributed.render_frame: MIN/SUM all-reduces between the passes) plus an all-gather of the
-visible-node records, both over RCCL.
+N>1 (weak scaling, BASELINE config 4's shape): ONE global cube over a terrain of N tiles of 36 M points each.  Every rank generates its
+tile ON THE DEVICE (simlod_generate_terrain), the ranks histogram the points over the 512 level-3 cells of the global cube, the cells
+are dealt to ranks by point count (distributed.balanced_owners), and the records are routed with one all-to-all over RCCL
+(distributed.route_points) — all of that BEFORE the timed region: config 4 is "spatially pre-partitioned", the timed step is the
+ingest of resident points into the rank's sub-octrees (no data-path collective), value = all points / max over ranks.  The routing
+time is reported under "partition".  A frame is composed exactly (distributed.render_frame: MIN/SUM all-reduces between the passes)
+plus an all-gather of the visible-node records, over RCCL.
 """
 import argparse
 import ctypes
@@ -104,18 +108,47 @@ def main():
 
     n_points = args.points
     batch = abi.MAX_BATCH_SIZE
-    n_batches = (n_points + batch - 1) // batch
-    assert n_batches <= abi.BATCH_STREAM_SIZE, "the workload must fit the 50-slot ring (resident input)"
-    gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
-    pts, box = gen(n_points, seed=7 + rank)                   # rank r owns tile r of the tiled terrain (pre-partitioned)
-    dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
-    L = lib()
-    sizes = torch.tensor([min(batch, n_points - i * batch) for i in range(n_batches)], dtype=torch.int32, device=dev.device)
-    ring_view = dev.ring.view(torch.uint8)
-    for i in range(n_batches):           # H2D once, outside every timed region: inputs are resident in HBM
-        chunk = pts[i * batch:(i + 1) * batch]
-        ring_view[i * batch * 16: i * batch * 16 + len(chunk) * 16].copy_(torch.from_numpy(chunk.view(np.uint8).reshape(-1)))
-    T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886, (box[0] / 2, box[1] / 2, 0.35 * box[2])),
+    partition = None
+    if not use_dist:
+        n_batches = (n_points + batch - 1) // batch
+        assert n_batches <= abi.BATCH_STREAM_SIZE, "the workload must fit the 50-slot ring (resident input)"
+        gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
+        pts, box = gen(n_points, seed=7)
+        dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
+        L = lib()
+        ring_view = dev.ring.view(torch.uint8)
+        for i in range(n_batches):           # H2D once, outside every timed region: inputs are resident in HBM
+            chunk = pts[i * batch:(i + 1) * batch]
+            ring_view[i * batch * 16: i * batch * 16 + len(chunk) * 16].copy_(torch.from_numpy(chunk.view(np.uint8).reshape(-1)))
+        my_points = n_points
+    else:
+        from simlod_amd import distributed
+        tiles_x = int(np.ceil(np.sqrt(world)))
+        tiles_y = (world + tiles_x - 1) // tiles_x
+        tile_extent = (6000.0, 4000.0, 400.0)
+        box = np.array([tiles_x * tile_extent[0], tiles_y * tile_extent[1], tile_extent[2]], dtype=np.float32)
+        dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
+        L = lib()
+        generated = torch.empty(n_points * 16, dtype=torch.uint8, device=dev.device)
+        dev.generate_terrain(generated, rank * n_points, n_points, 7, tiles_x, tile_extent)       # rank r makes tile r of the global stream
+        torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        codes = distributed.cell_codes(generated, box, 3)
+        owner, counts = distributed.balanced_owners(codes, world, 3)
+        mine, recv = distributed.route_points(generated, codes, owner)
+        torch.cuda.synchronize(); barrier()
+        t_part = time.perf_counter() - t0
+        load = np.array([int(counts[owner.cpu().numpy() == r].sum()) for r in range(world)])
+        my_points = int(mine.shape[0])
+        n_batches = (my_points + batch - 1) // batch
+        assert n_batches <= abi.BATCH_STREAM_SIZE, f"rank {rank} owns {my_points} points: more than the 50-slot ring holds resident"
+        dev.ring.view(torch.uint8)[: my_points * 16].copy_(mine.reshape(-1))
+        partition = {"level": 3, "cells_occupied": int((counts > 0).sum()), "per_rank_points": load.tolist(), "max_over_mean": float(load.max() / load.mean()),
+                     "histogram_assign_route_ms": t_part * 1e3, "kept_local": int(recv[rank]), "what": "all-reduce of 512-cell histograms, greedy by count, one all_to_all_single of the records"}
+        del generated, mine, codes
+        pts = None
+    sizes = torch.tensor([min(batch, my_points - i * batch) for i in range(n_batches)], dtype=torch.int32, device=dev.device)
+    T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886 * float(box[0]) / 6000.0, (box[0] / 2, box[1] / 2, 0.35 * box[2])),
                                camera.perspective(aspect=W / H))
     u = dev.uniforms(W, H, T, box, hqs=True)
 
@@ -140,7 +173,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     ms_per_step = float(tmax.item()) * 1e3 / args.steps
     stats = dev.read_stats()
-    assert int(stats["numPointsProcessed"]) == n_points and int(stats["numPoints"]) == n_points, "ingest lost points"
+    assert int(stats["numPointsProcessed"]) == my_points and int(stats["numPoints"]) == my_points, "ingest lost points"
     assert int(stats["dbg"]) == 0, f"device error bits {int(stats['dbg']):#x}"
     value = world * n_points / (ms_per_step * 1e-3) / 1e6
 
@@ -305,8 +338,9 @@ def main():
             "config": {"workload": f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M "
                                    f"ring batches resident in HBM, reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
                                    f"(<= 20 batches and <= 10 ms each, Stats read back between launches); "
-                                   f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order, "parallelism": f"spatial sub-octree per GPU x{world}"},
-            "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu, "loader": loader,
+                                   f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order if not use_dist else "device-generated tiles, swath order",
+                       "parallelism": f"one global cube, level-3 cells dealt to {world} rank(s) by point count"},
+            "partition": partition, "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu, "loader": loader,
             "octree": {k: int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels", "allocatedBytes_persistent")},
         }
         print(json.dumps(out))

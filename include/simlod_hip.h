@@ -142,6 +142,14 @@ int simlod_profile_collect(SimlodProfileEntry* out, int capacity, int* count);
 int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format,
                       const double scale[3], const double offset[3], SimlodPoint* out, void* stream);
 
+/* ---- workload generator (BASELINE config 4; no counterpart in the reference) ------------------------------------------------------------
+ * Points firstIndex .. firstIndex + numPoints - 1 of a procedurally generated, tiled terrain, written to `out` (device memory): the
+ * stream is tile after tile (`pointsPerTile` points each, tiles laid out row-major with `tilesX` tiles per row, each tileExtent[0] x
+ * tileExtent[1] metres, heights within [0, tileExtent[2])), inside a tile swath by swath like an airborne LAS scan.  One continuous
+ * surface over all tiles; a pure function of (seed, index), so every rank of a multi-GPU job can generate any part of the stream. */
+int simlod_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed,
+                            uint32_t tilesX, const float tileExtent[3], void* stream);
+
 /* Version / build info string (static storage). */
 const char* simlod_build_info(void);
 

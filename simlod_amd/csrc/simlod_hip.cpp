@@ -142,6 +142,11 @@ int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPer
 	return launch_decode_las(records, numPoints, bytesPerPoint, format, scale, offset, out, (hipStream_t)stream);
 }
 
+int simlod_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
+                            const float tileExtent[3], void* stream) {
+	return launch_generate_terrain(out, numPoints, firstIndex, pointsPerTile, seed, tilesX, tileExtent, (hipStream_t)stream);
+}
+
 int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms, SimlodNode* nodes, uint32_t* colorbuffer,
                          SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
 	(void)cudaprint;

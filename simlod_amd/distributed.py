@@ -2,9 +2,12 @@
 the sub-octrees of a set of top-level cells of the SAME global cube, so node coordinates, names, voxel grids and the
 LOD maths are those of the single-GPU octree.
 
-  ingest   a point belongs to the rank that owns its level-`level` cell (level 1 = the eight octants).  Pre-partitioned
-           inputs (BASELINE config 4: tiles assigned by octant) need no exchange at all; a mixed batch is routed with
-           ONE collective (exchange_points).
+  ingest   a point belongs to the rank that owns its level-`level` cell of the global cube.  Cells are dealt to ranks BY POINT COUNT
+           (balanced_owners: every rank histograms its share of the input over the 8^level cells, one all-reduce(SUM) makes the
+           global histogram, the same greedy assignment runs on every rank), and a mixed input is routed with ONE all-to-all
+           (route_points: all_to_all_single of the 16-byte records, split sizes from an all-to-all of the counts) — every rank
+           receives exactly what it owns, nothing else.  Pre-partitioned inputs (BASELINE config 4) send most records to
+           themselves.
   render   every rank rasterises its own visible nodes; the frame is the element-wise MIN of the uint64 framebuffers
            (depth bits << 32 | colour, exactly what atomicMin builds on one GPU, render.cu:95-100) — one all-reduce —
            and the visible-node records are all-gathered so every rank holds the merged list (stats, LOD bookkeeping).
@@ -56,6 +59,54 @@ def exchange_points(points, owners, group=None):
     dist.all_gather(go, pad_o, group=group)
     mine = [gr[r][go[r] == rank] for r in range(world)]
     return torch.cat(mine, dim=0)
+
+
+def cell_codes(points, box_size, level):
+    """Level-`level` cell code (x<<2|y<<1|z per level, as cell_of) of every 16-byte record of a torch tensor, on the tensor's
+    device (CUDA for RCCL jobs, CPU under gloo): the builder's quantisation X = uint32(2^20 * p / size), boxMin = 0."""
+    xyz = points.reshape(-1, 16)[:, :12].contiguous().view(torch.float32).reshape(-1, 3)
+    size = float(np.float32(max(box_size)))
+    q = (xyz * (float(2 ** 20) / size)).to(torch.int64).clamp_(0, 2 ** 20 - 1)
+    code = torch.zeros(q.shape[0], dtype=torch.int64, device=points.device)
+    for lv in range(level):
+        s = 19 - lv
+        code = (code << 3) | (((q[:, 0] >> s) & 1) << 2) | (((q[:, 1] >> s) & 1) << 1) | ((q[:, 2] >> s) & 1)
+    return code
+
+
+def balanced_owners(codes, world, level, group=None):
+    """Owner rank of each of the 8^level cells, the same table on every rank: global point count per cell (all-reduce of the local
+    histograms), cells taken heaviest first, each to the rank that is lightest so far (ties: lowest cell, lowest rank).
+    Returns (owner table int64[8^level] on the codes' device, global counts int64[8^level] on the host)."""
+    ncell = 8 ** level
+    hist = torch.bincount(codes, minlength=ncell).to(torch.int64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    counts = hist.cpu().numpy()
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.zeros(ncell, dtype=np.int64)
+    for c in sorted(range(ncell), key=lambda c: (-int(counts[c]), c)):
+        r = int(np.argmin(load))                   # first minimum = lowest rank
+        owner[c] = r
+        load[r] += counts[c]
+    return torch.from_numpy(owner).to(codes.device), counts
+
+
+def route_points(points, codes, owner_table, group=None):
+    """Send every record to the rank that owns its cell: ONE all-to-all of the records (plus one of the counts).  Returns the records
+    this rank owns — from rank 0 first, original order inside a source rank — and the number it received from each rank."""
+    world = dist.get_world_size(group)
+    rec = points.reshape(-1, 16)
+    dest = owner_table[codes]
+    order = torch.argsort(dest, stable=True)
+    send = rec[order].contiguous()
+    send_counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    recv_counts = torch.zeros_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    rs, ss = [int(v) for v in recv_counts.cpu()], [int(v) for v in send_counts.cpu()]
+    out = torch.empty((sum(rs), 16), dtype=torch.uint8, device=points.device)
+    dist.all_to_all_single(out, send, rs, ss, group=group)
+    return out, rs
 
 
 def compose_min(framebuffer_u64_as_i64, group=None):

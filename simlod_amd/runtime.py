@@ -61,6 +61,7 @@ def lib():
         L.simlod_build_info.restype = ctypes.c_char_p
         L.simlod_decode_las.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double), vp, vp]
+        L.simlod_generate_terrain.argtypes = [vp, u64, u64, u64, u32, u32, ctypes.POINTER(ctypes.c_float), vp]
         _lib = L
     return _lib
 
@@ -71,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
     "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
-    "simlod_profile_enable", "simlod_profile_collect",
+    "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain",
 ]
 
 
@@ -209,6 +210,14 @@ class DeviceOctree:
         self.drain(uniforms)
         self.processed_host = self.uploaded_host
         return h
+
+    def generate_terrain(self, out, first_index, points_per_tile, seed, tiles_x, tile_extent):
+        """BASELINE config 4's input made on the device: points first_index .. first_index + len(out)/16 - 1 of the tiled-terrain stream
+        into the uint8 device tensor `out` (simlod_generate_terrain)."""
+        n = out.numel() // 16
+        ext = (ctypes.c_float * 3)(*[float(v) for v in tile_extent])
+        _check(self.L.simlod_generate_terrain(self._p(out), ctypes.c_uint64(n), ctypes.c_uint64(first_index), ctypes.c_uint64(points_per_tile),
+                                              ctypes.c_uint32(seed), ctypes.c_uint32(tiles_x), ext, self._stream()), "simlod_generate_terrain")
 
     def construct(self, uniforms):
         u, up = self._u(uniforms)

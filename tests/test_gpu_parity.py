@@ -932,3 +932,43 @@ def test_coalesced_ingest_builds_the_same_octree_content(built_libs, kind, n):
         assert_stats_equal(dev.read_stats(), so, STATS_RENDER_FIELDS, kind)
     finally:
         lib().simlod_set_ingest_mode(0)
+
+
+# ---- BASELINE config 4: tiles generated on the device, one global cube -------------------------------------------------------------------
+def test_device_generated_tiles_are_deterministic_seamless_and_ingest_like_the_oracle(built_libs):
+    """simlod_generate_terrain: any index range of the tiled-terrain stream, on the device.  Same (seed, index) -> same point whichever
+    call produced it; every point inside its tile; the octree built from generated points equals the oracle's on the same points."""
+    import torch
+    dev = _device(ring_slots=8)
+    ppt, tiles_x, ext = 700_000, 2, (600.0, 400.0, 40.0)
+    n = 4 * ppt                                            # four tiles, 2 x 2
+    whole = torch.empty(n * 16, dtype=torch.uint8, device=dev.device)
+    dev.generate_terrain(whole, 0, ppt, 7, tiles_x, ext)
+    part = torch.empty(900_000 * 16, dtype=torch.uint8, device=dev.device)
+    dev.generate_terrain(part, 1_000_000, ppt, 7, tiles_x, ext)                  # a range that straddles the tile 1 / tile 2 boundary
+    torch.cuda.synchronize()
+    pts = whole.cpu().numpy().view(abi.point_dtype)
+    assert np.array_equal(part.cpu().numpy(), whole[1_000_000 * 16: 1_900_000 * 16].cpu().numpy())
+    other = torch.empty(1000 * 16, dtype=torch.uint8, device=dev.device)
+    dev.generate_terrain(other, 0, ppt, 8, tiles_x, ext)
+    assert not np.array_equal(other.cpu().numpy(), whole[:16000].cpu().numpy()), "the seed must matter"
+    tile = np.arange(n) // ppt
+    assert (pts["x"] >= (tile % 2) * ext[0]).all() and (pts["x"] <= (tile % 2 + 1) * ext[0]).all()
+    assert (pts["y"] >= (tile // 2) * ext[1]).all() and (pts["y"] <= (tile // 2 + 1) * ext[1]).all()
+    assert (pts["z"] >= 0).all() and (pts["z"] < ext[2]).all() and float(pts["z"].std()) > 1.0
+    assert ((pts["color"] >> 24) == 255).all()
+    box = np.array([2 * ext[0], 2 * ext[1], ext[2]], dtype=np.float32)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    u = dev.uniforms(W, H, T, box)
+    dev.reset(u)
+    for i in range(0, n, abi.MAX_BATCH_SIZE):                # device to ring, no host round trip
+        dev.upload(whole[i * 16: min(n, i + abi.MAX_BATCH_SIZE) * 16].view(-1, 16))
+    dev.drain(u)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "generated tiles")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "generated tiles")
