@@ -37,20 +37,27 @@ struct RenderArgs {
 	int32_t      W, H, pointSize;
 	uint32_t     numPixels, nodeCapacity, frameCounter;
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
-	uint64_t     offWork, offItems, offDepth, offColor, offOverflow;
+	uint64_t     offWork, offItems, offDepth, offColor, offOverflow, offDir;
 	uint32_t     itemCap, useTiles;
 };
 
-// work area: [0..2] draw cursors of the three draw modes, [3] number of draw items
-static constexpr int WORK_WORDS = 4;
-static constexpr uint32_t ITEM_CHUNKS = 8;          // a draw item = up to 8 consecutive chunks (8000 samples) of one visible node
+// work area: [0..2] draw cursors of the three draw modes, [3] number of draw items, [4] chunk directory entries in use
+static constexpr int WORK_WORDS = 5;
+// A draw item = up to 64 consecutive chunks (64 000 samples) of one visible node's list: a whole leaf, or a slice of a long voxel list.
+// ONE workgroup draws an item, accumulating in a 128 x 128-pixel LDS tile laid over the node's screen box: the LOD rule draws a node
+// while its box spans 64..128 pixels (render.cu:893-901), so nearly every sample of a node lands in the tile, pixels that several
+// samples of the node hit (five per pixel on average for a full leaf) cost LDS atomics, and the framebuffer sees one global atomic per
+// TOUCHED pixel and item instead of one per sample.  Samples outside the tile take the global path.
+static constexpr uint32_t ITEM_CHUNKS = 64;
+static constexpr uint32_t DTPB = 1024;              // draw workgroup: 16 waves share one tile (128 KB of LDS: one workgroup per CU)
 
 struct DrawItem {
-	const SimlodChunk* first;
+	uint32_t dirBase;                               // first entry of the item's chunks in the frame's chunk directory
 	uint32_t samples, visibleIdx;
-	int32_t  tileX, tileY;                          // origin of the 32x32-pixel LDS tile, or tileX < 0: no tile
+	int32_t  tileX, tileY;                          // origin of the LDS tile, or tileX < 0: no tile
 };
-static constexpr int TILE = 32;                     // LDS tile edge for nodes that are small on screen (BASELINE config 5)
+static constexpr int TILE = 128;
+static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a frame: 2 G visible samples
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
 enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4 };
@@ -147,51 +154,66 @@ __global__ __launch_bounds__(TPB) void r_vis1(RenderArgs a) {
 }
 
 // ---- visibility pass 2: emit the disjunct set of nodes to draw (render.cu:746-756, 906-933) ----------------------
-__device__ void make_visible(const RenderArgs& a, const SimlodNode* node) {
-	const uint32_t idx = atomicAdd(counter_at(a, C_VISIBLE), 1u);
+// The lanes of a wave that emit a node take their slots with ONE atomic per wave and counter (device-scope atomics on one word
+// retire at ~11 ns each: 700 visible nodes x 3 counters would serialise for 20 us).
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+__device__ void make_visible(const RenderArgs& a, const SimlodNode* node) {     // node == nullptr: this lane emits nothing (all lanes call)
+	const bool emit = node != nullptr;
+	const unsigned long long mask = __ballot(emit);
+	if (mask == 0ull) return;
+	const uint32_t lane = (uint32_t)lane_id(), leader = (uint32_t)__ffsll((long long)mask) - 1u;
+	const uint32_t pts = emit && node->numPoints > 0 ? node->numPoints : 0u, vox = emit && node->numPoints == 0 && node->numVoxels > 0 ? node->numVoxels : 0u;
+	const uint32_t nLeaves = wave_sum_u32(pts > 0 ? 1u : 0u), nInner = wave_sum_u32(vox > 0 ? 1u : 0u), sumPts = wave_sum_u32(pts), sumVox = wave_sum_u32(vox);
+	uint32_t first = 0;
+	if (lane == leader) {
+		first = atomicAdd(counter_at(a, C_VISIBLE), (uint32_t)__popcll(mask));
+		if (nLeaves) { atomicAdd(counter_at(a, C_LEAVES), nLeaves); atomicAdd(counter_at(a, C_POINTS), sumPts); }
+		if (nInner) { atomicAdd(counter_at(a, C_INNER), nInner); atomicAdd(counter_at(a, C_VOXELS), sumVox); }
+	}
+	first = __shfl(first, (int)leader);
+	if (!emit) return;
+	const uint32_t idx = first + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 	if (idx >= SIMLOD_MAX_VISIBLE_NODES) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); return; }
 	const ulonglong1* src = reinterpret_cast<const ulonglong1*>(node);
 	ulonglong1* dst = reinterpret_cast<ulonglong1*>(a.mom + R_OFF_VISIBLE + (uint64_t)idx * sizeof(SimlodNode));
 #pragma unroll
 	for (int k = 0; k < (int)(sizeof(SimlodNode) / 8); k++) dst[k] = src[k];
-	if (node->numPoints > 0) { atomicAdd(counter_at(a, C_LEAVES), 1u); atomicAdd(counter_at(a, C_POINTS), node->numPoints); }
-	else if (node->numVoxels > 0) { atomicAdd(counter_at(a, C_INNER), 1u); atomicAdd(counter_at(a, C_VOXELS), node->numVoxels); }
 }
 
 __global__ __launch_bounds__(TPB) void r_vis2(RenderArgs a) {
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= numNodes) return;
-	const SimlodNode* n = a.nodes + i;
-	if (!n->isLarge) return;
-	if (!node_is_leaf(n)) {
-		for (int k = 0; k < 8; k++) {
-			const SimlodNode* ch = n->children[k];
-			if (ch == nullptr || ch->isLarge || !ch->visible) continue;
-			make_visible(a, ch);
-		}
-	} else if (n->visible) {
-		make_visible(a, n);
+	const SimlodNode* n = i < numNodes ? a.nodes + i : nullptr;
+	const bool large = n != nullptr && n->isLarge;
+	const bool leaf = large && node_is_leaf(n);
+	for (int k = 0; k < 8; k++) {                      // every lane of the wave goes through the same eight emission rounds
+		const SimlodNode* ch = large && !leaf ? n->children[k] : nullptr;
+		if (ch != nullptr && (ch->isLarge || !ch->visible)) ch = nullptr;
+		make_visible(a, ch);
 	}
+	make_visible(a, leaf && n->visible ? n : nullptr);
 }
 
-// ---- draw items: cut every visible node's chunk lists into pieces of <= 8 chunks -------------------------------------
-// The reference gives one workgroup a whole node (render.cu:179-207): a 50 000-point leaf next to a 300-voxel node.  One
-// lane per visible node walks the node's two lists ONCE per frame (the only serial pointer chase left in a frame) and
-// emits evenly sized items, so that the draw kernels are balanced over all 256 CUs whatever the node sizes are.
+// ---- draw items + the frame's chunk directory ----------------------------------------------------------------------------------------
+// The reference gives one workgroup a whole node and lets it chase the chunk list while it draws (render.cu:106-159, 179-207).  Here
+// one lane per visible node walks the node's two lists ONCE per frame — the only serial pointer chase left in a frame — and writes
+// every chunk address into a directory; a draw workgroup then streams an item's samples straight through the directory.
 __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 	const uint32_t numVisible = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= numVisible || !a.showPoints) return;
 	const SimlodNode* node = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE) + i;
-	uint32_t* numItems = reinterpret_cast<uint32_t*>(a.mom + a.offWork) + 3;
+	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
 	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
-	// Screen box of the node's cube: a node that fits a 32x32-pixel tile is accumulated in LDS and flushed once per touched
-	// pixel (samples that fall outside the tile anyway take the global path, so this is an optimisation hint only).
+	const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
+	// the LDS tile sits at the low corner of the node's screen box (samples that fall outside it take the global path)
 	int tileX = -1, tileY = -1;
 	if (a.useTiles) {
 		const float nodeSize = a.cubeSize / exp2_int(node->level);
-		float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+		float mnx = 3.0e38f, mny = 3.0e38f;
 		bool front = true;
 		for (int k = 0; k < 8; k++) {
 			const float x = a.minx + ((float)node->X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)node->Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
@@ -199,26 +221,30 @@ __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 			const float cw = dot_row(a.transform.rows[3], x, y, z);
 			if (!(cw > 0.0f)) { front = false; break; }
 			const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
-			mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx); mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+			mnx = fminf(mnx, sx); mny = fminf(mny, sy);
 		}
-		if (front && mxx - mnx + (float)a.pointSize + 2.0f <= (float)TILE && mxy - mny + (float)a.pointSize + 2.0f <= (float)TILE && mnx > -1.0e6f && mny > -1.0e6f) {
-			tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0);
-		}
+		if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) { tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0); }
 	}
 	const SimlodChunk* heads[2] = {node->points, node->voxelChunks};
 	const uint32_t counts[2] = {node->numPoints, node->numVoxels};
 	for (int l = 0; l < 2; l++) {
-		uint32_t left = counts[l];
-		if (left == 0 || heads[l] == nullptr) continue;
-		const uint32_t pieces = (left + ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK - 1) / (ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK);
-		const uint32_t base = atomicAdd(numItems, pieces);
+		const uint32_t total = counts[l];
+		if (total == 0 || heads[l] == nullptr) continue;
+		const uint32_t numChunks = (total + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t pieces = (numChunks + ITEM_CHUNKS - 1) / ITEM_CHUNKS;
+		const uint32_t dirBase = atomicAdd(work + 4, numChunks), itemBase = atomicAdd(work + 3, pieces);
+		if (dirBase + numChunks > MAX_DIR_CHUNKS || itemBase + pieces > a.itemCap) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); continue; }
 		const SimlodChunk* chunk = heads[l];
-		for (uint32_t p = 0; p < pieces && chunk != nullptr; p++) {
-			const uint32_t take = min(left, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK);
-			if (base + p < a.itemCap) { DrawItem it; it.first = chunk; it.samples = take; it.visibleIdx = i; it.tileX = tileX; it.tileY = tileY; items[base + p] = it; }
-			else atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);
-			left -= take;
-			for (uint32_t k = 0; k < ITEM_CHUNKS && chunk != nullptr && left > 0; k++) chunk = chunk->next;
+		uint32_t k = 0;
+		for (; k < numChunks && chunk != nullptr; k++) { dir[dirBase + k] = chunk; chunk = chunk->next; }
+		const uint32_t have = min(total, k * SIMLOD_POINTS_PER_CHUNK);          // a list shorter than its counter says: draw what is there
+		for (uint32_t p = 0; p < pieces; p++) {
+			const uint32_t firstSample = p * ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK;
+			DrawItem it;
+			it.dirBase = dirBase + p * ITEM_CHUNKS;
+			it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
+			it.visibleIdx = i; it.tileX = tileX; it.tileY = tileY;
+			items[itemBase + p] = it;
 		}
 	}
 }
@@ -251,7 +277,8 @@ struct DrawCtx {
 	uint32_t* depth;
 	unsigned long long* color;   // HQS colour sums, packed: B (14 bits) | G << 14 | R << 28 | count << 42
 	unsigned long long* overflow;// 2 x u64 per pixel {R | G << 32, B | count << 32}: samples beyond the 64th of a pixel
-	unsigned long long* tile;    // LDS: TILE*TILE x 2 words (MIN64: word 0 = min; DEPTH: low 32 bits of word 0; COLOR: both words)
+	unsigned long long* tile;    // LDS, TILE*TILE entries: MIN64 the 64-bit minimum, COLOR the packed sums (DEPTH uses tile32)
+	uint32_t* tile32;            // LDS, TILE*TILE entries: DEPTH the minimum of the depth bits
 	int tileX, tileY;            // tile origin; tileX < 0: no tile
 };
 
@@ -281,13 +308,20 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 				const unsigned t = tx + ty * TILE;
 				if (MODE == MODE_MIN64) {
 					const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
-					if (enc < c.tile[2 * t]) atomicMin(&c.tile[2 * t], enc);
+					if (enc < c.tile[t]) atomicMin(&c.tile[t], enc);
 				} else if (MODE == MODE_DEPTH) {
-					uint32_t* d = reinterpret_cast<uint32_t*>(&c.tile[2 * t]);
-					if (dbits < *d) atomicMin(d, dbits);
+					if (dbits < c.tile32[t]) atomicMin(&c.tile32[t], dbits);
 				} else if (depth < __uint_as_float(c.depth[pixel]) * 1.01f) {
-					atomicAdd(&c.tile[2 * t + 0], (unsigned long long)(color & 0xffu) | ((unsigned long long)((color >> 8) & 0xffu) << 32));
-					atomicAdd(&c.tile[2 * t + 1], (unsigned long long)((color >> 16) & 0xffu) | (1ull << 32));
+					// the packed sums of the global plane, in LDS: B | G << 14 | R << 28 | count << 42; the 65th sample of a pixel
+					// inside one item takes its addend back and goes to the global overflow plane (exact for any count)
+					const unsigned long long r = color & 0xffu, g = (color >> 8) & 0xffu, b = (color >> 16) & 0xffu;
+					const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
+					const unsigned long long old = atomicAdd(&c.tile[t], pk);
+					if ((old >> 42) >= 64ull) {
+						atomicAdd(&c.tile[t], 0ull - pk);
+						atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
+						atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
+					}
 				}
 				continue;
 			}
@@ -318,50 +352,52 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 }
 
 template <int MODE>
-__device__ __forceinline__ void draw_list(const DrawCtx& c, const SimlodChunk* chunk, uint32_t count, uint32_t overrideColor, bool useOverride) {
-	uint32_t done = 0;
-	while (done < count && chunk != nullptr) {        // render.cu:106-159: chunk i holds samples [1000 i, 1000 i + 1000)
-		const SimlodChunk* next = chunk->next;         // start the pointer chase before streaming the chunk
-		const uint32_t inChunk = min(count - done, SIMLOD_POINTS_PER_CHUNK);
-		const float4* src = reinterpret_cast<const float4*>(chunk->points);
-		for (uint32_t j = threadIdx.x; j < inChunk; j += TPB) draw_sample<MODE>(c, src[j], overrideColor, useOverride);
-		done += inChunk;
-		chunk = next;
+__device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* const* dir, uint32_t count, uint32_t overrideColor, bool useOverride) {
+	// render.cu:106-159: chunk i holds samples [1000 i, 1000 i + 1000); the chunk addresses come from the frame's directory
+	for (uint32_t s = threadIdx.x; s < count; s += DTPB) {
+		const SimlodChunk* chunk = dir[s / SIMLOD_POINTS_PER_CHUNK];
+		draw_sample<MODE>(c, reinterpret_cast<const float4*>(chunk->points)[s % SIMLOD_POINTS_PER_CHUNK], overrideColor, useOverride);
 	}
 }
 
 template <int MODE>
-__device__ __forceinline__ void tile_clear(unsigned long long* tile) {
-	for (int t = threadIdx.x; t < TILE * TILE; t += TPB) { tile[2 * t] = MODE == MODE_COLOR ? 0ull : ~0ull; tile[2 * t + 1] = 0ull; }
+__device__ __forceinline__ void tile_clear(const DrawCtx& c) {
+	for (int t = threadIdx.x; t < TILE * TILE; t += DTPB) {
+		if (MODE == MODE_DEPTH) c.tile32[t] = 0xffffffffu; else c.tile[t] = MODE == MODE_COLOR ? 0ull : ~0ull;
+	}
 }
 
 // One global atomic per TOUCHED pixel of the tile; the merged values go through the same test-before-atomic as single samples.
 template <int MODE>
 __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
-	for (int t = threadIdx.x; t < TILE * TILE; t += TPB) {
+	for (int t = threadIdx.x; t < TILE * TILE; t += DTPB) {
 		const int px = c.tileX + (t % TILE), py = c.tileY + (t / TILE);
+		if (px > c.W || py > c.H) continue;
 		const uint32_t pixel = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
 		if (pixel >= c.numPixels) continue;
 		if (MODE == MODE_MIN64) {
-			const unsigned long long v = c.tile[2 * t];
+			const unsigned long long v = c.tile[t];
 			if (v != ~0ull && v < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), v);
 		} else if (MODE == MODE_DEPTH) {
-			const uint32_t v = (uint32_t)c.tile[2 * t];
+			const uint32_t v = c.tile32[t];
 			if (v != 0xffffffffu && v < c.depth[pixel]) atomicMin(&c.depth[pixel], v);
 		} else {
-			const unsigned long long rg = c.tile[2 * t], bc = c.tile[2 * t + 1];
-			if ((bc >> 32) != 0ull) { atomicAdd(&c.overflow[2 * pixel + 0], rg); atomicAdd(&c.overflow[2 * pixel + 1], bc); }   // exact: resolve adds both planes
+			const unsigned long long pk = c.tile[t];
+			if (pk != 0ull) {                                 // exact: resolve adds the packed plane and the {R, G, B, count} plane
+				atomicAdd(&c.overflow[2 * pixel + 0], ((pk >> 28) & 0x3fffull) | (((pk >> 14) & 0x3fffull) << 32));
+				atomicAdd(&c.overflow[2 * pixel + 1], (pk & 0x3fffull) | ((pk >> 42) << 32));
+			}
 		}
 	}
 }
 
 template <int MODE>
-__global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
+__global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	if (!a.showPoints) return;
 	__shared__ uint32_t sh_idx;
-	__shared__ unsigned long long sh_tile[TILE * TILE * 2];
+	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? TILE * TILE / 2 : TILE * TILE];
 	DrawCtx c;
-	c.tile = sh_tile; c.tileX = -1; c.tileY = -1;
+	c.tile = sh_tile; c.tile32 = reinterpret_cast<uint32_t*>(sh_tile); c.tileX = -1; c.tileY = -1;
 	c.r0 = a.transform.rows[0]; c.r1 = a.transform.rows[1]; c.r3 = a.transform.rows[3];
 	c.width = a.width; c.height = a.height;
 	c.wlim = (double)a.width - 2.0; c.hlim = (double)a.height - 2.0;
@@ -374,9 +410,9 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 	uint32_t* cursor = work + MODE;
 	const uint32_t numItems = min(work[3], a.itemCap);
 	const DrawItem* items = reinterpret_cast<const DrawItem*>(a.mom + a.offItems);
+	const SimlodChunk* const* dir = reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offDir);
 	const SimlodNode* visible = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE);
-	// Workgroup-level queue of draw items.  The first item of a workgroup is its own index — 2048 workgroups fetching
-	// their first item from ONE counter would serialise at ~11 ns per atomic — the following ones come from a shared
+	// Workgroup-level queue of draw items.  The first item of a workgroup is its own index, the following ones come from a shared
 	// cursor that starts behind the statically assigned range.
 	uint32_t idx = blockIdx.x;
 	while (idx < numItems) {
@@ -388,8 +424,8 @@ __global__ __launch_bounds__(TPB) void r_draw(RenderArgs a) {
 			useOverride = true;
 		}
 		c.tileX = it.tileX; c.tileY = it.tileY;
-		if (it.tileX >= 0) { tile_clear<MODE>(sh_tile); __syncthreads(); }
-		draw_list<MODE>(c, it.first, it.samples, overrideColor, useOverride);
+		if (it.tileX >= 0) { tile_clear<MODE>(c); __syncthreads(); }
+		draw_item<MODE>(c, dir + it.dirBase, it.samples, overrideColor, useOverride);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
@@ -653,12 +689,12 @@ __global__ __launch_bounds__(TPB) void k_reset(uint8_t* pers, SimlodNode* nodes,
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-static constexpr uint32_t MAX_DRAW_ITEMS = 400000;   // 100 000 visible nodes x 2 lists + 1.6 G visible samples / 8000
+static constexpr uint32_t MAX_DRAW_ITEMS = 400000;   // 100 000 visible nodes x 2 lists + slices of long voxel lists
 static inline uint64_t align16(uint64_t v) { return (v + 15) / 16 * 16; }
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 	const uint64_t px = (uint64_t)width * height;
-	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + 256;
+	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + (uint64_t)MAX_DIR_CHUNKS * 8 + 256;
 }
 
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
@@ -667,12 +703,13 @@ int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, Siml
 	return (int)hipGetLastError();
 }
 
-static void render_plane_offsets(uint64_t numPixels, uint64_t& offWork, uint64_t& offItems, uint64_t& offDepth, uint64_t& offColor, uint64_t& offOverflow) {
+static void render_plane_offsets(uint64_t numPixels, uint64_t& offWork, uint64_t& offItems, uint64_t& offDepth, uint64_t& offColor, uint64_t& offOverflow, uint64_t* offDir = nullptr) {
 	offWork = R_OFF_FB + align16(numPixels * 8);
 	offItems = offWork + 256;
 	offDepth = offItems + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem);
 	offColor = offDepth + align16(numPixels * 4);
 	offOverflow = offColor + align16(numPixels * 8);
+	if (offDir != nullptr) *offDir = offOverflow + numPixels * 16;
 }
 
 uint64_t render_depth_plane_offset(uint32_t width, uint32_t height) {
@@ -701,16 +738,15 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.nodeCapacity = node_capacity();
 	a.frameCounter = (uint32_t)u->frameCounter;
 	a.showPoints = u->showPoints; a.colorByNode = u->colorByNode; a.colorByLOD = u->colorByLOD; a.hqs = u->useHighQualityShading;
-	render_plane_offsets(a.numPixels, a.offWork, a.offItems, a.offDepth, a.offColor, a.offOverflow);
+	render_plane_offsets(a.numPixels, a.offWork, a.offItems, a.offDepth, a.offColor, a.offOverflow, &a.offDir);
 	a.itemCap = MAX_DRAW_ITEMS;
 	a.useTiles = (uint32_t)tune("SIMLOD_RASTER_LDS_TILES", 1);
 
 	const DeviceInfo& dev = device_info();
 	const uint32_t gridPixels = dev.numCUs * 8;
 	const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
-	// four draw workgroups per CU: measured at 1080p on the 36 M terrain, 8 -> 4 takes the plain frame from 0.40 to 0.36 ms and the
-	// HQS frame from 1.05 to 1.01 ms (2: 0.37 / 1.05, 12: 0.40 / 1.07) — fewer waves contend for the same framebuffer lines
-	const uint32_t gridDraw = dev.numCUs * (uint32_t)tune("SIMLOD_DRAW_MULT", 4);
+	// one draw workgroup per CU: its 128 x 128-pixel tile takes 64-128 KB of the CU's 160 KB of LDS
+	const uint32_t gridDraw = dev.numCUs * (uint32_t)tune("SIMLOD_DRAW_MULT", 1);
 	const bool whole = parts == RENDER_ALL;
 	auto lines = [&]() {
 		if (!u->showBoundingBox) return;
@@ -722,11 +758,11 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 		SIMLOD_LAUNCH(r_vis1, dim3(gridNodes), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(r_vis2, dim3(gridNodes), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(r_items, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a);
-		if (a.hqs) SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(TPB), stream, a);
-		else { SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(TPB), stream, a); lines(); }
+		if (a.hqs) SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw * 2), dim3(DTPB), stream, a);
+		else { SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(DTPB), stream, a); lines(); }
 	}
 	if (a.hqs && (parts & RENDER_COLOR)) {
-		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(DTPB), stream, a);
 		if (!whole) SIMLOD_LAUNCH(r_unpack, dim3(gridPixels), dim3(TPB), stream, a);     // ranks all-reduce(SUM) the {R,G,B,count} plane
 	}
 	if (a.hqs && (parts & RENDER_RESOLVE)) {
