@@ -188,13 +188,17 @@ __global__ __launch_bounds__(TPB) void r_vis2(RenderArgs a) {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	const SimlodNode* n = i < numNodes ? a.nodes + i : nullptr;
 	const bool large = n != nullptr && n->isLarge;
-	const bool leaf = large && node_is_leaf(n);
-	for (int k = 0; k < 8; k++) {                      // every lane of the wave goes through the same eight emission rounds
-		const SimlodNode* ch = large && !leaf ? n->children[k] : nullptr;
-		if (ch != nullptr && (ch->isLarge || !ch->visible)) ch = nullptr;
-		make_visible(a, ch);
-	}
-	make_visible(a, leaf && n->visible ? n : nullptr);
+	// the eight child pointers, then the eight children's flags: two rounds of independent loads instead of eight dependent pairs
+	const SimlodNode* ch[8];
+	bool leaf = true;
+#pragma unroll
+	for (int k = 0; k < 8; k++) { ch[k] = large ? n->children[k] : nullptr; leaf = leaf && ch[k] == nullptr; }
+	bool take[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++) take[k] = ch[k] != nullptr && !ch[k]->isLarge && ch[k]->visible;
+#pragma unroll
+	for (int k = 0; k < 8; k++) make_visible(a, take[k] ? ch[k] : nullptr);      // every lane of the wave goes through the same emission rounds
+	make_visible(a, large && leaf && n->visible ? n : nullptr);
 }
 
 // ---- draw items + the frame's chunk directory ----------------------------------------------------------------------------------------

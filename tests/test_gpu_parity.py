@@ -823,7 +823,7 @@ def test_reference_host_functions_drive_the_library(built_libs, tmp_path, kind):
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "reference host functions")
     img = np.fromfile(str(tmp_path / "f.ppm"), dtype=np.uint8, offset=15).reshape(360, 640, 3)
     drawn = int((img != np.array([0x11, 0x22, 0x33], dtype=np.uint8)).any(axis=2).sum())
-    assert drawn > 5000, f"only {drawn} pixels drawn; harness said: {out.stdout[-600:]}"
+    assert drawn > (5000 if kind == "simlod" else 1500), f"only {drawn} pixels drawn; harness said: {out.stdout[-600:]}"
 
 
 def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs, chain):
