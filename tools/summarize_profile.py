@@ -16,6 +16,7 @@ def short(name):
     return n.strip()
 
 summary = {}
+seen_first = {}
 trace = find("trace/**/*kernel_trace.csv")
 if trace:
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
@@ -28,7 +29,10 @@ if trace:
     summary["kernel_trace"] = {k: {"calls": a[0], "total_us": round(a[1], 1), "avg_us": round(a[1] / a[0], 2), "min_us": round(a[2], 2),
                                    "max_us": round(a[3], 2), "pct": round(100 * a[1] / total, 2)} for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 
-for name, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+for name, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]),
+                       ("pmc_sq", ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]),
+                       ("pmc_lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS"]),
+                       ("pmc_atomic", ["TCC_EA0_ATOMIC_sum", "TCC_ATOMIC_sum"]), ("pmc_atomic2", ["TCC_EA0_ATOMIC_LEVEL_sum", "TCC_EA0_RDREQ_sum"])):
     path = find(f"{name}/**/*counter_collection.csv")
     if not path:
         continue
@@ -39,9 +43,10 @@ for name, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE
             c = row["Counter_Name"]
             if c in counters:
                 agg[k][c] += float(row["Counter_Value"])
-                if c == counters[0]:
+                first = seen_first.setdefault((name, k), c)
+                if c == first:
                     calls[k] += 1
-    summary[name] = {k: {"dispatches": calls[k], **{c: v[c] for c in counters}} for k, v in agg.items()}
+    summary[name] = {k: {"dispatches": calls[k], **{c: v[c] for c in counters if c in v}} for k, v in agg.items()}
 
 # HBM traffic per kernel, as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE counts 64 B per
 # 128-B request of a wide coalesced stream (read side may be under-counted by up to 2x; scattered 4-16 B accesses are uncalibrated).
@@ -52,6 +57,19 @@ if "pmc_fetch" in summary and "pmc_write" in summary:
         traffic[k] = {"dispatches": v["dispatches"], "fetch_bytes_raw": v["FETCH_SIZE"] * 1024, "fetch_bytes_x2": v["FETCH_SIZE"] * 2048,
                       "write_bytes": w["WRITE_SIZE"] * 1024}
 summary["hbm_traffic"] = traffic
+# wave-level picture per kernel: share of wave cycles spent waiting (s_waitcnt / barriers), issuing, stalled at issue
+if "pmc_sq" in summary:
+    for k, v in summary["pmc_sq"].items():
+        wc = v.get("SQ_WAVE_CYCLES", 0.0)
+        if wc > 0:
+            v["wait_any_frac"] = v.get("SQ_WAIT_ANY", 0.0) / wc
+            v["wait_inst_frac"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
+            v["active_inst_frac"] = v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+if "pmc_l2" in summary:
+    for k, v in summary["pmc_l2"].items():
+        t = v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)
+        if t > 0:
+            v["hit_rate"] = v.get("TCC_HIT_sum", 0.0) / t
 os.makedirs("gpurun_out", exist_ok=True)
 with open(os.path.join("gpurun_out", f"profile_summary_{tag}.json"), "w") as f:
     json.dump(summary, f, indent=1)
