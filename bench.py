@@ -190,6 +190,8 @@ def main():
             dev.render(u)
 
     raster = {}
+    tfile = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    rtraffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
     for name, hqs in (("hqs", 1), ("plain", 0)):
         u["useHighQualityShading"] = hqs
         for _ in range(2):
@@ -214,7 +216,9 @@ def main():
         raster[name] = {"value": vs / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,
                         "visible_samples": int(vs), "visible_nodes": int(st["numVisibleNodes"]),
                         "roofline": {"bound": "hbm", "achieved": rb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "algorithmic_bytes_per_frame": rb, "traffic": None}}
+                                     "algorithmic_bytes_per_frame": rb,
+                                     "traffic": (rtraffic["r_draw<MODE_DEPTH>"] + rtraffic["r_draw<MODE_COLOR>"] if hqs else rtraffic["r_draw<MODE_MIN64>"]) if "r_draw<MODE_MIN64>" in rtraffic else None,
+                                     "traffic_source": "profiles/traffic_r02.json: draw kernels of one frame (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if rtraffic else None}}
     u["useHighQualityShading"] = 1
 
     # ---- per-kernel attribution with HIP events on the launch stream (separate, untimed pass) --------------------
@@ -353,6 +357,9 @@ def main():
         # B0: the reference's own sources compiled as host code (oracle/_ref, built where /root/reference exists and
         # shipped as binaries), timed on BASELINE config 1: 1 M uniform points, one batch, 512 x 512 frame.  Quadratic list walks
         #  make it a correctness reference, not a fast CPU implementation.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)                 # the reference's reset.cu prints ("resetting octree"): stdout must carry ONE JSON line only
+        os.dup2(2, 1)
         try:
             if oracle.have_ref():
                 p1, b1 = synthetic.uniform_cube(1_000_000, seed=1234)
@@ -371,6 +378,10 @@ def main():
                                                        "compiled as host C++ (clang -O2) vs the restatement", "kind": "reference", **res}
         except Exception as e:                     # the baseline must never take the bench down
             cpu["config1_reference_B0"] = {"error": repr(e)}
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     if rank == 0:
         out = {

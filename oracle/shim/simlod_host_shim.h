@@ -12,6 +12,12 @@
  * grid.num_blocks() returns 0x7fffffff so that render.cu:1273 computes tilesPerBlock = 0 and the
  * launch-geometry-dependent EDL pass is skipped: the framebuffer that comes back is the
  * pre-EDL uint64 image.
+ *
+ * -DSIMLOD_SHIM_EDL (oracle/_ref/libref_render_edl.so): the EDL pass runs, one in-tile thread per kernel call.
+ * grid.num_blocks() is only used by the EDL block (render.cu:1273, 1279); it returns 1 — ONE block takes every full 16x16 tile —
+ * and from that call on block.thread_rank() returns simlod_shim_edl_rank instead of 0, so a call shades pixel #rank of every tile
+ * (render.cu:1284).  256 calls with rank = 0..255, each re-rendering the same frame, shade every pixel of every full tile with the
+ * reference's own EDL arithmetic; the caller collects pixel #rank of each tile after call #rank.
  */
 #pragma once
 
@@ -84,17 +90,28 @@ template <class T, class U> inline T atomicMin(T* p, U v) { T old = *p; if ((T)v
 template <class T, class U> inline T atomicMax(T* p, U v) { T old = *p; if ((T)v > old) *p = (T)v; return old; }
 
 /* ---- cooperative groups ---------------------------------------------------------------------------- */
+#ifdef SIMLOD_SHIM_EDL
+extern "C" { inline int simlod_shim_edl_rank = 0; inline int simlod_shim_in_edl = 0; }
+#endif
 namespace cooperative_groups {
 struct grid_group {
 	void sync() const {}
 	unsigned long long thread_rank() const { return 0; }
 	unsigned long long size() const { return 1; }
 	unsigned long long num_threads() const { return 1; }
+#ifdef SIMLOD_SHIM_EDL
+	unsigned num_blocks() const { simlod_shim_in_edl = 1; return 1u; }
+#else
 	unsigned num_blocks() const { return 0x7fffffffu; }   /* disables EDL, see header comment */
+#endif
 };
 struct thread_block {
 	void sync() const {}
+#ifdef SIMLOD_SHIM_EDL
+	unsigned thread_rank() const { return simlod_shim_in_edl ? (unsigned)simlod_shim_edl_rank : 0u; }
+#else
 	unsigned thread_rank() const { return 0; }
+#endif
 	unsigned size() const { return 1; }
 	unsigned num_threads() const { return 1; }
 	dim3 group_index() const { return dim3{0, 0, 0}; }
