@@ -137,3 +137,29 @@ def test_render_edge_cases_match_reference(built_libs, variant):
     assert_stats_equal(frames["port"][1], frames["ref"][1], STATS_RENDER_FIELDS, variant)
     assert np.array_equal(frames["ref"][2], frames["port"][2])
     assert int((frames["ref"][0] != abi.CLEAR_PIXEL).sum()) > 50
+
+
+def test_edl_restatement_matches_the_reference_edl_block():
+    """EDL (render.cu:1255-1325) pinned to the reference itself: tests/golden/edl_uniform_3x40k.npz was minted by running the
+    reference's own render.cu with its EDL pass enabled, one in-tile thread per call (tests/golden/make_golden_edl.py).  The
+    restatement's EDL'd RGBA8 image must agree within 1 per channel (log2 / exp come from different libms) on every full 16x16 tile.
+    The last row is left out: there the reference reads the depth of pixel W*H — one past the framebuffer (render.cu:1303)."""
+    import os
+    from cases import H, W, batches_of, case, uniforms_for
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "edl_uniform_3x40k.npz"))
+    pts, box, batch, T = case("uniform_3x40k")
+    u = uniforms_for(box, T)
+    o = oracle.HostOctree("port", persistent_bytes=1 << 28, ring_slots=8)
+    o.reset(u)
+    for b in batches_of("uniform_3x40k", pts, batch):
+        o.upload(b)
+    while int(o.stats["batchletIndex"][0]) < int(o.num_uploaded[0]):
+        o.construct(u)
+    rows = np.arange(W * H) // W
+    cmp = rows < H - 1
+    for mode, hqs in (("plain", False), ("hqs", True)):
+        fb, col = o.render(uniforms_for(box, T, hqs=hqs), edl=True)
+        want = G[f"color_{mode}"]
+        d = np.abs(col.view(np.uint8).astype(np.int16) - want.view(np.uint8).astype(np.int16)).reshape(-1, 4).max(axis=1)
+        assert int(d[cmp].max()) <= 1, f"{mode}: {int((d[cmp] > 1).sum())} pixels differ by more than 1 from the reference's EDL output"
+        assert int((want & 0xffffff != (fb & 0xffffff).astype(np.uint32)).sum()) > 1000, "the fixture must actually be shaded"
