@@ -81,6 +81,15 @@ int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms /*host
                          uint32_t* colorbuffer, SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint,
                          void* stream);
 
+/* colorfilter.cu:163-169  `kernel` of the colour-filter module (its host call is commented out in the reference,
+ * main_progressive_octree.cpp:430-462): every voxel of every inner node becomes the average colour of the child samples in its cell,
+ * bottom-up, ten levels of inner nodes per call.  `buffer` is the momentary buffer (Uniforms.momentaryBufferCapacity bytes, at least
+ * simlod_colorfilter_buffer_min_bytes()); `numNodes` is a DEVICE pointer to the node count, or NULL for Stats.numNodes.  Voxel
+ * positions, counts and list structure stay as they are; Node.isFiltered is set on every node that was processed. */
+int simlod_launch_colorfilter(const SimlodUniforms* uniforms /*host*/, uint32_t* buffer, SimlodNode* nodes, uint32_t* numNodes,
+                              SimlodStats* stats, void* stream);
+uint64_t simlod_colorfilter_buffer_min_bytes(void);
+
 /* kernel_render in four parts, for frames composed across GPUs (the reference is single-GPU).  Every rank calls the
  * parts in order on its own octree and reduces the named plane of the render buffer over all ranks in between:
  *   part 0  clear, visibility, first pass — plain: the 64-bit atomicMin pass and the debug lines; HQS: the depth pass
@@ -104,7 +113,7 @@ typedef struct SimlodFunction SimlodFunction;
 
 /* Mirrors CudaModularProgram's constructor: module paths are matched by file name (reset.cu,
  * progressive_octree_voxels.cu, render.cu, utils.cu); the device code is precompiled for gfx950, nothing is
- * compiled at run time.  Unknown kernel names make the call fail with hipErrorNotFound. */
+ * compiled at run time (colorfilter.cu -> `kernel` is known as well).  Unknown kernel names make the call fail with hipErrorNotFound. */
 int simlod_program_create(SimlodProgram** out, const char* const* modules, int numModules,
                           const char* const* kernels, int numKernels);
 void simlod_program_destroy(SimlodProgram* program);

@@ -261,6 +261,25 @@ def rebase_image_to(nodes, num_nodes, persistent, old_nodes_base, old_persistent
     return r
 
 
+_REF_FILTER = os.path.join(_HERE, "_ref", "libref_filter.so")
+
+
+def have_ref_filter():
+    return os.path.exists(_REF_FILTER)
+
+
+def ref_colorfilter(nodes, num_nodes, uniforms, stats=None):
+    """The reference's colour filter (colorfilter.cu `kernel`, compiled in place into oracle/_ref/libref_filter.so) on a HOST-addressed
+    octree image, in place: voxel colours become averages, Node.isFiltered is set."""
+    lib = ctypes.CDLL(_REF_FILTER)
+    port_lib().ref_call_filter.argtypes = [ctypes.c_void_p] * 6
+    u = np.ascontiguousarray(uniforms).reshape(1)
+    buf = np.zeros(16 << 20, dtype=np.uint8)
+    n = np.array([num_nodes], dtype=np.uint32)
+    st = np.zeros(1, dtype=abi.stats_dtype) if stats is None else stats
+    port_lib().ref_call_filter(ctypes.cast(lib.kernel, ctypes.c_void_p), _ptr(u), _ptr(buf), _ptr(nodes), _ptr(n), _ptr(st))
+
+
 def check_invariants(nodes, num_nodes, allow_overfull=False):
     """Structural invariants of a HOST-addressed image; returns dict of totals or raises AssertionError(rule).
     allow_overfull: accept leaves above 50 000 points (splits deferred for lack of scratch space)."""

@@ -32,6 +32,12 @@ void ref_call_render(void* fn, uint32_t* buffer, const SimlodUniforms* u, Simlod
 	((ref_render_fn)fn)(buffer, *u, nodes, (unsigned long long)(uintptr_t)surface, stats, frameStart, cudaprint);
 }
 
+/* colorfilter.cu:163-169 (oracle/_ref/libref_filter.so) */
+typedef void (*ref_filter_fn)(const SimlodUniforms, uint32_t*, SimlodNode*, uint32_t*, SimlodStats*);
+void ref_call_filter(void* fn, const SimlodUniforms* u, uint32_t* buffer, SimlodNode* nodes, uint32_t* numNodes, SimlodStats* stats) {
+	((ref_filter_fn)fn)(*u, buffer, nodes, numNodes, stats);
+}
+
 void ref_call_reset(void* fn, const SimlodUniforms* u, uint8_t* persistent, SimlodNode* nodes, SimlodStats* stats,
                     void* cudaprint, uint32_t* numBatchesUploaded, uint32_t* batchSizes) {
 	((ref_reset_fn)fn)(*u, persistent, nodes, stats, cudaprint, numBatchesUploaded, batchSizes);

@@ -99,6 +99,7 @@ struct grid_group {
 	unsigned long long thread_rank() const { return 0; }
 	unsigned long long size() const { return 1; }
 	unsigned long long num_threads() const { return 1; }
+	unsigned block_rank() const { return 0; }                /* colorfilter.cu:192 */
 #ifdef SIMLOD_SHIM_EDL
 	unsigned num_blocks() const { simlod_shim_in_edl = 1; return 1u; }
 #else

@@ -66,7 +66,7 @@ void profile_mark(const char* kernelName, hipStream_t stream) {
 
 void profile_close(hipStream_t stream) { profile_mark(nullptr, stream); }
 
-enum KernelKind { KIND_RESET = 0, KIND_CONSTRUCT = 1, KIND_RENDER = 2 };
+enum KernelKind { KIND_RESET = 0, KIND_CONSTRUCT = 1, KIND_RENDER = 2, KIND_FILTER = 3 };
 
 }  // namespace simlod
 
@@ -142,6 +142,13 @@ int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPer
 	return launch_decode_las(records, numPoints, bytesPerPoint, format, scale, offset, out, (hipStream_t)stream);
 }
 
+int simlod_launch_colorfilter(const SimlodUniforms* uniforms, uint32_t* buffer, SimlodNode* nodes, uint32_t* numNodes, SimlodStats* stats, void* stream) {
+	if (!uniforms || !buffer || !nodes || (!numNodes && !stats)) return (int)hipErrorInvalidValue;
+	return launch_colorfilter(uniforms, buffer, nodes, numNodes, stats, (hipStream_t)stream);
+}
+
+uint64_t simlod_colorfilter_buffer_min_bytes(void) { return colorfilter_min_bytes(node_capacity()); }
+
 int simlod_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
                             const float tileExtent[3], void* stream) {
 	return launch_generate_terrain(out, numPoints, firstIndex, pointsPerTile, seed, tilesX, tileExtent, (hipStream_t)stream);
@@ -173,19 +180,21 @@ int simlod_program_create(SimlodProgram** out, const char* const* modules, int n
 	if (!out) return (int)hipErrorInvalidValue;
 	*out = nullptr;
 	SimlodProgram* p = new SimlodProgram();
-	bool hasReset = false, hasUpdate = false, hasRender = false;
+	bool hasReset = false, hasUpdate = false, hasRender = false, hasFilter = false;
 	for (int i = 0; i < numModules; i++) {
 		p->modules.emplace_back(modules[i] ? modules[i] : "");
 		const std::string& m = p->modules.back();
 		hasReset |= ends_with(m, "reset.cu");
 		hasUpdate |= ends_with(m, "progressive_octree_voxels.cu");
 		hasRender |= ends_with(m, "render.cu");
+		hasFilter |= ends_with(m, "colorfilter.cu");
 	}
 	for (int i = 0; i < numKernels; i++) {
 		const std::string k = kernels[i] ? kernels[i] : "";
 		SimlodFunction f;
 		f.name = k;
 		if (k == "kernel" && hasReset) f.kind = KIND_RESET;
+		else if (k == "kernel" && hasFilter) f.kind = KIND_FILTER;
 		else if (k == "kernel_construct" && hasUpdate) f.kind = KIND_CONSTRUCT;
 		else if (k == "kernel_render" && hasRender) f.kind = KIND_RENDER;
 		else { delete p; return (int)hipErrorNotFound; }
@@ -221,6 +230,8 @@ int simlod_launch_cooperative(SimlodFunction* fn, unsigned gx, unsigned gy, unsi
 		return simlod_launch_construct((const SimlodUniforms*)args[0], *(SimlodPoint**)args[1], *(uint32_t**)args[2], *(uint8_t**)args[3],
 		                               *(SimlodNode**)args[4], *(SimlodStats**)args[5], *(uint64_t**)args[6], *(void**)args[7],
 		                               *(uint32_t**)args[8], *(uint32_t**)args[9], stream);
+	case KIND_FILTER:     // colorfilter.cu:164-169: (Uniforms, buffer, nodes, numNodes, stats)
+		return simlod_launch_colorfilter((const SimlodUniforms*)args[0], *(uint32_t**)args[1], *(SimlodNode**)args[2], *(uint32_t**)args[3], *(SimlodStats**)args[4], stream);
 	case KIND_RENDER:     // main_progressive_octree.cpp:499-507
 		return simlod_launch_render(*(uint32_t**)args[0], (const SimlodUniforms*)args[1], *(SimlodNode**)args[2], *(uint32_t**)args[3],
 		                            *(SimlodStats**)args[4], *(uint64_t**)args[5], *(void**)args[6], stream);

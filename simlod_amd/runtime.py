@@ -61,6 +61,8 @@ def lib():
         L.simlod_build_info.restype = ctypes.c_char_p
         L.simlod_decode_las.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double), vp, vp]
+        L.simlod_launch_colorfilter.argtypes = [vp] * 6
+        L.simlod_colorfilter_buffer_min_bytes.restype = u64
         L.simlod_generate_terrain.argtypes = [vp, u64, u64, u64, u32, u32, ctypes.POINTER(ctypes.c_float), vp]
         _lib = L
     return _lib
@@ -72,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
     "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
-    "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain",
+    "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 
 
@@ -210,6 +212,18 @@ class DeviceOctree:
         self.drain(uniforms)
         self.processed_host = self.uploaded_host
         return h
+
+    def colorfilter(self, uniforms):
+        """colorfilter.cu's `kernel`: average voxel colours, bottom-up (simlod_launch_colorfilter); the momentary buffer is its scratch."""
+        # scratch = the render buffer, not kernel_construct's momentary buffer: the builder's recycle stack lives there and has to survive
+        # (the reference, whose filter call is dead code, would run it on the momentary buffer after the last batch only)
+        uu = np.array(uniforms, copy=True)
+        need = int(self.L.simlod_colorfilter_buffer_min_bytes())
+        if self.render_buffer.numel() < need:
+            self.render_buffer = torch.empty(need, dtype=torch.uint8, device=self.device)
+        uu["momentaryBufferCapacity"] = self.render_buffer.numel()
+        u, up = self._u(uu)
+        _check(self.L.simlod_launch_colorfilter(up, self._p(self.render_buffer), self._p(self.nodes), None, self._p(self.stats), self._stream()), "colorfilter kernel")
 
     def generate_terrain(self, out, first_index, points_per_tile, seed, tiles_x, tile_extent):
         """BASELINE config 4's input made on the device: points first_index .. first_index + len(out)/16 - 1 of the tiled-terrain stream

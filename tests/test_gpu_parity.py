@@ -981,3 +981,43 @@ def test_device_generated_tiles_are_deterministic_seamless_and_ingest_like_the_o
     assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "generated tiles")
     nodes, pers, nn = host_image_of(dev)
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "generated tiles")
+
+
+# ---- row f-4: voxel colour filtering (colorfilter.cu) -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,n", [("uniform", 1_000_000), ("terrain", 3_000_000)])
+def test_colorfilter_equals_the_reference_kernel_on_the_same_octree(built_libs, kind, n):
+    """simlod_launch_colorfilter against colorfilter.cu itself (oracle/_ref/libref_filter.so: the reference's file compiled in place
+    as host code): same octree image in, the voxels of every inner node must come out with the same positions AND the same averaged
+    colours (as multisets: the order inside a node's voxel list follows the order of first hits, scheduling dependent in the reference
+    too), Node.isFiltered must agree, points must be untouched."""
+    if not oracle.have_ref_filter():
+        pytest.skip("oracle/_ref/libref_filter.so was not built (no reference checkout where the snapshot was made)")
+    pts, box = synthetic.uniform_cube(n, seed=41) if kind == "uniform" else synthetic.terrain(n, seed=6, box=(1500.0, 1000.0, 100.0), tile=125.0)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(ring_slots=4)
+    u = dev.uniforms(W, H, T, box)
+    _ingest(dev, u, [pts[i:i + abi.MAX_BATCH_SIZE] for i in range(0, n, abi.MAX_BATCH_SIZE)])
+    nodes_a, pers_a, nn = host_image_of(dev)                      # the image as built ...
+    oracle.ref_colorfilter(nodes_a, nn, u)                        # ... filtered by the reference's own kernel on the host
+    dev.colorfilter(u)                                            # ... and by the HIP kernels on the device
+    nodes_b, pers_b, nn_b = host_image_of(dev)
+    assert nn == nn_b
+    assert np.array_equal(nodes_a["isFiltered"][:nn], nodes_b["isFiltered"][:nn])
+    inner = 0
+    for i in range(nn):
+        nv = int(nodes_a[i]["numVoxelsStored"])
+        assert nv == int(nodes_b[i]["numVoxelsStored"]) and int(nodes_a[i]["numPoints"]) == int(nodes_b[i]["numPoints"])
+        if nv == 0:
+            continue
+        va = oracle.gather_samples(int(nodes_a[i]["voxelChunks"]), nv)
+        vb = oracle.gather_samples(int(nodes_b[i]["voxelChunks"]), nv)
+        ka, kb = np.sort(va.view(np.dtype((np.void, 16))).reshape(-1)), np.sort(vb.view(np.dtype((np.void, 16))).reshape(-1))
+        assert np.array_equal(ka, kb), f"node {i} (level {int(nodes_a[i]['level'])}): filtered voxels differ from the reference kernel's"
+        inner += 1
+    assert inner >= (1 if kind == "uniform" else 20)
+    d = oracle.dump_image(nodes_b, nn)
+    hs, hx = points_multiset_hash(pts)
+    with np.errstate(over="ignore"):
+        assert hs == np.uint64(d["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(d["pointsXor"]), "the filter must not touch the points"
+    dev.render(u)                                                 # and the octree is still drawable
+    assert int((dev.framebuffer(W, H) != abi.CLEAR_PIXEL).sum()) > 1000
