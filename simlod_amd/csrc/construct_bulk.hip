@@ -713,16 +713,22 @@ __global__ __launch_bounds__(TPB, 4) void k_ingest(BuildArgs a) {
 			const uint32_t i = j * TPB + threadIdx.x;
 			p[j] = i < cnt ? pts[i] : make_float4(0, 0, 0, 0);
 		}
+		{
+			uint32_t X[P], Y[P], Z[P], level[P];
+			bool walking[P];
+#pragma unroll
+			for (int j = 0; j < P; j++) {
+				walking[j] = (uint32_t)j * TPB + threadIdx.x < cnt;
+				X[j] = quantize(F_GRID, p[j].x, a.minx, a.size); Y[j] = quantize(F_GRID, p[j].y, a.miny, a.size); Z[j] = quantize(F_GRID, p[j].z, a.minz, a.size);
+				leafOf[j] = walking[j] ? 0u : NONE; level[j] = 0; er[j] = NONE;
+			}
+			descend_lockstep<P>(a.nodes, leafOf, level, X, Y, Z, walking);
+		}
 #pragma unroll
 		for (int j = 0; j < P; j++) {
 			const uint32_t i = j * TPB + threadIdx.x;
-			leafOf[j] = NONE; er[j] = NONE;
-			if (i >= cnt) continue;
-			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
-			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
-			const uint32_t Z = quantize(F_GRID, p[j].z, a.minz, a.size);
-			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
-			leafOf[j] = leafIdx;
+			if (i >= cnt) { leafOf[j] = NONE; continue; }
+			const uint32_t leafIdx = leafOf[j];
 			uint32_t rank;
 			const int e = tab_add(sh.lt, leafIdx, 1u, &rank);
 			if (e >= 0) er[j] = ((uint32_t)e << 16) | rank;
@@ -1174,15 +1180,27 @@ __global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
 			p[j] = q < numPending ? point_of(a, ctl, pendIdx[q]) : spilled[q - numPending];
 			leafOf[j] = meta & 0x7ffffu;
 		}
+		{
+			uint32_t X[P], Y[P], Z[P], level[P];
+			bool walking[P];
 #pragma unroll
-		for (int j = 0; j < P; j++) {
-			if (leafOf[j] == NONE) continue;
-			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
-			const uint32_t cached = leafOf[j];
-			leafOf[j] = (uint32_t)(descend(a.nodes + cached, (int)a.nodes[cached].level, X, Y, Z) - a.nodes);
-			uint32_t rank;
-			const int e = tab_add(sh.lt, leafOf[j], 1u, &rank);
-			if (e >= 0) er[j] = ((uint32_t)e << 16) | rank;
+			for (int j = 0; j < P; j++) {
+				walking[j] = leafOf[j] != NONE;
+				X[j] = quantize(F_GRID, p[j].x, a.minx, a.size); Y[j] = quantize(F_GRID, p[j].y, a.miny, a.size); Z[j] = quantize(F_GRID, p[j].z, a.minz, a.size);
+				level[j] = walking[j] ? a.nodes[leafOf[j]].level : 0u;              // from the cached node down
+				if (!walking[j]) leafOf[j] = 0u;
+			}
+			bool valid[P];
+#pragma unroll
+			for (int j = 0; j < P; j++) valid[j] = walking[j];
+			descend_lockstep<P>(a.nodes, leafOf, level, X, Y, Z, walking);
+#pragma unroll
+			for (int j = 0; j < P; j++) {
+				if (!valid[j]) { leafOf[j] = NONE; continue; }
+				uint32_t rank;
+				const int e = tab_add(sh.lt, leafOf[j], 1u, &rank);
+				if (e >= 0) er[j] = ((uint32_t)e << 16) | rank;
+			}
 		}
 		__syncthreads();
 		timer.lap(0);
@@ -1648,9 +1666,10 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X: the barrier's agent-scope release / acquire and the polling cost grow with the participants
-		const uint32_t expandWgs = (uint32_t)std::max(1, std::min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
+		// (one batch at a time; a coalesced group scans tens of millions of waiting samples per round: every CU takes part)
+		const uint32_t expandWgs = (uint32_t)std::max(1, std::min(tune("SIMLOD_EXPAND_WGS", coalesce ? (int)dev.numCUs : (int)dev.numCUs / 2), (int)dev.numCUs));
 		const bool cooperative = tune("SIMLOD_EXPAND_COOPERATIVE", 0) != 0;
-		const bool peek = tune("SIMLOD_PEEK", 1) != 0;
+		const bool peek = tune("SIMLOD_PEEK", coalesce ? 0 : 1) != 0;    // the forecast pays when batches come one at a time (measured: coalesced 6.49 vs 6.60 ms without)
 		const uint32_t groups = coalesce ? (limit + a.groupMax - 1) / a.groupMax : limit;
 		for (uint32_t g = 0; g < groups; g++) {
 			if (peek) SIMLOD_LAUNCH(k_peek, dim3(dev.numCUs * 2), dim3(TPB), stream, a);

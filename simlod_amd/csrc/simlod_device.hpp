@@ -56,6 +56,27 @@ __device__ __forceinline__ SimlodNode* descend(SimlodNode* cur, int level, uint3
 	return cur;
 }
 
+// P descents in lockstep, one level per step: the P child-pointer loads of a step are independent, so a thread keeps P L2 round trips
+// in flight instead of walking its samples one after the other (a descent is a chain of 5-8 dependent loads).
+template <int P>
+__device__ __forceinline__ void descend_lockstep(SimlodNode* nodes, uint32_t (&cur)[P], uint32_t (&level)[P], const uint32_t (&X)[P], const uint32_t (&Y)[P],
+                                                 const uint32_t (&Z)[P], bool (&walking)[P]) {
+	bool any = true;
+#pragma unroll 1
+	for (int step = 0; step < SIMLOD_MAX_DEPTH && any; ++step) {
+		SimlodNode* ch[P];
+#pragma unroll
+		for (int j = 0; j < P; j++)
+			ch[j] = walking[j] && level[j] < (uint32_t)SIMLOD_MAX_DEPTH ? nodes[cur[j]].children[child_index(X[j], Y[j], Z[j], (int)level[j])] : nullptr;
+		any = false;
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			if (ch[j] != nullptr) { cur[j] = (uint32_t)(ch[j] - nodes); level[j] += 1u; any = true; }
+			else walking[j] = false;
+		}
+	}
+}
+
 __device__ __forceinline__ uint64_t wall_ns() { return (uint64_t)wall_clock64() * 10ull; }   // 100 MHz constant clock
 
 // AllocatorGlobal::alloc for `count` objects of `size` bytes each, as ONE atomic (utils.h.cu:185-197 advances the
