@@ -101,6 +101,7 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)       # the C library's buffer too (the print came through printf), while fd 1 still points away
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run"
@@ -383,6 +384,7 @@ def main():
             cpu["config1_reference_B0"] = {"error": repr(e)}
         finally:
             sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)       # the C library's buffer too (the print came through printf), while fd 1 still points away
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 

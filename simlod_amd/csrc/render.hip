@@ -55,8 +55,10 @@ struct DrawItem {
 	uint32_t dirBase;                               // first entry of the item's chunks in the frame's chunk directory
 	uint32_t samples, visibleIdx;
 	int32_t  tileX, tileY;                          // origin of the LDS tile, or tileX < 0: no tile
+	uint32_t tileWH;                                // its extent, width | height << 16: the node's screen box, at most TILE x TILE
 };
 static constexpr int TILE = 128;
+static constexpr int TILE_EXACT_AREA = TILE * TILE / 2;   // HQS colour: tiles up to this area keep two 64-bit words per pixel (exact 32-bit sums)
 static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a frame: 2 G visible samples
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
@@ -215,9 +217,10 @@ __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 	const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
 	// the LDS tile sits at the low corner of the node's screen box (samples that fall outside it take the global path)
 	int tileX = -1, tileY = -1;
+	uint32_t tileW = TILE, tileH = TILE;
 	if (a.useTiles) {
 		const float nodeSize = a.cubeSize / exp2_int(node->level);
-		float mnx = 3.0e38f, mny = 3.0e38f;
+		float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
 		bool front = true;
 		for (int k = 0; k < 8; k++) {
 			const float x = a.minx + ((float)node->X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)node->Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
@@ -225,9 +228,14 @@ __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 			const float cw = dot_row(a.transform.rows[3], x, y, z);
 			if (!(cw > 0.0f)) { front = false; break; }
 			const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
-			mnx = fminf(mnx, sx); mny = fminf(mny, sy);
+			mnx = fminf(mnx, sx); mny = fminf(mny, sy); mxx = fmaxf(mxx, sx); mxy = fmaxf(mxy, sy);
 		}
-		if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) { tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0); }
+		if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) {
+			tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0);
+			// the tile covers the node's screen box (a small node clears and flushes a small tile), capped at TILE x TILE
+			tileW = (uint32_t)min(max((int)fminf(mxx, 1.0e6f) - tileX + a.pointSize + 2, 1), TILE);
+			tileH = (uint32_t)min(max((int)fminf(mxy, 1.0e6f) - tileY + a.pointSize + 2, 1), TILE);
+		}
 	}
 	const SimlodChunk* heads[2] = {node->points, node->voxelChunks};
 	const uint32_t counts[2] = {node->numPoints, node->numVoxels};
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
 			DrawItem it;
 			it.dirBase = dirBase + p * ITEM_CHUNKS;
 			it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
-			it.visibleIdx = i; it.tileX = tileX; it.tileY = tileY;
+			it.visibleIdx = i; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16);
 			items[itemBase + p] = it;
 		}
 	}
@@ -284,6 +292,8 @@ struct DrawCtx {
 	unsigned long long* tile;    // LDS, TILE*TILE entries: MIN64 the 64-bit minimum, COLOR the packed sums (DEPTH uses tile32)
 	uint32_t* tile32;            // LDS, TILE*TILE entries: DEPTH the minimum of the depth bits
 	int tileX, tileY;            // tile origin; tileX < 0: no tile
+	int tileW, tileH;            // tile extent
+	bool tileExact;              // COLOR: two words per pixel {R | G << 32, B | count << 32} instead of the packed word
 };
 
 template <int MODE>
@@ -308,13 +318,16 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 		if (pixel >= c.numPixels) continue;                 // only reachable for pointSize >= 4 (out of bounds in the reference)
 		if (c.tileX >= 0) {                                 // LDS-staged accumulation for nodes that are small on screen
 			const unsigned tx = (unsigned)(px - c.tileX), ty = (unsigned)(py - c.tileY);
-			if (tx < (unsigned)TILE && ty < (unsigned)TILE) {
-				const unsigned t = tx + ty * TILE;
+			if (tx < (unsigned)c.tileW && ty < (unsigned)c.tileH) {
+				const unsigned t = tx + ty * (unsigned)c.tileW;
 				if (MODE == MODE_MIN64) {
 					const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
 					if (enc < c.tile[t]) atomicMin(&c.tile[t], enc);
 				} else if (MODE == MODE_DEPTH) {
 					if (dbits < c.tile32[t]) atomicMin(&c.tile32[t], dbits);
+				} else if (depth < __uint_as_float(c.depth[pixel]) * 1.01f && c.tileExact) {
+					atomicAdd(&c.tile[2 * t + 0], (unsigned long long)(color & 0xffu) | ((unsigned long long)((color >> 8) & 0xffu) << 32));
+					atomicAdd(&c.tile[2 * t + 1], (unsigned long long)((color >> 16) & 0xffu) | (1ull << 32));
 				} else if (depth < __uint_as_float(c.depth[pixel]) * 1.01f) {
 					// the packed sums of the global plane, in LDS: B | G << 14 | R << 28 | count << 42; the 65th sample of a pixel
 					// inside one item takes its addend back and goes to the global overflow plane (exact for any count)
@@ -366,7 +379,8 @@ __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* c
 
 template <int MODE>
 __device__ __forceinline__ void tile_clear(const DrawCtx& c) {
-	for (int t = threadIdx.x; t < TILE * TILE; t += DTPB) {
+	const int words = c.tileW * c.tileH * (MODE == MODE_COLOR && c.tileExact ? 2 : 1);
+	for (int t = threadIdx.x; t < words; t += DTPB) {
 		if (MODE == MODE_DEPTH) c.tile32[t] = 0xffffffffu; else c.tile[t] = MODE == MODE_COLOR ? 0ull : ~0ull;
 	}
 }
@@ -374,8 +388,8 @@ __device__ __forceinline__ void tile_clear(const DrawCtx& c) {
 // One global atomic per TOUCHED pixel of the tile; the merged values go through the same test-before-atomic as single samples.
 template <int MODE>
 __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
-	for (int t = threadIdx.x; t < TILE * TILE; t += DTPB) {
-		const int px = c.tileX + (t % TILE), py = c.tileY + (t / TILE);
+	for (int t = threadIdx.x; t < c.tileW * c.tileH; t += DTPB) {
+		const int px = c.tileX + (t % c.tileW), py = c.tileY + (t / c.tileW);
 		if (px > c.W || py > c.H) continue;
 		const uint32_t pixel = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
 		if (pixel >= c.numPixels) continue;
@@ -385,6 +399,9 @@ __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
 		} else if (MODE == MODE_DEPTH) {
 			const uint32_t v = c.tile32[t];
 			if (v != 0xffffffffu && v < c.depth[pixel]) atomicMin(&c.depth[pixel], v);
+		} else if (c.tileExact) {
+			const unsigned long long rg = c.tile[2 * t], bc = c.tile[2 * t + 1];
+			if ((bc >> 32) != 0ull) { atomicAdd(&c.overflow[2 * pixel + 0], rg); atomicAdd(&c.overflow[2 * pixel + 1], bc); }
 		} else {
 			const unsigned long long pk = c.tile[t];
 			if (pk != 0ull) {                                 // exact: resolve adds the packed plane and the {R, G, B, count} plane
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	__shared__ uint32_t sh_idx;
 	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? TILE * TILE / 2 : TILE * TILE];
 	DrawCtx c;
-	c.tile = sh_tile; c.tile32 = reinterpret_cast<uint32_t*>(sh_tile); c.tileX = -1; c.tileY = -1;
+	c.tile = sh_tile; c.tile32 = reinterpret_cast<uint32_t*>(sh_tile); c.tileX = -1; c.tileY = -1; c.tileW = TILE; c.tileH = TILE; c.tileExact = false;
 	c.r0 = a.transform.rows[0]; c.r1 = a.transform.rows[1]; c.r3 = a.transform.rows[3];
 	c.width = a.width; c.height = a.height;
 	c.wlim = (double)a.width - 2.0; c.hlim = (double)a.height - 2.0;
@@ -427,7 +444,8 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 			overrideColor = a.colorByNode ? node_color(node) : lod_color((int)node->level);
 			useOverride = true;
 		}
-		c.tileX = it.tileX; c.tileY = it.tileY;
+		c.tileX = it.tileX; c.tileY = it.tileY; c.tileW = (int)(it.tileWH & 0xffffu); c.tileH = (int)(it.tileWH >> 16);
+		c.tileExact = c.tileW * c.tileH <= TILE_EXACT_AREA;
 		if (it.tileX >= 0) { tile_clear<MODE>(c); __syncthreads(); }
 		draw_item<MODE>(c, dir + it.dirBase, it.samples, overrideColor, useOverride);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
