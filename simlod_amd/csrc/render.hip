@@ -368,12 +368,128 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 	}
 }
 
+// One sample per lane, the whole wave in step (point size 1, tile in use): when every lane that hits the tile hits the SAME pixel —
+// the rule in BASELINE config 5, where thousands of samples of a node fall on one pixel — the wave reduces its values with
+// cross-lane shuffles and ONE lane issues the LDS atomic (64 same-address LDS atomics serialise).  Otherwise every lane issues its
+// own, as draw_sample does.  Same test-before-atomic rules, same values: the tile ends up identical.
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+	for (int o = 32; o > 0; o >>= 1) {
+		const unsigned long long w = ((unsigned long long)__shfl_xor((uint32_t)(v >> 32), o, 64) << 32) | __shfl_xor((uint32_t)v, o, 64);
+		v = w < v ? w : v;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+	return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, const bool have, const uint32_t overrideColor, const bool useOverride) {
+	const float cx = dot_row(c.r0, p.x, p.y, p.z);
+	const float cy = dot_row(c.r1, p.x, p.y, p.z);
+	const float depth = dot_row(c.r3, p.x, p.y, p.z);
+	const float nx = cx / depth, ny = cy / depth;
+	const double fx = ((double)nx * 0.5 + 0.5) * (double)c.width;
+	const double fy = ((double)ny * 0.5 + 0.5) * (double)c.height;
+	const int x = (int)fx, y = (int)fy;
+	bool valid = have && (x > 1 && (double)x < c.wlim) && (y > 1 && (double)y < c.hlim);
+	if (MODE != MODE_MIN64) valid = valid && depth > 0.0f;
+	const uint32_t dbits = __float_as_uint(depth);
+	const uint32_t color = useOverride ? overrideColor : __float_as_uint(p.w);
+	const int px = min(max(x, 0), c.W), py = min(max(y, 0), c.H);
+	const uint32_t pixel = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
+	valid = valid && pixel < c.numPixels;
+	const unsigned tx = (unsigned)(px - c.tileX), ty = (unsigned)(py - c.tileY);
+	const bool inTile = valid && tx < (unsigned)c.tileW && ty < (unsigned)c.tileH;
+	const unsigned t = tx + ty * (unsigned)c.tileW;
+	bool accept = true;
+	if (MODE == MODE_COLOR) accept = valid && depth < __uint_as_float(c.depth[valid ? pixel : 0u]) * 1.01f;
+	const bool mine = inTile && accept;
+	const unsigned long long mask = __ballot(mine);
+	bool uniform = false;
+	unsigned t0 = 0;
+	if (mask != 0ull && (MODE != MODE_COLOR || c.tileExact)) {
+		t0 = (unsigned)__shfl((int)t, (int)(__ffsll((long long)mask) - 1), 64);
+		uniform = __popcll(mask) >= 8 && __ballot(mine && t == t0) == mask;
+	}
+	if (uniform) {                                   // wave-uniform branch: every lane takes part in the shuffles
+		const bool leader = (unsigned)lane_id() == (unsigned)(__ffsll((long long)mask) - 1);
+		if (MODE == MODE_MIN64) {
+			const unsigned long long v = wave_min_u64(mine ? (((unsigned long long)dbits << 32) | color) : ~0ull);
+			if (leader && v < c.tile[t0]) atomicMin(&c.tile[t0], v);
+		} else if (MODE == MODE_DEPTH) {
+			const uint32_t v = wave_min_u32(mine ? dbits : 0xffffffffu);
+			if (leader && v < c.tile32[t0]) atomicMin(&c.tile32[t0], v);
+		} else {
+			uint32_t rg = mine ? ((color & 0xffu) | (((color >> 8) & 0xffu) << 16)) : 0u, bc = mine ? (((color >> 16) & 0xffu) | (1u << 16)) : 0u;
+			for (int o = 32; o > 0; o >>= 1) { rg += __shfl_xor(rg, o, 64); bc += __shfl_xor(bc, o, 64); }   // 64 x 255 < 2^16: no carry between the halves
+			if (leader) {
+				atomicAdd(&c.tile[2 * t0 + 0], (unsigned long long)(rg & 0xffffu) | ((unsigned long long)(rg >> 16) << 32));
+				atomicAdd(&c.tile[2 * t0 + 1], (unsigned long long)(bc & 0xffffu) | ((unsigned long long)(bc >> 16) << 32));
+			}
+		}
+	} else if (mine) {
+		if (MODE == MODE_MIN64) {
+			const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
+			if (enc < c.tile[t]) atomicMin(&c.tile[t], enc);
+		} else if (MODE == MODE_DEPTH) {
+			if (dbits < c.tile32[t]) atomicMin(&c.tile32[t], dbits);
+		} else if (c.tileExact) {
+			atomicAdd(&c.tile[2 * t + 0], (unsigned long long)(color & 0xffu) | ((unsigned long long)((color >> 8) & 0xffu) << 32));
+			atomicAdd(&c.tile[2 * t + 1], (unsigned long long)((color >> 16) & 0xffu) | (1ull << 32));
+		} else {
+			const unsigned long long r = color & 0xffu, g = (color >> 8) & 0xffu, b = (color >> 16) & 0xffu;
+			const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
+			const unsigned long long old = atomicAdd(&c.tile[t], pk);
+			if ((old >> 42) >= 64ull) {
+				atomicAdd(&c.tile[t], 0ull - pk);
+				atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
+				atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
+			}
+		}
+	}
+	if (valid && !inTile) {                          // outside the tile: the global path of draw_sample
+		if (MODE == MODE_MIN64) {
+			const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
+			if (enc < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), enc);
+		} else if (MODE == MODE_DEPTH) {
+			if (dbits < c.depth[pixel]) atomicMin(&c.depth[pixel], dbits);
+		} else if (accept) {
+			const unsigned long long r = color & 0xffu, g = (color >> 8) & 0xffu, b = (color >> 16) & 0xffu;
+			const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
+			const unsigned long long old = atomicAdd(&c.color[pixel], pk);
+			if ((old >> 42) >= 64ull) {
+				atomicAdd(&c.color[pixel], 0ull - pk);
+				atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
+				atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
+			}
+		}
+	}
+}
+
 template <int MODE>
 __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* const* dir, uint32_t count, uint32_t overrideColor, bool useOverride) {
-	// render.cu:106-159: chunk i holds samples [1000 i, 1000 i + 1000); the chunk addresses come from the frame's directory
-	for (uint32_t s = threadIdx.x; s < count; s += DTPB) {
-		const SimlodChunk* chunk = dir[s / SIMLOD_POINTS_PER_CHUNK];
-		draw_sample<MODE>(c, reinterpret_cast<const float4*>(chunk->points)[s % SIMLOD_POINTS_PER_CHUNK], overrideColor, useOverride);
+	// render.cu:106-159: chunk i holds samples [1000 i, 1000 i + 1000); the chunk addresses come from the frame's directory (staged in LDS).
+	// Four samples per thread are loaded before the first is drawn: the loads overlap instead of queueing behind the atomics.
+	constexpr uint32_t DU = 4;
+	const bool wave = c.pointSize == 1 && c.tileX >= 0;
+	for (uint32_t base = 0; base < count; base += DTPB * DU) {          // uniform trip count: the whole wave stays in step
+		float4 p[DU];
+		bool have[DU];
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) {
+			const uint32_t s = base + u * DTPB + threadIdx.x;
+			have[u] = s < count;
+			p[u] = have[u] ? reinterpret_cast<const float4*>(dir[s / SIMLOD_POINTS_PER_CHUNK]->points)[s % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
+		}
+		if (wave) {
+#pragma unroll
+			for (uint32_t u = 0; u < DU; u++) draw_wave<MODE>(c, p[u], have[u], overrideColor, useOverride);
+		} else {
+#pragma unroll
+			for (uint32_t u = 0; u < DU; u++) if (have[u]) draw_sample<MODE>(c, p[u], overrideColor, useOverride);
+		}
 	}
 }
 
@@ -416,6 +532,7 @@ template <int MODE>
 __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	if (!a.showPoints) return;
 	__shared__ uint32_t sh_idx;
+	__shared__ const SimlodChunk* sh_dir[ITEM_CHUNKS];
 	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? TILE * TILE / 2 : TILE * TILE];
 	DrawCtx c;
 	c.tile = sh_tile; c.tile32 = reinterpret_cast<uint32_t*>(sh_tile); c.tileX = -1; c.tileY = -1; c.tileW = TILE; c.tileH = TILE; c.tileExact = false;
@@ -446,8 +563,10 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 		}
 		c.tileX = it.tileX; c.tileY = it.tileY; c.tileW = (int)(it.tileWH & 0xffffu); c.tileH = (int)(it.tileWH >> 16);
 		c.tileExact = c.tileW * c.tileH <= TILE_EXACT_AREA;
-		if (it.tileX >= 0) { tile_clear<MODE>(c); __syncthreads(); }
-		draw_item<MODE>(c, dir + it.dirBase, it.samples, overrideColor, useOverride);
+		if (threadIdx.x < ITEM_CHUNKS && threadIdx.x * SIMLOD_POINTS_PER_CHUNK < it.samples) sh_dir[threadIdx.x] = dir[it.dirBase + threadIdx.x];
+		if (it.tileX >= 0) tile_clear<MODE>(c);
+		__syncthreads();
+		draw_item<MODE>(c, sh_dir, it.samples, overrideColor, useOverride);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
