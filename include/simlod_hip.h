@@ -57,6 +57,14 @@ int simlod_set_ingest_mode(uint32_t mode);
  * main_progressive_octree.cpp:1012-1050).  A launch never ingests more than this many batches.  Process-wide. */
 int simlod_set_construct_batch_limit(uint32_t maxBatches);
 
+/* kernel_render reads the chunk lists of visible nodes through a table kernel_construct keeps in ITS momentary buffer (one row of chunk
+ * addresses per node), for as long as a stamp in that buffer says the table describes the octree in `nodes` as it is now: same node
+ * array, same Stats.batchletIndex / numNodes / numPoints / numVoxels / allocatedBytes_persistent as after the last kernel_construct.
+ * kernel_reset drops the association.  A host that writes an octree image into `nodes` / the persistent buffer by other means
+ * (memcpy of a saved image) calls this afterwards; kernel_render then walks the `next` pointers, as the reference does
+ * (render.cu:106-159), until kernel_construct has run again. */
+int simlod_octree_image_replaced(const SimlodNode* nodes);
+
 /* Byte offset of the uint64 framebuffer inside kernel_render's momentary `buffer` (identical to where the
  * reference's bump allocator places it, render.cu:1108-1123) and the minimum size of that buffer. */
 uint64_t simlod_render_framebuffer_offset(void);

@@ -56,6 +56,7 @@ struct Ctl {
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
+	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
 };
 
 struct BuildArgs {
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 		const SimlodNode* c = n->children[k];
 		if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
 	}
-	if (ctl_of(a)->rebuildLeafChunks && node_is_leaf(n)) {
+	if (ctl_of(a)->rebuildLeafChunks) {      // a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser)
 		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
-		const SimlodChunk* c = n->points;
+		const SimlodChunk* c = node_is_leaf(n) ? n->points : n->voxelChunks;
 		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
 	}
 }
@@ -768,12 +769,14 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		if (required > existing) {
 			const uint32_t additional = required - existing;
 			uint8_t* fresh = persistent_alloc(a.pers, sizeof(SimlodChunk), additional);   // voxel chunks never come from the pool
+			const bool inner = !node_is_leaf(node);
 			for (uint32_t k = 0; k < additional; k++) {
 				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
 				c->next = nullptr;
 				if (tail == nullptr) { node->voxelChunks = c; head = c; } else tail->next = c;
 				tail = c;
 				chunkDir[base + e++] = c;
+				if (inner && existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;   // an inner node's row lists its voxel chunks
 			}
 			tail_of(head) = tail;
 		}
@@ -1019,6 +1022,7 @@ __global__ void k_finish(BuildArgs a, uint32_t fits) {
 		ctl->tableBatch = s->batchletIndex;
 		ctl->tableNodes = (uint64_t)a.nodes;
 		ctl->tablePers = (uint64_t)a.pers;
+		ctl->tableSig = table_signature(s);
 		ctl->tableMagic = TABLE_MAGIC;
 	}
 }
@@ -1081,6 +1085,11 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
+	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_items)
+		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
+		note_leaf_table(LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
+		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS});
+	} else forget_leaf_table(nodes);
 	const DeviceInfo& dev = device_info();
 
 	const uint32_t limit = std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH);

@@ -204,6 +204,10 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 			slots[k] = c;
 			if (c != nullptr) { last = c; c = c->next; }
 		}
+		if (!leaf) {                           // an inner node's row lists its voxel chunks (for the rasteriser, render.hip r_items)
+			SimlodChunk* v = n->voxelChunks;
+			for (uint32_t k = 0; k < LEAF_SLOTS && v != nullptr; k++) { slots[k] = v; v = v->next; }
+		}
 		// the tail pointers (8 spare bytes of a head chunk) are this implementation's own: an image built elsewhere has none
 		while (c != nullptr) { last = c; c = c->next; }
 		if (leaf && n->points != nullptr) tail_of(n->points) = last;
@@ -341,6 +345,8 @@ __device__ void make_voxel_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, ui
 	SimlodChunk* c = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), 1));   // voxel chunks never come from the pool (voxels.cu:656-659)
 	c->next = nullptr;
 	if (k == 0u) { a.nodes[node].voxelChunks = c; tail_of(c) = c; }
+	// an inner node's row of the leaf chunk table lists its voxel chunks: the rasteriser reads the list from there (render.hip r_items)
+	if (k < LEAF_SLOTS && !node_is_leaf(a.nodes + node)) at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)node * LEAF_SLOTS + k] = c;
 	dir_insert(a, ctl, KIND_VOX, node, k, c);
 }
 __device__ SimlodChunk* wait_voxel_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, uint32_t k) {
@@ -1470,6 +1476,7 @@ __global__ __launch_bounds__(TPB) void k_link(BuildArgs a) {
 		if (k == 0u) continue;
 		SimlodChunk* prev;
 		if (kind == KIND_VOX) prev = (k - 1u) * CHUNK < at<const uint32_t>(a, a.offVoxStart)[node] ? tail_of(a.nodes[node].voxelChunks) : dir_find(a, ctl, KIND_VOX, node, k - 1u);
+		else if (!node_is_leaf(a.nodes + node)) continue;         // split since: its point chunks went back to the pool, its row now lists voxel chunks
 		else if (k - 1u < LEAF_SLOTS) prev = leafChunks[(uint64_t)node * LEAF_SLOTS + k - 1u];
 		else prev = (k - 1u) * CHUNK < at<const uint32_t>(a, a.offPtStart)[node] ? tail_of(a.nodes[node].points) : dir_find(a, ctl, KIND_PT, node, k - 1u);
 		if (prev != nullptr) prev->next = dir[h].ptr;
@@ -1582,6 +1589,7 @@ __global__ void k_finish(BuildArgs a, uint32_t fits) {
 		ctl->tableBatch = s->batchletIndex;
 		ctl->tableNodes = (uint64_t)a.nodes;
 		ctl->tablePers = (uint64_t)a.pers;
+		ctl->tableSig = table_signature(s);
 		ctl->tableMagic = TABLE_MAGIC;
 	}
 }
@@ -1650,6 +1658,11 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
+	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_items)
+		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
+		note_leaf_table(LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
+		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS});
+	} else forget_leaf_table(nodes);
 	const DeviceInfo& dev = device_info();
 	const uint32_t coalesce = ingest_mode();
 	const uint32_t limit = std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH);

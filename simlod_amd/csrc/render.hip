@@ -39,6 +39,13 @@ struct RenderArgs {
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
 	uint64_t     offWork, offItems, offDepth, offColor, offOverflow, offDir;
 	uint32_t     itemCap, useTiles;
+	// the builder's leaf chunk table (simlod_internal.hpp LeafTableRef), or table == nullptr: r_items walks every list
+	const SimlodChunk* const* leafTable;
+	const uint32_t* leafTableMagic;
+	const uint32_t* leafTableBatch;
+	const uint64_t* leafTableNodes;
+	const uint64_t* leafTableSig;
+	uint32_t     leafTableMagicValue, leafTableSlots;
 };
 
 // work area: [0..2] draw cursors of the three draw modes, [3] number of draw items, [4] chunk directory entries in use
@@ -62,7 +69,7 @@ static constexpr int TILE_EXACT_AREA = TILE * TILE / 2;   // HQS colour: tiles u
 static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a frame: 2 G visible samples
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
-enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4 };
+enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5 };   // [5]: lists r_items read through the builder's chunk table
 
 // ---- clear (render.cu:1126-1131, 233-241) ---------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void r_clear(RenderArgs a) {
@@ -120,14 +127,12 @@ __device__ bool intersects_frustum(const SimlodMat4& m, const float mn[3], const
 	return inside;
 }
 
-__global__ __launch_bounds__(TPB) void r_vis1(RenderArgs a) {
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= numNodes) return;
-	SimlodNode* n = a.nodes + i;
-	const float nodeSize = a.cubeSize / exp2_int(n->level);
+// render.cu:760-861: a node's box is inside when it meets the frustum, large when its screen box spans more than 2 x minNodeSize pixels.
+// Pure geometry of (level, X, Y, Z): a node can evaluate its PARENT's `large` — (level - 1, X/2, Y/2, Z/2) — without reading it.
+__device__ __forceinline__ void node_geometry(const RenderArgs& a, uint32_t level, uint32_t X, uint32_t Y, uint32_t Z, bool& inside, bool& large) {
+	const float nodeSize = a.cubeSize / exp2_int(level);
 	const float cmin[3] = {a.minx, a.miny, a.minz};
-	const uint32_t XYZ[3] = {n->X, n->Y, n->Z};
+	const uint32_t XYZ[3] = {X, Y, Z};
 	float mn[3], mx[3];
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
@@ -149,116 +154,145 @@ __global__ __launch_bounds__(TPB) void r_vis1(RenderArgs a) {
 	const float miny = fminf(fminf(fminf(sy[0], sy[1]), fminf(sy[2], sy[3])), fminf(fminf(sy[4], sy[5]), fminf(sy[6], sy[7])));
 	const float maxy = fmaxf(fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3])), fmaxf(fmaxf(sy[4], sy[5]), fmaxf(sy[6], sy[7])));
 	const float dx = maxx - minx, dy = maxy - miny;
-	const bool visible = intersects_frustum(a.transformUpdate, mn, mx) && (n->numPoints > 0 || n->numVoxels > 0);
+	inside = intersects_frustum(a.transformUpdate, mn, mx);
 	const double lim = 2.0 * (double)a.minNodeSize;
-	n->visible = visible ? 1 : 0;
-	n->isLarge = ((double)dx > lim || (double)dy > lim) ? 1 : 0;                      // render.cu:860-861
+	large = (double)dx > lim || (double)dy > lim;                                           // render.cu:860-861
 }
 
-// ---- visibility pass 2: emit the disjunct set of nodes to draw (render.cu:746-756, 906-933) ----------------------
-// The lanes of a wave that emit a node take their slots with ONE atomic per wave and counter (device-scope atomics on one word
-// retire at ~11 ns each: 700 visible nodes x 3 counters would serialise for 20 us).
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
 	return v;
 }
-__device__ void make_visible(const RenderArgs& a, const SimlodNode* node) {     // node == nullptr: this lane emits nothing (all lanes call)
-	const bool emit = node != nullptr;
-	const unsigned long long mask = __ballot(emit);
-	if (mask == 0ull) return;
-	const uint32_t lane = (uint32_t)lane_id(), leader = (uint32_t)__ffsll((long long)mask) - 1u;
-	const uint32_t pts = emit && node->numPoints > 0 ? node->numPoints : 0u, vox = emit && node->numPoints == 0 && node->numVoxels > 0 ? node->numVoxels : 0u;
-	const uint32_t nLeaves = wave_sum_u32(pts > 0 ? 1u : 0u), nInner = wave_sum_u32(vox > 0 ? 1u : 0u), sumPts = wave_sum_u32(pts), sumVox = wave_sum_u32(vox);
-	uint32_t first = 0;
-	if (lane == leader) {
-		first = atomicAdd(counter_at(a, C_VISIBLE), (uint32_t)__popcll(mask));
-		if (nLeaves) { atomicAdd(counter_at(a, C_LEAVES), nLeaves); atomicAdd(counter_at(a, C_POINTS), sumPts); }
-		if (nInner) { atomicAdd(counter_at(a, C_INNER), nInner); atomicAdd(counter_at(a, C_VOXELS), sumVox); }
-	}
-	first = __shfl(first, (int)leader);
-	if (!emit) return;
-	const uint32_t idx = first + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-	if (idx >= SIMLOD_MAX_VISIBLE_NODES) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); return; }
-	const ulonglong1* src = reinterpret_cast<const ulonglong1*>(node);
-	ulonglong1* dst = reinterpret_cast<ulonglong1*>(a.mom + R_OFF_VISIBLE + (uint64_t)idx * sizeof(SimlodNode));
-#pragma unroll
-	for (int k = 0; k < (int)(sizeof(SimlodNode) / 8); k++) dst[k] = src[k];
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v) {      // exclusive prefix sum over the wave
+	uint32_t incl = v;
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane_id() >= o) incl += t; }
+	return incl - v;
 }
 
-__global__ __launch_bounds__(TPB) void r_vis2(RenderArgs a) {
+// ---- visibility, draw items and the frame's chunk directory: ONE launch, one lane per node -------------------------------------------------
+// The reference flags every node (render.cu:760-861), then lets every LARGE node emit its small visible children, and itself when it is
+// a visible leaf (render.cu:746-756, 906-933), then gives one workgroup a whole node and lets it chase the chunk list while it draws
+// (render.cu:106-159, 179-207).  Here a node decides about ITSELF: drawn when visible and either small under a large parent — the
+// parent's `large` is geometry of (level - 1, X/2, Y/2, Z/2), computed right here with the parent's own arithmetic — or a large leaf.
+// No lane waits for another's flags, so flags, emission and draw items are one kernel whose critical path is four memory round trips
+// (node fields; one reservation per wave; the chunk-table row; stores) instead of three kernels with twelve.
+// Draw items: a lane writes its node's chunk addresses into the frame's directory — copied from the builder's chunk table when that is
+// valid, else by walking the list (the only serial pointer chase left in a frame) — and cuts the list into items of <= 64 chunks.
+__global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	if (blockIdx.x * TPB >= numNodes) return;                                          // whole workgroup: the lanes of a wave reserve together
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	const SimlodNode* n = i < numNodes ? a.nodes + i : nullptr;
-	const bool large = n != nullptr && n->isLarge;
-	// the eight child pointers, then the eight children's flags: two rounds of independent loads instead of eight dependent pairs
-	const SimlodNode* ch[8];
+	const bool active = i < numNodes;
+	SimlodNode* n = a.nodes + (active ? i : 0u);
+	// The builder keeps, per node, the addresses of the first chunks of its list (construct_*.hip, leaf chunk table: a leaf's row lists
+	// its point chunks, an inner node's its voxel chunks) and stamps the table with the octree it describes (k_finish).  When that stamp
+	// matches THIS octree as it is now, and the node's row starts at the list's head, the row IS the list.
+	const bool tableValid = a.leafTable != nullptr && *a.leafTableMagic == a.leafTableMagicValue && *a.leafTableBatch == a.stats->batchletIndex &&
+	                        *a.leafTableNodes == (uint64_t)a.nodes && *a.leafTableSig == table_signature(a.stats);
+	const uint32_t level = n->level, X = n->X, Y = n->Y, Z = n->Z;
+	const uint32_t counts[2] = {n->numPoints, n->numVoxels};
+	const SimlodChunk* heads[2] = {n->points, n->voxelChunks};
 	bool leaf = true;
 #pragma unroll
-	for (int k = 0; k < 8; k++) { ch[k] = large ? n->children[k] : nullptr; leaf = leaf && ch[k] == nullptr; }
-	bool take[8];
-#pragma unroll
-	for (int k = 0; k < 8; k++) take[k] = ch[k] != nullptr && !ch[k]->isLarge && ch[k]->visible;
-#pragma unroll
-	for (int k = 0; k < 8; k++) make_visible(a, take[k] ? ch[k] : nullptr);      // every lane of the wave goes through the same emission rounds
-	make_visible(a, large && leaf && n->visible ? n : nullptr);
-}
+	for (int k = 0; k < 8; k++) leaf = leaf && n->children[k] == nullptr;
+	bool inside, large, parentInside, parentLarge = false;
+	node_geometry(a, level, X, Y, Z, inside, large);
+	if (level > 0u) node_geometry(a, level - 1u, X >> 1, Y >> 1, Z >> 1, parentInside, parentLarge);
+	const bool visible = inside && (counts[0] > 0u || counts[1] > 0u);
+	if (active) { n->visible = visible ? 1 : 0; n->isLarge = large ? 1 : 0; }
+	const bool emit = active && visible && (large ? leaf : parentLarge);
+	if (__ballot(emit) == 0ull) return;
 
-// ---- draw items + the frame's chunk directory ----------------------------------------------------------------------------------------
-// The reference gives one workgroup a whole node and lets it chase the chunk list while it draws (render.cu:106-159, 179-207).  Here
-// one lane per visible node walks the node's two lists ONCE per frame — the only serial pointer chase left in a frame — and writes
-// every chunk address into a directory; a draw workgroup then streams an item's samples straight through the directory.
-__global__ __launch_bounds__(TPB) void r_items(RenderArgs a) {
-	const uint32_t numVisible = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= numVisible || !a.showPoints) return;
-	const SimlodNode* node = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE) + i;
-	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
-	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
-	const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
-	// the LDS tile sits at the low corner of the node's screen box (samples that fall outside it take the global path)
-	int tileX = -1, tileY = -1;
-	uint32_t tileW = TILE, tileH = TILE;
-	if (a.useTiles) {
-		const float nodeSize = a.cubeSize / exp2_int(node->level);
-		float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
-		bool front = true;
-		for (int k = 0; k < 8; k++) {
-			const float x = a.minx + ((float)node->X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)node->Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
-			const float z = a.minz + ((float)node->Z + ((k & 1) ? 1.0f : 0.0f)) * nodeSize;
-			const float cw = dot_row(a.transform.rows[3], x, y, z);
-			if (!(cw > 0.0f)) { front = false; break; }
-			const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
-			mnx = fminf(mnx, sx); mny = fminf(mny, sy); mxx = fmaxf(mxx, sx); mxy = fmaxf(mxy, sy);
-		}
-		if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) {
-			tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0);
-			// the tile covers the node's screen box (a small node clears and flushes a small tile), capped at TILE x TILE
-			tileW = (uint32_t)min(max((int)fminf(mxx, 1.0e6f) - tileX + a.pointSize + 2, 1), TILE);
-			tileH = (uint32_t)min(max((int)fminf(mxy, 1.0e6f) - tileY + a.pointSize + 2, 1), TILE);
-		}
-	}
-	const SimlodChunk* heads[2] = {node->points, node->voxelChunks};
-	const uint32_t counts[2] = {node->numPoints, node->numVoxels};
+	// one reservation per wave and counter (returning device-scope atomics on one word retire at ~11 ns each, and a lane waits ~2.5 us
+	// for each one it depends on): visible-list slots, directory entries, draw items
+	const bool draws = emit && a.showPoints;
+	uint32_t numChunks[2], pieces[2];
+#pragma unroll
 	for (int l = 0; l < 2; l++) {
-		const uint32_t total = counts[l];
-		if (total == 0 || heads[l] == nullptr) continue;
-		const uint32_t numChunks = (total + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t pieces = (numChunks + ITEM_CHUNKS - 1) / ITEM_CHUNKS;
-		const uint32_t dirBase = atomicAdd(work + 4, numChunks), itemBase = atomicAdd(work + 3, pieces);
-		if (dirBase + numChunks > MAX_DIR_CHUNKS || itemBase + pieces > a.itemCap) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); continue; }
-		const SimlodChunk* chunk = heads[l];
-		uint32_t k = 0;
-		for (; k < numChunks && chunk != nullptr; k++) { dir[dirBase + k] = chunk; chunk = chunk->next; }
-		const uint32_t have = min(total, k * SIMLOD_POINTS_PER_CHUNK);          // a list shorter than its counter says: draw what is there
-		for (uint32_t p = 0; p < pieces; p++) {
-			const uint32_t firstSample = p * ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK;
-			DrawItem it;
-			it.dirBase = dirBase + p * ITEM_CHUNKS;
-			it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
-			it.visibleIdx = i; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16);
-			items[itemBase + p] = it;
+		const bool have = draws && counts[l] != 0u && heads[l] != nullptr;
+		numChunks[l] = have ? (counts[l] + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+		pieces[l] = (numChunks[l] + ITEM_CHUNKS - 1) / ITEM_CHUNKS;
+	}
+	const uint32_t myChunks = numChunks[0] + numChunks[1], myPieces = pieces[0] + pieces[1];
+	const uint32_t slotsBefore = wave_prefix_u32(emit ? 1u : 0u), chunksBefore = wave_prefix_u32(myChunks), piecesBefore = wave_prefix_u32(myPieces);
+	const uint32_t waveSlots = (uint32_t)__popcll(__ballot(emit)), waveChunks = wave_sum_u32(myChunks), wavePieces = wave_sum_u32(myPieces);
+	const bool isLeafDraw = emit && counts[0] > 0u, isInnerDraw = emit && counts[0] == 0u && counts[1] > 0u;   // render.cu:748-754
+	const uint32_t wLeaves = (uint32_t)__popcll(__ballot(isLeafDraw)), wInner = (uint32_t)__popcll(__ballot(isInnerDraw));
+	const uint32_t wPts = wave_sum_u32(isLeafDraw ? counts[0] : 0u), wVox = wave_sum_u32(isInnerDraw ? counts[1] : 0u);
+	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
+	uint32_t slot = 0, dirBase = 0, itemBase = 0;
+	if (lane_id() == 0) {
+		slot = atomicAdd(counter_at(a, C_VISIBLE), waveSlots);
+		if (waveChunks != 0u) { dirBase = atomicAdd(work + 4, waveChunks); itemBase = atomicAdd(work + 3, wavePieces); }
+		if (wLeaves) { atomicAdd(counter_at(a, C_LEAVES), wLeaves); atomicAdd(counter_at(a, C_POINTS), wPts); }
+		if (wInner) { atomicAdd(counter_at(a, C_INNER), wInner); atomicAdd(counter_at(a, C_VOXELS), wVox); }
+	}
+	slot = __shfl(slot, 0) + slotsBefore; dirBase = __shfl(dirBase, 0) + chunksBefore; itemBase = __shfl(itemBase, 0) + piecesBefore;
+	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
+	uint32_t throughTable = 0;
+	if (emit) {
+		const bool listed = slot < SIMLOD_MAX_VISIBLE_NODES;
+		if (!listed) atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);
+		else {
+			const ulonglong1* src = reinterpret_cast<const ulonglong1*>(n);
+			ulonglong1* dst = reinterpret_cast<ulonglong1*>(reinterpret_cast<SimlodNode*>(a.mom + R_OFF_VISIBLE) + slot);
+#pragma unroll
+			for (int w = 0; w < (int)(sizeof(SimlodNode) / 8); w++) dst[w] = src[w];
+		}
+		// the LDS tile sits at the low corner of the node's screen box (samples that fall outside it take the global path)
+		int tileX = -1, tileY = -1;
+		uint32_t tileW = TILE, tileH = TILE;
+		if (a.useTiles && myPieces != 0u) {
+			const float nodeSize = a.cubeSize / exp2_int(level);
+			float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+			bool front = true;
+			for (int k = 0; k < 8; k++) {
+				const float x = a.minx + ((float)X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
+				const float z = a.minz + ((float)Z + ((k & 1) ? 1.0f : 0.0f)) * nodeSize;
+				const float cw = dot_row(a.transform.rows[3], x, y, z);
+				if (!(cw > 0.0f)) { front = false; break; }
+				const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
+				mnx = fminf(mnx, sx); mny = fminf(mny, sy); mxx = fmaxf(mxx, sx); mxy = fmaxf(mxy, sy);
+			}
+			if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) {
+				tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0);
+				// the tile covers the node's screen box (a small node clears and flushes a small tile), capped at TILE x TILE
+				tileW = (uint32_t)min(max((int)fminf(mxx, 1.0e6f) - tileX + a.pointSize + 2, 1), TILE);
+				tileH = (uint32_t)min(max((int)fminf(mxy, 1.0e6f) - tileY + a.pointSize + 2, 1), TILE);
+			}
+		}
+		const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
+		const SimlodChunk* const* slots = tableValid ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
+		for (int l = 0; l < 2; l++, dirBase += numChunks[l - 1], itemBase += pieces[l - 1]) {
+			if (numChunks[l] == 0u) continue;
+			if (!listed || dirBase + numChunks[l] > MAX_DIR_CHUNKS || itemBase + pieces[l] > a.itemCap) {
+				atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);
+				for (uint32_t p = 0; p < pieces[l] && itemBase + p < a.itemCap; p++) items[itemBase + p] = DrawItem{0u, 0u, 0u, -1, -1, 0u};   // reserved, but empty
+				continue;
+			}
+			uint32_t k = 0;
+			const SimlodChunk* chunk = heads[l];
+			if (slots != nullptr && slots[0] == heads[l]) {
+				// independent loads instead of a pointer chase (a stale row never starts with the list's head)
+				const uint32_t fromTable = min(numChunks[l], a.leafTableSlots);
+				for (; k < fromTable && slots[k] != nullptr; k++) dir[dirBase + k] = slots[k];
+				chunk = k < numChunks[l] ? slots[k - 1]->next : nullptr;          // a longer list (or a row with a gap) continues by pointer
+				throughTable++;
+			}
+			for (; k < numChunks[l] && chunk != nullptr; k++) { dir[dirBase + k] = chunk; chunk = chunk->next; }
+			const uint32_t have = min(counts[l], k * SIMLOD_POINTS_PER_CHUNK);      // a list shorter than its counter says: draw what is there
+			for (uint32_t p = 0; p < pieces[l]; p++) {
+				const uint32_t firstSample = p * ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK;
+				DrawItem it;
+				it.dirBase = dirBase + p * ITEM_CHUNKS;
+				it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
+				it.visibleIdx = slot; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16);
+				items[itemBase + p] = it;
+			}
 		}
 	}
+	const uint32_t waveTable = wave_sum_u32(throughTable);
+	if (lane_id() == 0 && waveTable != 0u) atomicAdd(counter_at(a, C_TABLE_LISTS), waveTable);
 }
 
 // ---- draw ---------------------------------------------------------------------------------------------------------------
@@ -840,6 +874,7 @@ uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream) {
+	forget_leaf_table(nodes);
 	SIMLOD_LAUNCH(k_reset, dim3(64), dim3(TPB), stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter);
 	return (int)hipGetLastError();
 }
@@ -880,6 +915,11 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.frameCounter = (uint32_t)u->frameCounter;
 	a.showPoints = u->showPoints; a.colorByNode = u->colorByNode; a.colorByLOD = u->colorByLOD; a.hqs = u->useHighQualityShading;
 	render_plane_offsets(a.numPixels, a.offWork, a.offItems, a.offDepth, a.offColor, a.offOverflow, &a.offDir);
+	LeafTableRef lt;
+	if (tune("SIMLOD_RASTER_LEAF_TABLE", 1) && find_leaf_table(nodes, lt)) {
+		a.leafTable = lt.table; a.leafTableMagic = lt.magic; a.leafTableBatch = lt.batch; a.leafTableNodes = lt.tableNodes; a.leafTableSig = lt.sig;
+		a.leafTableMagicValue = lt.magicValue; a.leafTableSlots = lt.slots;
+	}
 	a.itemCap = MAX_DRAW_ITEMS;
 	a.useTiles = (uint32_t)tune("SIMLOD_RASTER_LDS_TILES", 1);
 
@@ -896,9 +936,7 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	};
 	if (parts & RENDER_FIRST) {
 		SIMLOD_LAUNCH(r_clear, dim3(gridPixels), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(r_vis1, dim3(gridNodes), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(r_vis2, dim3(gridNodes), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(r_items, dim3((SIMLOD_MAX_VISIBLE_NODES + TPB - 1) / TPB), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(r_visible, dim3(gridNodes), dim3(TPB), stream, a);
 		if (a.hqs) SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw * 2), dim3(DTPB), stream, a);
 		else { SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(DTPB), stream, a); lines(); }
 	}

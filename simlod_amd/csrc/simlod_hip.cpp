@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,41 @@ const DeviceInfo& device_info() {
 }
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height);
+
+// ---- builder -> rasteriser: where each octree's leaf chunk table lives (simlod_internal.hpp LeafTableRef) --------
+static std::mutex g_leafTablesLock;
+static std::vector<LeafTableRef> g_leafTables;
+
+void note_leaf_table(const LeafTableRef& ref) {
+	std::lock_guard<std::mutex> hold(g_leafTablesLock);
+	for (LeafTableRef& r : g_leafTables)
+		if (r.nodes == ref.nodes) { r = ref; return; }
+	if (g_leafTables.size() >= 64) g_leafTables.erase(g_leafTables.begin());
+	g_leafTables.push_back(ref);
+}
+
+void forget_leaf_table(const void* nodes) {
+	std::lock_guard<std::mutex> hold(g_leafTablesLock);
+	for (size_t i = 0; i < g_leafTables.size(); i++)
+		if (g_leafTables[i].nodes == nodes) { g_leafTables.erase(g_leafTables.begin() + (long)i); return; }
+}
+
+bool find_leaf_table(const void* nodes, LeafTableRef& ref) {
+	std::lock_guard<std::mutex> hold(g_leafTablesLock);
+	for (size_t i = 0; i < g_leafTables.size(); i++) {
+		if (g_leafTables[i].nodes != nodes) continue;
+		// the host may have freed the construct buffer since: the kernel must not touch an address that is no longer mapped
+		hipPointerAttribute_t attr;
+		if (hipPointerGetAttributes(&attr, g_leafTables[i].block) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+			(void)hipGetLastError();
+			g_leafTables.erase(g_leafTables.begin() + (long)i);
+			return false;
+		}
+		ref = g_leafTables[i];
+		return true;
+	}
+	return false;
+}
 
 // ---- optional per-kernel profiling ------------------------------------------------------------------------------
 struct ProfileMark { const char* name; hipEvent_t ev; };
@@ -115,6 +151,11 @@ int simlod_set_ingest_mode(uint32_t mode) {
 int simlod_set_construct_batch_limit(uint32_t maxBatches) {
 	if (maxBatches == 0u) return (int)hipErrorInvalidValue;
 	g_batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
+	return 0;
+}
+
+int simlod_octree_image_replaced(const SimlodNode* nodes) {
+	forget_leaf_table(nodes);
 	return 0;
 }
 

@@ -51,6 +51,7 @@ struct Ctl {
 	uint64_t placeVoxels;        // byte 192: ... and the voxels k_place created, since the host last cleared them
 	uint64_t expandNs[8];        // byte 200: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
 	uint32_t batchSize[SIMLOD_MAX_BATCHES_PER_LAUNCH], batchSlot[SIMLOD_MAX_BATCHES_PER_LAUNCH];
+	uint64_t tableSig;           // table_signature() of the Stats the table belongs to (k_finish)
 	uint64_t phaseNs[24];        // SIMLOD_PHASE_TIMERS=1 — wall time per phase summed over workgroups: k_ingest [0..7], k_place [8..15], k_voxelize [16..23]
 };
 static_assert(offsetof(Ctl, spilledTotal) == 176, "bench.py reads Ctl.spilledTotal at byte 176");
@@ -86,6 +87,28 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 uint64_t construct_min_bytes();
 
 }  // namespace batch
+
+// The builder's leaf chunk table, as the rasteriser may use it (render.hip r_items): row i holds the point chunks of leaf i in list order.
+// The three stamp words live in the builder's control block on the device; the table describes the octree `nodes` as it is NOW only
+// while *magic == magicValue, *batch == Stats.batchletIndex and *tableNodes == nodes and *sig == table_signature(Stats) (the builder clears the stamp while it works and
+// re-stamps in k_finish), which r_items checks on the device every frame.
+struct LeafTableRef {
+	const void*               nodes;
+	const void*               block;       // start of the buffer the table lives in (the construct kernel's momentary buffer)
+	const SimlodChunk* const* table;
+	const uint32_t*           magic;
+	const uint32_t*           batch;
+	const uint64_t*           tableNodes;
+	const uint64_t*           sig;         // table_signature() of the Stats the table was stamped for
+	uint32_t                  magicValue, slots;
+};
+// what the stamp remembers of the Stats block: an octree image that reached the buffers some other way (a host upload) differs here
+__host__ __device__ inline uint64_t table_signature(const SimlodStats* s) {
+	return ((uint64_t)s->numNodes | (uint64_t)s->numPoints << 32) ^ (s->allocatedBytes_persistent * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)s->numVoxels << 20);
+}
+void note_leaf_table(const LeafTableRef& ref);                 // construct chains: after a launch whose layout fits
+void forget_leaf_table(const void* nodes);                     // reset
+bool find_leaf_table(const void* nodes, LeafTableRef& ref);    // false also when the table's buffer is no longer a live device allocation
 
 struct DeviceInfo {
 	int      device;

@@ -39,6 +39,7 @@ def lib():
         L.simlod_set_node_capacity.argtypes = [u32]
         L.simlod_set_ingest_mode.argtypes = [u32]
         L.simlod_set_construct_batch_limit.argtypes = [u32]
+        L.simlod_octree_image_replaced.argtypes = [vp]
         L.simlod_render_framebuffer_offset.restype = u64
         L.simlod_render_buffer_bytes.restype = u64
         L.simlod_render_buffer_bytes.argtypes = [u32, u32]
@@ -74,6 +75,7 @@ EXPORTED_SYMBOLS = [
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
     "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
+    "simlod_octree_image_replaced",
     "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 
@@ -287,6 +289,12 @@ class DeviceOctree:
         off = abi.stats_dtype.fields["numVisibleNodes"][1]
         return self.render_buffer, self.stats[off: off + 4].view(torch.int32)
 
+    def lists_read_through_table(self):
+        """How many chunk lists the last frame's r_items read through the builder's chunk table instead of chasing `next`
+        (render.hip: counter 5 of the frame counters behind the visible-node array)."""
+        off = abi.MAX_VISIBLE_NODES * abi.node_dtype.itemsize + 5 * 16
+        return int(self.render_buffer[off: off + 4].view(torch.int32).item())
+
     # -- readback ------------------------------------------------------------------------------------------------
     def read_stats(self):
         return self.stats.cpu().numpy().view(abi.stats_dtype)[0].copy()
@@ -338,6 +346,7 @@ class DeviceOctree:
         st["numNodes"] = num_nodes
         self.stats.copy_(torch.from_numpy(st.view(np.uint8).reshape(-1)))
         self.momentary[:4096].zero_()          # control block: the builder's side tables describe the previous octree
+        _check(self.L.simlod_octree_image_replaced(self.nodes.data_ptr()), "simlod_octree_image_replaced")
 
     def download_image(self):
         """(nodes, persistent, numNodes, device base addresses) — the octree image as host arrays, pointers untouched."""

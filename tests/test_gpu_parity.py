@@ -1021,3 +1021,66 @@ def test_colorfilter_equals_the_reference_kernel_on_the_same_octree(built_libs, 
         assert hs == np.uint64(d["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(d["pointsXor"]), "the filter must not touch the points"
     dev.render(u)                                                 # and the octree is still drawable
     assert int((dev.framebuffer(W, H) != abi.CLEAR_PIXEL).sum()) > 1000
+
+
+# ---- the rasteriser reads chunk lists through the builder's chunk table ------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["batch", "bulk", "coalesced"])
+def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(built_libs, mode):
+    """render.hip r_items copies a visible node's chunk addresses from the builder's table (leaf rows: point chunks, inner rows: voxel
+    chunks) while the table's stamp says it describes the octree as it is now.  After every drain of a growing octree, after a reset and
+    a rebuild with other points in the same buffers, and for an image uploaded behind the builder's back: the frame equals the oracle's
+    rasteriser on the same image, and equals the frame drawn with the table switched off (SIMLOD_RASTER_LEAF_TABLE=0)."""
+    from simlod_amd.runtime import lib
+    if mode == "bulk":
+        os.environ["SIMLOD_EXACT_CHAIN"] = "bulk"
+    box = (3000.0, 2000.0, 200.0)
+    T = camera.lookat_transform((1.2 * box[0], -0.6 * box[1], 1.1 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    try:
+        dev = _device(ring_slots=8, coalesce=(mode == "coalesced"), momentary_bytes=400_000_000)
+        u = None
+
+        def frames(tag, expect_table):
+            nodes, pers, nn = host_image_of(dev)
+            for hqs in (0, 1):
+                u["useHighQualityShading"] = hqs
+                fo, _, so = _oracle_render(nodes, nn, u)
+                dev.render(u)
+                used = dev.lists_read_through_table()
+                f1, s1 = dev.framebuffer(W, H), dev.read_stats()
+                os.environ["SIMLOD_RASTER_LEAF_TABLE"] = "0"
+                dev.render(u)
+                os.environ.pop("SIMLOD_RASTER_LEAF_TABLE")
+                assert dev.lists_read_through_table() == 0
+                assert np.array_equal(f1, dev.framebuffer(W, H)), f"{tag} hqs={hqs}: table on != table off"
+                assert np.array_equal(f1, fo), f"{tag} hqs={hqs}: {int((f1 != fo).sum())} pixels differ from the oracle"
+                assert_stats_equal(s1, so, STATS_RENDER_FIELDS, tag)
+                if expect_table:
+                    assert used >= int(so["numVisibleNodes"]) - 1, f"{tag}: only {used} of {int(so['numVisibleNodes'])} lists came from the table"
+                else:
+                    assert used == 0, tag
+
+        for seed, n in ((9, 5_000_000), (23, 3_300_000)):        # second pass: reset, other points, same buffers
+            pts, _ = synthetic.terrain(n, seed=seed, box=box, tile=125.0)
+            u = dev.uniforms(W, H, T, box)
+            dev.reset(u)
+            step = 2 * abi.MAX_BATCH_SIZE
+            for i in range(0, n, step):
+                for j in range(i, min(i + step, n), abi.MAX_BATCH_SIZE):
+                    dev.upload(pts[j:j + abi.MAX_BATCH_SIZE])
+                dev.drain(u)
+                assert int(dev.read_stats()["dbg"]) == 0
+                frames(f"{mode} seed {seed} after {min(i + step, n)} points", True)
+        # an octree image written by the host: no builder launch describes it, the table must not be trusted
+        ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+        pts, _ = synthetic.terrain(2_200_000, seed=5, box=box, tile=125.0)
+        ref.reset(u)
+        ref.add_points(u, pts)
+        nn, used = int(ref.stats["numNodes"][0]), int(ref.stats["allocatedBytes_persistent"][0])
+        nodes, pers = ref.nodes[:nn].copy(), ref.persistent[:used].copy()
+        oracle.rebase_image_to(nodes, nn, pers, ref.nodes.ctypes.data, ref.persistent.ctypes.data, dev.nodes.data_ptr(), dev.persistent.data_ptr())
+        dev.upload_image(nodes, pers, nn)
+        frames(f"{mode} uploaded image", False)
+    finally:
+        os.environ.pop("SIMLOD_EXACT_CHAIN", None)
+        os.environ.pop("SIMLOD_RASTER_LEAF_TABLE", None)
+        lib().simlod_set_ingest_mode(0)
