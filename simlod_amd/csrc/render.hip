@@ -48,8 +48,14 @@ struct RenderArgs {
 	uint32_t     leafTableMagicValue, leafTableSlots;
 };
 
-// work area: [0..2] draw cursors of the three draw modes, [3] number of draw items, [4] chunk directory entries in use
-static constexpr int WORK_WORDS = 5;
+// work area: [0..2] draw cursors of the three draw modes, [3] unused, [4] chunk directory entries in use, [8..11] draw items per size class
+static constexpr int WORK_WORDS = 12;
+// Draw items are queued by size, biggest first (longest-processing-time order): the draw workgroups take items from one shared
+// cursor, and a 64 000-sample item taken last would keep one CU busy long after the others ran dry (measured on the bench frame:
+// average workgroup 55 us, slowest 92 us with the items in emission order).  Class of an item = its chunk count: > 32, > 16, > 8, rest;
+// class c has its own array (itemCap entries) and counter, position q of the cursor maps to the classes in order.
+static constexpr int ITEM_CLASSES = 4;
+__device__ __forceinline__ uint32_t item_class(uint32_t chunks) { return chunks > 32u ? 0u : (chunks > 16u ? 1u : (chunks > 8u ? 2u : 3u)); }
 // A draw item = up to 64 consecutive chunks (64 000 samples) of one visible node's list: a whole leaf, or a slice of a long voxel list.
 // ONE workgroup draws an item, accumulating in a 128 x 128-pixel LDS tile laid over the node's screen box: the LOD rule draws a node
 // while its box spans 64..128 pixels (render.cu:893-901), so nearly every sample of a node lands in the tile, pixels that several
@@ -101,7 +107,10 @@ __device__ __forceinline__ float dot_row(const simlod_float4& r, float x, float 
 	return s;
 }
 
-__device__ bool intersects_frustum(const SimlodMat4& m, const float mn[3], const float mx[3]) {
+// math.cuh:154-201: six planes from the rows of the matrix, normalised; a box is outside when its corner farthest along a plane's
+// normal is behind the plane.  The planes are the same for every node: plane i is normalised ONCE per workgroup (24 correctly rounded
+// divisions and 6 square roots that every lane used to repeat), into LDS.
+__device__ __forceinline__ void frustum_plane(const SimlodMat4& m, int i, float out[4]) {
 	const simlod_float4* R = m.rows;
 	const float m0 = R[0].x, m1 = R[1].x, m2 = R[2].x, m3 = R[3].x;
 	const float m4 = R[0].y, m5 = R[1].y, m6 = R[2].y, m7 = R[3].y;
@@ -111,13 +120,17 @@ __device__ bool intersects_frustum(const SimlodMat4& m, const float mn[3], const
 		{m3 - m0, m7 - m4, m11 - m8, m15 - m12}, {m3 + m0, m7 + m4, m11 + m8, m15 + m12},
 		{m3 + m1, m7 + m5, m11 + m9, m15 + m13}, {m3 - m1, m7 - m5, m11 - m9, m15 - m13},
 		{m3 - m2, m7 - m6, m11 - m10, m15 - m14}, {m3 + m2, m7 + m6, m11 + m10, m15 + m14}};
+	const float x = P[i][0], y = P[i][1], z = P[i][2], w = P[i][3];
+	float d2 = x * x; d2 = d2 + y * y; d2 = d2 + z * z;
+	const float len = sqrtf(d2);
+	out[0] = x / len; out[1] = y / len; out[2] = z / len; out[3] = w / len;
+}
+
+__device__ __forceinline__ bool intersects_frustum(const float (*planes)[4], const float mn[3], const float mx[3]) {
 	bool inside = true;
 #pragma unroll
 	for (int i = 0; i < 6; i++) {
-		const float x = P[i][0], y = P[i][1], z = P[i][2], w = P[i][3];
-		float d2 = x * x; d2 = d2 + y * y; d2 = d2 + z * z;
-		const float len = sqrtf(d2);
-		const float nx = x / len, ny = y / len, nz = z / len, c = w / len;
+		const float nx = planes[i][0], ny = planes[i][1], nz = planes[i][2], c = planes[i][3];
 		const float vx = nx > 0.0f ? mx[0] : mn[0];
 		const float vy = ny > 0.0f ? mx[1] : mn[1];
 		const float vz = nz > 0.0f ? mx[2] : mn[2];
@@ -129,7 +142,8 @@ __device__ bool intersects_frustum(const SimlodMat4& m, const float mn[3], const
 
 // render.cu:760-861: a node's box is inside when it meets the frustum, large when its screen box spans more than 2 x minNodeSize pixels.
 // Pure geometry of (level, X, Y, Z): a node can evaluate its PARENT's `large` — (level - 1, X/2, Y/2, Z/2) — without reading it.
-__device__ __forceinline__ void node_geometry(const RenderArgs& a, uint32_t level, uint32_t X, uint32_t Y, uint32_t Z, bool& inside, bool& large) {
+template <bool FRUSTUM>
+__device__ __forceinline__ void node_geometry(const RenderArgs& a, const float (*planes)[4], uint32_t level, uint32_t X, uint32_t Y, uint32_t Z, bool& inside, bool& large) {
 	const float nodeSize = a.cubeSize / exp2_int(level);
 	const float cmin[3] = {a.minx, a.miny, a.minz};
 	const uint32_t XYZ[3] = {X, Y, Z};
@@ -154,7 +168,7 @@ __device__ __forceinline__ void node_geometry(const RenderArgs& a, uint32_t leve
 	const float miny = fminf(fminf(fminf(sy[0], sy[1]), fminf(sy[2], sy[3])), fminf(fminf(sy[4], sy[5]), fminf(sy[6], sy[7])));
 	const float maxy = fmaxf(fmaxf(fmaxf(sy[0], sy[1]), fmaxf(sy[2], sy[3])), fmaxf(fmaxf(sy[4], sy[5]), fmaxf(sy[6], sy[7])));
 	const float dx = maxx - minx, dy = maxy - miny;
-	inside = intersects_frustum(a.transformUpdate, mn, mx);
+	inside = FRUSTUM ? intersects_frustum(planes, mn, mx) : false;
 	const double lim = 2.0 * (double)a.minNodeSize;
 	large = (double)dx > lim || (double)dy > lim;                                           // render.cu:860-861
 }
@@ -181,6 +195,9 @@ __device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v) {      // exclus
 __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
 	if (blockIdx.x * TPB >= numNodes) return;                                          // whole workgroup: the lanes of a wave reserve together
+	__shared__ float planes[6][4];
+	if (threadIdx.x < 6) frustum_plane(a.transformUpdate, (int)threadIdx.x, planes[threadIdx.x]);
+	__syncthreads();
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	const bool active = i < numNodes;
 	SimlodNode* n = a.nodes + (active ? i : 0u);
@@ -195,11 +212,11 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 	bool leaf = true;
 #pragma unroll
 	for (int k = 0; k < 8; k++) leaf = leaf && n->children[k] == nullptr;
-	bool inside, large, parentInside, parentLarge = false;
-	node_geometry(a, level, X, Y, Z, inside, large);
-	if (level > 0u) node_geometry(a, level - 1u, X >> 1, Y >> 1, Z >> 1, parentInside, parentLarge);
+	bool inside, large, unused, parentLarge = false;
+	node_geometry<true>(a, planes, level, X, Y, Z, inside, large);
 	const bool visible = inside && (counts[0] > 0u || counts[1] > 0u);
 	if (active) { n->visible = visible ? 1 : 0; n->isLarge = large ? 1 : 0; }
+	if (active && visible && !large && level > 0u) node_geometry<false>(a, planes, level - 1u, X >> 1, Y >> 1, Z >> 1, unused, parentLarge);   // only who needs it
 	const bool emit = active && visible && (large ? leaf : parentLarge);
 	if (__ballot(emit) == 0ull) return;
 
@@ -214,20 +231,38 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 		pieces[l] = (numChunks[l] + ITEM_CHUNKS - 1) / ITEM_CHUNKS;
 	}
 	const uint32_t myChunks = numChunks[0] + numChunks[1], myPieces = pieces[0] + pieces[1];
-	const uint32_t slotsBefore = wave_prefix_u32(emit ? 1u : 0u), chunksBefore = wave_prefix_u32(myChunks), piecesBefore = wave_prefix_u32(myPieces);
-	const uint32_t waveSlots = (uint32_t)__popcll(__ballot(emit)), waveChunks = wave_sum_u32(myChunks), wavePieces = wave_sum_u32(myPieces);
+	uint32_t myClass[ITEM_CLASSES] = {0u, 0u, 0u, 0u};                                   // a list's pieces: full ones (class 0), then the rest
+#pragma unroll
+	for (int l = 0; l < 2; l++) {
+		if (pieces[l] == 0u) continue;
+		const uint32_t lastClass = item_class(numChunks[l] - (pieces[l] - 1u) * ITEM_CHUNKS);
+		myClass[0] += pieces[l] - 1u;
+#pragma unroll
+		for (int cl = 0; cl < ITEM_CLASSES; cl++) myClass[cl] += lastClass == (uint32_t)cl ? 1u : 0u;
+	}
+	const uint32_t slotsBefore = wave_prefix_u32(emit ? 1u : 0u), chunksBefore = wave_prefix_u32(myChunks);
+	const uint32_t waveSlots = (uint32_t)__popcll(__ballot(emit)), waveChunks = wave_sum_u32(myChunks);
+	uint32_t classBase[ITEM_CLASSES], waveClass[ITEM_CLASSES];
+#pragma unroll
+	for (int cl = 0; cl < ITEM_CLASSES; cl++) { classBase[cl] = wave_prefix_u32(myClass[cl]); waveClass[cl] = wave_sum_u32(myClass[cl]); }
 	const bool isLeafDraw = emit && counts[0] > 0u, isInnerDraw = emit && counts[0] == 0u && counts[1] > 0u;   // render.cu:748-754
 	const uint32_t wLeaves = (uint32_t)__popcll(__ballot(isLeafDraw)), wInner = (uint32_t)__popcll(__ballot(isInnerDraw));
 	const uint32_t wPts = wave_sum_u32(isLeafDraw ? counts[0] : 0u), wVox = wave_sum_u32(isInnerDraw ? counts[1] : 0u);
 	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
-	uint32_t slot = 0, dirBase = 0, itemBase = 0;
+	uint32_t slot = 0, dirBase = 0, waveBase[ITEM_CLASSES] = {0u, 0u, 0u, 0u};
 	if (lane_id() == 0) {
 		slot = atomicAdd(counter_at(a, C_VISIBLE), waveSlots);
-		if (waveChunks != 0u) { dirBase = atomicAdd(work + 4, waveChunks); itemBase = atomicAdd(work + 3, wavePieces); }
+		if (waveChunks != 0u) {
+			dirBase = atomicAdd(work + 4, waveChunks);
+#pragma unroll
+			for (int cl = 0; cl < ITEM_CLASSES; cl++) if (waveClass[cl] != 0u) waveBase[cl] = atomicAdd(work + 8 + cl, waveClass[cl]);
+		}
 		if (wLeaves) { atomicAdd(counter_at(a, C_LEAVES), wLeaves); atomicAdd(counter_at(a, C_POINTS), wPts); }
 		if (wInner) { atomicAdd(counter_at(a, C_INNER), wInner); atomicAdd(counter_at(a, C_VOXELS), wVox); }
 	}
-	slot = __shfl(slot, 0) + slotsBefore; dirBase = __shfl(dirBase, 0) + chunksBefore; itemBase = __shfl(itemBase, 0) + piecesBefore;
+	slot = __shfl(slot, 0) + slotsBefore; dirBase = __shfl(dirBase, 0) + chunksBefore;
+#pragma unroll
+	for (int cl = 0; cl < ITEM_CLASSES; cl++) classBase[cl] += __shfl(waveBase[cl], 0);      // this lane's next free slot in class cl
 	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
 	uint32_t throughTable = 0;
 	if (emit) {
@@ -263,31 +298,47 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 		}
 		const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
 		const SimlodChunk* const* slots = tableValid ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
-		for (int l = 0; l < 2; l++, dirBase += numChunks[l - 1], itemBase += pieces[l - 1]) {
+		for (int l = 0; l < 2; l++, dirBase += numChunks[l - 1]) {
 			if (numChunks[l] == 0u) continue;
-			if (!listed || dirBase + numChunks[l] > MAX_DIR_CHUNKS || itemBase + pieces[l] > a.itemCap) {
-				atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);
-				for (uint32_t p = 0; p < pieces[l] && itemBase + p < a.itemCap; p++) items[itemBase + p] = DrawItem{0u, 0u, 0u, -1, -1, 0u};   // reserved, but empty
-				continue;
-			}
+			const bool fits = listed && dirBase + numChunks[l] <= MAX_DIR_CHUNKS;
+			if (!fits) atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW);                // its items are reserved: they stay, empty
 			uint32_t k = 0;
-			const SimlodChunk* chunk = heads[l];
-			if (slots != nullptr && slots[0] == heads[l]) {
-				// independent loads instead of a pointer chase (a stale row never starts with the list's head)
-				const uint32_t fromTable = min(numChunks[l], a.leafTableSlots);
-				for (; k < fromTable && slots[k] != nullptr; k++) dir[dirBase + k] = slots[k];
-				chunk = k < numChunks[l] ? slots[k - 1]->next : nullptr;          // a longer list (or a row with a gap) continues by pointer
-				throughTable++;
+			if (fits) {
+				const SimlodChunk* chunk = heads[l];
+				if (slots != nullptr && slots[0] == heads[l]) {
+					// independent loads instead of a pointer chase (a stale row never starts with the list's head)
+					const uint32_t fromTable = min(numChunks[l], a.leafTableSlots);
+					while (k < fromTable) {                                         // sixteen independent loads in flight, not one
+						const SimlodChunk* row[16];
+#pragma unroll
+						for (uint32_t j = 0; j < 16; j++) row[j] = k + j < fromTable ? slots[k + j] : nullptr;
+						uint32_t good = 0;
+#pragma unroll
+						for (uint32_t j = 0; j < 16; j++) good += (good == j && row[j] != nullptr) ? 1u : 0u;
+#pragma unroll
+						for (uint32_t j = 0; j < 16; j++)
+							if (j < good) dir[dirBase + k + j] = row[j];
+						k += good;
+						if (good < 16u) break;                                      // the end of the row's entries (or a gap)
+					}
+					chunk = k < numChunks[l] ? slots[k - 1]->next : nullptr;        // a longer list (or a row with a gap) continues by pointer
+					throughTable++;
+				}
+				for (; k < numChunks[l] && chunk != nullptr; k++) { dir[dirBase + k] = chunk; chunk = chunk->next; }
 			}
-			for (; k < numChunks[l] && chunk != nullptr; k++) { dir[dirBase + k] = chunk; chunk = chunk->next; }
 			const uint32_t have = min(counts[l], k * SIMLOD_POINTS_PER_CHUNK);      // a list shorter than its counter says: draw what is there
 			for (uint32_t p = 0; p < pieces[l]; p++) {
 				const uint32_t firstSample = p * ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK;
+				const uint32_t cl = p + 1u < pieces[l] ? 0u : item_class(numChunks[l] - p * ITEM_CHUNKS);
+				uint32_t at = 0;
+#pragma unroll
+				for (int q = 0; q < ITEM_CLASSES; q++) if (cl == (uint32_t)q) at = classBase[q]++;
+				if (at >= a.itemCap) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); continue; }
 				DrawItem it;
 				it.dirBase = dirBase + p * ITEM_CHUNKS;
 				it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
 				it.visibleIdx = slot; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16);
-				items[itemBase + p] = it;
+				items[(uint64_t)cl * a.itemCap + at] = it;
 			}
 		}
 	}
@@ -502,12 +553,91 @@ __device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, cons
 	}
 }
 
+// Point size 1, tile in use — the common case — DU samples per lane in three stages, so that nothing in the loop waits for anything:
+//   1. project all DU samples (pure arithmetic; HQS colour: the DU depth-buffer loads go out together),
+//   2. tiles of a few pixels only (BASELINE config 5: thousands of samples of a node on one pixel): draw_wave, which merges a wave's
+//      samples with shuffles when they all hit the same pixel,
+//   3. otherwise every lane issues its LDS atomics straight away — no read-compare first: an LDS atomic that does not change the word
+//      costs what the read would, and returns nothing to wait for.  min and add commute: the tile ends up identical.
+template <int MODE, uint32_t DU>
+__device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[DU], const bool (&have)[DU], const uint32_t overrideColor, const bool useOverride) {
+	uint32_t pixel[DU], t[DU], dbits[DU], color[DU];
+	float depth[DU];
+	bool valid[DU], inTile[DU], accept[DU];
+#pragma unroll
+	for (uint32_t u = 0; u < DU; u++) {
+		const float cx = dot_row(c.r0, p[u].x, p[u].y, p[u].z);
+		const float cy = dot_row(c.r1, p[u].x, p[u].y, p[u].z);
+		depth[u] = dot_row(c.r3, p[u].x, p[u].y, p[u].z);
+		const float nx = cx / depth[u], ny = cy / depth[u];
+		const double fx = ((double)nx * 0.5 + 0.5) * (double)c.width;
+		const double fy = ((double)ny * 0.5 + 0.5) * (double)c.height;
+		const int x = (int)fx, y = (int)fy;
+		valid[u] = have[u] && (x > 1 && (double)x < c.wlim) && (y > 1 && (double)y < c.hlim);
+		if (MODE != MODE_MIN64) valid[u] = valid[u] && depth[u] > 0.0f;
+		dbits[u] = __float_as_uint(depth[u]);
+		color[u] = useOverride ? overrideColor : __float_as_uint(p[u].w);
+		const int px = min(max(x, 0), c.W), py = min(max(y, 0), c.H);
+		pixel[u] = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
+		valid[u] = valid[u] && pixel[u] < c.numPixels;
+		const unsigned tx = (unsigned)(px - c.tileX), ty = (unsigned)(py - c.tileY);
+		inTile[u] = valid[u] && tx < (unsigned)c.tileW && ty < (unsigned)c.tileH;
+		t[u] = tx + ty * (unsigned)c.tileW;
+		accept[u] = true;
+	}
+	if (MODE == MODE_COLOR) {
+		uint32_t ref[DU];
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) ref[u] = c.depth[valid[u] ? pixel[u] : 0u];
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) accept[u] = valid[u] && depth[u] < __uint_as_float(ref[u]) * 1.01f;          // render.cu:485-493
+	}
+#pragma unroll
+	for (uint32_t u = 0; u < DU; u++) {
+		if (inTile[u] && accept[u]) {
+			if (MODE == MODE_MIN64) atomicMin(&c.tile[t[u]], ((unsigned long long)dbits[u] << 32) | color[u]);
+			else if (MODE == MODE_DEPTH) atomicMin(&c.tile32[t[u]], dbits[u]);
+			else if (c.tileExact) {
+				atomicAdd(&c.tile[2 * t[u] + 0], (unsigned long long)(color[u] & 0xffu) | ((unsigned long long)((color[u] >> 8) & 0xffu) << 32));
+				atomicAdd(&c.tile[2 * t[u] + 1], (unsigned long long)((color[u] >> 16) & 0xffu) | (1ull << 32));
+			} else {
+				const unsigned long long r = color[u] & 0xffu, g = (color[u] >> 8) & 0xffu, b = (color[u] >> 16) & 0xffu;
+				const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
+				const unsigned long long old = atomicAdd(&c.tile[t[u]], pk);
+				if ((old >> 42) >= 64ull) {
+					atomicAdd(&c.tile[t[u]], 0ull - pk);
+					atomicAdd(&c.overflow[2 * pixel[u] + 0], r | (g << 32));
+					atomicAdd(&c.overflow[2 * pixel[u] + 1], b | (1ull << 32));
+				}
+			}
+		}
+		if (valid[u] && !inTile[u]) {                  // outside the tile: the global path of draw_sample
+			if (MODE == MODE_MIN64) {
+				const unsigned long long enc = ((unsigned long long)dbits[u] << 32) | color[u];
+				if (enc < c.fb[pixel[u]]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel[u]]), enc);
+			} else if (MODE == MODE_DEPTH) {
+				if (dbits[u] < c.depth[pixel[u]]) atomicMin(&c.depth[pixel[u]], dbits[u]);
+			} else if (accept[u]) {
+				const unsigned long long r = color[u] & 0xffu, g = (color[u] >> 8) & 0xffu, b = (color[u] >> 16) & 0xffu;
+				const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
+				const unsigned long long old = atomicAdd(&c.color[pixel[u]], pk);
+				if ((old >> 42) >= 64ull) {
+					atomicAdd(&c.color[pixel[u]], 0ull - pk);
+					atomicAdd(&c.overflow[2 * pixel[u] + 0], r | (g << 32));
+					atomicAdd(&c.overflow[2 * pixel[u] + 1], b | (1ull << 32));
+				}
+			}
+		}
+	}
+}
+
 template <int MODE>
 __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* const* dir, uint32_t count, uint32_t overrideColor, bool useOverride) {
 	// render.cu:106-159: chunk i holds samples [1000 i, 1000 i + 1000); the chunk addresses come from the frame's directory (staged in LDS).
 	// Four samples per thread are loaded before the first is drawn: the loads overlap instead of queueing behind the atomics.
 	constexpr uint32_t DU = 4;
 	const bool wave = c.pointSize == 1 && c.tileX >= 0;
+	const bool merge = c.tileW * c.tileH <= 64;     // a node a few pixels across: most lanes of a wave hit the same pixel
 	for (uint32_t base = 0; base < count; base += DTPB * DU) {          // uniform trip count: the whole wave stays in step
 		float4 p[DU];
 		bool have[DU];
@@ -517,9 +647,11 @@ __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* c
 			have[u] = s < count;
 			p[u] = have[u] ? reinterpret_cast<const float4*>(dir[s / SIMLOD_POINTS_PER_CHUNK]->points)[s % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
 		}
-		if (wave) {
+		if (wave && merge) {
 #pragma unroll
 			for (uint32_t u = 0; u < DU; u++) draw_wave<MODE>(c, p[u], have[u], overrideColor, useOverride);
+		} else if (wave) {
+			draw_staged<MODE, DU>(c, p, have, overrideColor, useOverride);
 		} else {
 #pragma unroll
 			for (uint32_t u = 0; u < DU; u++) if (have[u]) draw_sample<MODE>(c, p[u], overrideColor, useOverride);
@@ -535,7 +667,7 @@ __device__ __forceinline__ void tile_clear(const DrawCtx& c) {
 	}
 }
 
-// One global atomic per TOUCHED pixel of the tile; the merged values go through the same test-before-atomic as single samples.
+// One global atomic per TOUCHED pixel of the tile.
 template <int MODE>
 __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
 	for (int t = threadIdx.x; t < c.tileW * c.tileH; t += DTPB) {
@@ -544,11 +676,13 @@ __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
 		const uint32_t pixel = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
 		if (pixel >= c.numPixels) continue;
 		if (MODE == MODE_MIN64) {
+			// no read-compare first: a thread flushes up to 16 pixels, and 16 dependent framebuffer reads were most of an item's time;
+			// the atomic returns nothing to wait for, and a node's pixels are mostly its own, so few of them would have been spared
 			const unsigned long long v = c.tile[t];
-			if (v != ~0ull && v < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), v);
+			if (v != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), v);
 		} else if (MODE == MODE_DEPTH) {
 			const uint32_t v = c.tile32[t];
-			if (v != 0xffffffffu && v < c.depth[pixel]) atomicMin(&c.depth[pixel], v);
+			if (v != 0xffffffffu) atomicMin(&c.depth[pixel], v);
 		} else if (c.tileExact) {
 			const unsigned long long rg = c.tile[2 * t], bc = c.tile[2 * t + 1];
 			if ((bc >> 32) != 0ull) { atomicAdd(&c.overflow[2 * pixel + 0], rg); atomicAdd(&c.overflow[2 * pixel + 1], bc); }
@@ -580,7 +714,9 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	c.overflow = reinterpret_cast<unsigned long long*>(a.mom + a.offOverflow);
 	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
 	uint32_t* cursor = work + MODE;
-	const uint32_t numItems = min(work[3], a.itemCap);
+	uint32_t classEnd[ITEM_CLASSES];                                                       // position q of the cursor: class c while q < classEnd[c]
+	for (int cl = 0; cl < ITEM_CLASSES; cl++) classEnd[cl] = (cl > 0 ? classEnd[cl - 1] : 0u) + min(work[8 + cl], a.itemCap);
+	const uint32_t numItems = classEnd[ITEM_CLASSES - 1];
 	const DrawItem* items = reinterpret_cast<const DrawItem*>(a.mom + a.offItems);
 	const SimlodChunk* const* dir = reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offDir);
 	const SimlodNode* visible = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE);
@@ -588,7 +724,9 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	// cursor that starts behind the statically assigned range.
 	uint32_t idx = blockIdx.x;
 	while (idx < numItems) {
-		const DrawItem it = items[idx];
+		uint32_t cl = 0;
+		while (idx >= classEnd[cl]) cl++;
+		const DrawItem it = items[(uint64_t)cl * a.itemCap + (idx - (cl > 0u ? classEnd[cl - 1u] : 0u))];
 		uint32_t overrideColor = 0; bool useOverride = false;
 		if (MODE != MODE_DEPTH && (a.colorByNode || a.colorByLOD)) {
 			const SimlodNode* node = visible + it.visibleIdx;
@@ -869,7 +1007,7 @@ static inline uint64_t align16(uint64_t v) { return (v + 15) / 16 * 16; }
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 	const uint64_t px = (uint64_t)width * height;
-	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + (uint64_t)MAX_DIR_CHUNKS * 8 + 256;
+	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * ITEM_CLASSES * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + (uint64_t)MAX_DIR_CHUNKS * 8 + 256;
 }
 
 int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
@@ -882,7 +1020,7 @@ int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, Siml
 static void render_plane_offsets(uint64_t numPixels, uint64_t& offWork, uint64_t& offItems, uint64_t& offDepth, uint64_t& offColor, uint64_t& offOverflow, uint64_t* offDir = nullptr) {
 	offWork = R_OFF_FB + align16(numPixels * 8);
 	offItems = offWork + 256;
-	offDepth = offItems + (uint64_t)MAX_DRAW_ITEMS * sizeof(DrawItem);
+	offDepth = offItems + (uint64_t)MAX_DRAW_ITEMS * ITEM_CLASSES * sizeof(DrawItem);
 	offColor = offDepth + align16(numPixels * 4);
 	offOverflow = offColor + align16(numPixels * 8);
 	if (offDir != nullptr) *offDir = offOverflow + numPixels * 16;
