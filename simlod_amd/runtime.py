@@ -20,7 +20,8 @@ import torch
 
 from . import abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsimlod_hip.so")
+# SIMLOD_HIP_LIB: another build of the same library (A/B measurements of two kernel variants on one GPU box, tools/)
+_LIB_PATH = os.environ.get("SIMLOD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsimlod_hip.so")
 _lib = None
 
 
