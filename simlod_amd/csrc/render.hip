@@ -79,14 +79,23 @@ enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_T
 
 // ---- clear (render.cu:1126-1131, 233-241) ---------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void r_clear(RenderArgs a) {
-	uint64_t* fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
-	const uint32_t stride = gridDim.x * TPB;
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) fb[i] = SIMLOD_CLEAR_PIXEL;
+	// 16-byte stores (every plane starts 16-byte aligned): the planes are 8, 4, 8 and 16 bytes per pixel
+	const uint32_t stride = gridDim.x * TPB, first = blockIdx.x * TPB + threadIdx.x;
+	auto fill = [&](uint64_t offset, uint64_t bytes, uint4 value, uint64_t tailWord, uint32_t tailBytes) {
+		uint4* q = reinterpret_cast<uint4*>(a.mom + offset);
+		const uint32_t n16 = (uint32_t)(bytes / 16);
+		for (uint32_t i = first; i < n16; i += stride) q[i] = value;
+		if (first == 0 && bytes % 16 != 0) {                           // an odd pixel count leaves one 4- or 8-byte element
+			if (tailBytes == 8) *reinterpret_cast<uint64_t*>(a.mom + offset + (uint64_t)n16 * 16) = tailWord;
+			else for (uint64_t b = (uint64_t)n16 * 16; b < bytes; b += 4) *reinterpret_cast<uint32_t*>(a.mom + offset + b) = (uint32_t)tailWord;
+		}
+	};
+	const uint32_t lo = (uint32_t)SIMLOD_CLEAR_PIXEL, hi = (uint32_t)(SIMLOD_CLEAR_PIXEL >> 32);
+	fill(R_OFF_FB, (uint64_t)a.numPixels * 8, make_uint4(lo, hi, lo, hi), SIMLOD_CLEAR_PIXEL, 8);
 	if (a.hqs) {
-		uint32_t* depth = reinterpret_cast<uint32_t*>(a.mom + a.offDepth);
-		unsigned long long* packed = reinterpret_cast<unsigned long long*>(a.mom + a.offColor);
-		uint4* overflow = reinterpret_cast<uint4*>(a.mom + a.offOverflow);
-		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) { depth[i] = 0x7f800000u; packed[i] = 0ull; overflow[i] = make_uint4(0, 0, 0, 0); }
+		fill(a.offDepth, (uint64_t)a.numPixels * 4, make_uint4(0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u), 0x7f800000u, 4);
+		fill(a.offColor, (uint64_t)a.numPixels * 8, make_uint4(0, 0, 0, 0), 0ull, 8);
+		fill(a.offOverflow, (uint64_t)a.numPixels * 16, make_uint4(0, 0, 0, 0), 0ull, 8);
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		*a.frameStart = wall_ns();                                    // render.cu:1100-1102
