@@ -57,6 +57,8 @@ struct Ctl {
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
+	uint32_t numVoxItems;              // k_alloc (points): (leaf, sample range) pieces for k_voxelize
+	uint32_t numEmits;                 // k_voxelize: samples that colour at least one new voxel (entries of the emit list)
 };
 
 struct BuildArgs {
@@ -70,8 +72,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offWin, offSpilled;
-	uint32_t     nodeCapacity, spilledCap, dirCap, workCap;
+	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offEmit, offVoxItems, offSpilled;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap;
 };
 
 
@@ -189,6 +191,8 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->numSpilled = 0;
 	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
 	ctl->dirCount = 0;
+	ctl->numVoxItems = 0;
+	ctl->numEmits = 0;
 	ctl->abortBatch = 0;
 	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
 	ctl->active = 1;
@@ -353,7 +357,6 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	if ((ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	uint32_t* winMask = at<uint32_t>(a, a.offWin);
 	unsigned long long* splitInfo = at<unsigned long long>(a, a.offSplitTag);   // per node: round tag << 32 | first child << 5 | level
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
@@ -527,7 +530,6 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				const uint32_t dst = item.dstBase + j;
 				spilled[dst] = p;
 				leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = item.childOffset + (uint32_t)c;
-				winMask[SIMLOD_MAX_BATCH_SIZE + dst] = item.level << 24;     // `sample` starts at the spilling node's level
 				atomicAdd(&sh_childCount[c], 1u);
 			}
 			__syncthreads();
@@ -591,117 +593,243 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	}
 }
 
-// ---- sample: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483)
-// The reference tests the sample's cell in EVERY node of the path, root first.  Occupancy is hierarchical, though: a
-// cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit in a node
-// had, in the same pass, been offered to all its ancestors — so "bit set in node N" implies "covering bit set in every
-// ancestor of N".  This kernel therefore walks the path BOTTOM-UP and stops at the first level whose bit is already
-// set, or where its own atomicOr lost the race (the winner keeps climbing).  Same bitsets, same voxel counts, one
-// winner per cell as in the reference; what it removes is the contention: measured on MI355X, a top-down pass issued
-// 2-4 atomicOr per sample, thousands of them on the same still-clear upper-level words of newly entered territory
-// (device-scope atomics retire at ~25 G/s on distinct words but ~88 M/s on one word); bottom-up issues about one per
-// NEW voxel, and steady-state samples cost one 4-byte probe instead of one per level.
-// Per-workgroup set of (node, cell) claims.  While the octree is still shallow the deepest grid of a sample is coarse: on the
-// terrain workload the 1 M points of an early batch fall into 4 nodes and ~1000 occupancy words, 890 k of them see a clear
-// bit (tools/analyze_candidates.py), and thousands of atomicOr per word serialise at ~11 ns each.  So only the FIRST sample of
-// a workgroup that sees a clear cell issues the global atomicOr; the others know the cell is being taken care of and stop,
-// exactly as if they had lost the race.  key = table entry of the node (10 bits) << 21 | cell (21 bits).
-static constexpr int SET_BITS = 12;
-static constexpr int SET_CAP = 1 << SET_BITS;
-
-// true: the caller is the first of its workgroup to claim `key` (or the set has no room: claim anyway, merely redundant)
-__device__ __forceinline__ bool set_insert(uint32_t* set, uint32_t key) {
-	uint32_t h = (key * 2654435761u) >> (32 - SET_BITS);
-#pragma unroll 1
-	for (int probe = 0; probe < 8; ++probe) {
-		uint32_t k = set[h];
-		if (k == TBL_EMPTY) k = atomicCAS(&set[h], TBL_EMPTY, key);
-		if (k == TBL_EMPTY) return true;
-		if (k == key) return false;
-		h = (h + 1) & (SET_CAP - 1);
-	}
-	return true;
+// ---- voxelize: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483) ----------------
+// The reference offers every sample to the grid of EVERY node of its path, root first.  Two properties make that cheap here:
+//  * Occupancy is hierarchical: a cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit
+//    in a node had, in the same pass, been offered to all its ancestors — so "bit set in node N" implies "covering bit set in every
+//    ancestor of N".  A sample therefore climbs BOTTOM-UP and stops at the first cell that is already set.  The same argument covers the
+//    points a split moved into new leaves (voxels.cu:325-415 re-samples them from the split node's level down): above the split node
+//    their cells were set when they first arrived, so their climb ends there by itself.
+//  * After k_insert the new samples of a leaf lie together in its chunks, and the part of an ancestor's grid a leaf can touch is a
+//    small cube: 64^3 cells of the parent, 32^3 of the grandparent, ... one cell from the 8th ancestor on — 37 KB of bits in all.
+// So this kernel runs AFTER k_insert, one workgroup per (leaf, range of <= 8192 new samples): it loads the leaf's cubes into LDS, keeps
+// its 8 samples per thread in registers, and does the whole test-and-set in LDS.  Round 1 sampled BEFORE the insert, per batch sample,
+// with device-scope atomicOr: a 1 M-point batch is spatially compact, nearly every sample of a freshly entered region found its cell
+// clear at the same moment, and a thousand workgroups queued their atomics on the same few hundred words (measured: one wave waited
+// 55-190 us for a single level's atomics; the kernel took 80-90 us with the memory system idle; more samples in flight per thread, or
+// fewer workgroups, both made it SLOWER).  Here the global memory sees one atomicOr per touched WORD and piece — it returns which of
+// the new cells are really new (the pieces of one leaf share cubes; different leaves never share a cell below the 8th ancestor) —
+// and nothing in the two passes over the samples leaves the CU.
+//   pass A  every sample: mark its cell in the deepest cube; if the cell was clear, mark `fresh` and climb to the next cube ...
+//   write-back  old = atomicOr(grid word, fresh bits); won = fresh & ~old; Node.numVoxels += popcount(won)   (voxels.cu:96-101)
+//   pass B  every sample: if its cell is still marked won, take the mark: this sample colours the voxel (which sample of a cell does
+//           is scheduling dependent in the reference too).  Samples that took marks go on the emit list
+//           {leaf, index in the leaf, levels won}; k_insert's second part regenerates their voxels once k_alloc has made room.
+static constexpr uint32_t VTPB = 1024;
+static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
+static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
+static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
+static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
+struct VoxItem { uint32_t leaf, s0, s1, pad; };                 // samples [s0, s1) of the leaf's storage
+struct Emit { uint32_t leaf, index, levels; };                  // levels: bit L = the sample colours a new voxel of its level-L ancestor
+struct VoxShared {
+	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row
+	uint32_t fresh[CUBE_WORDS];                                 // pass A: cells this piece set; after the write-back: cells it won
+	uint32_t hiOcc[PATH_WORDS], hiFresh[PATH_WORDS];            // ancestors d >= 8: the ONE cell the whole leaf falls into
+	unsigned long long anc[PATH_WORDS];
+	uint32_t cnt[PATH_WORDS];
+	uint32_t emitCount, emitBase;
+};
+__device__ __forceinline__ uint32_t cube_offset(uint32_t d) {          // word offset of cube d in VoxShared::occ / fresh
+	return d == 1u ? 0u : d == 2u ? 8192u : d == 3u ? 9216u : d == 4u ? 9472u : d == 5u ? 9536u : d == 6u ? 9552u : 9556u;
+}
+__device__ __forceinline__ uint32_t grid_cell(uint32_t level, uint32_t pX, uint32_t pY, uint32_t pZ) {   // voxels.cu:78-92
+	const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;
+	return ((pX >> shf) & 127u) + ((pY >> shf) & 127u) * SIMLOD_GRID_SIZE + ((pZ >> shf) & 127u) * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
+}
+// word and bit of grid cell `cell` of ancestor d inside the leaf's cube (side = 128 >> d; the cube is aligned to its side)
+__device__ __forceinline__ void cube_cell(uint32_t d, uint32_t cell, uint32_t& word, uint32_t& bit) {
+	const uint32_t side = 128u >> d, lx = (cell & 127u) & (side - 1u), ly = ((cell >> 7) & 127u) & (side - 1u), lz = (cell >> 14) & (side - 1u);
+	const uint32_t row = ly + side * lz;
+	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
+	else { word = cube_offset(d) + row; bit = lx; }
 }
 
-template <uint32_t SPT>
-__global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
-	constexpr uint32_t SPB = TPB * SPT;
+__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
-	__shared__ BlockTable tbl;                         // node -> voxels created by this workgroup
-	__shared__ uint32_t claimed[SET_CAP];              // (node, cell) pairs this workgroup already claimed
-	const uint32_t n = ctl->batchSize;
-	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const float4* spilled = at<const float4>(a, a.offSpilled);
-	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
-	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
-	uint32_t* winMask = at<uint32_t>(a, a.offWin);
-	const uint32_t numChunks = (total + SPB - 1) / SPB;
-	table_init(tbl);                                   // lives for the whole workgroup: no barrier inside the chunk loop
-	for (uint32_t i = threadIdx.x; i < (uint32_t)SET_CAP; i += TPB) claimed[i] = TBL_EMPTY;
-	__syncthreads();
-	constexpr int WIN = 3;                             // ancestors fetched and probed together
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-#pragma unroll 1
-		for (uint32_t j = 0; j < SPT; j++) {
-			const uint32_t t = chunk * SPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			uint32_t idx, startLevel = 0;
-			float4 p;
-			if (t < n) { idx = t; p = pts[t]; }
-			else { idx = SIMLOD_MAX_BATCH_SIZE + (t - n); p = spilled[t - n]; startLevel = winMask[idx] >> 24; }
-			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
-			// the leaf was cached by count/expand; grids live in the inner nodes above it (and in a root that is still a leaf)
-			const uint32_t leafIdx = leafOf[idx];
-			const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
-			uint32_t wins = 0;
-			bool go = true;
-#pragma unroll 1
-			for (uint32_t k0 = 0; go && k0 < PATH_WORDS - 1; k0 += WIN) {
-				unsigned long long ent[WIN];
-				uint32_t* word[WIN];
-				uint32_t seen[WIN], cell[WIN];
+	const uint32_t numItems = min(ctl->numVoxItems, a.voxItemCap);
+	if (numItems == 0u) return;
+	__shared__ VoxShared sh;
+	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
+	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
+	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	Emit* emits = at<Emit>(a, a.offEmit);
+	const uint32_t tag = ctl->batchIndex + 1u;
+	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
+		const VoxItem it = items[item];
+		const SimlodNode* leaf = a.nodes + it.leaf;
+		const NodeDir nd = nodeDir[it.leaf];
+		const uint32_t LX = leaf->X, LY = leaf->Y, LZ = leaf->Z;
+		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
+		__syncthreads();                                       // the previous item's LDS state is no longer read
+		if (threadIdx.x < PATH_WORDS) {
+			// ancestor d (1 = parent) is anc[d - 1]; a root that is still a leaf samples itself (voxels.cu:449-463: every node of the
+			// path that has a grid is sampled, and the root has one from the reset on)
+			unsigned long long e;
+			if (it.leaf == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; e = (threadIdx.x == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
+			else e = threadIdx.x < PATH_WORDS - 1 ? rec[threadIdx.x] : 0ull;
+			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0;
+		}
+		if (threadIdx.x == 0) sh.emitCount = 0;
+		// the piece's samples: 8 per thread, all loads in flight together
+		uint32_t pX[VOX_SPT], pY[VOX_SPT], pZ[VOX_SPT], levels[VOX_SPT];
+		float color[VOX_SPT];
+		bool live[VOX_SPT];
+		{
+			float4 p[VOX_SPT];
 #pragma unroll
-				for (int w = 0; w < WIN; w++) {              // independent loads: the entries ...
-					if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; ent[w] = (k0 + w == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
-					else ent[w] = k0 + w < PATH_WORDS - 1 ? rec[k0 + w] : 0ull;
-				}
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				const uint32_t i = it.s0 + j * VTPB + threadIdx.x;
+				live[j] = i < it.s1 && nd.ptTag == tag;
+				p[j] = live[j] ? reinterpret_cast<const float4*>(chunkDir[nd.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - nd.ptFirst)]->points)[i % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
+			}
 #pragma unroll
-				for (int w = 1; w < WIN; w++) if (ent[w - 1] == 0ull) ent[w] = 0ull;   // what lies behind the terminator was never written
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				pX[j] = quantize(F_FULL, p[j].x, a.minx, a.size); pY[j] = quantize(F_FULL, p[j].y, a.miny, a.size); pZ[j] = quantize(F_FULL, p[j].z, a.minz, a.size);
+				color[j] = p[j].w; levels[j] = 0u;
+			}
+		}
+		__syncthreads();
+		uint32_t depth = 0;
+		while (depth < PATH_WORDS - 1 && sh.anc[depth] != 0ull) depth++;
+		// voxels.cu:449: the traverse loop samples levels 0..19 only — an ancestor at level 20 does not exist (leaves are at most at 20)
+		const uint32_t ldsDepth = it.leaf == 0u ? 0u : min(depth, LDS_LEVELS);       // a root that is still a leaf: its "cube" is the whole grid
+
+		// the leaf's cubes, as the grids hold them now; the single cells of the ancestors above
+		for (uint32_t d = 1; d <= ldsDepth; d++) {
+			const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
+			const uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
+			const uint32_t rows = side * side;
+			if (d == 1u) for (uint32_t w = threadIdx.x; w < rows * 2u; w += VTPB) {
+				const uint32_t row = w >> 1, ly = row % side, lz = row / side;
+				sh.occ[w] = grid[((ox + 128u * (oy + ly) + 16384u * (oz + lz)) >> 5) + (w & 1u)];
+				sh.fresh[w] = 0;
+			} else for (uint32_t row = threadIdx.x; row < rows; row += VTPB) {
+				const uint32_t ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
+				const uint32_t mask = side >= 32u ? 0xffffffffu : (1u << side) - 1u;
+				sh.occ[cube_offset(d) + row] = (grid[cell >> 5] >> (cell & 31u)) & mask;
+				sh.fresh[cube_offset(d) + row] = 0;
+			}
+		}
+		if (it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth) {       // d = threadIdx.x + 1 >= 8: every sample of the leaf has the same cell
+			const unsigned long long ent = sh.anc[threadIdx.x];
+			const uint32_t d = threadIdx.x + 1u, level = path_level(ent);
+			// the leaf's own corner stands for all its samples: 2^(28 - leafLevel) fine units per leaf, leafLevel = level + d
+			const uint32_t sft = 28u - (level + d), cell = grid_cell(level, LX << sft, LY << sft, LZ << sft);
+			sh.hiOcc[threadIdx.x] = (path_grid(a.pers, ent)->values[cell >> 5] >> (cell & 31u)) & 1u;
+		}
+		__syncthreads();
+
+		// pass A: test-and-set, bottom-up, climbing while the cell is new
+		if (it.leaf != 0u) {
 #pragma unroll
-				for (int w = 0; w < WIN; w++) {              // ... then the occupancy words of all of them
-					const uint32_t level = path_level(ent[w]);
-					const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;           // voxels.cu:78-85
-					const uint32_t cx = (pX >> shf) & 127u, cy = (pY >> shf) & 127u, cz = (pZ >> shf) & 127u;
-					cell[w] = cx + cy * SIMLOD_GRID_SIZE + cz * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
-					word[w] = &path_grid(a.pers, ent[w])->values[cell[w] >> 5];
-					// voxels.cu:449: the traverse loop samples levels 0..19 only; spilled samples start at the spilling node's level
-					if (ent[w] == 0ull || level < startLevel || level >= (uint32_t)SIMLOD_MAX_DEPTH) { ent[w] = 0ull; seen[w] = 0u; }
-					else seen[w] = *word[w];        // a plain load on purpose: measured, device-scope probes of the hot occupancy lines cost 20 % more
-				}
-#pragma unroll
-				for (int w = 0; w < WIN; w++) {              // bottom-up: claim while winning
-					if (!go) break;
-					if (ent[w] == 0ull) { go = false; break; }
-					const uint32_t bit = cell[w] & 31u;
-					if (((seen[w] >> bit) & 1u) != 0u) { go = false; break; }               // voxels.cu:93-94; the ancestors are set as well
-					const uint32_t nodeIdx = path_node(ent[w]);
-					uint32_t rank;
-					const int e = table_add(tbl, nodeIdx, 0u, &rank);
-					if (e >= 0 && !set_insert(claimed, ((uint32_t)e << 21) | cell[w])) { go = false; break; }   // a sample of this workgroup already claims the cell
-					if (((atomicOr(word[w], 1u << bit) >> bit) & 1u) != 0u) { go = false; break; }              // voxels.cu:96; lost: the winner climbs on
-					wins |= 1u << path_level(ent[w]);                                       // first point in the cell, voxels.cu:99
-					if (e >= 0) atomicAdd(&tbl.vals[e], 1u); else atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u);   // voxels.cu:101
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				if (!live[j]) continue;
+				for (uint32_t d = 1; d <= depth; d++) {
+					const unsigned long long ent = sh.anc[d - 1];
+					const uint32_t level = path_level(ent);
+					if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;
+					if (d <= ldsDepth) {
+						uint32_t word, bit;
+						cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word, bit);
+						if (((sh.occ[word] >> bit) & 1u) != 0u) break;                                 // voxels.cu:93-94; the ancestors are set as well
+						if (((atomicOr(&sh.occ[word], 1u << bit) >> bit) & 1u) != 0u) break;           // another sample of the piece was first: it climbs on
+						atomicOr(&sh.fresh[word], 1u << bit);
+					} else {
+						if (sh.hiOcc[d - 1] != 0u) break;
+						if (atomicOr(&sh.hiOcc[d - 1], 1u) != 0u) break;
+						sh.hiFresh[d - 1] = 1u;
+					}
 				}
 			}
-			winMask[idx] = wins;
+		} else {
+			// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample
+			const unsigned long long ent = sh.anc[0];
+			if (ent != 0ull) {
+#pragma unroll
+				for (uint32_t j = 0; j < VOX_SPT; j++) {
+					if (!live[j]) continue;
+					const uint32_t cell = grid_cell(0u, pX[j], pY[j], pZ[j]), bit = cell & 31u;
+					uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
+					if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
+					if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
+					levels[j] |= 1u;
+					atomicAdd(&sh.cnt[1], 1u);
+				}
+			}
 		}
-	}
-	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY && tbl.vals[e] != 0u) atomicAdd(&a.nodes[key].numVoxels, tbl.vals[e]);
+		__syncthreads();
+
+		// write-back: the grids learn the new cells, and tell which of them are new for everybody (pieces of one leaf share the cubes)
+		for (uint32_t d = 1; d <= ldsDepth; d++) {
+			const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
+			uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
+			const uint32_t rows = side * side, words = d == 1u ? rows * 2u : rows;
+			uint32_t mine = 0;
+			for (uint32_t w = threadIdx.x; w < words; w += VTPB) {
+				const uint32_t f = sh.fresh[cube_offset(d) + w];
+				if (f == 0u) continue;
+				const uint32_t row = d == 1u ? w >> 1 : w, ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
+				const uint32_t sft = d == 1u ? 0u : (cell & 31u);
+				const uint32_t old = atomicOr(&grid[(cell >> 5) + (d == 1u ? (w & 1u) : 0u)], f << sft);   // voxels.cu:96
+				const uint32_t won = f & ~(old >> sft);
+				sh.fresh[cube_offset(d) + w] = won;
+				mine += __popc(won);
+			}
+			if (mine != 0u) atomicAdd(&sh.cnt[d], mine);
+		}
+		if (it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth && sh.hiFresh[threadIdx.x] != 0u) {
+			const unsigned long long ent = sh.anc[threadIdx.x];
+			const uint32_t d = threadIdx.x + 1u, level = path_level(ent), sft = 28u - (level + d), cell = grid_cell(level, LX << sft, LY << sft, LZ << sft);
+			const uint32_t old = atomicOr(&path_grid(a.pers, ent)->values[cell >> 5], 1u << (cell & 31u));
+			const uint32_t won = ((old >> (cell & 31u)) & 1u) ^ 1u;
+			sh.hiFresh[threadIdx.x] = won;
+			sh.cnt[d] = won;
+		}
+		__syncthreads();
+		if (threadIdx.x >= 1u && threadIdx.x <= depth && sh.cnt[threadIdx.x] != 0u)
+			atomicAdd(&a.nodes[path_node(sh.anc[threadIdx.x - 1u])].numVoxels, sh.cnt[threadIdx.x]);         // voxels.cu:101
+
+		// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
+		uint32_t levelsWithNew = 0;
+		for (uint32_t d = 1; d <= depth; d++) if (sh.cnt[d] != 0u) levelsWithNew |= 1u << d;
+		if (it.leaf != 0u && levelsWithNew != 0u) {
+#pragma unroll
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				if (!live[j]) continue;
+				for (uint32_t left = levelsWithNew; left != 0u; left &= left - 1u) {       // only the cubes that gained cells
+					const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
+					const uint32_t level = path_level(sh.anc[d - 1]);
+					if (d <= ldsDepth) {
+						uint32_t word, bit;
+						cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word, bit);
+						if (((sh.fresh[word] >> bit) & 1u) == 0u) continue;
+						if (((atomicAnd(&sh.fresh[word], ~(1u << bit)) >> bit) & 1u) == 0u) continue;     // somebody else took the mark
+					} else {
+						if (sh.hiFresh[d - 1] == 0u) continue;
+						if (atomicExch(&sh.hiFresh[d - 1], 0u) == 0u) continue;
+					}
+					levels[j] |= 1u << level;
+				}
+			}
+		}
+		// the samples that colour voxels go on the emit list: one reservation per piece
+		uint32_t mineEmits = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < VOX_SPT; j++) mineEmits += levels[j] != 0u ? 1u : 0u;
+		uint32_t at0 = mineEmits != 0u ? atomicAdd(&sh.emitCount, mineEmits) : 0u;
+		__syncthreads();
+		if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&ctl->numEmits, sh.emitCount);
+		__syncthreads();
+		if (mineEmits != 0u) {
+			at0 += sh.emitBase;
+#pragma unroll
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				if (levels[j] == 0u) continue;
+				emits[at0++] = Emit{it.leaf, it.s0 + j * VTPB + threadIdx.x, levels[j]};          // never more entries than samples: no overflow to handle
+			}
+		}
 	}
 }
 
@@ -709,18 +837,20 @@ __global__ __launch_bounds__(TPB) void k_sample(BuildArgs a) {
 // (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
 __device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
 
-__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i) {
+// part 0 (before k_insert): the point chunks of leaves, and k_voxelize's work list; part 1 (after k_voxelize, when Node.numVoxels is
+// final for this batch): the voxel chunks of inner nodes
+__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i, uint32_t part) {
 	SimlodNode* node = a.nodes + i;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	const uint32_t tag = ctl->batchIndex + 1u;
-	node->countIteration = tag;
+	if (part == 0u) node->countIteration = tag;
 
 	// -- points of leaves -------------------------------------------------------------------------------------
 	const uint32_t counter = node->counter, stored = node->numPoints;
-	if (stored < counter && node_is_leaf(node)) {
+	if (part == 0u && stored < counter && node_is_leaf(node)) {
 		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
@@ -751,7 +881,14 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		}
 		NodeDir& d = nodeDir[i];
 		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
+		// k_voxelize's work: the leaf's new samples [stored, counter), in pieces one workgroup takes
+		const uint32_t pieces = (counter - stored + VOX_PIECE - 1) / VOX_PIECE;
+		const uint32_t at0 = atomicAdd(&ctl->numVoxItems, pieces);
+		if (at0 + pieces > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+		VoxItem* items = at<VoxItem>(a, a.offVoxItems);
+		for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), 0u};
 	}
+	if (part == 0u) return;
 
 	// -- voxels of inner nodes (and of the root while it is still a leaf) --------------------------------------
 	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
@@ -786,11 +923,11 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 }
 
 // A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
-__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a) {
+__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a, uint32_t part) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i);
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i, part);
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -824,16 +961,18 @@ __device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32
 	return v;
 }
 
-__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
+// part 0: the points (before k_voxelize, which reads them back leaf by leaf); part 1: the voxels of k_voxelize's emit list
+__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
 	__shared__ InsertShared sh;
 	const uint32_t n = ctl->batchSize;
-	const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+	const uint32_t total = part == 0u ? n + min(ctl->numSpilled, a.spilledCap) : ctl->numEmits;
+	if (total == 0u) return;
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
-	const uint32_t* winMask = at<const uint32_t>(a, a.offWin);
+	const Emit* emits = at<const Emit>(a, a.offEmit);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
@@ -843,17 +982,17 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
 	// global atomic each, (3) store — the slot inside the range comes from an LDS cursor.
 
+	if (blockIdx.x >= numChunks) return;
 	// ======== points ========
 	table_init(sh.tbl);
 	__syncthreads();
-	bool anyWins = false;
+	if (part == 0u) {
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 #pragma unroll
 		for (uint32_t j = 0; j < PPT; j++) {
 			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 			if (t >= total) continue;
 			const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-			anyWins |= (winMask[idx] & 0xfffffu) != 0u;
 			uint32_t rank;
 			(void)table_add(sh.tbl, leafOf[idx], 1u, &rank);
 		}
@@ -894,10 +1033,10 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 		}
 	}
 
-	// ======== voxels: the samples that won a cell in `sample` regenerate their voxel(s) ========
-	if (!__syncthreads_or(anyWins ? 1 : 0)) return;
-	table_init(sh.tbl);
-	__syncthreads();
+	return;
+	}
+
+	// ======== voxels: the samples on k_voxelize's emit list regenerate their voxel(s) ========
 	for (int pass = 0; pass < 2; pass++) {
 		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
 		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
@@ -905,16 +1044,17 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a) {
 			for (uint32_t j = 0; j < PPT; j++) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				if (t >= total) continue;
-				const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-				uint32_t left = winMask[idx] & 0xfffffu;
+				const Emit em = emits[t];
+				uint32_t left = em.levels & 0xfffffu;
 				if (left == 0u) continue;
-				// the won levels are among the deepest ancestors of the cached leaf: read them off its path
-				const uint32_t leafIdx = leafOf[idx];
+				// the won levels are among the ancestors of the sample's leaf: read them off its path
+				const uint32_t leafIdx = em.leaf;
 				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
 				float4 p = make_float4(0, 0, 0, 0);
 				uint32_t pX = 0, pY = 0, pZ = 0;
 				if (pass == 1) {
-					p = t < n ? pts[t] : spilled[t - n];
+					const NodeDir ld = nodeDir[leafIdx];                                              // the sample itself: in the leaf's chunks since part 0
+					p = reinterpret_cast<const float4*>(chunkDir[ld.ptBase + (em.index / SIMLOD_POINTS_PER_CHUNK - ld.ptFirst)]->points)[em.index % SIMLOD_POINTS_PER_CHUNK];
 					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
 				}
 #pragma unroll 1
@@ -1039,6 +1179,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	off += align_up((uint64_t)dirCap * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * PATH_WORDS * 8, 256);
+	off += align_up((uint64_t)(nodeCapacity + 65536) * sizeof(VoxItem), 256);
 	return off;
 }
 
@@ -1056,18 +1197,20 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	const uint64_t fixedEnd = off;
-	// what is left is shared by the per-sample arrays: 4 B leaf + 4 B win mask for batch and spilled samples, 16 B per spilled sample
-	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 8;
+	// what is left is shared by the per-sample arrays: 4 B leaf + a 12 B emit-list entry for batch and spilled samples, 16 B per spilled sample
+	a.voxItemCap = a.nodeCapacity + 65536;                                     // one piece per leaf with new samples + one per 8192 samples beyond
+	a.offVoxItems = off; off += align_up((uint64_t)a.voxItemCap * sizeof(VoxItem), 256);
+	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 16;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
 	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
-	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (24 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
+	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (32 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
 	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
 	a.spilledCap = (uint32_t)cap;
 	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 spilled points + one partial chunk per split
 	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
 	(void)fixedEnd;
 	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
-	a.offWin = off;      off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offEmit = off;     off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * sizeof(Emit), 256);
 	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
 	a.scratchBytes = off;
 	return off <= capacity;
@@ -1100,7 +1243,6 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
-		const int sampleSpt = tune("SIMLOD_SAMPLE_SPT", 4);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
@@ -1109,14 +1251,11 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		for (uint32_t b = 0; b < limit; b++) {
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
-			switch (sampleSpt) {
-			case 1: SIMLOD_LAUNCH(k_sample<1>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			case 2: SIMLOD_LAUNCH(k_sample<2>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			case 8: SIMLOD_LAUNCH(k_sample<8>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			default: SIMLOD_LAUNCH(k_sample<4>, dim3(gridPoints), dim3(TPB), stream, a); break;
-			}
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u);
+			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a);
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 1u);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 1u);
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
 		}
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
