@@ -620,8 +620,12 @@ static constexpr uint32_t VOX_SPT = 8;                          // samples per t
 static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
 static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
 static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
-struct VoxItem { uint32_t leaf, s0, s1, pad; };                 // samples [s0, s1) of the leaf's storage
-struct Emit { uint32_t leaf, index, levels; };                  // levels: bit L = the sample colours a new voxel of its level-L ancestor
+struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; the leaf's chunk directory and coordinates
+// emit-list entry, one per sample that colours at least one new voxel: work item (20 bits) << 44 | index inside the item's range
+// (13 bits) << 20 | levels (bit L = the sample colours a new voxel of its level-L ancestor, L < 20)
+typedef unsigned long long Emit;
+__device__ __forceinline__ Emit emit_pack(uint32_t item, uint32_t rel, uint32_t levels) { return ((Emit)item << 44) | ((Emit)rel << 20) | levels; }
+static_assert(VOX_PIECE <= (1u << 13), "Emit: 13 bits for the index inside a piece");
 struct VoxShared {
 	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row
 	uint32_t fresh[CUBE_WORDS];                                 // pass A: cells this piece set; after the write-back: cells it won
@@ -644,6 +648,19 @@ __device__ __forceinline__ void cube_cell(uint32_t d, uint32_t cell, uint32_t& w
 	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
 	else { word = cube_offset(d) + row; bit = lx; }
 }
+// LDS word w of the cubes -> which ancestor's grid word it mirrors: d (0: none), the word's index in that grid, the bit offset of the
+// cube's row inside the word, and the row's mask
+__device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t LY, uint32_t LZ, uint32_t& gridWord, uint32_t& shift, uint32_t& mask) {
+	const uint32_t d = w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : w < 9557u ? 7u : 0u;
+	if (d == 0u) { gridWord = 0; shift = 0; mask = 0; return 0u; }
+	const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
+	const uint32_t rel = w - cube_offset(d), row = d == 1u ? rel >> 1 : rel, ly = row % side, lz = row / side;
+	const uint32_t cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
+	gridWord = (cell >> 5) + (d == 1u ? (rel & 1u) : 0u);
+	shift = d <= 2u ? 0u : (cell & 31u);
+	mask = side >= 32u ? 0xffffffffu : (1u << side) - 1u;
+	return d;
+}
 
 __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
@@ -652,15 +669,14 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	if (numItems == 0u) return;
 	__shared__ VoxShared sh;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
-	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	Emit* emits = at<Emit>(a, a.offEmit);
-	const uint32_t tag = ctl->batchIndex + 1u;
+	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
+		// Global memory is touched in six steps, each one round trip with everything it needs in flight together: the item; the leaf's
+		// path; chunk addresses + cube words; the samples; the write-back atomics; the emit reservation.
 		const VoxItem it = items[item];
-		const SimlodNode* leaf = a.nodes + it.leaf;
-		const NodeDir nd = nodeDir[it.leaf];
-		const uint32_t LX = leaf->X, LY = leaf->Y, LZ = leaf->Z;
+		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
 		if (threadIdx.x < PATH_WORDS) {
@@ -672,162 +688,174 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0;
 		}
 		if (threadIdx.x == 0) sh.emitCount = 0;
-		// the piece's samples: 8 per thread, all loads in flight together
-		uint32_t pX[VOX_SPT], pY[VOX_SPT], pZ[VOX_SPT], levels[VOX_SPT];
-		float color[VOX_SPT];
+		const SimlodChunk* chunk[VOX_SPT];
 		bool live[VOX_SPT];
-		{
-			float4 p[VOX_SPT];
 #pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				const uint32_t i = it.s0 + j * VTPB + threadIdx.x;
-				live[j] = i < it.s1 && nd.ptTag == tag;
-				p[j] = live[j] ? reinterpret_cast<const float4*>(chunkDir[nd.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - nd.ptFirst)]->points)[i % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
-			}
-#pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				pX[j] = quantize(F_FULL, p[j].x, a.minx, a.size); pY[j] = quantize(F_FULL, p[j].y, a.miny, a.size); pZ[j] = quantize(F_FULL, p[j].z, a.minz, a.size);
-				color[j] = p[j].w; levels[j] = 0u;
-			}
+		for (uint32_t j = 0; j < VOX_SPT; j++) {
+			const uint32_t i = it.s0 + j * VTPB + threadIdx.x;
+			live[j] = i < it.s1;
+			chunk[j] = live[j] ? chunkDir[it.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - it.ptFirst)] : nullptr;
 		}
 		__syncthreads();
 		uint32_t depth = 0;
 		while (depth < PATH_WORDS - 1 && sh.anc[depth] != 0ull) depth++;
-		// voxels.cu:449: the traverse loop samples levels 0..19 only — an ancestor at level 20 does not exist (leaves are at most at 20)
+		// voxels.cu:449: the traverse loop samples levels 0..19 only — an ancestor is at level 19 at most (leaves are at most at 20)
 		const uint32_t ldsDepth = it.leaf == 0u ? 0u : min(depth, LDS_LEVELS);       // a root that is still a leaf: its "cube" is the whole grid
 
-		// the leaf's cubes, as the grids hold them now; the single cells of the ancestors above
-		for (uint32_t d = 1; d <= ldsDepth; d++) {
-			const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
-			const uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
-			const uint32_t rows = side * side;
-			if (d == 1u) for (uint32_t w = threadIdx.x; w < rows * 2u; w += VTPB) {
-				const uint32_t row = w >> 1, ly = row % side, lz = row / side;
-				sh.occ[w] = grid[((ox + 128u * (oy + ly) + 16384u * (oz + lz)) >> 5) + (w & 1u)];
-				sh.fresh[w] = 0;
-			} else for (uint32_t row = threadIdx.x; row < rows; row += VTPB) {
-				const uint32_t ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
-				const uint32_t mask = side >= 32u ? 0xffffffffu : (1u << side) - 1u;
-				sh.occ[cube_offset(d) + row] = (grid[cell >> 5] >> (cell & 31u)) & mask;
-				sh.fresh[cube_offset(d) + row] = 0;
+		// the leaf's cubes, as the grids hold them now; the single cells of the ancestors above; the samples
+		{
+			uint32_t raw[WPT], sft[WPT], msk[WPT];
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				uint32_t gw;
+				const uint32_t d = cube_word(k * VTPB + threadIdx.x, LX, LY, LZ, gw, sft[k], msk[k]);
+				if (d == 0u || d > ldsDepth) { msk[k] = 0u; raw[k] = 0u; }
+				else raw[k] = path_grid(a.pers, sh.anc[d - 1])->values[gw];
 			}
-		}
-		if (it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth) {       // d = threadIdx.x + 1 >= 8: every sample of the leaf has the same cell
-			const unsigned long long ent = sh.anc[threadIdx.x];
-			const uint32_t d = threadIdx.x + 1u, level = path_level(ent);
-			// the leaf's own corner stands for all its samples: 2^(28 - leafLevel) fine units per leaf, leafLevel = level + d
-			const uint32_t sft = 28u - (level + d), cell = grid_cell(level, LX << sft, LY << sft, LZ << sft);
-			sh.hiOcc[threadIdx.x] = (path_grid(a.pers, ent)->values[cell >> 5] >> (cell & 31u)) & 1u;
-		}
-		__syncthreads();
-
-		// pass A: test-and-set, bottom-up, climbing while the cell is new
-		if (it.leaf != 0u) {
+			uint32_t hi = 0;
+			const bool hiMine = it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth;   // d = threadIdx.x + 1 >= 8: every sample of the leaf has the same cell
+			if (hiMine) {
+				const unsigned long long ent = sh.anc[threadIdx.x];
+				const uint32_t d = threadIdx.x + 1u, level = path_level(ent);
+				// the leaf's own corner stands for all its samples: 2^(28 - leafLevel) fine units per leaf, leafLevel = level + d
+				const uint32_t s2 = 28u - (level + d), cell = grid_cell(level, LX << s2, LY << s2, LZ << s2);
+				hi = (path_grid(a.pers, ent)->values[cell >> 5] >> (cell & 31u)) & 1u;
+			}
+			float4 p[VOX_SPT];
+#pragma unroll
+			for (uint32_t j = 0; j < VOX_SPT; j++)
+				p[j] = live[j] ? reinterpret_cast<const float4*>(chunk[j]->points)[(it.s0 + j * VTPB + threadIdx.x) % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				const uint32_t w = k * VTPB + threadIdx.x;
+				if (w < CUBE_WORDS) { sh.occ[w] = (raw[k] >> sft[k]) & msk[k]; sh.fresh[w] = 0u; }
+			}
+			if (hiMine) sh.hiOcc[threadIdx.x] = hi;
+			__syncthreads();
+			// (the samples stay in registers: coordinates and the levels they end up colouring)
+			uint32_t pX[VOX_SPT], pY[VOX_SPT], pZ[VOX_SPT], levels[VOX_SPT];
 #pragma unroll
 			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				if (!live[j]) continue;
+				pX[j] = quantize(F_FULL, p[j].x, a.minx, a.size); pY[j] = quantize(F_FULL, p[j].y, a.miny, a.size); pZ[j] = quantize(F_FULL, p[j].z, a.minz, a.size);
+				levels[j] = 0u;
+			}
+
+			// pass A: test-and-set, bottom-up, one level at a time for the thread's eight samples (their LDS atomics overlap); a sample
+			// climbs while its cell is new
+			if (it.leaf != 0u) {
+				bool go[VOX_SPT];
+#pragma unroll
+				for (uint32_t j = 0; j < VOX_SPT; j++) go[j] = live[j];
 				for (uint32_t d = 1; d <= depth; d++) {
-					const unsigned long long ent = sh.anc[d - 1];
-					const uint32_t level = path_level(ent);
-					if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;
+					bool any = false;
+#pragma unroll
+					for (uint32_t j = 0; j < VOX_SPT; j++) any = any || go[j];
+					if (!any) break;
+					const uint32_t level = path_level(sh.anc[d - 1]);
 					if (d <= ldsDepth) {
-						uint32_t word, bit;
-						cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word, bit);
-						if (((sh.occ[word] >> bit) & 1u) != 0u) break;                                 // voxels.cu:93-94; the ancestors are set as well
-						if (((atomicOr(&sh.occ[word], 1u << bit) >> bit) & 1u) != 0u) break;           // another sample of the piece was first: it climbs on
-						atomicOr(&sh.fresh[word], 1u << bit);
+						uint32_t word[VOX_SPT], bit[VOX_SPT], old[VOX_SPT];
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word[j], bit[j]); old[j] = go[j] ? sh.occ[word[j]] : 0xffffffffu; }
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) old[j] = atomicOr(&sh.occ[word[j]], 1u << bit[j]); }   // voxels.cu:93-96
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) atomicOr(&sh.fresh[word[j]], 1u << bit[j]); }   // lost: the winner climbs on
 					} else {
-						if (sh.hiOcc[d - 1] != 0u) break;
-						if (atomicOr(&sh.hiOcc[d - 1], 1u) != 0u) break;
-						sh.hiFresh[d - 1] = 1u;
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) {
+							if (!go[j]) continue;
+							if (sh.hiOcc[d - 1] != 0u || atomicOr(&sh.hiOcc[d - 1], 1u) != 0u) { go[j] = false; continue; }
+							sh.hiFresh[d - 1] = 1u;
+						}
+					}
+				}
+			} else {
+				// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample
+				const unsigned long long ent = sh.anc[0];
+				if (ent != 0ull) {
+#pragma unroll
+					for (uint32_t j = 0; j < VOX_SPT; j++) {
+						if (!live[j]) continue;
+						const uint32_t cell = grid_cell(0u, pX[j], pY[j], pZ[j]), bit = cell & 31u;
+						uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
+						if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
+						if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
+						levels[j] |= 1u;
+						atomicAdd(&sh.cnt[1], 1u);
 					}
 				}
 			}
-		} else {
-			// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample
-			const unsigned long long ent = sh.anc[0];
-			if (ent != 0ull) {
+			__syncthreads();
+
+			// write-back: the grids learn the new cells and tell which of them are new for everybody (pieces of one leaf share the cubes):
+			// every thread's atomics are in flight together
+			{
+				uint32_t f[WPT], old[WPT], gw[WPT];
 #pragma unroll
-				for (uint32_t j = 0; j < VOX_SPT; j++) {
-					if (!live[j]) continue;
-					const uint32_t cell = grid_cell(0u, pX[j], pY[j], pZ[j]), bit = cell & 31u;
-					uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
-					if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
-					if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
-					levels[j] |= 1u;
-					atomicAdd(&sh.cnt[1], 1u);
+				for (uint32_t k = 0; k < WPT; k++) {
+					const uint32_t w = k * VTPB + threadIdx.x;
+					const uint32_t d = cube_word(w, LX, LY, LZ, gw[k], sft[k], msk[k]);
+					f[k] = (d != 0u && d <= ldsDepth) ? sh.fresh[w] : 0u;
+					old[k] = f[k] != 0u ? atomicOr(&path_grid(a.pers, sh.anc[d - 1])->values[gw[k]], f[k] << sft[k]) : 0u;   // voxels.cu:96
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < WPT; k++) {
+					if (f[k] == 0u) continue;
+					const uint32_t w = k * VTPB + threadIdx.x;
+					const uint32_t won = f[k] & ~(old[k] >> sft[k]);
+					sh.fresh[w] = won;
+					if (won != 0u) atomicAdd(&sh.cnt[w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : 7u], (uint32_t)__popc(won));
+				}
+				if (hiMine && sh.hiFresh[threadIdx.x] != 0u) {
+					const unsigned long long ent = sh.anc[threadIdx.x];
+					const uint32_t d = threadIdx.x + 1u, level = path_level(ent), s2 = 28u - (level + d), cell = grid_cell(level, LX << s2, LY << s2, LZ << s2);
+					const uint32_t o = atomicOr(&path_grid(a.pers, ent)->values[cell >> 5], 1u << (cell & 31u));
+					const uint32_t won = ((o >> (cell & 31u)) & 1u) ^ 1u;
+					sh.hiFresh[threadIdx.x] = won;
+					sh.cnt[d] = won;
 				}
 			}
-		}
-		__syncthreads();
+			__syncthreads();
+			if (threadIdx.x >= 1u && threadIdx.x <= depth && sh.cnt[threadIdx.x] != 0u)
+				atomicAdd(&a.nodes[path_node(sh.anc[threadIdx.x - 1u])].numVoxels, sh.cnt[threadIdx.x]);         // voxels.cu:101
 
-		// write-back: the grids learn the new cells, and tell which of them are new for everybody (pieces of one leaf share the cubes)
-		for (uint32_t d = 1; d <= ldsDepth; d++) {
-			const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
-			uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
-			const uint32_t rows = side * side, words = d == 1u ? rows * 2u : rows;
-			uint32_t mine = 0;
-			for (uint32_t w = threadIdx.x; w < words; w += VTPB) {
-				const uint32_t f = sh.fresh[cube_offset(d) + w];
-				if (f == 0u) continue;
-				const uint32_t row = d == 1u ? w >> 1 : w, ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
-				const uint32_t sft = d == 1u ? 0u : (cell & 31u);
-				const uint32_t old = atomicOr(&grid[(cell >> 5) + (d == 1u ? (w & 1u) : 0u)], f << sft);   // voxels.cu:96
-				const uint32_t won = f & ~(old >> sft);
-				sh.fresh[cube_offset(d) + w] = won;
-				mine += __popc(won);
-			}
-			if (mine != 0u) atomicAdd(&sh.cnt[d], mine);
-		}
-		if (it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth && sh.hiFresh[threadIdx.x] != 0u) {
-			const unsigned long long ent = sh.anc[threadIdx.x];
-			const uint32_t d = threadIdx.x + 1u, level = path_level(ent), sft = 28u - (level + d), cell = grid_cell(level, LX << sft, LY << sft, LZ << sft);
-			const uint32_t old = atomicOr(&path_grid(a.pers, ent)->values[cell >> 5], 1u << (cell & 31u));
-			const uint32_t won = ((old >> (cell & 31u)) & 1u) ^ 1u;
-			sh.hiFresh[threadIdx.x] = won;
-			sh.cnt[d] = won;
-		}
-		__syncthreads();
-		if (threadIdx.x >= 1u && threadIdx.x <= depth && sh.cnt[threadIdx.x] != 0u)
-			atomicAdd(&a.nodes[path_node(sh.anc[threadIdx.x - 1u])].numVoxels, sh.cnt[threadIdx.x]);         // voxels.cu:101
-
-		// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
-		uint32_t levelsWithNew = 0;
-		for (uint32_t d = 1; d <= depth; d++) if (sh.cnt[d] != 0u) levelsWithNew |= 1u << d;
-		if (it.leaf != 0u && levelsWithNew != 0u) {
-#pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				if (!live[j]) continue;
+			// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
+			uint32_t levelsWithNew = 0;
+			for (uint32_t d = 1; d <= depth; d++) if (sh.cnt[d] != 0u) levelsWithNew |= 1u << d;
+			if (it.leaf != 0u) {
 				for (uint32_t left = levelsWithNew; left != 0u; left &= left - 1u) {       // only the cubes that gained cells
 					const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
 					const uint32_t level = path_level(sh.anc[d - 1]);
 					if (d <= ldsDepth) {
-						uint32_t word, bit;
-						cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word, bit);
-						if (((sh.fresh[word] >> bit) & 1u) == 0u) continue;
-						if (((atomicAnd(&sh.fresh[word], ~(1u << bit)) >> bit) & 1u) == 0u) continue;     // somebody else took the mark
+						uint32_t word[VOX_SPT], bit[VOX_SPT], cur[VOX_SPT];
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word[j], bit[j]); cur[j] = live[j] ? sh.fresh[word[j]] : 0u; }
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) cur[j] = ((cur[j] >> bit[j]) & 1u) != 0u ? atomicAnd(&sh.fresh[word[j]], ~(1u << bit[j])) : 0u;   // take the mark
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++) if (((cur[j] >> bit[j]) & 1u) != 0u) levels[j] |= 1u << level;                        // (unless somebody else just did)
 					} else {
-						if (sh.hiFresh[d - 1] == 0u) continue;
-						if (atomicExch(&sh.hiFresh[d - 1], 0u) == 0u) continue;
+#pragma unroll
+						for (uint32_t j = 0; j < VOX_SPT; j++)
+							if (live[j] && sh.hiFresh[d - 1] != 0u && atomicExch(&sh.hiFresh[d - 1], 0u) != 0u) levels[j] |= 1u << level;
 					}
-					levels[j] |= 1u << level;
 				}
 			}
-		}
-		// the samples that colour voxels go on the emit list: one reservation per piece
-		uint32_t mineEmits = 0;
+			// the samples that colour voxels go on the emit list: one reservation per piece
+			uint32_t mineEmits = 0;
 #pragma unroll
-		for (uint32_t j = 0; j < VOX_SPT; j++) mineEmits += levels[j] != 0u ? 1u : 0u;
-		uint32_t at0 = mineEmits != 0u ? atomicAdd(&sh.emitCount, mineEmits) : 0u;
-		__syncthreads();
-		if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&ctl->numEmits, sh.emitCount);
-		__syncthreads();
-		if (mineEmits != 0u) {
-			at0 += sh.emitBase;
+			for (uint32_t j = 0; j < VOX_SPT; j++) mineEmits += levels[j] != 0u ? 1u : 0u;
+			uint32_t at0 = mineEmits != 0u ? atomicAdd(&sh.emitCount, mineEmits) : 0u;
+			__syncthreads();
+			if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&ctl->numEmits, sh.emitCount);
+			__syncthreads();
+			if (mineEmits != 0u) {
+				at0 += sh.emitBase;
 #pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				if (levels[j] == 0u) continue;
-				emits[at0++] = Emit{it.leaf, it.s0 + j * VTPB + threadIdx.x, levels[j]};          // never more entries than samples: no overflow to handle
+				for (uint32_t j = 0; j < VOX_SPT; j++) {
+					if (levels[j] == 0u) continue;
+					emits[at0++] = emit_pack(item, j * VTPB + threadIdx.x, levels[j]);                // never more entries than samples: no overflow to handle
+				}
 			}
 		}
 	}
@@ -886,7 +914,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t at0 = atomicAdd(&ctl->numVoxItems, pieces);
 		if (at0 + pieces > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 		VoxItem* items = at<VoxItem>(a, a.offVoxItems);
-		for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), 0u};
+		for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
 	}
 	if (part == 0u) return;
 
@@ -973,6 +1001,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
 	const Emit* emits = at<const Emit>(a, a.offEmit);
+	const VoxItem* voxItems = at<const VoxItem>(a, a.offVoxItems);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
@@ -1045,16 +1074,17 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				if (t >= total) continue;
 				const Emit em = emits[t];
-				uint32_t left = em.levels & 0xfffffu;
+				uint32_t left = (uint32_t)em & 0xfffffu;
 				if (left == 0u) continue;
 				// the won levels are among the ancestors of the sample's leaf: read them off its path
-				const uint32_t leafIdx = em.leaf;
+				const VoxItem vi = voxItems[(uint32_t)(em >> 44)];
+				const uint32_t leafIdx = vi.leaf;
 				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
 				float4 p = make_float4(0, 0, 0, 0);
 				uint32_t pX = 0, pY = 0, pZ = 0;
 				if (pass == 1) {
-					const NodeDir ld = nodeDir[leafIdx];                                              // the sample itself: in the leaf's chunks since part 0
-					p = reinterpret_cast<const float4*>(chunkDir[ld.ptBase + (em.index / SIMLOD_POINTS_PER_CHUNK - ld.ptFirst)]->points)[em.index % SIMLOD_POINTS_PER_CHUNK];
+					const uint32_t index = vi.s0 + ((uint32_t)(em >> 20) & 0x1fffu);                   // the sample itself: in the leaf's chunks since part 0
+					p = reinterpret_cast<const float4*>(chunkDir[vi.ptBase + (index / SIMLOD_POINTS_PER_CHUNK - vi.ptFirst)]->points)[index % SIMLOD_POINTS_PER_CHUNK];
 					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
 				}
 #pragma unroll 1
@@ -1197,13 +1227,13 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	const uint64_t fixedEnd = off;
-	// what is left is shared by the per-sample arrays: 4 B leaf + a 12 B emit-list entry for batch and spilled samples, 16 B per spilled sample
-	a.voxItemCap = a.nodeCapacity + 65536;                                     // one piece per leaf with new samples + one per 8192 samples beyond
+	// what is left is shared by the per-sample arrays: 4 B leaf + an 8 B emit-list entry for batch and spilled samples, 16 B per spilled sample
+	a.voxItemCap = min(a.nodeCapacity + 65536u, 1u << 20);                     // one piece per leaf with new samples + one per 8192 samples beyond; Emit has 20 bits for it
 	a.offVoxItems = off; off += align_up((uint64_t)a.voxItemCap * sizeof(VoxItem), 256);
-	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 16;
+	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 12;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
 	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
-	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (32 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
+	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (28 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
 	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
 	a.spilledCap = (uint32_t)cap;
 	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 spilled points + one partial chunk per split
