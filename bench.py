@@ -250,8 +250,9 @@ def main():
         chain = {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms, "what": "whole kernel_construct chain, one 36 M ingest"}
         # Algorithmic bytes per kernel for one whole ingest.
-        #  batch chain: k_count reads every point (16 B), k_sample reads it again (16 B), k_insert reads and stores it (32 B) and stores the
-        #    new voxels (16 B each), k_expand reads a moved point and writes it to the spill buffer (32 B);
+        #  batch chain: k_count reads every point (16 B); k_insert reads and stores it (32 B; moved points too), and in its second part reads
+        #    the sample of every new voxel and stores the voxel (32 B each); k_voxelize reads every stored sample back (16 B; the cube words
+        #    it loads and writes, ~40 KB per 8192 samples, are not counted); k_expand reads a moved point and writes it to the spill buffer (32 B);
         #  bulk chain: k_ingest reads every point, stores the ones it places itself and their voxels; k_place reads and stores the samples of
         #    overflowing leaves and the moved points; k_voxelize reads them back twice and stores their voxels; k_expand as above plus one
         #    read of every waiting sample per split round (lower bound: one round).
@@ -259,11 +260,12 @@ def main():
             per_ingest = {"k_ingest": 16.0 * n_points + 16.0 * (n_points - placed) + 16.0 * (new_voxels - place_voxels), "k_place": 32.0 * (placed + moved),
                           "k_voxelize": 32.0 * (placed + moved) + 16.0 * place_voxels, "k_expand": 32.0 * moved + 16.0 * placed}
         else:
-            per_ingest = {"k_count": 16.0 * n_points, "k_sample": 16.0 * (n_points + moved), "k_insert": 32.0 * (n_points + moved) + 16.0 * new_voxels, "k_expand": 32.0 * moved}
+            per_ingest = {"k_count": 16.0 * n_points, "k_voxelize": 16.0 * (n_points + moved), "k_insert": 32.0 * (n_points + moved) + 32.0 * new_voxels, "k_expand": 32.0 * moved}
         base = lambda k: k.split("<")[0]                                     # k_sample<4> -> k_sample
         dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
-        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, bulk_chain and args.coalesce)))
+        per_batch = 2 if (not bulk_chain and dom in ("k_insert", "k_alloc")) else 1        # the batch chain runs these twice per batch (points, voxels)
+        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], per_batch * n_batches, bulk_chain and args.coalesce)))
         bytes_per_launch = per_ingest[dom] / active
         avg_ms = prof_c[dom_full][1] / active
         traffic, traffic_src = None, None
