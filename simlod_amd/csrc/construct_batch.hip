@@ -620,7 +620,7 @@ static constexpr uint32_t VOX_SPT = 8;                          // samples per t
 static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
 static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
 static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
-struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; the leaf's chunk directory and coordinates
+struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; its chunk directory, its coordinates; leaf = node index | level << 24
 // emit-list entry, one per sample that colours at least one new voxel: work item (20 bits) << 44 | index inside the item's range
 // (13 bits) << 20 | levels (bit L = the sample colours a new voxel of its level-L ancestor, L < 20)
 typedef unsigned long long Emit;
@@ -675,7 +675,8 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
 		// Global memory is touched in six steps, each one round trip with everything it needs in flight together: the item; the leaf's
 		// path; chunk addresses + cube words; the samples; the write-back atomics; the emit reservation.
-		const VoxItem it = items[item];
+		VoxItem it = items[item];
+		it.leaf &= 0xffffffu;                                  // (the level in the top byte is for k_insert)
 		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
@@ -914,7 +915,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t at0 = atomicAdd(&ctl->numVoxItems, pieces);
 		if (at0 + pieces > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 		VoxItem* items = at<VoxItem>(a, a.offVoxItems);
-		for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
+		for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
 	}
 	if (part == 0u) return;
 
@@ -1069,16 +1070,15 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
 	for (int pass = 0; pass < 2; pass++) {
 		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
 		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-#pragma unroll 1
+#pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				if (t >= total) continue;
 				const Emit em = emits[t];
 				uint32_t left = (uint32_t)em & 0xfffffu;
 				if (left == 0u) continue;
-				// the won levels are among the ancestors of the sample's leaf: read them off its path
 				const VoxItem vi = voxItems[(uint32_t)(em >> 44)];
-				const uint32_t leafIdx = vi.leaf;
+				const uint32_t leafIdx = vi.leaf & 0xffffffu, leafLevel = vi.leaf >> 24;
 				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
 				float4 p = make_float4(0, 0, 0, 0);
 				uint32_t pX = 0, pY = 0, pZ = 0;
@@ -1087,14 +1087,11 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
 					p = reinterpret_cast<const float4*>(chunkDir[vi.ptBase + (index / SIMLOD_POINTS_PER_CHUNK - vi.ptFirst)]->points)[index % SIMLOD_POINTS_PER_CHUNK];
 					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
 				}
-#pragma unroll 1
-				for (uint32_t k = 0; left != 0u && k < PATH_WORDS - 1; k++) {
-					const unsigned long long ent = leafIdx == 0u ? (k == 0 ? PATH_VALID : 0ull) : rec[k];   // a root that is still a leaf samples itself
-					if (ent == 0ull) break;
+				for (; left != 0u; left &= left - 1u) {
+					// the level-L ancestor is entry (leaf level - 1 - L) of the leaf's path; a root that is still a leaf samples itself
+					const int level = __ffs((int)left) - 1;
+					const unsigned long long ent = leafIdx == 0u ? PATH_VALID : rec[leafLevel - 1u - (uint32_t)level];
 					const uint32_t curIdx = path_node(ent);
-					const int level = (int)path_level(ent);
-					if (((left >> level) & 1u) == 0u) continue;
-					left &= ~(1u << level);
 					if (pass == 0) {
 						uint32_t rank;
 						(void)table_add(sh.tbl, curIdx, 1u, &rank);
