@@ -421,10 +421,20 @@ __device__ __forceinline__ bool leaf_is_hot(const BuildArgs& a, uint32_t leafIdx
 	return start + PEEK * est > MAXPTS - MAXPTS / 16u;
 }
 
-// k_place stores samples in `leafIdx`: the first to do so in this group puts the leaf on k_voxelize's work list
+// k_place stores samples in `leafIdx`: the first to do so in this group puts the leaf on k_voxelize's work list, one entry
+// (leaf | piece << 19) per VOX_PIECE samples
+static constexpr uint32_t VOX_SPT = 8, VOX_PIECE = 1024u * VOX_SPT;
 __device__ __forceinline__ void note_placed(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx) {
 	const uint32_t tag = ctl->ordinal + 1u;
-	if (atomicExch(at<uint32_t>(a, a.offPlacedTag) + leafIdx, tag) != tag) at<uint32_t>(a, a.offVoxList)[atomicAdd(&ctl->numVoxLeaves, 1u)] = leafIdx;
+	if (atomicExch(at<uint32_t>(a, a.offPlacedTag) + leafIdx, tag) != tag) {
+		// pieces of VOX_PIECE samples: Node.counter is final since k_expand — that many samples the leaf holds when k_place is done
+		const uint32_t start = at<const uint32_t>(a, a.offPtStart)[leafIdx], end = a.nodes[leafIdx].counter;
+		const uint32_t pieces = end > start ? (end - start + VOX_PIECE - 1u) / VOX_PIECE : 1u;
+		const uint32_t at0 = atomicAdd(&ctl->numVoxLeaves, pieces);
+		uint32_t* list = at<uint32_t>(a, a.offVoxList);
+		for (uint32_t q = 0; q < pieces && at0 + q < a.voxListCap; q++) list[at0 + q] = leafIdx | q << 19;
+		if (at0 + pieces > a.voxListCap) panic(ctl, SIMLOD_ERR_DIRECTORY_FULL);
+	}
 }
 
 // ---- one tile of samples: slots, stores, voxel sampling -----------------------------------------------------------------------------
@@ -1238,25 +1248,39 @@ __global__ __launch_bounds__(TPB) void k_place(BuildArgs a) {
 // Leaves with few new samples (and a root that is still a leaf: its cube is the whole grid) take the per-sample path with global
 // atomics; there is nothing to contend for.
 static constexpr uint32_t VTPB = 1024;
-static constexpr uint32_t VCHUNKS = 64;           // chunk pointers of the leaf's new range kept in LDS (a leaf below its limit has at most 50 chunks)
 static constexpr uint32_t BULK_MIN = 768;
 static constexpr uint32_t LDS_LEVELS = 7;           // ancestors whose cube of this leaf has at least one whole cell: side 128 >> d
+static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
+static_assert(VOX_PIECE == VTPB * VOX_SPT, "a piece = VOX_SPT samples per thread");
 struct VoxShared {
-	uint32_t occ[8192 + 1024 + 256 + 64 + 16 + 4 + 4];   // cubes d = 1..7: rows of (128 >> d) x-bits, one row per word from d = 2 on
-	uint32_t fresh[8192 + 1024 + 256 + 64 + 16 + 4 + 4]; // cells this pass set
+	uint32_t occ[CUBE_WORDS];                        // cubes d = 1..7: rows of (128 >> d) x-bits, one row per word from d = 2 on
+	uint32_t fresh[CUBE_WORDS];                      // pass A: cells this piece set; after the write-back: cells it won
 	unsigned long long anc[PATH_WORDS];
 	uint32_t cnt[PATH_WORDS], base[PATH_WORDS], cursor[PATH_WORDS];
 	SimlodChunk* ptr[PATH_WORDS][2];
-	const SimlodChunk* chunks[VCHUNKS];
 };
 __device__ __forceinline__ uint32_t cube_offset(uint32_t d) {          // word offset of cube d in VoxShared::occ / fresh
 	return d == 1u ? 0u : d == 2u ? 8192u : d == 3u ? 9216u : d == 4u ? 9472u : d == 5u ? 9536u : d == 6u ? 9552u : 9556u;
 }
-// word and bit of cell (lx, ly, lz) of cube d (side = 128 >> d)
-__device__ __forceinline__ void cube_cell(uint32_t d, uint32_t lx, uint32_t ly, uint32_t lz, uint32_t& word, uint32_t& bit) {
-	const uint32_t side = 128u >> d, row = ly + side * lz;
+// word and bit of grid cell `cell` of ancestor d inside the leaf's cube (side = 128 >> d; the cube is aligned to its side)
+__device__ __forceinline__ void cube_cell(uint32_t d, uint32_t cell, uint32_t& word, uint32_t& bit) {
+	const uint32_t side = 128u >> d, lx = (cell & 127u) & (side - 1u), ly = ((cell >> 7) & 127u) & (side - 1u), lz = (cell >> 14) & (side - 1u);
+	const uint32_t row = ly + side * lz;
 	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
 	else { word = cube_offset(d) + row; bit = lx; }
+}
+// LDS word w of the cubes -> which ancestor's grid word it mirrors: d (0: none), the word's index in that grid, the bit offset of the
+// cube's row inside the word, and the row's mask
+__device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t LY, uint32_t LZ, uint32_t& gridWord, uint32_t& shift, uint32_t& mask) {
+	const uint32_t d = w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : w < 9557u ? 7u : 0u;
+	if (d == 0u) { gridWord = 0; shift = 0; mask = 0; return 0u; }
+	const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
+	const uint32_t rel = w - cube_offset(d), row = d == 1u ? rel >> 1 : rel, ly = row % side, lz = row / side;
+	const uint32_t cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
+	gridWord = (cell >> 5) + (d == 1u ? (rel & 1u) : 0u);
+	shift = d <= 2u ? 0u : (cell & 31u);
+	mask = side >= 32u ? 0xffffffffu : (1u << side) - 1u;
+	return d;
 }
 
 __device__ __forceinline__ const SimlodChunk* placed_chunk(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t k, uint32_t start) {
@@ -1279,90 +1303,87 @@ __device__ __forceinline__ float4 voxel_at(const BuildArgs& a, uint32_t level, u
 	return v;
 }
 
-// sample #i of the leaf's storage; the chunk pointers of the first VCHUNKS chunks of the new range come from LDS
-__device__ __forceinline__ const float4* sample_addr(const BuildArgs& a, Ctl* ctl, const VoxShared& sh, uint32_t leafIdx, uint32_t i, uint32_t s0) {
-	const uint32_t k = i / CHUNK, rel = k - s0 / CHUNK;
-	const SimlodChunk* c = rel < VCHUNKS ? sh.chunks[rel] : placed_chunk(a, ctl, leafIdx, k, s0);
-	return c != nullptr ? reinterpret_cast<const float4*>(c->points) + i % CHUNK : nullptr;
-}
-
+// One workgroup per work-list entry: a leaf's piece of VOX_PIECE new samples, eight per thread, kept in registers through both passes.
+// Global memory is touched in a few steps, each one round trip with everything it needs in flight together: the leaf and its path; chunk
+// addresses + cube words; the samples; the write-back atomics (old = atomicOr(word, fresh): the pieces of one leaf share its cubes, the
+// returned word tells which cells are new for everybody); the voxel slot reservations; the voxel stores.
 __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
-	const uint32_t numLeaves = ctl->numVoxLeaves;
-	if (numLeaves == 0u) return;
+	const uint32_t numItems = min(ctl->numVoxLeaves, a.voxListCap);
+	if (numItems == 0u) return;
 	__shared__ VoxShared sh;
 	const uint32_t* list = at<const uint32_t>(a, a.offVoxList);
 	const uint32_t* ptStart = at<const uint32_t>(a, a.offPtStart);
-	for (uint32_t item = blockIdx.x; item < numLeaves; item += gridDim.x) {
-		const uint32_t leafIdx = list[item];
+	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
+	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
+		const uint32_t leafIdx = list[item] & 0x7ffffu, piece = list[item] >> 19;
 		const SimlodNode* leaf = a.nodes + leafIdx;
-		const uint32_t s0 = ptStart[leafIdx], s1 = leaf->numPoints;
+		const uint32_t first = ptStart[leafIdx], last = leaf->numPoints;
+		const uint32_t s0 = first + piece * VOX_PIECE, s1 = min(s0 + VOX_PIECE, last);
 		if (s1 <= s0 || !node_is_leaf(leaf)) continue;
 		const uint32_t lvl = leaf->level, LX = leaf->X, LY = leaf->Y, LZ = leaf->Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)leafIdx * PATH_WORDS;
 		PhaseTimer timer(ctl, 16);
 		__syncthreads();
 		if (threadIdx.x < PATH_WORDS) { sh.anc[threadIdx.x] = path_entry(a, rec, leafIdx, threadIdx.x); sh.cnt[threadIdx.x] = 0; sh.cursor[threadIdx.x] = 0; sh.base[threadIdx.x] = NONE; }
-		const uint32_t kFirst = s0 / CHUNK;
-		if (threadIdx.x >= 64u && threadIdx.x < 64u + VCHUNKS) {
-			const uint32_t k = kFirst + threadIdx.x - 64u;
-			sh.chunks[threadIdx.x - 64u] = k * CHUNK < s1 ? placed_chunk(a, ctl, leafIdx, k, s0) : nullptr;
+		const SimlodChunk* chunk[VOX_SPT];
+		bool live[VOX_SPT];
+#pragma unroll
+		for (uint32_t j = 0; j < VOX_SPT; j++) {
+			const uint32_t i = s0 + j * VTPB + threadIdx.x;
+			live[j] = i < s1;
+			chunk[j] = live[j] ? placed_chunk(a, ctl, leafIdx, i / CHUNK, first) : nullptr;
+			live[j] = live[j] && chunk[j] != nullptr;
 		}
 		__syncthreads();
 		// ancestor d (1 = parent) is sh.anc[d - 1]; a root that is still a leaf has itself as "ancestor 1" and no cube
 		uint32_t depth = 0;
 		while (depth < PATH_WORDS - 1 && sh.anc[depth] != 0ull) depth++;
-		const bool bulk = leafIdx != 0u && s1 - s0 >= BULK_MIN;
+		const bool bulk = leafIdx != 0u && last - first >= BULK_MIN;
 		const uint32_t ldsDepth = bulk ? min(depth, LDS_LEVELS) : 0u;
 
-		if (bulk) {
-			// the leaf's cubes, as the grids hold them now
-			for (uint32_t d = 1; d <= ldsDepth; d++) {
-				const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
-				const uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
-				const uint32_t rows = side * side;
-				if (d == 1u) for (uint32_t w = threadIdx.x; w < rows * 2u; w += VTPB) {
-					const uint32_t row = w >> 1, ly = row % side, lz = row / side;
-					sh.occ[w] = grid[((ox + 128u * (oy + ly) + 16384u * (oz + lz)) >> 5) + (w & 1u)];
-					sh.fresh[w] = 0;
-				} else for (uint32_t row = threadIdx.x; row < rows; row += VTPB) {
-					const uint32_t ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
-					const uint32_t mask = side >= 32u ? 0xffffffffu : (1u << side) - 1u;
-					sh.occ[cube_offset(d) + row] = (grid[cell >> 5] >> (cell & 31u)) & mask;
-					sh.fresh[cube_offset(d) + row] = 0;
+		// the leaf's cubes, as the grids hold them now; the samples
+		uint32_t sft[WPT], msk[WPT];
+		float4 p[VOX_SPT];
+		{
+			uint32_t raw[WPT];
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				uint32_t gw;
+				const uint32_t d = cube_word(k * VTPB + threadIdx.x, LX, LY, LZ, gw, sft[k], msk[k]);
+				if (d == 0u || d > ldsDepth) { msk[k] = 0u; raw[k] = 0u; }
+				else raw[k] = path_grid(a.pers, sh.anc[d - 1])->values[gw];
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < VOX_SPT; j++)
+				p[j] = live[j] ? reinterpret_cast<const float4*>(chunk[j]->points)[(s0 + j * VTPB + threadIdx.x) % CHUNK] : make_float4(0, 0, 0, 0);
+			if (bulk) {
+#pragma unroll
+				for (uint32_t k = 0; k < WPT; k++) {
+					const uint32_t w = k * VTPB + threadIdx.x;
+					if (w < CUBE_WORDS) { sh.occ[w] = (raw[k] >> sft[k]) & msk[k]; sh.fresh[w] = 0u; }
 				}
 			}
-			__syncthreads();
 		}
+		__syncthreads();
 		timer.lap(0);
+		uint32_t pX[VOX_SPT], pY[VOX_SPT], pZ[VOX_SPT];
+#pragma unroll
+		for (uint32_t j = 0; j < VOX_SPT; j++) { pX[j] = quantize(F_FULL, p[j].x, a.minx, a.size); pY[j] = quantize(F_FULL, p[j].y, a.miny, a.size); pZ[j] = quantize(F_FULL, p[j].z, a.minz, a.size); }
 
 		// pass A: test-and-set, bottom-up, climbing while the cell is new
-		constexpr uint32_t VU = 4;                          // samples whose loads a thread has in flight together
-		for (uint32_t i0 = s0 + threadIdx.x; i0 < s1; i0 += VTPB * VU) {
-		float4 pv[VU];
-		bool ok[VU];
 #pragma unroll
-		for (uint32_t uu = 0; uu < VU; uu++) {
-			const uint32_t i = i0 + uu * VTPB;
-			const float4* src = i < s1 ? sample_addr(a, ctl, sh, leafIdx, i, s0) : nullptr;
-			ok[uu] = src != nullptr;
-			pv[uu] = src != nullptr ? *src : make_float4(0, 0, 0, 0);
-		}
-#pragma unroll
-		for (uint32_t uu = 0; uu < VU; uu++) {
-			if (!ok[uu]) continue;
-			const float4 p = pv[uu];
-			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+		for (uint32_t j = 0; j < VOX_SPT; j++) {
+			if (!live[j]) continue;
 			for (uint32_t d = 1; d <= depth; d++) {
 				const unsigned long long ent = sh.anc[d - 1];
 				const uint32_t level = path_level(ent);
 				if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;                 // voxels.cu:449: levels 0..19 only
-				const uint32_t cell = cell_of(level, pX, pY, pZ);
+				const uint32_t cell = cell_of(level, pX[j], pY[j], pZ[j]);
 				if (d <= ldsDepth) {
-					const uint32_t side = 128u >> d;
 					uint32_t word, bit;
-					cube_cell(d, (cell & 127u) & (side - 1u), ((cell >> 7) & 127u) & (side - 1u), (cell >> 14) & (side - 1u), word, bit);
+					cube_cell(d, cell, word, bit);
 					if (((sh.occ[word] >> bit) & 1u) != 0u) break;
 					if (((atomicOr(&sh.occ[word], 1u << bit) >> bit) & 1u) != 0u) break;
 					atomicOr(&sh.fresh[word], 1u << bit);
@@ -1377,35 +1398,36 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 					const uint32_t slot = atomicAdd(&a.nodes[nodeIdx].numVoxels, 1u), k = slot / CHUNK;
 					if (slot % CHUNK == 0u) make_voxel_chunk(a, ctl, nodeIdx, k);
 					SimlodChunk* vc = wait_voxel_chunk(a, ctl, nodeIdx, k);
-					if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> sd, LY >> sd, LZ >> sd, cell, p.w);
+					if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> sd, LY >> sd, LZ >> sd, cell, p[j].w);
 				}
 			}
-		}
 		}
 		if (!bulk) { timer.lap(5); continue; }
 		__syncthreads();
 		timer.lap(1);
 
-		// new cells per cube; the cubes go back to the grids (d = 1, 2: whole words that belong to this leaf alone; above: shared words)
-		for (uint32_t d = 1; d <= ldsDepth; d++) {
-			const uint32_t side = 128u >> d, ox = (LX & ((1u << d) - 1u)) * side, oy = (LY & ((1u << d) - 1u)) * side, oz = (LZ & ((1u << d) - 1u)) * side;
-			uint32_t* grid = path_grid(a.pers, sh.anc[d - 1])->values;
-			const uint32_t rows = side * side, words = d == 1u ? rows * 2u : rows;
-			uint32_t mine = 0;
-			for (uint32_t w = threadIdx.x; w < words; w += VTPB) {
-				const uint32_t f = sh.fresh[cube_offset(d) + w];
-				if (f == 0u) continue;
-				mine += __popc(f);
-				const uint32_t row = d == 1u ? w >> 1 : w, ly = row % side, lz = row / side, cell = ox + 128u * (oy + ly) + 16384u * (oz + lz);
-				if (d == 1u) grid[(cell >> 5) + (w & 1u)] = sh.occ[w];
-				else if (d == 2u) grid[cell >> 5] = sh.occ[cube_offset(d) + w];
-				else atomicOr(&grid[cell >> 5], f << (cell & 31u));
+		// write-back: the grids learn the new cells and tell which of them are new for everybody; every thread's atomics in flight together
+		{
+			uint32_t f[WPT], old[WPT], gw[WPT];
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				const uint32_t w = k * VTPB + threadIdx.x;
+				const uint32_t d = cube_word(w, LX, LY, LZ, gw[k], sft[k], msk[k]);
+				f[k] = (d != 0u && d <= ldsDepth) ? sh.fresh[w] : 0u;
+				old[k] = f[k] != 0u ? atomicOr(&path_grid(a.pers, sh.anc[d - 1])->values[gw[k]], f[k] << sft[k]) : 0u;   // voxels.cu:96
 			}
-			if (mine != 0u) atomicAdd(&sh.cnt[d], mine);
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				if (f[k] == 0u) continue;
+				const uint32_t w = k * VTPB + threadIdx.x;
+				const uint32_t won = f[k] & ~(old[k] >> sft[k]);
+				sh.fresh[w] = won;
+				if (won != 0u) atomicAdd(&sh.cnt[w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : 7u], (uint32_t)__popc(won));
+			}
 		}
 		__syncthreads();
 		timer.lap(2);
-		// voxel slot ranges: one atomic per (leaf, ancestor); chunks whose first slot falls into a range; then the lookups
+		// voxel slot ranges: one atomic per (piece, ancestor); chunks whose first slot falls into a range; then the lookups
 		if (threadIdx.x >= 1u && threadIdx.x <= ldsDepth && sh.cnt[threadIdx.x] != 0u) {
 			const uint32_t d = threadIdx.x, nodeIdx = path_node(sh.anc[d - 1]), cnt = sh.cnt[d];
 			const uint32_t old = atomicAdd(&a.nodes[nodeIdx].numVoxels, cnt);                  // voxels.cu:101
@@ -1421,41 +1443,28 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 		__syncthreads();
 		timer.lap(3);
 
-		// pass B: every new cell becomes a voxel, coloured by whichever of its samples gets there first
+		// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
 		uint32_t levelsWithNew = 0;
 		for (uint32_t d = 1; d <= ldsDepth; d++) if (sh.cnt[d] != 0u) levelsWithNew |= 1u << d;
 		if (levelsWithNew == 0u) { timer.lap(4); continue; }
-		for (uint32_t i0 = s0 + threadIdx.x; i0 < s1; i0 += VTPB * VU) {
-		float4 pv[VU];
-		bool ok[VU];
 #pragma unroll
-		for (uint32_t uu = 0; uu < VU; uu++) {
-			const uint32_t i = i0 + uu * VTPB;
-			const float4* src = i < s1 ? sample_addr(a, ctl, sh, leafIdx, i, s0) : nullptr;
-			ok[uu] = src != nullptr;
-			pv[uu] = src != nullptr ? *src : make_float4(0, 0, 0, 0);
-		}
-#pragma unroll
-		for (uint32_t uu = 0; uu < VU; uu++) {
-			if (!ok[uu]) continue;
-			const float4 p = pv[uu];
-			const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+		for (uint32_t j = 0; j < VOX_SPT; j++) {
+			if (!live[j]) continue;
 			for (uint32_t left = levelsWithNew; left != 0u; left &= left - 1u) {       // only the cubes that gained cells
 				const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
 				const unsigned long long ent = sh.anc[d - 1];
 				const uint32_t level = path_level(ent);
 				if (level >= (uint32_t)SIMLOD_MAX_DEPTH) continue;
-				const uint32_t cell = cell_of(level, pX, pY, pZ), side = 128u >> d;
+				const uint32_t cell = cell_of(level, pX[j], pY[j], pZ[j]);
 				uint32_t word, bit;
-				cube_cell(d, (cell & 127u) & (side - 1u), ((cell >> 7) & 127u) & (side - 1u), (cell >> 14) & (side - 1u), word, bit);
+				cube_cell(d, cell, word, bit);
 				if (((sh.fresh[word] >> bit) & 1u) == 0u) continue;
 				if (((atomicAnd(&sh.fresh[word], ~(1u << bit)) >> bit) & 1u) == 0u) continue;     // somebody else took the mark
 				const uint32_t base = sh.base[d], slot = base + atomicAdd(&sh.cursor[d], 1u), kk = slot / CHUNK, dk = kk - base / CHUNK;
 				const uint32_t nodeIdx = path_node(ent);
 				SimlodChunk* vc = dk == 0u ? sh.ptr[d][0] : dk == 1u ? sh.ptr[d][1] : wait_voxel_chunk(a, ctl, nodeIdx, kk);
-				if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> d, LY >> d, LZ >> d, cell, p.w);
+				if (vc != nullptr) reinterpret_cast<float4*>(vc->points)[slot % CHUNK] = voxel_at(a, level, LX >> d, LY >> d, LZ >> d, cell, p[j].w);
 			}
-		}
 		}
 		timer.lap(4);
 	}
@@ -1615,7 +1624,8 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offVoxStart = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off;    off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
-	a.offVoxList = off;  off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.voxListCap = a.nodeCapacity + 8192u;                     // one piece per leaf that received samples + one per 8192 samples beyond (a group has at most 20 M)
+	a.offVoxList = off;  off += align_up((uint64_t)a.voxListCap * 4, 256);
 	a.offHist = off;     off += HIST_BYTES;
 	a.offDir = off;      off += align_up((uint64_t)a.dirCap * sizeof(DirEntry), 256);
 	// what is left is shared by the per-sample arrays: 8 B per sample of a group that may have to wait for k_place, 20 B per moved point

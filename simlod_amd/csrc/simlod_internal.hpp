@@ -70,7 +70,7 @@ struct BuildArgs {
 	uint64_t     persCapacity, frameCounter, scratchBytes;
 	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offEst, offPlacedTag, offParent, offPtStart, offVoxStart, offLeafChunks, offPaths, offHist, offDir,
 	             offPendIdx, offPendLeaf, offSpMeta, offSpilled, offVoxList;
-	uint32_t     nodeCapacity, spilledCap, pendCap, histCap, dirCap, groupMax;
+	uint32_t     nodeCapacity, spilledCap, pendCap, histCap, dirCap, groupMax, voxListCap;
 };
 
 bool layout_construct(BuildArgs& a, uint64_t capacity);
