@@ -55,6 +55,7 @@ struct Ctl {
 	uint64_t phaseNs[24];        // SIMLOD_PHASE_TIMERS=1 — wall time per phase summed over workgroups: k_ingest [0..7], k_place [8..15], k_voxelize [16..23]
 };
 static_assert(offsetof(Ctl, spilledTotal) == 176, "bench.py reads Ctl.spilledTotal at byte 176");
+static_assert(offsetof(Ctl, phaseNs) == 432, "tools/phases.py reads Ctl.phaseNs at byte 432");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
 struct BuildArgs {

@@ -14,10 +14,10 @@ dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, momentary_bytes=700_000_0
 u = dev.uniforms(W, H, T, box)
 for rep in range(2):
     dev.reset(u)
-    dev.momentary[424:424 + 192].zero_()
+    dev.momentary[432:432 + 192].zero_()
     dev.add_points(u, pts)
     torch.cuda.synchronize()
-ph = dev.momentary[424:424 + 192].cpu().numpy().view(np.uint64).astype(np.float64) / 1e3
+ph = dev.momentary[432:432 + 192].cpu().numpy().view(np.uint64).astype(np.float64) / 1e3
 nb = (n + 999999) // 1000000
 names = ["load+descend+count", "flush points (atomics, chunk alloc, lookups)", "store + sample", "flush voxels", "store voxels (+ queue entries)"]
 vn = ["cube load", "pass A", "write-back", "slot ranges + chunks", "pass B", "light path (whole)"]
