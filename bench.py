@@ -261,7 +261,7 @@ def main():
                           "k_voxelize": 32.0 * (placed + moved) + 16.0 * place_voxels, "k_expand": 32.0 * moved + 16.0 * placed}
         else:
             per_ingest = {"k_count": 16.0 * n_points, "k_voxelize": 16.0 * (n_points + moved), "k_insert": 32.0 * (n_points + moved) + 32.0 * new_voxels, "k_expand": 32.0 * moved}
-        base = lambda k: k.split("<")[0]                                     # k_sample<4> -> k_sample
+        base = lambda k: k.split("<")[0]                                     # k_ingest<4> -> k_ingest
         dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
         per_batch = 2 if (not bulk_chain and dom in ("k_insert", "k_alloc")) else 1        # the batch chain runs these twice per batch (points, voxels)

@@ -5,8 +5,8 @@
 // kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
 // memory image.  Design:
 //
-//   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, sample, alloc, insert,
-//     end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
+//   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, alloc + insert (points), voxelize,
+//     alloc + insert (voxels), end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
 //     over 256 CUs / 8 XCDs costs 4-26 us; control flow stays on the device (a control block at byte 0 of the
 //     momentary buffer), inactive kernels exit at once, so the call is fully asynchronous like the reference's;
 //   * every point is read with one coalesced 16-byte load per phase and descends the tree ONCE: the leaf found
@@ -16,12 +16,13 @@
 //     atomic per workgroup and counter): device-scope atomics on one word retire at ~88 M/s on this chip, and a spatially
 //     compact batch sends most of its points to a few dozen leaves;
 //   * voxel sampling walks the root path BOTTOM-UP (occupancy is hierarchical: a set bit implies the covering bits of all
-//     ancestors) and reads the path from a per-node ancestor table instead of chasing parent -> node -> grid pointers;
+//     ancestors), AFTER the insert, leaf by leaf, in LDS copies of the cubes of the ancestors' grids a leaf can touch
+//     (k_voxelize): the grids see one atomicOr per touched word instead of one per sample;
 //   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of every
 //     list remembers its tail (8 spare bytes of Chunk), a per-batch chunk directory gives O(1) slot->chunk, and a leaf chunk
 //     table lets a split read the whole list of a leaf with one wave;
-//   * new voxels are not copied through a 24-byte backlog record: `sample` leaves a 20-bit per-point mask of the
-//     levels the point won, `insert` regenerates the voxel from (level, cell) while the point is in registers;
+//   * new voxels are not copied through a 24-byte backlog record: `voxelize` leaves an 8-byte entry per sample that colours
+//     voxels (which sample, which levels), `insert` regenerates the voxels from (level, cell) and the sample;
 //   * no capacity limit loses a point: a split reserves its node slots and spill space in one compare-and-swap or does not
 //     happen yet (the leaf grows and is queued again by a later batch).
 //
@@ -144,7 +145,7 @@ static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
 // Ancestor paths: PATH_WORDS 64-bit entries per node, entry k = the k-th ancestor (parent first), zero-terminated.
 // An entry packs everything `sample` and `insert` need to know about that ancestor — its occupancy grid (offset into the
 // persistent buffer), level and node index — so a sample reads its whole root path with independent loads instead of chasing
-// parent -> node -> grid pointers level by level (the chain of dependent L2 round trips that bounded k_sample).
+// parent -> node -> grid pointers level by level.
 // Rebuilt for every node at the start of a launch (k_paths), extended for the eight children at a split (k_expand).
 static constexpr uint32_t PATH_WORDS = SIMLOD_MAX_DEPTH + 1;
 static constexpr unsigned long long PATH_VALID = 1ull << 63;

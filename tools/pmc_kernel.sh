@@ -13,7 +13,7 @@ for r in csv.DictReader(open(p)):
     k = r["Kernel_Name"].split("(")[0].replace("simlod::", "").replace("void ", "")
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in agg.items():
-    if k.startswith(("k_sample", "k_count", "k_insert", "k_expand", "r_draw")):
+    if k.startswith(("k_voxelize", "k_count", "k_insert", "k_expand", "r_draw")):
         print(k, {c: round(x) for c, x in v.items()})
 PY
 find $OUT -name "*.csv" -size +2M -delete
