@@ -65,7 +65,7 @@ static constexpr uint32_t ITEM_CHUNKS = 64;
 static constexpr uint32_t DTPB = 1024;              // draw workgroup: 16 waves share one tile (128 KB of LDS: one workgroup per CU)
 
 struct DrawItem {
-	uint32_t dirBase;                               // first entry of the item's chunks in the frame's chunk directory
+	const SimlodChunk* const* chunks;               // the item's chunk addresses: in the frame's chunk directory, or straight in a row of the builder's chunk table
 	uint32_t samples, visibleIdx;
 	int32_t  tileX, tileY;                          // origin of the LDS tile, or tileX < 0: no tile
 	uint32_t tileWH;                                // its extent, width | height << 16: the node's screen box, at most TILE x TILE
@@ -240,6 +240,10 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 		pieces[l] = (numChunks[l] + ITEM_CHUNKS - 1) / ITEM_CHUNKS;
 	}
 	const uint32_t myChunks = numChunks[0] + numChunks[1], myPieces = pieces[0] + pieces[1];
+	// A node has one list worth drawing (a leaf its points, an inner node its voxels): that one may come from the builder's chunk table
+	const int rowList = numChunks[0] != 0u ? 0 : 1;
+	const SimlodChunk* const* slots = tableValid && draws && a.leafTableSlots <= 64u ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
+	const uint32_t fromTable = slots != nullptr ? min(numChunks[rowList], a.leafTableSlots) : 0u;
 	uint32_t myClass[ITEM_CLASSES] = {0u, 0u, 0u, 0u};                                   // a list's pieces: full ones (class 0), then the rest
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
@@ -273,6 +277,12 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 #pragma unroll
 	for (int cl = 0; cl < ITEM_CLASSES; cl++) classBase[cl] += __shfl(waveBase[cl], 0);      // this lane's next free slot in class cl
 	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
+	const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
+	// A list that fits a row of the builder's chunk table (<= 50 chunks: every leaf below its limit, most inner nodes) is not copied at
+	// all: its draw item points INTO the row, once the row is seen to start with the list's head (r_draw ends the item at a gap, should
+	// a row ever have one).  Measured: copying the rows into the frame's directory — per lane, or by whole waves — was 10 us of this
+	// kernel's 28 (the visible nodes are neighbours in the node array: a few waves had all the copying to do).
+	const bool rowDirect = fromTable != 0u && numChunks[rowList] <= a.leafTableSlots && slots[0] == heads[rowList];
 	uint32_t throughTable = 0;
 	if (emit) {
 		const bool listed = slot < SIMLOD_MAX_VISIBLE_NODES;
@@ -305,8 +315,6 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 				tileH = (uint32_t)min(max((int)fminf(mxy, 1.0e6f) - tileY + a.pointSize + 2, 1), TILE);
 			}
 		}
-		const SimlodChunk** dir = reinterpret_cast<const SimlodChunk**>(a.mom + a.offDir);
-		const SimlodChunk* const* slots = tableValid ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
 		for (int l = 0; l < 2; l++, dirBase += numChunks[l - 1]) {
 			if (numChunks[l] == 0u) continue;
 			const bool fits = listed && dirBase + numChunks[l] <= MAX_DIR_CHUNKS;
@@ -314,25 +322,7 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 			uint32_t k = 0;
 			if (fits) {
 				const SimlodChunk* chunk = heads[l];
-				if (slots != nullptr && slots[0] == heads[l]) {
-					// independent loads instead of a pointer chase (a stale row never starts with the list's head)
-					const uint32_t fromTable = min(numChunks[l], a.leafTableSlots);
-					while (k < fromTable) {                                         // sixteen independent loads in flight, not one
-						const SimlodChunk* row[16];
-#pragma unroll
-						for (uint32_t j = 0; j < 16; j++) row[j] = k + j < fromTable ? slots[k + j] : nullptr;
-						uint32_t good = 0;
-#pragma unroll
-						for (uint32_t j = 0; j < 16; j++) good += (good == j && row[j] != nullptr) ? 1u : 0u;
-#pragma unroll
-						for (uint32_t j = 0; j < 16; j++)
-							if (j < good) dir[dirBase + k + j] = row[j];
-						k += good;
-						if (good < 16u) break;                                      // the end of the row's entries (or a gap)
-					}
-					chunk = k < numChunks[l] ? slots[k - 1]->next : nullptr;        // a longer list (or a row with a gap) continues by pointer
-					throughTable++;
-				}
+				if (l == rowList && rowDirect) { k = numChunks[l]; chunk = nullptr; throughTable++; }   // nothing to copy
 				for (; k < numChunks[l] && chunk != nullptr; k++) { dir[dirBase + k] = chunk; chunk = chunk->next; }
 			}
 			const uint32_t have = min(counts[l], k * SIMLOD_POINTS_PER_CHUNK);      // a list shorter than its counter says: draw what is there
@@ -344,7 +334,7 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 				for (int q = 0; q < ITEM_CLASSES; q++) if (cl == (uint32_t)q) at = classBase[q]++;
 				if (at >= a.itemCap) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); continue; }
 				DrawItem it;
-				it.dirBase = dirBase + p * ITEM_CHUNKS;
+				it.chunks = (l == rowList && rowDirect ? slots : dir + dirBase) + p * ITEM_CHUNKS;
 				it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
 				it.visibleIdx = slot; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16);
 				items[(uint64_t)cl * a.itemCap + at] = it;
@@ -727,7 +717,6 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	for (int cl = 0; cl < ITEM_CLASSES; cl++) classEnd[cl] = (cl > 0 ? classEnd[cl - 1] : 0u) + min(work[8 + cl], a.itemCap);
 	const uint32_t numItems = classEnd[ITEM_CLASSES - 1];
 	const DrawItem* items = reinterpret_cast<const DrawItem*>(a.mom + a.offItems);
-	const SimlodChunk* const* dir = reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offDir);
 	const SimlodNode* visible = reinterpret_cast<const SimlodNode*>(a.mom + R_OFF_VISIBLE);
 	// Workgroup-level queue of draw items.  The first item of a workgroup is its own index, the following ones come from a shared
 	// cursor that starts behind the statically assigned range.
@@ -744,10 +733,20 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 		}
 		c.tileX = it.tileX; c.tileY = it.tileY; c.tileW = (int)(it.tileWH & 0xffffu); c.tileH = (int)(it.tileWH >> 16);
 		c.tileExact = c.tileW * c.tileH <= TILE_EXACT_AREA;
-		if (threadIdx.x < ITEM_CHUNKS && threadIdx.x * SIMLOD_POINTS_PER_CHUNK < it.samples) sh_dir[threadIdx.x] = dir[it.dirBase + threadIdx.x];
+		bool gap = false;
+		if (threadIdx.x < ITEM_CHUNKS && threadIdx.x * SIMLOD_POINTS_PER_CHUNK < it.samples) {
+			const SimlodChunk* ch = it.chunks[threadIdx.x];
+			sh_dir[threadIdx.x] = ch;
+			gap = ch == nullptr;
+		}
 		if (it.tileX >= 0) tile_clear<MODE>(c);
-		__syncthreads();
-		draw_item<MODE>(c, sh_dir, it.samples, overrideColor, useOverride);
+		uint32_t samples = it.samples;
+		if (__syncthreads_or(gap ? 1 : 0)) {             // a table row with a gap (never seen; rows are complete while their stamp is valid): draw what precedes it
+			uint32_t whole = 0;
+			while (whole < ITEM_CHUNKS && whole * SIMLOD_POINTS_PER_CHUNK < it.samples && sh_dir[whole] != nullptr) whole++;
+			samples = min(samples, whole * SIMLOD_POINTS_PER_CHUNK);
+		}
+		draw_item<MODE>(c, sh_dir, samples, overrideColor, useOverride);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
