@@ -315,14 +315,21 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
 			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
 		}
+		// the eight descents of a thread in lockstep, one level per step: eight L2 round trips in flight instead of eight chains of 5-8
+		// dependent loads one after the other (that was the kernel: 21 us)
+		uint32_t X[CPT], Y[CPT], Z[CPT], cur[CPT], level[CPT];
+		bool walking[CPT];
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
+			X[j] = quantize(F_GRID, p[j].x, a.minx, a.size); Y[j] = quantize(F_GRID, p[j].y, a.miny, a.size); Z[j] = quantize(F_GRID, p[j].z, a.minz, a.size);
+			cur[j] = 0u; level[j] = 0u; walking[j] = chunk * CPB + j * TPB + threadIdx.x < n;
+		}
+		descend_lockstep<(int)CPT>(a.nodes, cur, level, X, Y, Z, walking);
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
 			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
 			if (i >= n) continue;
-			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size);
-			const uint32_t Y = quantize(F_GRID, p[j].y, a.miny, a.size);
-			const uint32_t Z = quantize(F_GRID, p[j].z, a.minz, a.size);
-			const uint32_t leafIdx = (uint32_t)(descend(a.nodes, 0, X, Y, Z) - a.nodes);
+			const uint32_t leafIdx = cur[j];
 			leafOf[i] = leafIdx;
 			uint32_t rank;
 			if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, spillList, &ctl->numSpilling);
