@@ -30,6 +30,7 @@
 // bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
 // chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
 // (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
+#include <mutex>
 #include "simlod_device.hpp"
 #include "simlod_hip.h"
 #include "simlod_internal.hpp"
@@ -58,9 +59,16 @@ struct Ctl {
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
-	uint32_t numVoxItems;              // k_alloc (points): (leaf, sample range) pieces for k_voxelize
-	uint32_t numEmits;                 // k_voxelize: samples that colour at least one new voxel (entries of the emit list)
-	uint32_t numVoxSmall;              // k_alloc (points): leaves with few new samples, for the wave-per-leaf path of k_voxelize (they fill the item array from its end)
+	// Per-batch state that the VOXEL TAIL of a batch (k_alloc / k_insert part 1) still reads while the next batch's k_count and k_expand
+	// are already running on the caller's stream (launch_construct): two copies, indexed by the batch's ordinal & 1.  k_end prepares
+	// the next batch in the other copy.  The arrays behind them (emit list, work items, chunk directory) exist once: the next batch
+	// first writes them in its k_alloc part 0, which waits for the tail.
+	uint32_t numVoxItems[2];           // k_alloc (points): (leaf, sample range) pieces for k_voxelize
+	uint32_t numEmits[2];              // k_voxelize: samples that colour at least one new voxel (entries of the emit list)
+	uint32_t numVoxSmall[2];           // k_alloc (points): leaves with few new samples, for the wave-per-leaf path of k_voxelize (they fill the item array from its end)
+	uint32_t dirCountOf[2];            // chunk directory entries in use (point entries of k_alloc part 0, then voxel entries of part 1)
+	uint32_t activeOf[2], tagOf[2];    // the batch is being processed; its tag (batch index + 1) in NodeDir
+	uint32_t nodesOf[2];               // Stats.numNodes after the batch's k_expand: part 1 must not look at nodes the NEXT batch's k_expand is creating
 };
 
 struct BuildArgs {
@@ -170,7 +178,9 @@ __device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->e
 
 // Make batch #ordinal of this launch current, or deactivate (progressive_octree_voxels.cu:890-912).
 __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
+	const uint32_t par = ordinal & 1u;
 	ctl->active = 0;
+	ctl->activeOf[par] = 0;
 	if (ordinal >= ctl->numBatches || ctl->stop) return;
 	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
 	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
@@ -192,13 +202,15 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->workSnap[0] = ctl->workSnap[1] = 0;
 	ctl->numSpilled = 0;
 	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
-	ctl->dirCount = 0;
-	ctl->numVoxItems = 0;
-	ctl->numVoxSmall = 0;
-	ctl->numEmits = 0;
+	ctl->dirCountOf[par] = 0;
+	ctl->numVoxItems[par] = 0;
+	ctl->numVoxSmall[par] = 0;
+	ctl->numEmits[par] = 0;
+	ctl->tagOf[par] = batchIndex + 1u;
 	ctl->abortBatch = 0;
 	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
 	ctl->active = 1;
+	ctl->activeOf[par] = 1;
 }
 
 // ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
@@ -681,7 +693,8 @@ __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t 
 // pieces.  (Measured: without this path the uniformly scattered
 // 350 M-point replay of the C++ harness, 40 000 leaves touched per batch, took 408 ms of kernel time instead of 157 ms.)
 __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, const uint32_t wave, const uint32_t numWaves) {
-	const uint32_t numSmall = min(ctl->numVoxSmall, a.voxItemCap);
+	const uint32_t par = ctl->ordinal & 1u;
+	const uint32_t numSmall = min(ctl->numVoxSmall[par], a.voxItemCap);
 	if (numSmall == 0u) return;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -766,7 +779,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 			}
 			if (total != 0u) {
 				uint32_t at0 = 0;
-				if (lane == 0u) at0 = atomicAdd(&ctl->numEmits, total);
+				if (lane == 0u) at0 = atomicAdd(&ctl->numEmits[par], total);
 				at0 = __shfl(at0, 0, 64);
 #pragma unroll
 				for (uint32_t u = 0; u < U; u++) if (levels[u] != 0u) emits[at0 + before[u]] = emit_pack(itemIndex[u], base + lane, levels[u]);
@@ -778,7 +791,8 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active || ctl->abortBatch) return;
-	const uint32_t numItems = min(ctl->numVoxItems, a.voxItemCap);
+	const uint32_t par = ctl->ordinal & 1u;
+	const uint32_t numItems = min(ctl->numVoxItems[par], a.voxItemCap);
 	__shared__ VoxShared sh;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -960,7 +974,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 			for (uint32_t j = 0; j < VOX_SPT; j++) mineEmits += levels[j] != 0u ? 1u : 0u;
 			uint32_t at0 = mineEmits != 0u ? atomicAdd(&sh.emitCount, mineEmits) : 0u;
 			__syncthreads();
-			if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&ctl->numEmits, sh.emitCount);
+			if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&ctl->numEmits[par], sh.emitCount);
 			__syncthreads();
 			if (mineEmits != 0u) {
 				at0 += sh.emitBase;
@@ -982,13 +996,13 @@ __device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *re
 
 // part 0 (before k_insert): the point chunks of leaves, and k_voxelize's work list; part 1 (after k_voxelize, when Node.numVoxels is
 // final for this batch): the voxel chunks of inner nodes
-__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i, uint32_t part) {
+__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i, uint32_t part, uint32_t par) {
 	SimlodNode* node = a.nodes + i;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
-	const uint32_t tag = ctl->batchIndex + 1u;
+	const uint32_t tag = ctl->tagOf[par];
 	if (part == 0u) node->countIteration = tag;
 
 	// -- points of leaves -------------------------------------------------------------------------------------
@@ -998,7 +1012,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
 		const uint32_t entries = required - first;
-		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
+		const uint32_t base = atomicAdd(&ctl->dirCountOf[par], entries);
 		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 		SimlodChunk* head = node->points;
 		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
@@ -1033,16 +1047,16 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 			const unsigned long long peers = __ballot(1);                                    // the lanes that are here with me
 			const int leader = __ffsll((long long)peers) - 1;
 			uint32_t k = 0;
-			if (lane_id() == leader) k = atomicAdd(&ctl->numVoxSmall, (uint32_t)__popcll(peers));
+			if (lane_id() == leader) k = atomicAdd(&ctl->numVoxSmall[par], (uint32_t)__popcll(peers));
 			k = __shfl(k, leader, 64) + (uint32_t)__popcll(peers & ((1ull << lane_id()) - 1ull));
 			__threadfence();
-			if (k + 1u + __hip_atomic_load(&ctl->numVoxItems, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+			if (k + 1u + __hip_atomic_load(&ctl->numVoxItems[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 			items[a.voxItemCap - 1u - k] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
 		} else {
 			const uint32_t pieces = (fresh + VOX_PIECE - 1) / VOX_PIECE;
-			const uint32_t at0 = atomicAdd(&ctl->numVoxItems, pieces);
+			const uint32_t at0 = atomicAdd(&ctl->numVoxItems[par], pieces);
 			__threadfence();
-			if (at0 + pieces + __hip_atomic_load(&ctl->numVoxSmall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+			if (at0 + pieces + __hip_atomic_load(&ctl->numVoxSmall[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 			for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
 		}
 	}
@@ -1056,7 +1070,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t existing = head == nullptr ? 0u : max(1u, (voxStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK);
 		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t entries = required - first;
-		const uint32_t base = atomicAdd(&ctl->dirCount, entries);
+		const uint32_t base = atomicAdd(&ctl->dirCountOf[par], entries);
 		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
 		uint32_t e = 0;
@@ -1064,7 +1078,8 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		if (required > existing) {
 			const uint32_t additional = required - existing;
 			uint8_t* fresh = persistent_alloc(a.pers, sizeof(SimlodChunk), additional);   // voxel chunks never come from the pool
-			const bool inner = !node_is_leaf(node);
+			// (never the root: this part may run while the NEXT batch's k_expand splits a root that was still a leaf and reads its row)
+			const bool inner = i != 0u && !node_is_leaf(node);
 			for (uint32_t k = 0; k < additional; k++) {
 				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
 				c->next = nullptr;
@@ -1081,11 +1096,14 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 }
 
 // A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
-__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a, uint32_t part) {
+// part 0 runs in the batch's own sequence; part 1 may run on the library's side stream while the next batch has begun: it knows its
+// batch by `par` (ordinal & 1), not by the control block's current-batch fields
+__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a, uint32_t part, uint32_t par) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i, part);
+	if (!ctl->activeOf[par] || ctl->abortBatch) return;
+	if (part == 0u && blockIdx.x == 0 && threadIdx.x == 0) ctl->nodesOf[par] = min(a.stats->numNodes, a.nodeCapacity);
+	const uint32_t numNodes = part == 0u ? min(a.stats->numNodes, a.nodeCapacity) : ctl->nodesOf[par];
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i, part, par);
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -1120,12 +1138,12 @@ __device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32
 }
 
 // part 0: the points (before k_voxelize, which reads them back leaf by leaf); part 1: the voxels of k_voxelize's emit list
-__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
+__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint32_t par) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
+	if (!ctl->activeOf[par] || ctl->abortBatch) return;
 	__shared__ InsertShared sh;
 	const uint32_t n = ctl->batchSize;
-	const uint32_t total = part == 0u ? n + min(ctl->numSpilled, a.spilledCap) : ctl->numEmits;
+	const uint32_t total = part == 0u ? n + min(ctl->numSpilled, a.spilledCap) : ctl->numEmits[par];
 	if (total == 0u) return;
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
@@ -1135,7 +1153,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part) {
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
-	const uint32_t tag = ctl->batchIndex + 1u;
+	const uint32_t tag = ctl->tagOf[par];
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
 	// Three workgroup-wide steps, each over ALL chunks this workgroup owns, so that barriers are paid per workgroup and not
 	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
@@ -1372,6 +1390,29 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	return off <= capacity;
 }
 
+// the library's side stream for the voxel tails, and the events that tie it to the caller's stream (one pair per batch of a launch)
+struct SideStream {
+	hipStream_t stream;
+	hipEvent_t voxelized[SIMLOD_MAX_BATCHES_PER_LAUNCH], tailDone[SIMLOD_MAX_BATCHES_PER_LAUNCH];
+};
+static SideStream* side_stream() {
+	static SideStream* cache[64];
+	static std::mutex lock;
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev < 0 || dev >= 64) return nullptr;
+	std::lock_guard<std::mutex> hold(lock);
+	if (cache[dev] == nullptr) {
+		SideStream* s = new SideStream();
+		bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+		for (uint32_t i = 0; ok && i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++)
+			ok = hipEventCreateWithFlags(&s->voxelized[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->tailDone[i], hipEventDisableTiming) == hipSuccess;
+		if (!ok) { (void)hipGetLastError(); delete s; return nullptr; }     // no side stream: everything stays on the caller's
+		cache[dev] = s;
+	}
+	return cache[dev];
+}
+
 int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
                      SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream) {
 	BuildArgs a{};
@@ -1404,16 +1445,31 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
 		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
+		// The voxel tail of a batch (k_alloc / k_insert part 1: ~35 us + two kernel boundaries) touches nothing the next batch's k_count
+		// and k_expand read or write (voxel chunks, numVoxelsStored, the emit list), so it runs on a side stream of the library while they
+		// run on the caller's: the tail starts when k_voxelize is done, the next batch's k_alloc part 0 — the first kernel that reuses the
+		// work items, the chunk directory and (through the recycle stack) the chunks the tail still reads — waits for it.  The per-batch
+		// words of the control block the tail needs exist twice (Ctl).  Off while per-kernel profiling is on (one stream, one timeline).
+		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
 		for (uint32_t b = 0; b < limit; b++) {
+			const uint32_t par = b & 1u;
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u);
+			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u, par);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u, par);
 			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a);
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 1u);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 1u);
+			hipStream_t tail = stream;
+			if (side != nullptr) {
+				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
+				tail = side->stream;
+			}
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, 1u, par);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), tail, a, 1u, par);
+			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
 			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
 		}
+		if (side != nullptr && limit > 0 && hipStreamWaitEvent(stream, side->tailDone[limit - 1], 0) != hipSuccess) return (int)hipGetLastError();
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
 	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
