@@ -44,7 +44,7 @@ struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
 	uint32_t active, batchSize, ringSlot, batchIndex;
 	uint32_t numSpilling;        // spilling leaves found by k_count; NOT modified by k_expand (its early-exit test must be stable)
-	uint32_t numSpilled, dirCount, errors;
+	uint32_t numSpilled, unused0, errors;   // (unused0: the directory counter moved to dirCountOf; the layout behind it stays)
 	uint32_t ordinal, abortBatch, barrierCount;
 	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
 	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]

@@ -706,9 +706,12 @@ def test_render_parts_equal_the_whole_frame_and_two_emulated_ranks_compose_exact
 
 
 # ---- BASELINE configs 3 and 5 at a size the oracle still finishes in seconds; the ring; ingest granularity ---------------------------
-def test_ring_wraps_around_more_than_twice(built_libs, chain):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_ring_wraps_around_more_than_twice(built_libs, chain, overlap, monkeypatch):
     """Config 3's mechanism: batches stream through the 50-slot ring (slot = batchletIndex % 50, voxels.cu:883-925) with the host's
-    back-pressure rule.  130 batches of 50 000 points wrap the ring 2.6 times; the octree must be the oracle's after the same 130 batches."""
+    back-pressure rule.  130 batches of 50 000 points wrap the ring 2.6 times; the octree must be the oracle's after the same 130 batches.
+    With the voxel tail of a batch on the library's side stream (the default of the exact chain) and on the caller's stream."""
+    monkeypatch.setenv("SIMLOD_OVERLAP_TAIL", overlap)
     pts, box = synthetic.terrain(6_500_000, seed=21, box=(2400.0, 1600.0, 160.0), tile=100.0)
     T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
     dev = _device(ring_slots=abi.BATCH_STREAM_SIZE)
