@@ -636,7 +636,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 //   write-back  old = atomicOr(grid word, fresh bits); won = fresh & ~old; Node.numVoxels += popcount(won)   (voxels.cu:96-101)
 //   pass B  every sample: if its cell is still marked won, take the mark: this sample colours the voxel (which sample of a cell does
 //           is scheduling dependent in the reference too).  Samples that took marks go on the emit list
-//           {leaf, index in the leaf, levels won}; k_insert's second part regenerates their voxels once k_alloc has made room.
+//           {work item, index in the piece, levels won}; k_insert's second part regenerates their voxels once k_alloc has made room.
 static constexpr uint32_t VTPB = 1024;
 static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
 static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
