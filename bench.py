@@ -282,7 +282,6 @@ def main():
     # ---- loader row: LAS format-2 records (26 B) -> Points (16 B) on the device, one 1 M-point batch ----
     loader = None
     if rank == 0 and not args.no_profile:
-        import ctypes
         from simlod_amd import lasio
         rs = np.random.RandomState(5)
         rec = lasio.las_records(rs.randint(0, 6_000_000, size=(batch, 3)).astype(np.int32), rs.randint(0, 65536, size=(batch, 3)).astype(np.uint16), 2)
@@ -330,7 +329,7 @@ def main():
 
     # ---- CPU baseline: the oracle's serial C restatement on a bounded sample of the same workload ------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not use_dist and not args.no_cpu_baseline:   # (the torchrun path generates its points on the device)
         import subprocess
         import tempfile
         # the serial restatement rebuilt -march=native ON this box, into a scratch file (the library that ships stays portable)

@@ -1087,3 +1087,22 @@ def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(b
         os.environ.pop("SIMLOD_EXACT_CHAIN", None)
         os.environ.pop("SIMLOD_RASTER_LEAF_TABLE", None)
         lib().simlod_set_ingest_mode(0)
+
+
+# ---- bench.py as the driver launches it for N > 1 ---------------------------------------------------------------------------------------
+def test_bench_runs_under_torch_distributed_run_and_prints_one_json_line(built_libs):
+    """The driver launches `bench.py --gpus N` through torch.distributed.run for N > 1: that path (RCCL process group, device-generated
+    tiles, partition, routed ingest, composed frames) must run and leave exactly ONE JSON line on stdout — here with one rank, the
+    only world size a 1-GPU box has; world 2 and 4 are covered on CPU (gloo) in test_distributed_cpu.py."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                          "--points", "4000000", "--frames", "2", "--no-profile"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "M points/s"
+    assert d["raster"]["plain"]["value"] > 0 and d["raster"]["hqs"]["value"] > 0 and d["partition"]["per_rank_points"] == [4000000]
