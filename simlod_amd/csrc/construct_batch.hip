@@ -692,8 +692,7 @@ __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t 
 // the ancestor, so Node.numVoxels takes one add per (leaf, level, step).  The waves of k_voxelize's workgroups do this after their
 // pieces.  (Measured: without this path the uniformly scattered
 // 350 M-point replay of the C++ harness, 40 000 leaves touched per batch, took 408 ms of kernel time instead of 157 ms.)
-__device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, const uint32_t wave, const uint32_t numWaves) {
-	const uint32_t par = ctl->ordinal & 1u;
+__device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, const uint32_t wave, const uint32_t numWaves, const uint32_t par, const bool rootOnly) {
 	const uint32_t numSmall = min(ctl->numVoxSmall[par], a.voxItemCap);
 	if (numSmall == 0u) return;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
@@ -714,7 +713,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 #pragma unroll
 		for (uint32_t u = 0; u < U; u++) {
 			const uint32_t leafIdx = it[u].leaf & 0xffffffu;
-			count[u] = k0 + u < numSmall ? it[u].s1 - it[u].s0 : 0u;
+			count[u] = k0 + u < numSmall && (leafIdx == 0u) == rootOnly ? it[u].s1 - it[u].s0 : 0u;   // a root that is still a leaf: the other launch's
 			// the leaf's path, one entry per lane (entry d - 1 = ancestor d; a root that is still a leaf samples itself, voxels.cu:449-463)
 			mine[u] = 0ull;
 			if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; if (lane == 0u && g != nullptr) mine[u] = path_pack(a.pers, 0u, 0u, g); }
@@ -788,10 +787,15 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 	}
 }
 
-__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
+// Launched twice per batch.  rootOnly = 0, on the library's side stream, while the next batch is already counted and split on the
+// caller's: everything except the samples of a root that is still a leaf.  rootOnly = 1, on the caller's stream: only those (the
+// whole octree holds fewer than 50 000 points then; the launch returns at once otherwise) — the next batch's k_expand may split that
+// root and CLEAR its grid (voxels.cu:371-382), which must not happen under a sampling pass that is still setting bits in it.  No
+// other grid is touched by both: a leaf that k_expand splits gets a NEW grid, and nothing samples into a leaf's own grid.
+__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, uint32_t rootOnly) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->active || ctl->abortBatch) return;
-	const uint32_t par = ctl->ordinal & 1u;
+	if (!ctl->activeOf[par] || ctl->abortBatch) return;
+	if (rootOnly != 0u && !node_is_leaf(a.nodes)) return;
 	const uint32_t numItems = min(ctl->numVoxItems[par], a.voxItemCap);
 	__shared__ VoxShared sh;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
@@ -803,6 +807,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 		// path; chunk addresses + cube words; the samples; the write-back atomics; the emit reservation.
 		VoxItem it = items[item];
 		it.leaf &= 0xffffffu;                                  // (the level in the top byte is for k_insert)
+		if ((it.leaf == 0u) != (rootOnly != 0u)) continue;     // whole workgroup
 		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a) {
 		}
 	}
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
-	voxelize_small(a, ctl, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
+	voxelize_small(a, ctl, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u, par, rootOnly != 0u);
 }
 
 // ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
@@ -1445,11 +1450,18 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
 		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
-		// The voxel tail of a batch (k_alloc / k_insert part 1: ~35 us + two kernel boundaries) touches nothing the next batch's k_count
-		// and k_expand read or write (voxel chunks, numVoxelsStored, the emit list), so it runs on a side stream of the library while they
-		// run on the caller's: the tail starts when k_voxelize is done, the next batch's k_alloc part 0 — the first kernel that reuses the
-		// work items, the chunk directory and (through the recycle stack) the chunks the tail still reads — waits for it.  The per-batch
-		// words of the control block the tail needs exist twice (Ctl).  Off while per-kernel profiling is on (one stream, one timeline).
+		// The VOXEL HALF of a batch — k_voxelize, then k_alloc / k_insert part 1: ~80 us + three kernel boundaries — touches nothing the next
+		// batch's k_count and k_expand read or write (occupancy grids of nodes that are already inner, voxel chunks, numVoxels*, the
+		// emit list; it reads the batch's samples from their leaf chunks, which k_expand may hand to the recycle stack but nobody
+		// overwrites before the next k_insert), so it runs on a side stream of the library while they run on the caller's: it starts
+		// when k_insert part 0 is done, and the next batch's k_alloc part 0 — the first kernel that reuses the work items, the chunk
+		// directory and, through the recycle stack, those chunks — waits for it.  The per-batch words of the control block it needs exist
+		// twice (Ctl).  One exception stays on the caller's stream: the samples of a root that is still a leaf (k_voxelize, rootOnly).
+		// Measured on the 36 M terrain: 8.46 ms per ingest with everything on one stream, 8.06 with parts 1 on the side, 7.72 with
+		// k_voxelize there too; the two halves are about equally long, but side by side each runs slower (they compete for the CUs'
+		// wave slots: a k_voxelize workgroup fills a CU), and every cross-stream dependency costs ~10 us of its own.  A side stream
+		// restricted to part of the CUs (hipExtStreamCreateWithCUMask) made everything slower (13.9 ms).  Fewer k_voxelize workgroups
+		// (128, 64) made the side the long pole (8.2, 9.4 ms).  Off while per-kernel profiling is on (one stream, one timeline).
 		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
 		for (uint32_t b = 0; b < limit; b++) {
 			const uint32_t par = b & 1u;
@@ -1458,12 +1470,13 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
 			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u, par);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u, par);
-			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a);
+			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a, par, 1u);      // a root that is still a leaf: here (else: returns at once)
 			hipStream_t tail = stream;
 			if (side != nullptr) {
 				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
 				tail = side->stream;
 			}
+			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), tail, a, par, 0u);
 			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, 1u, par);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), tail, a, 1u, par);
 			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
