@@ -1399,6 +1399,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 struct SideStream {
 	hipStream_t stream;
 	hipEvent_t voxelized[SIMLOD_MAX_BATCHES_PER_LAUNCH], tailDone[SIMLOD_MAX_BATCHES_PER_LAUNCH];
+	std::mutex enqueue;          // the events are reused by every launch on the device: one launch's records and waits are enqueued as a block
 };
 static SideStream* side_stream() {
 	static SideStream* cache[64];
@@ -1463,6 +1464,8 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// restricted to part of the CUs (hipExtStreamCreateWithCUMask) made everything slower (13.9 ms).  Fewer k_voxelize workgroups
 		// (128, 64) made the side the long pole (8.2, 9.4 ms).  Off while per-kernel profiling is on (one stream, one timeline).
 		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
+		std::unique_lock<std::mutex> block;
+		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
 		for (uint32_t b = 0; b < limit; b++) {
 			const uint32_t par = b & 1u;
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
