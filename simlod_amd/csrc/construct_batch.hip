@@ -1438,7 +1438,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	} else forget_leaf_table(nodes);
 	const DeviceInfo& dev = device_info();
 
-	const uint32_t limit = std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH);
+	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(stats));
 	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, (uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u);
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
@@ -1490,6 +1490,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	}
 	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
 	if (profile_enabled()) profile_close(stream);
+	if (note_launch_end(stats, numBatchesUploaded, stream) != 0) return (int)hipGetLastError();
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return (int)e;
 	return fits ? 0 : (int)hipErrorInvalidValue;

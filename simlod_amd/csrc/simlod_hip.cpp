@@ -81,6 +81,58 @@ bool find_leaf_table(const void* nodes, LeafTableRef& ref) {
 	return false;
 }
 
+// ---- launch feedback: how many batches the recent kernel_construct launches found (simlod_internal.hpp groups_for_launch) ----------
+struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter
+static std::mutex g_historyLock;
+static std::vector<LaunchHistory> g_history;
+static constexpr uint32_t NOTHING_SEEN = 0xffffffffu;
+
+static LaunchHistory* history_of(const void* stats, bool create) {
+	for (LaunchHistory& h : g_history) if (h.stats == stats) return &h;
+	if (!create) return nullptr;
+	void* pinned = nullptr;
+	if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	volatile uint32_t* seen = static_cast<volatile uint32_t*>(pinned);
+	seen[0] = NOTHING_SEEN; seen[1] = NOTHING_SEEN;
+	if (g_history.size() >= 64) { (void)hipHostFree(const_cast<uint32_t*>(g_history.front().seen)); g_history.erase(g_history.begin()); }
+	g_history.push_back(LaunchHistory{stats, seen, 0u, false});
+	return &g_history.back();
+}
+
+uint32_t groups_for_launch(const SimlodStats* stats) {
+	if (tune("SIMLOD_ADAPTIVE_GROUPS", 1) == 0) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	std::lock_guard<std::mutex> hold(g_historyLock);
+	LaunchHistory* h = history_of(stats, false);
+	if (h == nullptr) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	const uint32_t index = h->seen[0], uploaded = h->seen[1];
+	if (index == NOTHING_SEEN || uploaded == NOTHING_SEEN) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	const uint32_t pending = uploaded > index ? uploaded - index : 0u;
+	const uint32_t recent = h->havePrev && index >= h->prevIndex ? index - h->prevIndex : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (a smaller index: reset by other means)
+	h->prevIndex = index; h->havePrev = true;
+	const uint32_t want = pending + recent + 2u;
+	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want;
+}
+
+int note_launch_end(const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream) {
+	if (tune("SIMLOD_ADAPTIVE_GROUPS", 1) == 0) return 0;
+	volatile uint32_t* seen;
+	{
+		std::lock_guard<std::mutex> hold(g_historyLock);
+		LaunchHistory* h = history_of(stats, true);
+		if (h == nullptr) return 0;
+		seen = h->seen;
+	}
+	hipError_t e = hipMemcpyAsync(const_cast<uint32_t*>(seen), &stats->batchletIndex, 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint32_t*>(seen) + 1, numBatchesUploaded, 4, hipMemcpyDeviceToHost, stream);
+	return (int)e;
+}
+
+void forget_launch_history(const SimlodStats* stats) {
+	std::lock_guard<std::mutex> hold(g_historyLock);
+	LaunchHistory* h = history_of(stats, false);
+	if (h != nullptr) { h->seen[0] = NOTHING_SEEN; h->seen[1] = NOTHING_SEEN; h->havePrev = false; }
+}
+
 // ---- optional per-kernel profiling ------------------------------------------------------------------------------
 struct ProfileMark { const char* name; hipEvent_t ev; };
 static std::atomic<bool> g_profile{false};

@@ -111,6 +111,15 @@ void note_leaf_table(const LeafTableRef& ref);                 // construct chai
 void forget_leaf_table(const void* nodes);                     // reset
 bool find_leaf_table(const void* nodes, LeafTableRef& ref);    // false also when the table's buffer is no longer a live device allocation
 
+// How many per-batch kernel groups a kernel_construct launch should enqueue (the host cannot see how many batches are pending: the
+// upload counter lives on the device).  Every launch ends with two 4-byte copies — Stats.batchletIndex and the upload counter — into
+// page-locked host memory; the next launch reads whatever has arrived (no synchronisation) and enqueues what was left pending + what
+// the recent launches processed + 2, at least 2, at most 20.  Unknown octree, or just reset: 20.  An idle frame loop pays for 2
+// groups instead of 20 (0.84 ms -> 0.1 ms per launch on MI355X, tools/idle_launch.py); a burst is picked up one launch late.
+uint32_t groups_for_launch(const SimlodStats* stats);
+int note_launch_end(const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream);
+void forget_launch_history(const SimlodStats* stats);
+
 struct DeviceInfo {
 	int      device;
 	uint32_t numCUs;
