@@ -1449,7 +1449,10 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
-		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / 2), (int)dev.numCUs));
+		// (with the previous batch's voxel half running beside it on the side stream: one per FOUR CUs — 256: 8.3 ms per ingest, 128: 7.8,
+		// 96: 7.5, 64: 7.2, 48: 7.3, 32: 7.5)
+		const bool overlap = tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled();
+		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		// The VOXEL HALF of a batch — k_voxelize, then k_alloc / k_insert part 1: ~80 us + three kernel boundaries — touches nothing the next
 		// batch's k_count and k_expand read or write (occupancy grids of nodes that are already inner, voxel chunks, numVoxels*, the
