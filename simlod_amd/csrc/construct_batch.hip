@@ -60,7 +60,7 @@ struct Ctl {
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
 	// Per-batch state that the VOXEL TAIL of a batch (k_alloc / k_insert part 1) still reads while the next batch's k_count and k_expand
-	// are already running on the caller's stream (launch_construct): two copies, indexed by the batch's ordinal & 1.  k_end prepares
+	// are already running on the caller's stream (launch_construct): two copies, indexed by the batch's ordinal & 1.  the end-of-batch bookkeeping prepares
 	// the next batch in the other copy.  The arrays behind them (emit list, work items, chunk directory) exist once: the next batch
 	// first writes them in its k_alloc part 0, which waits for the tail.
 	uint32_t numVoxItems[2];           // k_alloc (points): (leaf, sample range) pieces for k_voxelize
@@ -787,14 +787,32 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 	}
 }
 
+// ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
+// One thread; rides in the rootOnly launch of k_voxelize, the last kernel of a batch on the caller's stream (nothing that launch or
+// the voxel half on the side stream reads is touched here: they know their batch by `par`).
+__device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
+	if (ctl->active && ctl->abortBatch) ctl->stop = 1;       // scratch overflow: this batch is lost, report through Stats.dbg
+	if (ctl->active && !ctl->abortBatch) {
+		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
+		a.stats->batchletIndex += 1;
+		a.stats->numPointsProcessed += ctl->batchSize;
+		ctl->expandNs[7] += min(ctl->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
+		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
+		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
+	}
+	prepare_batch(a, ctl, ordinal + 1);
+}
+
 // Launched twice per batch.  rootOnly = 0, on the library's side stream, while the next batch is already counted and split on the
 // caller's: everything except the samples of a root that is still a leaf.  rootOnly = 1, on the caller's stream: only those (the
 // whole octree holds fewer than 50 000 points then; the launch returns at once otherwise) — the next batch's k_expand may split that
 // root and CLEAR its grid (voxels.cu:371-382), which must not happen under a sampling pass that is still setting bits in it.  No
 // other grid is touched by both: a leaf that k_expand splits gets a NEW grid, and nothing samples into a leaf's own grid.
-__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, uint32_t rootOnly) {
+__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, uint32_t rootOnly, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->activeOf[par] || ctl->abortBatch) return;
+	const bool mine = ctl->activeOf[par] != 0u && ctl->abortBatch == 0u;          // read before the bookkeeping below moves on to the next batch
+	if (rootOnly != 0u && blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, ordinal);
+	if (!mine) return;
 	if (rootOnly != 0u && !node_is_leaf(a.nodes)) return;
 	const uint32_t numItems = min(ctl->numVoxItems[par], a.voxItemCap);
 	__shared__ VoxShared sh;
@@ -1027,7 +1045,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		if (additional > 0) {
 			// pop from the recycle stack, allocate what the stack cannot serve (voxels.cu:505-516): one atomic each
 			const unsigned long long firstIdx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional);
-			const unsigned long long pool = a.stats->chunkPoolSize;     // raised only by k_end
+			const unsigned long long pool = a.stats->chunkPoolSize;     // raised only by end_of_batch
 			const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
 			uint8_t* fresh = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
 			for (uint32_t k = 0; k < additional; k++) {
@@ -1280,22 +1298,6 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 	}
 }
 
-// ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
-__global__ void k_end(BuildArgs a, uint32_t ordinal) {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	Ctl* ctl = ctl_of(a);
-	if (ctl->active && ctl->abortBatch) ctl->stop = 1;       // scratch overflow: this batch is lost, report through Stats.dbg
-	if (ctl->active && !ctl->abortBatch) {
-		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
-		a.stats->batchletIndex += 1;
-		a.stats->numPointsProcessed += ctl->batchSize;
-		ctl->expandNs[7] += min(ctl->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
-		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
-		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
-	}
-	prepare_batch(a, ctl, ordinal + 1);
-}
-
 // ---- stats pass (voxels.cu:957-1009) -------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -1476,17 +1478,16 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
 			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u, par);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u, par);
-			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a, par, 1u);      // a root that is still a leaf: here (else: returns at once)
+			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a, par, 1u, b);   // a root that is still a leaf: here (else: only the end-of-batch bookkeeping)
 			hipStream_t tail = stream;
 			if (side != nullptr) {
 				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
 				tail = side->stream;
 			}
-			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), tail, a, par, 0u);
+			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, par, 0u, b);
 			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, 1u, par);
 			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), tail, a, 1u, par);
 			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
-			SIMLOD_LAUNCH(k_end, dim3(1), dim3(64), stream, a, b);
 		}
 		if (side != nullptr && limit > 0 && hipStreamWaitEvent(stream, side->tailDone[limit - 1], 0) != hipSuccess) return (int)hipGetLastError();
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
