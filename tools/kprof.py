@@ -17,7 +17,7 @@ for rep in range(2):
     dev.reset(u)
     if rep == 1:
         L.simlod_profile_enable(1)
-        dev.momentary[176:264].zero_()
+        dev.momentary[152:264].zero_()
     dev.add_points(u, pts)
     torch.cuda.synchronize()
 prof = bench.collect_profile(L)
@@ -25,8 +25,12 @@ st = dev.read_stats()
 nb = (n + 999999) // 1000000
 print("variant", os.environ.get("SIMLOD_VARIANT", "0"), "pts", int(st["numPoints"]), "voxels", int(st["numVoxels"]), "dbg", int(st["dbg"]))
 print({k: (c, round(ms, 2), "%.0f us/batch" % (ms * 1e3 / nb)) for k, (c, ms) in prof.items() if "k_" in k})
-c = dev.momentary[176:264].cpu().numpy().view(np.uint64)
-print("moved points %d, samples through k_place %d, voxels by k_place %d | k_expand: %d rounds in %d calls with spills" % (c[0], c[1], c[2], c[3 + 4], c[3 + 5]))
+if os.environ.get("SIMLOD_EXACT_CHAIN") == "bulk":     # construct_bulk.hip: Ctl.spilledTotal at byte 176, expandNs behind it
+    c = dev.momentary[176:264].cpu().numpy().view(np.uint64)
+    print("moved points %d, samples through k_place %d, voxels by k_place %d | k_expand: %d rounds in %d calls with spills" % (c[0], c[1], c[2], c[3 + 4], c[3 + 5]))
+else:                                                   # construct_batch.hip: Ctl.expandNs at byte 152, [7] = moved points
+    c = dev.momentary[152:216].cpu().numpy().view(np.uint64)
+    print("moved points %d | k_expand: %d rounds in %d calls with spills" % (c[7], c[5], c[6]))
 for hq in (1, 0):
     u["useHighQualityShading"] = hq
     dev.render(u); torch.cuda.synchronize()
