@@ -1106,3 +1106,26 @@ def test_bench_runs_under_torch_distributed_run_and_prints_one_json_line(built_l
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "M points/s"
     assert d["raster"]["plain"]["value"] > 0 and d["raster"]["hqs"]["value"] > 0 and d["partition"]["per_rank_points"] == [4000000]
+
+
+@pytest.mark.parametrize("kind", ["uniform", "terrain"])
+def test_many_tiny_batches_match_oracle(built_libs, chain, kind):
+    """300 batches of 3 000 points, 20 per launch: the root stays a leaf for the first 16 batches (its samples are voxelized on the
+    caller's stream), then splits while the previous batch's voxel half may still be running on the side stream; every later batch
+    leaves a few samples in many leaves (the wave-per-leaf path of k_voxelize).  Octree and Stats == oracle after the same batches."""
+    n, bs = 900_000, 3_000
+    pts, box = (synthetic.uniform_cube(n, seed=41) if kind == "uniform" else synthetic.terrain(n, seed=43, box=(900.0, 600.0, 60.0), tile=30.0))
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(ring_slots=abi.BATCH_STREAM_SIZE)
+    u = dev.uniforms(W, H, T, box)
+    _ingest(dev, u, [pts[i:i + bs] for i in range(0, n, bs)])
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0 and int(ds["batchletIndex"]) == n // bs
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+    ref.reset(u)
+    ref.add_points(u, pts, bs)
+    assert ref.last_error() == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, kind)
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), kind)
+    oracle.check_invariants(nodes, nn)
