@@ -640,6 +640,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 static constexpr uint32_t VTPB = 1024;
 static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
 static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
+static constexpr uint32_t VOX_BIG_ITEMS = 65536;                // entries of the item array for k_voxelize's pieces; the rest: one small item per leaf
 static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with fewer new samples than this takes the wave-per-leaf path
 static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
 static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
@@ -693,7 +694,7 @@ __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t 
 // pieces.  (Measured: without this path the uniformly scattered
 // 350 M-point replay of the C++ harness, 40 000 leaves touched per batch, took 408 ms of kernel time instead of 157 ms.)
 __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, const uint32_t wave, const uint32_t numWaves, const uint32_t par, const bool rootOnly) {
-	const uint32_t numSmall = min(ctl->numVoxSmall[par], a.voxItemCap);
+	const uint32_t numSmall = min(ctl->numVoxSmall[par], a.voxItemCap - VOX_BIG_ITEMS);
 	if (numSmall == 0u) return;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -707,7 +708,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 		uint32_t maxCount = 0, maxDepth = 0;
 #pragma unroll
 		for (uint32_t u = 0; u < U; u++) {
-			itemIndex[u] = a.voxItemCap - 1u - min(k0 + u, numSmall - 1u);
+			itemIndex[u] = VOX_BIG_ITEMS + min(k0 + u, numSmall - 1u);
 			it[u] = items[itemIndex[u]];
 		}
 #pragma unroll
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, ui
 	if (rootOnly != 0u && blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, ordinal);
 	if (!mine) return;
 	if (rootOnly != 0u && !node_is_leaf(a.nodes)) return;
-	const uint32_t numItems = min(ctl->numVoxItems[par], a.voxItemCap);
+	const uint32_t numItems = min(ctl->numVoxItems[par], VOX_BIG_ITEMS);
 	__shared__ VoxShared sh;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -1062,7 +1063,8 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		NodeDir& d = nodeDir[i];
 		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
 		// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
-		// voxelize_small's, one wave per leaf (big items fill the item array from the front, small ones from the back)
+		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
+		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
 		VoxItem* items = at<VoxItem>(a, a.offVoxItems);
 		const uint32_t fresh = counter - stored;
 		if (fresh < VOX_SMALL) {
@@ -1072,14 +1074,12 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 			uint32_t k = 0;
 			if (lane_id() == leader) k = atomicAdd(&ctl->numVoxSmall[par], (uint32_t)__popcll(peers));
 			k = __shfl(k, leader, 64) + (uint32_t)__popcll(peers & ((1ull << lane_id()) - 1ull));
-			__threadfence();
-			if (k + 1u + __hip_atomic_load(&ctl->numVoxItems[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
-			items[a.voxItemCap - 1u - k] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
+			if (VOX_BIG_ITEMS + k >= a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }      // cannot happen: one small item per leaf at most
+			items[VOX_BIG_ITEMS + k] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
 		} else {
 			const uint32_t pieces = (fresh + VOX_PIECE - 1) / VOX_PIECE;
 			const uint32_t at0 = atomicAdd(&ctl->numVoxItems[par], pieces);
-			__threadfence();
-			if (at0 + pieces + __hip_atomic_load(&ctl->numVoxSmall[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+			if (at0 + pieces > VOX_BIG_ITEMS) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }          // a batch + moved points beyond 33 M samples
 			for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
 		}
 	}
@@ -1379,7 +1379,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	const uint64_t fixedEnd = off;
 	// what is left is shared by the per-sample arrays: 4 B leaf + an 8 B emit-list entry for batch and spilled samples, 16 B per spilled sample
-	a.voxItemCap = min(a.nodeCapacity + 65536u, 1u << 20);                     // one piece per leaf with new samples + one per 8192 samples beyond; Emit has 20 bits for it
+	a.voxItemCap = min(a.nodeCapacity + VOX_BIG_ITEMS, 1u << 20);              // VOX_BIG_ITEMS pieces + one small item per leaf; Emit has 20 bits for the index
 	a.offVoxItems = off; off += align_up((uint64_t)a.voxItemCap * sizeof(VoxItem), 256);
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 12;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
