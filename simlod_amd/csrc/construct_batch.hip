@@ -1036,22 +1036,39 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
 		const uint32_t entries = required - first;
+		const uint32_t additional = required - existing;
+		const uint32_t fresh = counter - stored;
+		// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
+		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
+		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
+		const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
+		// the three reservations travel together (each is a returning device-scope atomic: one round trip instead of three): chunk
+		// directory entries, chunks (recycle stack first, voxels.cu:505-516), work items
 		const uint32_t base = atomicAdd(&ctl->dirCountOf[par], entries);
-		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+		const unsigned long long firstIdx = additional > 0u ? atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional) : 0ull;
+		uint32_t itemAt = 0;
+		if (pieces != 0u) itemAt = atomicAdd(&ctl->numVoxItems[par], pieces);
+		else {
+			// one reservation per wave: a scattered batch has tens of thousands of these, and one returning atomic each on one word was 0.4 ms
+			const unsigned long long peers = __ballot(1);                                    // the lanes that are here with me
+			const int leader = __ffsll((long long)peers) - 1;
+			if (lane_id() == leader) itemAt = atomicAdd(&ctl->numVoxSmall[par], (uint32_t)__popcll(peers));
+			itemAt = VOX_BIG_ITEMS + __shfl(itemAt, leader, 64) + (uint32_t)__popcll(peers & ((1ull << lane_id()) - 1ull));
+		}
+		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by end_of_batch
 		SimlodChunk* head = node->points;
 		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+		if (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt >= a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }   // a batch + moved points beyond 33 M samples
 		uint32_t e = 0;
 		if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
-		const uint32_t additional = required - existing;
 		if (additional > 0) {
-			// pop from the recycle stack, allocate what the stack cannot serve (voxels.cu:505-516): one atomic each
-			const unsigned long long firstIdx = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional);
-			const unsigned long long pool = a.stats->chunkPoolSize;     // raised only by end_of_batch
+			// pop from the recycle stack, allocate what the stack cannot serve
 			const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
-			uint8_t* fresh = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
+			uint8_t* mem = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
 			for (uint32_t k = 0; k < additional; k++) {
 				SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
-				                              : reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				                              : reinterpret_cast<SimlodChunk*>(mem + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
 				c->next = nullptr;
 				if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
 				tail = c;
@@ -1062,26 +1079,9 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		}
 		NodeDir& d = nodeDir[i];
 		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
-		// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
-		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
-		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
 		VoxItem* items = at<VoxItem>(a, a.offVoxItems);
-		const uint32_t fresh = counter - stored;
-		if (fresh < VOX_SMALL) {
-			// one reservation per wave: a scattered batch has tens of thousands of these, and one returning atomic each on one word was 0.4 ms
-			const unsigned long long peers = __ballot(1);                                    // the lanes that are here with me
-			const int leader = __ffsll((long long)peers) - 1;
-			uint32_t k = 0;
-			if (lane_id() == leader) k = atomicAdd(&ctl->numVoxSmall[par], (uint32_t)__popcll(peers));
-			k = __shfl(k, leader, 64) + (uint32_t)__popcll(peers & ((1ull << lane_id()) - 1ull));
-			if (VOX_BIG_ITEMS + k >= a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }      // cannot happen: one small item per leaf at most
-			items[VOX_BIG_ITEMS + k] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
-		} else {
-			const uint32_t pieces = (fresh + VOX_PIECE - 1) / VOX_PIECE;
-			const uint32_t at0 = atomicAdd(&ctl->numVoxItems[par], pieces);
-			if (at0 + pieces > VOX_BIG_ITEMS) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }          // a batch + moved points beyond 33 M samples
-			for (uint32_t q = 0; q < pieces; q++) items[at0 + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
-		}
+		if (pieces == 0u) items[itemAt] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
+		else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
 	}
 	if (part == 0u) return;
 
