@@ -1093,14 +1093,15 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t existing = head == nullptr ? 0u : max(1u, (voxStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK);
 		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t entries = required - first;
+		// (both reservations in one round trip)
 		const uint32_t base = atomicAdd(&ctl->dirCountOf[par], entries);
-		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+		uint8_t* fresh = required > existing ? persistent_alloc(a.pers, sizeof(SimlodChunk), required - existing) : nullptr;   // voxel chunks never come from the pool
 		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
 		uint32_t e = 0;
 		if (first < existing) chunkDir[base + e++] = tail;
 		if (required > existing) {
 			const uint32_t additional = required - existing;
-			uint8_t* fresh = persistent_alloc(a.pers, sizeof(SimlodChunk), additional);   // voxel chunks never come from the pool
 			// (never the root: this part may run while the NEXT batch's k_expand splits a root that was still a leaf and reads its row)
 			const bool inner = i != 0u && !node_is_leaf(node);
 			for (uint32_t k = 0; k < additional; k++) {
