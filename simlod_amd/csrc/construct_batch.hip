@@ -1434,7 +1434,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
-	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_items)
+	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
 		note_leaf_table(LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
 		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS});

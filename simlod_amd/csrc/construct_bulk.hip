@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 			slots[k] = c;
 			if (c != nullptr) { last = c; c = c->next; }
 		}
-		if (!leaf) {                           // an inner node's row lists its voxel chunks (for the rasteriser, render.hip r_items)
+		if (!leaf) {                           // an inner node's row lists its voxel chunks (for the rasteriser, render.hip r_visible)
 			SimlodChunk* v = n->voxelChunks;
 			for (uint32_t k = 0; k < LEAF_SLOTS && v != nullptr; k++) { slots[k] = v; v = v->next; }
 		}
@@ -345,7 +345,7 @@ __device__ void make_voxel_chunk(const BuildArgs& a, Ctl* ctl, uint32_t node, ui
 	SimlodChunk* c = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), 1));   // voxel chunks never come from the pool (voxels.cu:656-659)
 	c->next = nullptr;
 	if (k == 0u) { a.nodes[node].voxelChunks = c; tail_of(c) = c; }
-	// an inner node's row of the leaf chunk table lists its voxel chunks: the rasteriser reads the list from there (render.hip r_items)
+	// an inner node's row of the leaf chunk table lists its voxel chunks: the rasteriser reads the list from there (render.hip r_visible)
 	if (k < LEAF_SLOTS && !node_is_leaf(a.nodes + node)) at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)node * LEAF_SLOTS + k] = c;
 	dir_insert(a, ctl, KIND_VOX, node, k, c);
 }
@@ -1668,7 +1668,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
-	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_items)
+	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
 		note_leaf_table(LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
 		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS});

@@ -4,7 +4,8 @@
 // Replaces modules/progressive_octree/render.cu:1084-1355 (one persistent cooperative CUDA kernel, ~25 grid.sync())
 // behind the same argument list, reading the same Node/Chunk image and leaving the same uint64 framebuffer
 // (depth bits << 32 | colour) at the same offset of the momentary buffer.  A frame is a chain of ordinary launches
-// (clear -> visibility 1 -> visibility 2 -> draw items -> draw [depth, colour, resolve] -> [debug lines] -> output; simlod_launch_render_part runs it in four parts for multi-GPU frames); the only cross-workgroup
+// (clear -> visibility + draw items -> draw [depth, colour, resolve] -> [debug lines] -> output; simlod_launch_render_part runs it
+// in four parts for multi-GPU frames); the only cross-workgroup
 // traffic inside a launch is device-scope atomics (visible-node list, work queue, framebuffer).
 //
 // Arithmetic contract: projection = four fp32 dot products evaluated left to right, IEEE divide,
@@ -39,7 +40,7 @@ struct RenderArgs {
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
 	uint64_t     offWork, offItems, offDepth, offColor, offOverflow, offDir;
 	uint32_t     itemCap, useTiles;
-	// the builder's leaf chunk table (simlod_internal.hpp LeafTableRef), or table == nullptr: r_items walks every list
+	// the builder's leaf chunk table (simlod_internal.hpp LeafTableRef), or table == nullptr: r_visible walks every list
 	const SimlodChunk* const* leafTable;
 	const uint32_t* leafTableMagic;
 	const uint32_t* leafTableBatch;
@@ -75,7 +76,7 @@ static constexpr int TILE_EXACT_AREA = TILE * TILE / 2;   // HQS colour: tiles u
 static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a frame: 2 G visible samples
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
-enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5 };   // [5]: lists r_items read through the builder's chunk table
+enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5 };   // [5]: lists r_visible read through the builder's chunk table
 
 // ---- clear (render.cu:1126-1131, 233-241) ---------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void r_clear(RenderArgs a) {

@@ -89,10 +89,10 @@ uint64_t construct_min_bytes();
 
 }  // namespace batch
 
-// The builder's leaf chunk table, as the rasteriser may use it (render.hip r_items): row i holds the point chunks of leaf i in list order.
+// The builder's leaf chunk table, as the rasteriser may use it (render.hip r_visible): row i holds the first chunks of node i's list in order (a leaf: points; an inner node: voxels).
 // The three stamp words live in the builder's control block on the device; the table describes the octree `nodes` as it is NOW only
 // while *magic == magicValue, *batch == Stats.batchletIndex and *tableNodes == nodes and *sig == table_signature(Stats) (the builder clears the stamp while it works and
-// re-stamps in k_finish), which r_items checks on the device every frame.
+// re-stamps in k_finish), which r_visible checks on the device every frame.
 struct LeafTableRef {
 	const void*               nodes;
 	const void*               block;       // start of the buffer the table lives in (the construct kernel's momentary buffer)

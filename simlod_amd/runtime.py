@@ -291,7 +291,7 @@ class DeviceOctree:
         return self.render_buffer, self.stats[off: off + 4].view(torch.int32)
 
     def lists_read_through_table(self):
-        """How many chunk lists the last frame's r_items read through the builder's chunk table instead of chasing `next`
+        """How many chunk lists the last frame's r_visible read through the builder's chunk table instead of chasing `next`
         (render.hip: counter 5 of the frame counters behind the visible-node array)."""
         off = abi.MAX_VISIBLE_NODES * abi.node_dtype.itemsize + 5 * 16
         return int(self.render_buffer[off: off + 4].view(torch.int32).item())
