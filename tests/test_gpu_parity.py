@@ -1029,7 +1029,7 @@ def test_colorfilter_equals_the_reference_kernel_on_the_same_octree(built_libs, 
 # ---- the rasteriser reads chunk lists through the builder's chunk table ------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["batch", "bulk", "coalesced"])
 def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(built_libs, mode):
-    """render.hip r_items copies a visible node's chunk addresses from the builder's table (leaf rows: point chunks, inner rows: voxel
+    """render.hip r_visible takes a visible node's chunk addresses from the builder's table (leaf rows: point chunks, inner rows: voxel
     chunks) while the table's stamp says it describes the octree as it is now.  After every drain of a growing octree, after a reset and
     a rebuild with other points in the same buffers, and for an image uploaded behind the builder's back: the frame equals the oracle's
     rasteriser on the same image, and equals the frame drawn with the table switched off (SIMLOD_RASTER_LEAF_TABLE=0)."""
