@@ -43,15 +43,15 @@ namespace batch {
 struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
 	uint32_t active, batchSize, ringSlot, batchIndex;
-	uint32_t numSpilling;        // spilling leaves found by k_count; NOT modified by k_expand (its early-exit test must be stable)
+	uint32_t unused3;
 	uint32_t numSpilled, unused0, errors;   // (unused0: the directory counter moved to dirCountOf; the layout behind it stays)
 	uint32_t ordinal, abortBatch, barrierCount;
 	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
-	uint32_t roundSpill[2];      // spilling leaves found by expand round r live in roundSpill[r & 1]
-	uint32_t numWork;            // spill-copy work items appended so far in this batch (monotonic)
+	uint32_t numClear;           // occupancy grids allocated / re-used by this batch's splits: k_insert clears them (list at offClear)
+	uint32_t unused1;
+	uint32_t numWork;            // spill-copy work items appended so far in this batch (by k_count's tail)
 	uint32_t pad1;
-	uint32_t spilledSnap[2];     // numSpilled / numWork as they were BEFORE round r's split phase: slot [r & 1]
-	uint32_t workSnap[2];
+	uint32_t unused2[4];
 	uint64_t startNs;
 	uint32_t statCounters[8];
 	unsigned long long reserve;        // k_expand: nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves both or neither
@@ -82,8 +82,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offEmit, offVoxItems, offSpilled;
-	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap;
+	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offEmit, offVoxItems, offSpilled;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap;
 };
 
 
@@ -194,12 +194,8 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	ctl->ringSlot = slot;
 	ctl->batchSize = size;
 	ctl->ordinal = ordinal;
-	ctl->numSpilling = 0;
-	ctl->roundSpill[0] = 0;
-	ctl->roundSpill[1] = 0;
+	ctl->numClear = 0;
 	ctl->numWork = 0;
-	ctl->spilledSnap[0] = ctl->spilledSnap[1] = 0;
-	ctl->workSnap[0] = ctl->workSnap[1] = 0;
 	ctl->numSpilled = 0;
 	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
 	ctl->dirCountOf[par] = 0;
@@ -280,27 +276,157 @@ __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
 static constexpr uint32_t PPT = 4;                 // points per thread per chunk
 static constexpr uint32_t PPB = TPB * PPT;         // points per workgroup chunk
 
-// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  A leaf is queued for splitting by whoever sees its counter
-// cross the limit — or, if it is already over the limit because an earlier batch could not split it (spill space, node array or
-// spill list exhausted: the split is deferred, nothing is lost), by whoever touches it first in this batch.  The exchange on the
-// per-node tag makes that exactly one caller per leaf and batch.
-__device__ __forceinline__ void count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt, uint32_t* spillList, uint32_t* spillCount) {
+// Split slots.  A leaf that has to split in this batch owns a SLOT: a record of what was reserved for it and a 512-bin histogram
+// — the three octree levels below it — of everything that lies in it (its stored points and the batch's samples).  The cascade is
+// decided from the histogram alone (k_expand), three levels per round.  Afterwards the same 512 words are the slot's MAP: bin ->
+// the node that bin's samples ended up in.  A sample of a slot is relabelled by rewriting its cached-leaf word as
+// LEAF_FLAG | slot << 9 | bin: whoever needs its leaf later (k_insert, the next round) reads ONE word of the map.
+static constexpr uint32_t SLOT_CAP = 2048;                  // slots per batch (12 bits of a relabelled word and of the reservation word)
+static constexpr uint32_t HIST_BINS = 512;
+static constexpr uint32_t LEAF_FLAG = 0x80000000u;          // cached-leaf word: FLAG | slot << 9 | bin   (else: a node index)
+static constexpr uint32_t MAP_LISTED = 0x80000000u;         // map entry: LISTED | level << 16 | slot of the NEXT round   (else: a node index)
+static constexpr uint32_t NONE = 0xffffffffu;
+struct SlotRec { uint32_t node, level, childBase, spillBase, stored, pad0, pad1, pad2; };   // node == NONE: nothing could be reserved, the leaf stays as it is
+
+// the three child choices below a node at `level`, most significant first (levels beyond MAX_DEPTH contribute zero bits)
+__device__ __forceinline__ uint32_t bin_of(uint32_t X, uint32_t Y, uint32_t Z, uint32_t level) {
+	uint32_t b = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 3; k++) {
+		const uint32_t lv = level + k;
+		b = (b << 3) | (lv < (uint32_t)SIMLOD_MAX_DEPTH ? (uint32_t)child_index(X, Y, Z, (int)lv) : 0u);
+	}
+	return b;
+}
+
+// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  Returns true for exactly one caller per leaf and batch: the one
+// that has to queue the leaf for splitting — whoever sees its counter cross the limit, or, if it is already over the limit because
+// an earlier batch could not split it (spill space, node array or slots exhausted: the split is deferred, nothing is lost), whoever
+// touches it first in this batch.  The exchange on the per-node tag decides.
+__device__ __forceinline__ bool count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt) {
 	SimlodNode* leaf = a.nodes + leafIdx;
 	const uint32_t old = atomicAdd(&leaf->counter, cnt);
 	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
 	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
 		const uint32_t tag = ctl->batchIndex + 1u;
-		if (atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag) {
-			const uint32_t s = atomicAdd(spillCount, 1u);
-			if (s < SPILLING_CAPACITY) spillList[s] = leafIdx; else raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW);
-		}
+		return atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag;
+	}
+	return false;
+}
+
+struct SpillWork {
+	const SimlodChunk* chunk;
+	uint32_t slot, dstBase, count, level;
+	uint32_t pad0, pad1;
+};
+
+// Reserve `slots` split slots, `nodes` node slots and `spill` points of spill space TOGETHER (one 64-bit word: slots << 52 | nodes in use
+// << 32 | spill in use), before anything is modified: a leaf that cannot be served now stays a leaf — too full, but intact — and is
+// queued again by a later batch.
+static constexpr int RSV_SLOT_SHIFT = 52;
+__device__ __forceinline__ uint32_t slots_in_use(const Ctl* ctl) {
+	return (uint32_t)(__hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> RSV_SLOT_SHIFT);
+}
+__device__ __forceinline__ bool reserve(const BuildArgs& a, Ctl* ctl, uint32_t slots, uint32_t nodes, uint32_t spill, uint32_t& slotBase, uint32_t& nodeBase, uint32_t& spillBase) {
+	unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for (;;) {
+		slotBase = (uint32_t)(cur >> RSV_SLOT_SHIFT); nodeBase = (uint32_t)(cur >> 32) & 0xfffffu; spillBase = (uint32_t)cur;
+		if (slotBase + slots > SLOT_CAP) { raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); return false; }     // more leaves cross the limit at once than a batch has slots for
+		if (nodeBase + nodes > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); return false; }
+		if ((unsigned long long)spillBase + spill > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); return false; }
+		const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + ((unsigned long long)slots << RSV_SLOT_SHIFT) + ((unsigned long long)nodes << 32) + spill);
+		if (prev == cur) { atomicAdd(&a.stats->numNodes, nodes); return true; }       // voxels.cu:317
+		cur = prev;
 	}
 }
 
-__device__ __forceinline__ void flush_counts(const BuildArgs& a, Ctl* ctl, BlockTable& tbl, uint32_t* spillList, uint32_t* spillCount) {
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], spillList, spillCount);
+// the occupancy grid of a node that splits in this batch: allocated if the node has none (voxels.cu:363-365), cleared in any case
+// (:371-382, also the root's, which has one from the reset on) — by k_insert, through this list; the grids are first read by k_voxelize
+__device__ __forceinline__ void note_clear(const BuildArgs& a, uint32_t c, SimlodOccupancyGrid* g) {
+	if (c < a.clearCap) at<SimlodOccupancyGrid*>(a, a.offClear)[c] = g;
+	else {                                                        // (never: the list holds a grid per node slot a batch can create)
+		uint4* w = reinterpret_cast<uint4*>(g->values);
+		for (uint32_t i = 0; i < SIMLOD_GRID_NUM_WORDS / 4; i++) w[i] = make_uint4(0, 0, 0, 0);
+	}
+}
+__device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& a, Ctl* ctl) {
+	SimlodOccupancyGrid* g = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
+	note_clear(a, atomicAdd(&ctl->numClear, 1u), g);
+	return g;
+}
+
+// Queue leaf `nodeIdx` for splitting: ONE WAVE.  Everything the split needs is reserved here, before anything is modified: a slot (and
+// with it a histogram), eight node slots and the spill space for the stored points together, the occupancy grid.  Then the leaf's
+// chunk list becomes spill-copy work items (chunk k comes from the leaf chunk table, not from a walk) and goes back to the recycle
+// stack (voxels.cu:346-357; nothing pops before k_alloc).  (voxels.cu:308-383 doSplitting, first half)
+__device__ void queue_split(const BuildArgs& a, Ctl* ctl, uint32_t nodeIdx) {
+	const uint32_t lane = (uint32_t)lane_id();
+	SimlodNode* node = a.nodes + nodeIdx;
+	uint32_t ok = 0, slot = 0, spillBase = 0, stored = 0, level = 0, w0 = 0;
+	unsigned long long top = 0;
+	uint32_t numChunks = 0;
+	SimlodChunk* head = nullptr;
+	if (lane == 0) {
+		stored = node->numPoints; level = node->level; head = node->points;
+		SimlodOccupancyGrid* grid = node->grid;
+		// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
+		numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+		uint32_t childBase = 0;
+		if (reserve(a, ctl, 1u, 8u, stored, slot, childBase, spillBase)) {
+			ok = 1;
+			// (four independent atomics with a return value: issued together, one round trip)
+			SimlodAllocatorGlobal* alloc = reinterpret_cast<SimlodAllocatorGlobal*>(a.pers);
+			const unsigned long long gridAt = grid == nullptr ? atomicAdd(reinterpret_cast<unsigned long long*>(&alloc->offset), (unsigned long long)SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid))) : 0ull;   // voxels.cu:363-365
+			const uint32_t c = atomicAdd(&ctl->numClear, 1u);
+			if (numChunks > 0) {
+				w0 = atomicAdd(&ctl->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
+				top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
+			}
+			atomicAdd(&ctl->numSpilled, stored);
+			if (grid == nullptr) { grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + gridAt); node->grid = grid; }
+			note_clear(a, c, grid);
+			at<SlotRec>(a, a.offSlots)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, 0u, 0u, 0u};
+			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)(ctl->ordinal + 1u) << 32) | (level << 16) | slot;
+		}
+	}
+	ok = __shfl(ok, 0);
+	if (!ok) return;
+	slot = __shfl(slot, 0); spillBase = __shfl(spillBase, 0); stored = __shfl(stored, 0); level = __shfl(level, 0); w0 = __shfl(w0, 0); numChunks = __shfl(numChunks, 0);
+	top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
+	// the slot's histogram starts from zero
+	{
+		uint4* h = reinterpret_cast<uint4*>(at<uint32_t>(a, a.offHist) + (uint64_t)slot * HIST_BINS);
+		h[lane] = make_uint4(0, 0, 0, 0); h[lane + 64] = make_uint4(0, 0, 0, 0);
+	}
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SpillWork* work = at<SpillWork>(a, a.offWork);
+	SimlodChunk* const* slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)nodeIdx * LEAF_SLOTS;
+	auto emit = [&](uint32_t ci, SimlodChunk* chunk) {
+		if (w0 + ci < a.workCap) {
+			SpillWork w;
+			w.chunk = chunk; w.slot = slot; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
+			w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
+			work[w0 + ci] = w;
+		} else raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW);
+		const unsigned long long q = top - numChunks + ci;
+		if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
+	};
+	SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
+	if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
+	for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
+		SimlodChunk* chunk = slots[ci];
+		emit(ci, chunk);
+		chunk->next = nullptr;
+	}
+	if (lane == 0) {
+		for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
+			SimlodChunk* next = beyond->next;
+			emit(ci, beyond);
+			beyond->next = nullptr;
+			beyond = next;
+		}
+		node->numPoints = 0;
+		node->points = nullptr;
 	}
 }
 
@@ -308,19 +434,28 @@ __device__ __forceinline__ void flush_counts(const BuildArgs& a, Ctl* ctl, Block
 // hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
 static constexpr uint32_t CPT = 8;
 static constexpr uint32_t CPB = TPB * CPT;
+static constexpr uint32_t CROSS_CAP = 128;         // leaves one workgroup can see cross the limit in one batch
 
 __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
 	__shared__ BlockTable tbl;
+	__shared__ uint32_t sh_cross[CROSS_CAP];
+	__shared__ uint32_t sh_numCross;
 	const uint32_t n = ctl->batchSize;
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	uint32_t* spillList = at<uint32_t>(a, a.offSpillA);
 	const uint32_t numChunks = (n + CPB - 1) / CPB;
+	if (blockIdx.x >= numChunks) return;
+	auto crossed = [&](uint32_t leafIdx) {
+		const uint32_t k = atomicAdd(&sh_numCross, 1u);
+		if (k < CROSS_CAP) sh_cross[k] = leafIdx;
+		else { at<uint32_t>(a, a.offRetryTag)[leafIdx] = 0u; raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); }   // deferred: a later batch queues it again
+	};
 	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
 	// other's slowest descent; one flush at the end.
 	table_init(tbl);
+	if (threadIdx.x == 0) sh_numCross = 0;
 	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		float4 p[CPT];
@@ -346,272 +481,329 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 			const uint32_t leafIdx = cur[j];
 			leafOf[i] = leafIdx;
 			uint32_t rank;
-			if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, spillList, &ctl->numSpilling);
+			if (table_add(tbl, leafIdx, 1u, &rank) < 0 && count_into(a, ctl, leafIdx, 1u)) crossed(leafIdx);
 		}
 	}
 	__syncthreads();
-	flush_counts(a, ctl, tbl, spillList, &ctl->numSpilling);
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = tbl.keys[e];
+		if (key != TBL_EMPTY && count_into(a, ctl, key, tbl.vals[e])) crossed(key);
+	}
+	__syncthreads();
+	// the leaves this workgroup saw cross the limit: reserved, listed and emptied here, wave by wave, so that k_expand starts with
+	// the histogram pass right away
+	const uint32_t numCross = min(sh_numCross, CROSS_CAP);
+	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if k_expand's grid barrier had given up, before anything is modified (tests the abort path)
+	if (numCross != 0u && (ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += TPB / 64u) queue_split(a, ctl, sh_cross[e]);
 }
 
-// ---- expand: split spilling leaves until none is left (voxels.cu:385-415, 245-289, 308-383) --------------------
-// Persistent, one workgroup per two CUs, hand-rolled grid barrier; exits at once when `count` found no spilling leaf.
-// Per round:  A) one workgroup per spilling leaf: eight children, occupancy grid (allocated, cleared), the leaf's chunk
-//                list is walked ONCE by one lane which turns every chunk into a work item and recycles the chunks;
-//             -- barrier --
-//             B) all workgroups: spill-copy work items (1000 stored points each, routed to the child they belong to)
-//                and the recount of the batch samples whose cached leaf was split; both feed the children's arrival
-//                counters, whoever sees a counter cross the limit appends the child to the next round's list;
-//             -- barrier --
-struct SpillWork {
-	const SimlodChunk* chunk;
-	uint32_t childOffset, dstBase, count, level;
-	uint32_t pad0, pad1;
+// ---- expand: split the queued leaves, cascades included (voxels.cu:385-415, 245-289, 308-383) ---------------------------
+// Persistent, hand-rolled grid barrier; exits at once when `count` queued nothing.  The reference counts, splits ONE level, counts
+// again, ... with ~8 grid.sync() per level.  Here a round settles THREE levels:
+//   H) all workgroups: the stored points of the round's slots move to the spill buffer (work items, round 0 only) and every batch
+//      sample / moved point that lies in a slot's node is added to the slot's 512-bin histogram (LDS first, one global add per
+//      workgroup and bin); its cached-leaf word becomes FLAG | slot | bin;
+//   -- barrier --
+//   D) one workgroup per slot: from the histogram alone, which children, grandchildren hold more than 50 000 and split in turn;
+//      all their nodes at once (counters filled in, grids allocated, ancestor paths, parents), the slot's map; great-grandchildren
+//      that are still too full get a slot of their own for the next round.
+//   Every workgroup can tell from the histograms whether a next round is possible; if not, the kernel ends after D without
+//   another barrier (the common case: one barrier per batch).
+static constexpr uint32_t ETPB = 1024;             // k_expand: at most one workgroup per CU (grid barrier participants), 16 waves each
+static constexpr int HT_BITS = 12;
+static constexpr uint32_t HT_CAP = 1u << HT_BITS;
+static constexpr uint32_t LOCAL_NODES = 8 + 64 + 512;          // nodes a slot can create: local numbering t = 0..7 | 8..71 | 72..583
+
+struct ExpandShared {
+	uint32_t keys[HT_CAP], vals[HT_CAP];           // H: (slot << 9 | bin) -> count
+	uint32_t bins[HIST_BINS], c2[64], c1[8];
+	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
+	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
+	SimlodOccupancyGrid* grid[8 + 64];             // grids of the children / grandchildren that split here
+	unsigned long long pathL[PATH_WORDS];          // the slot node's own ancestor path
+	uint32_t mask1, extraBase, ok, more;
+	unsigned long long mask2;
 };
 
-static constexpr uint32_t ETPB = 1024;             // k_expand: at most one workgroup per CU (grid barrier participants), 16 waves each
+__device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, uint32_t key, uint32_t cnt) {
+	uint32_t h = (key * 2654435761u) >> (32 - HT_BITS);
+#pragma unroll 1
+	for (int probe = 0; probe < 16; ++probe) {
+		uint32_t k = sh.keys[h];
+		if (k == TBL_EMPTY) { k = atomicCAS(&sh.keys[h], TBL_EMPTY, key); if (k == TBL_EMPTY) k = key; }
+		if (k == key) { atomicAdd(&sh.vals[h], cnt); return; }
+		h = (h + 1) & (HT_CAP - 1);
+	}
+	atomicAdd(at<uint32_t>(a, a.offHist) + key, cnt);          // no room in the table: straight to the histogram
+}
+// One histogram update per DISTINCT key of the wave (whole wave calls; `active` lanes carry a key): neighbouring samples of a batch fall
+// into a handful of bins, and 64 LDS atomics on one word take 64 turns.  A wave with many distinct keys finishes lane by lane.
+__device__ __forceinline__ void hist_add_wave(const BuildArgs& a, ExpandShared& sh, uint32_t key, bool active) {
+	unsigned long long todo = __ballot(active);
+	const uint32_t lane = (uint32_t)lane_id();
+#pragma unroll 1
+	for (int it = 0; todo != 0ull; ++it) {
+		if (it == 12) { if (((todo >> lane) & 1ull) != 0ull) hist_add(a, sh, key, 1u); break; }
+		const int leader = __ffsll((long long)todo) - 1;
+		const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+		const unsigned long long same = __ballot(active && key == k);
+		if ((int)lane == leader) hist_add(a, sh, k, (uint32_t)__popcll(same));
+		todo &= ~same;
+	}
+}
+
+// local node number t of a slot -> depth below the slot's node (1..3) and the octants chosen on the way
+__device__ __forceinline__ uint32_t local_depth(uint32_t t) { return t < 8u ? 1u : t < 72u ? 2u : 3u; }
 
 __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
-	if (ctl->numSpilling == 0) return;          // written by k_count, never modified here: a stable early-exit test
-	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if the grid barrier had given up (tests the abort path); a real give-up comes after
-	// the split phase has begun — either way the octree is not to be trusted any more: fatal, sticky until a reset
+	if (slots_in_use(ctl) == 0u) return;        // slots are handed out by k_count's tail; their number only ever grows here: a stable early-exit test
+	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if the grid barrier had given up (tests the abort path); either way the octree is
+	// not to be trusted any more (k_count's tail has already emptied the queued leaves): fatal, sticky until a reset
 	if ((ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	unsigned long long* splitInfo = at<unsigned long long>(a, a.offSplitTag);   // per node: round tag << 32 | first child << 5 | level
+	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
-	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
-	SimlodChunk* const* leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
-	SpillWork* work = at<SpillWork>(a, a.offWork);
+	SlotRec* slots = at<SlotRec>(a, a.offSlots);
+	uint32_t* hist = at<uint32_t>(a, a.offHist);
+	uint32_t* map = at<uint32_t>(a, a.offMap);        // (not the histogram's words: other workgroups may still be peeking at those)
+	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const uint32_t n = ctl->batchSize;
+	const uint32_t tag = ctl->ordinal + 1u;
 	uint32_t generation = 0;
 
-	__shared__ BlockTable tbl;
-	__shared__ uint32_t sh_childOffset, sh_ok, sh_spillBase;
-	__shared__ uint32_t sh_childCount[8];
-	__shared__ SimlodOccupancyGrid* sh_grid;
+	__shared__ ExpandShared sh;
+	const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
+	if (timer) ctl->expandNs[6] += 1;
 
-	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS; ++round) {
-		uint32_t* listCur = at<uint32_t>(a, (round & 1) ? a.offSpillB : a.offSpillA);
-		uint32_t* listNext = at<uint32_t>(a, (round & 1) ? a.offSpillA : a.offSpillB);
-		uint32_t* countCur = round == 0 ? &ctl->numSpilling : &ctl->roundSpill[(round - 1) & 1];
-		uint32_t* countNext = &ctl->roundSpill[round & 1];
-		uint32_t numSpilling = *countCur;
-		if (numSpilling > SPILLING_CAPACITY) numSpilling = SPILLING_CAPACITY;
-		if (numSpilling == 0) break;
-		const uint32_t tag = ctl->ordinal * 32u + round + 1u;
-		const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
+	uint32_t sb = 0, se = min(slots_in_use(ctl), SLOT_CAP);
+	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS && sb < se; ++round) {
 		uint64_t t0 = timer ? wall_ns() : 0, t1;
-		if (timer && round == 0) ctl->expandNs[6] += 1;
-		if (blockIdx.x == 0 && threadIdx.x == 0) *countNext = 0;   // last read one round ago, appended to only after the barrier below
-
-		// -- A: split ---------------------------------------------------------------------------------------------
-		for (uint32_t s = blockIdx.x; s < numSpilling; s += gridDim.x) {
-			const uint32_t nodeIdx = listCur[s];
-			SimlodNode* node = a.nodes + nodeIdx;
-			__syncthreads();
-			if (threadIdx.x == 0) {
-				// Reserve eight node slots and the spill space for the stored points TOGETHER (one 64-bit word), before anything is
-				// modified: a leaf that cannot be served now stays a leaf — too full, but intact — and is queued again by a later batch.
-				const uint32_t stored = node->numPoints;
-				uint32_t ok = 1, off = 0, base = 0;
-				unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				for (;;) {
-					off = (uint32_t)(cur >> 32); base = (uint32_t)cur;
-					if (off + 8u > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); ok = 0; break; }
-					if ((unsigned long long)base + stored > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); ok = 0; break; }
-					const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + (8ull << 32) + stored);
-					if (prev == cur) break;
-					cur = prev;
+		// -- H: histograms ---------------------------------------------------------------------------------------------------
+		for (uint32_t i = threadIdx.x; i < HT_CAP; i += ETPB) { sh.keys[i] = TBL_EMPTY; sh.vals[i] = 0u; }
+		__syncthreads();
+		const uint32_t stride = gridDim.x * ETPB;
+		if (round == 0) {
+			// the stored points of the queued leaves move into the spill buffer (voxels.cu:253-289): element e = point (e % 1000) of work item
+			// (e / 1000), one chunk per item — a flat index space, so every workgroup moves the same share
+			const uint32_t workEnd = min(ctl->numWork, a.workCap);
+			const uint32_t totalMoved = workEnd * SIMLOD_POINTS_PER_CHUNK;
+			constexpr uint32_t U = 4;
+			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < ((totalMoved + 63u) & ~63u); first += U * stride) {   // (whole waves enter: hist_add_wave)
+				SpillWork item[U]; float4 p[U]; bool live[U];
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t e = first + q * stride;
+					live[q] = e < totalMoved;
+					if (live[q]) item[q] = work[e / SIMLOD_POINTS_PER_CHUNK];
+					live[q] = live[q] && e % SIMLOD_POINTS_PER_CHUNK < item[q].count;
 				}
-				SimlodOccupancyGrid* grid = node->grid;
-				if (ok) {
-					atomicAdd(&a.stats->numNodes, 8u);         // voxels.cu:317
-					atomicAdd(&ctl->numSpilled, stored);
-					if (grid == nullptr) {                     // voxels.cu:363-365
-						grid = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
-						node->grid = grid;
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) p[q] = live[q] ? reinterpret_cast<const float4*>(item[q].chunk->points)[(first + q * stride) % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					uint32_t key = 0;
+					if (live[q]) {
+						const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size), Y = quantize(F_GRID, p[q].y, a.miny, a.size), Z = quantize(F_GRID, p[q].z, a.minz, a.size);
+						key = (item[q].slot << 9) | bin_of(X, Y, Z, item[q].level);
+						const uint32_t dst = item[q].dstBase + (first + q * stride) % SIMLOD_POINTS_PER_CHUNK;
+						spilled[dst] = p[q];
+						leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = LEAF_FLAG | key;
 					}
+					hist_add_wave(a, sh, key, live[q]);
 				}
-				sh_childOffset = off; sh_ok = ok; sh_grid = grid; sh_spillBase = base;
-			}
-			__syncthreads();
-			if (!sh_ok) continue;
-			const uint32_t childOffset = sh_childOffset;
-			const uint32_t level = node->level;
-			if (threadIdx.x < 8) {                          // the eight children, voxels.cu:318-343
-				const uint32_t i = threadIdx.x;
-				// written field by field straight to the node array (a 152-byte local would live in scratch memory)
-				SimlodNode& c = a.nodes[childOffset + i];
-				for (int k = 0; k < 8; k++) c.children[k] = nullptr;
-				c.counter = 0; c.numPoints = 0;
-				c.level = level + 1;
-				c.X = 2 * node->X + ((i >> 2) & 1u);
-				c.Y = 2 * node->Y + ((i >> 1) & 1u);
-				c.Z = 2 * node->Z + (i & 1u);
-				c.countIteration = 0; c.countFlag = 0;
-				for (int k = 0; k < 20; k++) c.name[k] = node->name[k];
-				if (level + 1 < 20) c.name[level + 1] = (uint8_t)('0' + i);
-				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
-				c.grid = nullptr; c.points = nullptr; c.voxelChunks = nullptr;
-				c.numVoxels = 0; c.numVoxelsStored = 0;
-				node->children[i] = a.nodes + childOffset + i;
-				parentOf[childOffset + i] = nodeIdx;
-				// the child's ancestors: this node (its grid is final now), then this node's own ancestors
-				const unsigned long long* mine = paths + (uint64_t)nodeIdx * PATH_WORDS;
-				unsigned long long* theirs = paths + (uint64_t)(childOffset + i) * PATH_WORDS;
-				theirs[0] = path_pack(a.pers, nodeIdx, level, sh_grid);
-				for (uint32_t k = 0; k + 1 < PATH_WORDS; k++) {
-					const unsigned long long e = k + 2 < PATH_WORDS ? mine[k] : 0ull;
-					theirs[k + 1] = e;
-					if (e == 0ull) break;
-				}
-			}
-			if (threadIdx.x >= 64 && threadIdx.x < 128) {
-				// Wave 1 turns every chunk of the leaf into a work item and hands the chunks back to the recycle stack
-				// (voxels.cu:346-357; nothing pops before k_alloc).  Chunk k comes from the leaf chunk table, not from a walk.
-				const uint32_t lane = threadIdx.x - 64;
-				const uint32_t stored = node->numPoints;
-				SimlodChunk* const head = node->points;
-				// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
-				const uint32_t numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
-				const uint32_t spillBase = sh_spillBase;
-				uint32_t w0 = 0;
-				unsigned long long top = 0;
-				if (lane == 0 && numChunks > 0) {
-					w0 = atomicAdd(&ctl->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
-					top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
-				}
-				w0 = __shfl(w0, 0);
-				top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
-				SimlodChunk* const* slots = leafChunks + (uint64_t)nodeIdx * LEAF_SLOTS;
-				auto emit = [&](uint32_t ci, SimlodChunk* chunk) {
-					if (w0 + ci < a.workCap) {
-						SpillWork w;
-						w.chunk = chunk; w.childOffset = childOffset; w.dstBase = spillBase + ci * SIMLOD_POINTS_PER_CHUNK;
-						w.count = min(stored - ci * SIMLOD_POINTS_PER_CHUNK, SIMLOD_POINTS_PER_CHUNK); w.level = level; w.pad0 = 0; w.pad1 = 0;
-						work[w0 + ci] = w;
-					} else raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW);
-					const unsigned long long q = top - numChunks + ci;
-					if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
-				};
-				SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
-				if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
-				for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
-					SimlodChunk* chunk = slots[ci];
-					emit(ci, chunk);
-					chunk->next = nullptr;
-				}
-				if (lane == 0) for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
-					SimlodChunk* next = beyond->next;
-					emit(ci, beyond);
-					beyond->next = nullptr;
-					beyond = next;
-				}
-				if (lane == 0) {
-					node->numPoints = 0;
-					node->points = nullptr;
-					splitInfo[nodeIdx] = ((unsigned long long)tag << 32) | ((unsigned long long)childOffset << 5) | level;
-				}
-			}
-			// meanwhile the other lanes clear the occupancy grid — of EVERY spilling node, also one that already had a
-			// grid (the root), voxels.cu:371-382
-			{
-				uint4* g = reinterpret_cast<uint4*>(sh_grid->values);
-				const uint4 z = make_uint4(0, 0, 0, 0);
-				if (threadIdx.x >= 128) for (uint32_t w = threadIdx.x - 128; w < SIMLOD_GRID_NUM_WORDS / 4; w += ETPB - 128) g[w] = z;
 			}
 		}
-
+		{
+			// the batch's samples (and, from the second round on, the moved points): eight per thread at a time, stage by stage — the
+			// cached-leaf words are in flight together, then the slot lookups, then the points of those that lie in one of the round's nodes
+			const uint32_t total = round == 0 ? n : n + min(ctl->numSpilled, a.spilledCap);
+			constexpr uint32_t U = 8;
+			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < ((total + 63u) & ~63u); first += U * stride) {
+				uint32_t idx[U], v[U], ent[U];
+				float4 p[U];
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t t = first + q * stride;
+					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+					v[q] = t < total ? leafOf[idx[q]] : NONE;
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					// ent = level << 16 | slot of the round's slot this sample lies in, or NONE
+					ent[q] = NONE;
+					if (v[q] == NONE) continue;
+					if (round == 0) {
+						const unsigned long long info = slotOf[v[q]];                 // (round 0: no word is relabelled yet)
+						if ((uint32_t)(info >> 32) == tag) ent[q] = (uint32_t)info;
+					} else if ((v[q] & LEAF_FLAG) != 0u) {
+						const uint32_t e = map[v[q] & 0x1fffffu];                     // the map of an earlier round
+						if ((e & MAP_LISTED) != 0u) ent[q] = e & 0x7fffffffu;
+					}
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					const uint32_t t = first + q * stride;
+					p[q] = ent[q] != NONE ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < U; q++) {
+					uint32_t key = 0;
+					if (ent[q] != NONE) {
+						const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size), Y = quantize(F_GRID, p[q].y, a.miny, a.size), Z = quantize(F_GRID, p[q].z, a.minz, a.size);
+						key = ((ent[q] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[q] >> 16);
+						leafOf[idx[q]] = LEAF_FLAG | key;
+					}
+					hist_add_wave(a, sh, key, ent[q] != NONE);
+				}
+			}
+		}
+		__syncthreads();
+		for (uint32_t e = threadIdx.x; e < HT_CAP; e += ETPB) {
+			const uint32_t key = sh.keys[e];
+			if (key != TBL_EMPTY) atomicAdd(hist + key, sh.vals[e]);
+		}
 		if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 		if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
-		// numSpilled / numWork are stable between this barrier and the next round's split phase: snapshot them for round+1
-		const uint32_t workEnd = min(ctl->numWork, a.workCap);
-		const uint32_t workBegin = ctl->workSnap[round & 1];
-		const uint32_t numSpilledPrev = ctl->spilledSnap[round & 1];
-		if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->workSnap[(round + 1) & 1] = workEnd; ctl->spilledSnap[(round + 1) & 1] = min(ctl->numSpilled, a.spilledCap); }
 
-		// -- B1: move the stored points of the split leaves into the spill buffer, routed to their child (voxels.cu:253-289)
-		for (uint32_t w = workBegin + blockIdx.x; w < workEnd; w += gridDim.x) {
-			const SpillWork item = work[w];
-			__syncthreads();
-			if (threadIdx.x < 8) sh_childCount[threadIdx.x] = 0;
-			__syncthreads();
-			const float4* src = reinterpret_cast<const float4*>(item.chunk->points);
-			for (uint32_t j = threadIdx.x; j < item.count; j += ETPB) {
-				const float4 p = src[j];
-				const uint32_t X = quantize(F_GRID, p.x, a.minx, a.size);
-				const uint32_t Y = quantize(F_GRID, p.y, a.miny, a.size);
-				const uint32_t Z = quantize(F_GRID, p.z, a.minz, a.size);
-				const int c = child_index(X, Y, Z, (int)item.level);
-				const uint32_t dst = item.dstBase + j;
-				spilled[dst] = p;
-				leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = item.childOffset + (uint32_t)c;
-				atomicAdd(&sh_childCount[c], 1u);
+		// -- can this round queue anything for a next one?  Only a great-grandchild bin above the limit can (everybody looks at all the
+		//    round's histograms: a few KB from L2); if none, the kernel ends after D without meeting again
+		if (threadIdx.x == 0) sh.more = 0;
+		__syncthreads();
+		if (se - sb > 64u) { if (threadIdx.x == 0) sh.more = 1; }
+		else {
+			bool mine = false;
+			for (uint32_t i = threadIdx.x; i < (se - sb) * HIST_BINS; i += ETPB) {
+				const uint32_t s = sb + i / HIST_BINS;
+				if (hist[(uint64_t)s * HIST_BINS + (i % HIST_BINS)] > SIMLOD_MAX_POINTS_PER_NODE && slots[s].node != NONE && slots[s].level + 3u < (uint32_t)SIMLOD_MAX_DEPTH) mine = true;
 			}
-			__syncthreads();
-			if (threadIdx.x < 8 && sh_childCount[threadIdx.x] > 0)
-				count_into(a, ctl, item.childOffset + threadIdx.x, sh_childCount[threadIdx.x], listNext, countNext);
+			if (mine) sh.more = 1;
 		}
+		__syncthreads();
+		const bool more = sh.more != 0u;
+		__syncthreads();
 
-		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; }
-		// -- B2: recount — only samples whose cached leaf was split in THIS round go one (or more) levels down ------------
-		// Also after the 20th split: the reference does not count again there (voxels.cu:394-412), allocates no chunks for the
-		// level-20 children and drops every point that lands in them (:599-604) — 50 001 points in one 2^-20 cell.  Here they are
-		// counted and stored; a level-20 leaf never asks for another split (count_into).
-		{
-			const uint32_t total = n + numSpilledPrev;
+		// -- D: decide and build ---------------------------------------------------------------------------------------------
+		for (uint32_t s = sb + blockIdx.x; s < se; s += gridDim.x) {
+			const SlotRec rec = slots[s];
+			if (rec.node == NONE) continue;                                     // nothing could be reserved for this leaf
+			const uint32_t L = rec.node, l = rec.level;
+			const uint32_t K = min(3u, (uint32_t)SIMLOD_MAX_DEPTH - l);         // levels below L that exist
+			const uint32_t t = threadIdx.x;
 			__syncthreads();
-			table_init(tbl);                           // one table for the whole scan of this workgroup, one flush
+			if (t < HIST_BINS) sh.bins[t] = hist[(uint64_t)s * HIST_BINS + t];
+			if (t < PATH_WORDS) sh.pathL[t] = t + 1 < PATH_WORDS ? paths[(uint64_t)L * PATH_WORDS + t] : 0ull;
+			for (uint32_t i = t; i < LOCAL_NODES; i += ETPB) sh.listed[i] = NONE;
+			if (t < 72u) sh.grid[t] = nullptr;
 			__syncthreads();
-			// four samples per thread at a time, stage by stage: the four cached-leaf loads are in flight together, then the four
-			// split tags, then the points and the first child pointer of those that have to move (a 1 M-sample batch is four
-			// samples per thread: the dependent chain leaf -> tag -> point -> child is paid once, not four times)
-			constexpr uint32_t U = 4;
-			const uint32_t stride = gridDim.x * ETPB;
-			for (uint32_t t0 = blockIdx.x * ETPB + threadIdx.x; t0 < total; t0 += U * stride) {
-				uint32_t idx[U], leaf[U]; unsigned long long info[U]; float4 p[U];
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					const uint32_t t = t0 + q * stride;
-					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-					leaf[q] = t < total ? leafOf[idx[q]] : 0xffffffffu;
+			if (t < 64u) { uint32_t c = 0; for (uint32_t k = 0; k < 8; k++) c += sh.bins[t * 8 + k]; sh.c2[t] = c; }
+			__syncthreads();
+			if (t < 8u) { uint32_t c = 0; for (uint32_t k = 0; k < 8; k++) c += sh.c2[t * 8 + k]; sh.c1[t] = c; }
+			__syncthreads();
+			if (t < 64u) {
+				// a child splits when it holds more than 50 000 and is above MAX_DEPTH (K >= 2 <=> level l + 1 <= 19); a grandchild likewise
+				const bool s1 = t < 8u && K >= 2u && sh.c1[t & 7u] > SIMLOD_MAX_POINTS_PER_NODE;
+				uint32_t mask1 = (uint32_t)__ballot(s1) & 0xffu;
+				const bool s2 = K >= 3u && ((mask1 >> (t >> 3)) & 1u) != 0u && sh.c2[t] > SIMLOD_MAX_POINTS_PER_NODE;
+				unsigned long long mask2 = __ballot(s2);
+				uint32_t n1 = (uint32_t)__popc(mask1), n2 = (uint32_t)__popcll(mask2);
+				uint32_t extraBase = 0;
+				if (t == 0 && n1 + n2 > 0u) {
+					uint32_t noSlot, noSpill;
+					if (!reserve(a, ctl, 0u, 8u * (n1 + n2), 0u, noSlot, extraBase, noSpill)) extraBase = NONE;    // no room for the cascade: the children stay too full (deferred)
 				}
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) info[q] = leaf[q] != 0xffffffffu ? splitInfo[leaf[q]] : 0ull;
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					const uint32_t t = t0 + q * stride;
-					p[q] = (uint32_t)(info[q] >> 32) == tag ? (t < n ? pts[t] : spilled[t - n]) : make_float4(0, 0, 0, 0);
-				}
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					if ((uint32_t)(info[q] >> 32) != tag) continue;
-					// the children of a leaf split in this round are leaves: the record of the split says where they are, no node is read
-					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size);
-					const uint32_t Y = quantize(F_GRID, p[q].y, a.miny, a.size);
-					const uint32_t Z = quantize(F_GRID, p[q].z, a.minz, a.size);
-					const uint32_t level = (uint32_t)info[q] & 31u, childOffset = ((uint32_t)info[q] >> 5) & 0x7ffffu;
-					const uint32_t leafIdx = childOffset + (uint32_t)child_index(X, Y, Z, (int)level);
-					leafOf[idx[q]] = leafIdx;
-					uint32_t rank;
-					if (table_add(tbl, leafIdx, 1u, &rank) < 0) count_into(a, ctl, leafIdx, 1u, listNext, countNext);
+				extraBase = __shfl(extraBase, 0);
+				if (extraBase == NONE) { mask1 = 0; mask2 = 0ull; n1 = 0; n2 = 0; }
+				if (t < 8u) sh.base2[t] = extraBase + 8u * (uint32_t)__popc(mask1 & ((1u << t) - 1u));
+				sh.base3[t] = extraBase + 8u * (n1 + (uint32_t)__popcll(mask2 & ((1ull << t) - 1ull)));
+				if (t == 0) { sh.mask1 = mask1; sh.mask2 = mask2; }
+			}
+			__syncthreads();
+			const uint32_t mask1 = sh.mask1;
+			const unsigned long long mask2 = sh.mask2;
+			// local node t: does it exist, how many samples, does it split here
+			auto exists = [&](uint32_t u) { return u < 8u ? true : u < 72u ? ((mask1 >> ((u - 8u) >> 3)) & 1u) != 0u : ((mask2 >> ((u - 72u) >> 3)) & 1ull) != 0ull; };
+			auto countOf = [&](uint32_t u) { return u < 8u ? sh.c1[u] : u < 72u ? sh.c2[u - 8u] : sh.bins[u - 72u]; };
+			auto splits = [&](uint32_t u) { return u < 8u ? ((mask1 >> u) & 1u) != 0u : u < 72u ? ((mask2 >> (u - 8u)) & 1ull) != 0ull : false; };
+			auto indexOf = [&](uint32_t u) { return u < 8u ? rec.childBase + u : u < 72u ? sh.base2[(u - 8u) >> 3] + ((u - 8u) & 7u) : sh.base3[(u - 72u) >> 3] + ((u - 72u) & 7u); };
+			if (t < LOCAL_NODES && exists(t)) {
+				const uint32_t level = l + local_depth(t);
+				if (splits(t)) sh.grid[t] = grid_for_split(a, ctl);
+				else if (countOf(t) > SIMLOD_MAX_POINTS_PER_NODE && level < (uint32_t)SIMLOD_MAX_DEPTH && local_depth(t) == 3u) {
+					// still too full after three levels: a slot of its own for the next round (its eight children reserved now, no stored points)
+					uint32_t slot = 0, childBase = 0, dummy;
+					if (reserve(a, ctl, 1u, 8u, 0u, slot, childBase, dummy)) {
+						uint4* h = reinterpret_cast<uint4*>(hist + (uint64_t)slot * HIST_BINS);
+						for (uint32_t i = 0; i < HIST_BINS / 4; i++) h[i] = make_uint4(0, 0, 0, 0);
+						slots[slot] = SlotRec{indexOf(t), level, childBase, 0u, 0u, 0u, 0u, 0u};
+						sh.listed[t] = MAP_LISTED | (level << 16) | slot;
+					}
 				}
 			}
 			__syncthreads();
-			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += ETPB) {
-				const uint32_t key = tbl.keys[e];
-				if (key != TBL_EMPTY) count_into(a, ctl, key, tbl.vals[e], listNext, countNext);
+			if (t < LOCAL_NODES && exists(t)) {
+				const uint32_t depth = local_depth(t), level = l + depth, idx = indexOf(t);
+				// octants chosen below L, first to last
+				const uint32_t rel = t < 8u ? t : t < 72u ? t - 8u : t - 72u;
+				uint32_t oct[3] = {0, 0, 0};
+				for (uint32_t k = 0; k < depth; k++) oct[k] = (rel >> (3u * (depth - 1u - k))) & 7u;
+				const SimlodNode* nodeL = a.nodes + L;
+				uint32_t X = nodeL->X, Y = nodeL->Y, Z = nodeL->Z;
+				for (uint32_t k = 0; k < depth; k++) { X = 2u * X + ((oct[k] >> 2) & 1u); Y = 2u * Y + ((oct[k] >> 1) & 1u); Z = 2u * Z + (oct[k] & 1u); }
+				const bool split = splits(t);
+				const bool nextRound = sh.listed[t] != NONE;
+				// written field by field straight to the node array (a 152-byte local would live in scratch memory); voxels.cu:318-343
+				SimlodNode& c = a.nodes[idx];
+				const uint32_t firstChild = !split ? 0u : t < 8u ? sh.base2[t] : sh.base3[t - 8u];
+				for (uint32_t k = 0; k < 8; k++) c.children[k] = split ? a.nodes + firstChild + k : nullptr;
+				c.counter = countOf(t); c.numPoints = 0;
+				c.level = level; c.X = X; c.Y = Y; c.Z = Z;
+				c.countIteration = 0; c.countFlag = 0;
+				for (int k = 0; k < 20; k++) c.name[k] = nodeL->name[k];
+				for (uint32_t k = 0; k < depth; k++) if (l + 1u + k < 20u) c.name[l + 1u + k] = (uint8_t)('0' + oct[k]);
+				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
+				c.grid = split ? sh.grid[t] : nullptr; c.points = nullptr; c.voxelChunks = nullptr;
+				c.numVoxels = 0; c.numVoxelsStored = 0;
+				if (nextRound) {                                                   // (its grid: like a queued leaf's, before its children exist)
+					c.grid = grid_for_split(a, ctl);
+				}
+				// parent, and the ancestor path: parent first, ..., then L, then L's own ancestors
+				const uint32_t parentLocal = depth == 1u ? NONE : depth == 2u ? (t - 8u) >> 3 : 8u + ((t - 72u) >> 3);
+				const uint32_t parentIdx = depth == 1u ? L : indexOf(parentLocal);
+				parentOf[idx] = parentIdx;
+				unsigned long long* mine = paths + (uint64_t)idx * PATH_WORDS;
+				uint32_t w = 0;
+				if (depth >= 3u) { const uint32_t g = 8u + ((t - 72u) >> 3); mine[w++] = path_pack(a.pers, indexOf(g), l + 2u, sh.grid[g]); }
+				if (depth >= 2u) { const uint32_t ch = depth == 2u ? (t - 8u) >> 3 : (t - 72u) >> 6; mine[w++] = path_pack(a.pers, indexOf(ch), l + 1u, sh.grid[ch]); }
+				mine[w++] = path_pack(a.pers, L, l, nodeL->grid);
+				for (uint32_t k = 0; w < PATH_WORDS; k++) {
+					const unsigned long long e = w + 1 < PATH_WORDS ? sh.pathL[k] : 0ull;
+					mine[w++] = e;
+					if (e == 0ull) break;
+				}
+				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
+			}
+			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
+			if (t < HIST_BINS) {
+				const uint32_t j = t >> 6, jk = t >> 3;
+				const uint32_t u = ((mask1 >> j) & 1u) == 0u ? j : ((mask2 >> jk) & 1ull) == 0ull ? 8u + jk : 72u + t;
+				const uint32_t ls = sh.listed[u];
+				map[(uint64_t)s * HIST_BINS + t] = ls != NONE ? ls : indexOf(u);
 			}
 		}
-		if (timer) { t1 = wall_ns(); ctl->expandNs[3] += t1 - t0; t0 = t1; }
+		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; ctl->expandNs[5] += 1; }
+		if (!more) break;
 		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-		if (timer) { t1 = wall_ns(); ctl->expandNs[4] += t1 - t0; ctl->expandNs[5] += 1; }
+		if (timer) { t1 = wall_ns(); ctl->expandNs[3] += t1 - t0; }
+		sb = se;
+		se = min(slots_in_use(ctl), SLOT_CAP);
 	}
 }
 
@@ -1171,7 +1363,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 	if (total == 0u) return;
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
-	const uint32_t* leafOf = at<const uint32_t>(a, a.offLeafOf);
+	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	const Emit* emits = at<const Emit>(a, a.offEmit);
 	const VoxItem* voxItems = at<const VoxItem>(a, a.offVoxItems);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
@@ -1183,19 +1375,43 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
 	// global atomic each, (3) store — the slot inside the range comes from an LDS cursor.
 
+	if (part == 0u) {
+		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
+		// k_voxelize samples into them (voxels.cu:371-382) — 256 KB each, the stores ride along with the loads below
+		const uint32_t numClear = min(ctl->numClear, a.clearCap);
+		SimlodOccupancyGrid* const* clearList = at<SimlodOccupancyGrid*>(a, a.offClear);
+		constexpr uint32_t W4 = SIMLOD_GRID_NUM_WORDS / 4;
+		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numClear * W4; i += gridDim.x * TPB)
+			reinterpret_cast<uint4*>(clearList[i / W4]->values)[i % W4] = make_uint4(0, 0, 0, 0);
+	}
 	if (blockIdx.x >= numChunks) return;
 	// ======== points ========
 	table_init(sh.tbl);
 	__syncthreads();
 	if (part == 0u) {
+	const uint32_t* map = at<const uint32_t>(a, a.offMap);
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		uint32_t v[PPT];
 #pragma unroll
 		for (uint32_t j = 0; j < PPT; j++) {
 			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			const uint32_t idx = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+			v[j] = t < total ? leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] : NONE;
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			// a sample that k_expand relabelled (slot, bin): its leaf is one word of the slot's map
+			if (v[j] == NONE || (v[j] & LEAF_FLAG) == 0u) continue;
+			uint32_t e = map[v[j] & 0x1fffffu];
+			if ((e & MAP_LISTED) != 0u) e = at<const SlotRec>(a, a.offSlots)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
+			v[j] = e;
+			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+			leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] = e;
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < PPT; j++) {
+			if (v[j] == NONE) continue;
 			uint32_t rank;
-			(void)table_add(sh.tbl, leafOf[idx], 1u, &rank);
+			(void)table_add(sh.tbl, v[j], 1u, &rank);
 		}
 	}
 	__syncthreads();
@@ -1355,7 +1571,7 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	uint64_t off = 4096;                                                       // Ctl
 	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
-	off += 2 * align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	off += align_up((uint64_t)SLOT_CAP * sizeof(SlotRec), 256) + 2 * align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256) + align_up(65536ull * 8, 256);
 	off += 4 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
@@ -1369,8 +1585,11 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.dirCap = 2 * a.nodeCapacity + 65536;
 	uint64_t off = 4096;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
-	a.offSpillA = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
-	a.offSpillB = off;   off += align_up((uint64_t)SPILLING_CAPACITY * 4, 256);
+	a.offSlots = off;    off += align_up((uint64_t)SLOT_CAP * sizeof(SlotRec), 256);
+	a.offHist = off;     off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
+	a.offMap = off;      off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
+	a.clearCap = 65536;
+	a.offClear = off;    off += align_up((uint64_t)a.clearCap * 8, 256);
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);

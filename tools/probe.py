@@ -1,0 +1,76 @@
+"""A/B probe of the exact ingest on the bench workload (36 M terrain, 36 resident ring batches): one terrain, several
+environment settings, each timed like bench.py's step (reset + republish + kernel_construct launches until drained), plus
+k_expand's phase timers of workgroup 0 (construct_batch.hip Ctl.expandNs, byte 152).
+
+    python tools/probe.py [--steps 5] [--points 36000000] "SIMLOD_EXPAND_WGS=64" "SIMLOD_EXPAND_WGS=128 SIMLOD_GRID_MULT=4" ...
+
+Every positional argument is one variant: space-separated NAME=VALUE pairs put into the environment for that variant only
+(the library reads its tuning knobs with getenv at every launch).  The empty string "" is the default configuration."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from simlod_amd import abi, camera, synthetic
+from simlod_amd.runtime import DeviceOctree
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--points", type=int, default=36_000_000)
+ap.add_argument("--order", default="shuffled")
+ap.add_argument("--coalesce", action="store_true")
+ap.add_argument("variants", nargs="*", default=[""])
+args = ap.parse_args()
+
+W, H = 1920, 1080
+gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
+pts, box = gen(args.points, seed=7)
+batch = abi.MAX_BATCH_SIZE
+nb = (args.points + batch - 1) // batch
+T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886 * float(box[0]) / 6000.0, (box[0] / 2, box[1] / 2, 0.35 * box[2])), camera.perspective(aspect=W / H))
+dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, momentary_bytes=(700 if args.coalesce else 300) * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
+u = dev.uniforms(W, H, T, box, hqs=True)
+rv = dev.ring.view(torch.uint8)
+for i in range(nb):
+    c = pts[i * batch:(i + 1) * batch]
+    rv[i * batch * 16: i * batch * 16 + len(c) * 16].copy_(torch.from_numpy(c.view(np.uint8).reshape(-1)))
+sizes = torch.tensor([min(batch, args.points - i * batch) for i in range(nb)], dtype=torch.int32, device=dev.device)
+
+
+def step():
+    dev.reset(u)
+    dev.batch_sizes[:nb] = sizes
+    dev.num_uploaded.fill_(nb)
+    dev.uploaded_host = nb
+    return dev.drain(u)
+
+
+for var in args.variants:
+    saved = {}
+    for kv in var.split():
+        k, v = kv.split("=", 1)
+        saved[k] = os.environ.get(k)
+        os.environ[k] = v
+    step()
+    torch.cuda.synchronize()
+    dev.momentary[152:216].zero_()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    st = dev.read_stats()
+    c = dev.momentary[152:216].cpu().numpy().view(np.uint64).astype(np.float64)
+    calls, rounds = max(c[6], 1), max(c[5], 1)
+    print(f"{var or 'default':60s} {ms:7.3f} ms/ingest  {args.points / ms / 1e3:7.0f} M pts/s  dbg={int(st['dbg'])} nodes={int(st['numNodes'])} | "
+          f"k_expand wg0 per call us: H {c[0] / 1e3 / calls:5.1f} bar {c[1] / 1e3 / calls:5.1f} D {c[2] / 1e3 / calls:5.1f} bar2 {c[3] / 1e3 / calls:5.1f} "
+          f"rounds/call {rounds / calls:4.2f} calls {int(c[6])}", flush=True)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
