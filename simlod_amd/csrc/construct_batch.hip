@@ -43,7 +43,7 @@ namespace batch {
 struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
 	uint32_t active, batchSize, ringSlot, batchIndex;
-	uint32_t unused3;
+	uint32_t slotsRound0;        // slots handed out by k_count's tail (snapshot by k_hist): k_expand's first round — its workgroups start at different times and the first to get to work hand out more
 	uint32_t numSpilled, unused0, errors;   // (unused0: the directory counter moved to dirCountOf; the layout behind it stays)
 	uint32_t ordinal, abortBatch, barrierCount;
 	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
@@ -498,6 +498,79 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += TPB / 64u) queue_split(a, ctl, sh_cross[e]);
 }
 
+// ---- hist: round 0 of the split cascade's histograms (voxels.cu:245-289) ---------------------------------------------------------
+// Every CU takes part (an ordinary launch; the rounds that follow, if any, run inside k_expand).  Index space: first the stored points
+// of the queued leaves — element e = point (e % 1000) of work item (e / 1000), one chunk per item: they move into the spill buffer
+// (voxels.cu:253-289) — then the batch's samples.  Whatever lies in a queued leaf is added to the leaf's histogram (per workgroup in LDS
+// first, one global add per workgroup and bin) and its cached-leaf word is relabelled FLAG | slot | bin.  Exits at once when k_count
+// queued nothing.
+__global__ __launch_bounds__(TPB) void k_hist(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (!ctl->active) return;
+	const uint32_t slots0 = slots_in_use(ctl);
+	if (blockIdx.x == 0 && threadIdx.x == 0) ctl->slotsRound0 = slots0;
+	if (slots0 == 0u) return;
+	__shared__ BlockTable tbl;
+	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
+	uint32_t* hist = at<uint32_t>(a, a.offHist);
+	const SpillWork* work = at<const SpillWork>(a, a.offWork);
+	float4* spilled = at<float4>(a, a.offSpilled);
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const uint32_t n = ctl->batchSize;
+	const uint32_t tag = ctl->ordinal + 1u;
+	const uint32_t moved = min(ctl->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
+	const uint32_t total = moved + n;
+	const uint32_t numChunks = (total + CPB - 1) / CPB;
+	if (blockIdx.x >= numChunks) return;
+	table_init(tbl);
+	__syncthreads();
+	auto add = [&](uint32_t key) {
+		uint32_t rank;
+		if (table_add(tbl, key, 1u, &rank) < 0) atomicAdd(hist + key, 1u);
+	};
+	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		// stage by stage, eight elements per thread: cached-leaf words / work items; slot lookups; points; histogram
+		uint32_t ent[CPT], dst[CPT];                       // ent = level << 16 | slot, or NONE; dst = where the word / the moved point goes
+		const float4* src[CPT];
+		uint32_t v[CPT];
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
+			const uint32_t e = chunk * CPB + j * TPB + threadIdx.x;
+			ent[j] = NONE; src[j] = nullptr; dst[j] = 0; v[j] = NONE;
+			if (e < moved) {
+				const SpillWork item = work[e / SIMLOD_POINTS_PER_CHUNK];
+				const uint32_t k = e % SIMLOD_POINTS_PER_CHUNK;
+				if (k < item.count) { ent[j] = (item.level << 16) | item.slot; src[j] = reinterpret_cast<const float4*>(item.chunk->points) + k; dst[j] = item.dstBase + k; }
+			} else if (e < total) v[j] = leafOf[e - moved];
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
+			if (v[j] == NONE) continue;
+			const uint32_t e = chunk * CPB + j * TPB + threadIdx.x;
+			const unsigned long long info = slotOf[v[j]];
+			if ((uint32_t)(info >> 32) == tag) { ent[j] = (uint32_t)info; src[j] = pts + (e - moved); dst[j] = e - moved; }
+		}
+		float4 p[CPT];
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) p[j] = ent[j] != NONE ? *src[j] : make_float4(0, 0, 0, 0);
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
+			if (ent[j] == NONE) continue;
+			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
+			const uint32_t key = ((ent[j] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[j] >> 16);
+			if (v[j] == NONE) { spilled[dst[j]] = p[j]; leafOf[SIMLOD_MAX_BATCH_SIZE + dst[j]] = LEAF_FLAG | key; }      // a stored point moves
+			else leafOf[dst[j]] = LEAF_FLAG | key;
+			add(key);
+		}
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+		const uint32_t key = tbl.keys[e];
+		if (key != TBL_EMPTY) atomicAdd(hist + key, tbl.vals[e]);
+	}
+}
+
 // ---- expand: split the queued leaves, cascades included (voxels.cu:385-415, 245-289, 308-383) ---------------------------
 // Persistent, hand-rolled grid barrier; exits at once when `count` queued nothing.  The reference counts, splits ONE level, counts
 // again, ... with ~8 grid.sync() per level.  Here a round settles THREE levels:
@@ -537,115 +610,62 @@ __device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, u
 	}
 	atomicAdd(at<uint32_t>(a, a.offHist) + key, cnt);          // no room in the table: straight to the histogram
 }
-// One histogram update per DISTINCT key of the wave (whole wave calls; `active` lanes carry a key): neighbouring samples of a batch fall
-// into a handful of bins, and 64 LDS atomics on one word take 64 turns.  A wave with many distinct keys finishes lane by lane.
-__device__ __forceinline__ void hist_add_wave(const BuildArgs& a, ExpandShared& sh, uint32_t key, bool active) {
-	unsigned long long todo = __ballot(active);
-	const uint32_t lane = (uint32_t)lane_id();
-#pragma unroll 1
-	for (int it = 0; todo != 0ull; ++it) {
-		if (it == 12) { if (((todo >> lane) & 1ull) != 0ull) hist_add(a, sh, key, 1u); break; }
-		const int leader = __ffsll((long long)todo) - 1;
-		const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
-		const unsigned long long same = __ballot(active && key == k);
-		if ((int)lane == leader) hist_add(a, sh, k, (uint32_t)__popcll(same));
-		todo &= ~same;
-	}
-}
-
 // local node number t of a slot -> depth below the slot's node (1..3) and the octants chosen on the way
 __device__ __forceinline__ uint32_t local_depth(uint32_t t) { return t < 8u ? 1u : t < 72u ? 2u : 3u; }
 
 __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (!ctl->active) return;
-	if (slots_in_use(ctl) == 0u) return;        // slots are handed out by k_count's tail; their number only ever grows here: a stable early-exit test
+	if (ctl->slotsRound0 == 0u) return;         // slots handed out by k_count's tail, as k_hist found them: stable while this kernel hands out more
 	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if the grid barrier had given up (tests the abort path); either way the octree is
 	// not to be trusted any more (k_count's tail has already emptied the queued leaves): fatal, sticky until a reset
 	if ((ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
 	SlotRec* slots = at<SlotRec>(a, a.offSlots);
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	uint32_t* map = at<uint32_t>(a, a.offMap);        // (not the histogram's words: other workgroups may still be peeking at those)
-	const SpillWork* work = at<const SpillWork>(a, a.offWork);
-	float4* spilled = at<float4>(a, a.offSpilled);
+	const float4* spilled = at<const float4>(a, a.offSpilled);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const uint32_t n = ctl->batchSize;
-	const uint32_t tag = ctl->ordinal + 1u;
 	uint32_t generation = 0;
 
 	__shared__ ExpandShared sh;
 	const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
 	if (timer) ctl->expandNs[6] += 1;
 
-	uint32_t sb = 0, se = min(slots_in_use(ctl), SLOT_CAP);
+	uint32_t sb = 0, se = min(ctl->slotsRound0, SLOT_CAP);
 	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS && sb < se; ++round) {
 		uint64_t t0 = timer ? wall_ns() : 0, t1;
-		// -- H: histograms ---------------------------------------------------------------------------------------------------
-		for (uint32_t i = threadIdx.x; i < HT_CAP; i += ETPB) { sh.keys[i] = TBL_EMPTY; sh.vals[i] = 0u; }
-		__syncthreads();
-		const uint32_t stride = gridDim.x * ETPB;
-		if (round == 0) {
-			// the stored points of the queued leaves move into the spill buffer (voxels.cu:253-289): element e = point (e % 1000) of work item
-			// (e / 1000), one chunk per item — a flat index space, so every workgroup moves the same share
-			const uint32_t workEnd = min(ctl->numWork, a.workCap);
-			const uint32_t totalMoved = workEnd * SIMLOD_POINTS_PER_CHUNK;
-			constexpr uint32_t U = 4;
-			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < ((totalMoved + 63u) & ~63u); first += U * stride) {   // (whole waves enter: hist_add_wave)
-				SpillWork item[U]; float4 p[U]; bool live[U];
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					const uint32_t e = first + q * stride;
-					live[q] = e < totalMoved;
-					if (live[q]) item[q] = work[e / SIMLOD_POINTS_PER_CHUNK];
-					live[q] = live[q] && e % SIMLOD_POINTS_PER_CHUNK < item[q].count;
-				}
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) p[q] = live[q] ? reinterpret_cast<const float4*>(item[q].chunk->points)[(first + q * stride) % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
-#pragma unroll
-				for (uint32_t q = 0; q < U; q++) {
-					uint32_t key = 0;
-					if (live[q]) {
-						const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size), Y = quantize(F_GRID, p[q].y, a.miny, a.size), Z = quantize(F_GRID, p[q].z, a.minz, a.size);
-						key = (item[q].slot << 9) | bin_of(X, Y, Z, item[q].level);
-						const uint32_t dst = item[q].dstBase + (first + q * stride) % SIMLOD_POINTS_PER_CHUNK;
-						spilled[dst] = p[q];
-						leafOf[SIMLOD_MAX_BATCH_SIZE + dst] = LEAF_FLAG | key;
-					}
-					hist_add_wave(a, sh, key, live[q]);
-				}
-			}
+		// -- H: histograms (round 0: k_hist has built them) --------------------------------------------------------------------------
+		if (round > 0) {
+			for (uint32_t i = threadIdx.x; i < HT_CAP; i += ETPB) { sh.keys[i] = TBL_EMPTY; sh.vals[i] = 0u; }
+			__syncthreads();
 		}
-		{
-			// the batch's samples (and, from the second round on, the moved points): eight per thread at a time, stage by stage — the
-			// cached-leaf words are in flight together, then the slot lookups, then the points of those that lie in one of the round's nodes
-			const uint32_t total = round == 0 ? n : n + min(ctl->numSpilled, a.spilledCap);
+		if (round > 0) {
+			// the batch's samples and the moved points, eight per thread at a time, stage by stage: the cached-leaf words are in flight
+			// together, then the map words of those that were relabelled, then the points of those whose node was queued again
+			const uint32_t stride = gridDim.x * ETPB;
+			const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
 			constexpr uint32_t U = 8;
-			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < ((total + 63u) & ~63u); first += U * stride) {
+			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < total; first += U * stride) {
 				uint32_t idx[U], v[U], ent[U];
 				float4 p[U];
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
 					const uint32_t t = first + q * stride;
 					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
-					v[q] = t < total ? leafOf[idx[q]] : NONE;
+					v[q] = t < total ? leafOf[idx[q]] : 0u;
 				}
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
 					// ent = level << 16 | slot of the round's slot this sample lies in, or NONE
 					ent[q] = NONE;
-					if (v[q] == NONE) continue;
-					if (round == 0) {
-						const unsigned long long info = slotOf[v[q]];                 // (round 0: no word is relabelled yet)
-						if ((uint32_t)(info >> 32) == tag) ent[q] = (uint32_t)info;
-					} else if ((v[q] & LEAF_FLAG) != 0u) {
-						const uint32_t e = map[v[q] & 0x1fffffu];                     // the map of an earlier round
-						if ((e & MAP_LISTED) != 0u) ent[q] = e & 0x7fffffffu;
-					}
+					if ((v[q] & LEAF_FLAG) == 0u) continue;
+					const uint32_t e = map[v[q] & 0x1fffffu];                         // the map of an earlier round
+					if ((e & MAP_LISTED) != 0u) ent[q] = e & 0x7fffffffu;
 				}
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
@@ -654,24 +674,24 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				}
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
-					uint32_t key = 0;
-					if (ent[q] != NONE) {
-						const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size), Y = quantize(F_GRID, p[q].y, a.miny, a.size), Z = quantize(F_GRID, p[q].z, a.minz, a.size);
-						key = ((ent[q] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[q] >> 16);
-						leafOf[idx[q]] = LEAF_FLAG | key;
-					}
-					hist_add_wave(a, sh, key, ent[q] != NONE);
+					if (ent[q] == NONE) continue;
+					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size), Y = quantize(F_GRID, p[q].y, a.miny, a.size), Z = quantize(F_GRID, p[q].z, a.minz, a.size);
+					const uint32_t key = ((ent[q] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[q] >> 16);
+					leafOf[idx[q]] = LEAF_FLAG | key;
+					hist_add(a, sh, key, 1u);
 				}
 			}
 		}
-		__syncthreads();
-		for (uint32_t e = threadIdx.x; e < HT_CAP; e += ETPB) {
-			const uint32_t key = sh.keys[e];
-			if (key != TBL_EMPTY) atomicAdd(hist + key, sh.vals[e]);
+		if (round > 0) {
+			__syncthreads();
+			for (uint32_t e = threadIdx.x; e < HT_CAP; e += ETPB) {
+				const uint32_t key = sh.keys[e];
+				if (key != TBL_EMPTY) atomicAdd(hist + key, sh.vals[e]);
+			}
+			if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
+			if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+			if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
 		}
-		if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-		if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
 
 		// -- can this round queue anything for a next one?  Only a great-grandchild bin above the limit can (everybody looks at all the
 		//    round's histograms: a few KB from L2); if none, the kernel ends after D without meeting again
@@ -1694,6 +1714,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		for (uint32_t b = 0; b < limit; b++) {
 			const uint32_t par = b & 1u;
 			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
+			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a);
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
 			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u, par);
