@@ -40,36 +40,36 @@ namespace batch {
 
 // Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
 // (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
+// Per-batch state, one copy per parity of the batch's ordinal in the launch: the voxel half of batch b (library's side stream) still
+// reads its copy while k_count .. k_expand of batch b + 1 work on the other, and the last kernel of batch b on the caller's stream
+// (k_insert part 0) prepares the copy of batch b + 1 — which is the copy of batch b - 1, whose voxel half k_insert has waited for.
+struct BatchCtl {
+	uint32_t active, batchSize, ringSlot, batchIndex;
+	uint32_t ordinal, tag, slotsRound0, numSpilled;   // tag = batch index + 1 (NodeDir); slotsRound0: slots handed out by k_count's tail, snapshot by k_hist: k_expand's first round
+	uint32_t numWork, numClear, numTouched, allocDone;   // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_insert's allocation list) | allocation workgroups of k_insert that are done
+	uint32_t barrierCount, nodes, numVoxItems, numVoxSmall;   // nodes = Stats.numNodes after the batch's k_expand: the voxel half must not look at nodes the NEXT batch's k_expand is creating
+	uint32_t numEmits, dirCount, pad0, pad1;
+	unsigned long long reserve;        // split slots << 52 | nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves all or nothing
+	unsigned long long pad2;
+};
+
+// Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
+// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
 struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
-	uint32_t active, batchSize, ringSlot, batchIndex;
-	uint32_t slotsRound0;        // slots handed out by k_count's tail (snapshot by k_hist): k_expand's first round — its workgroups start at different times and the first to get to work hand out more
-	uint32_t numSpilled, unused0, errors;   // (unused0: the directory counter moved to dirCountOf; the layout behind it stays)
-	uint32_t ordinal, abortBatch, barrierCount;
-	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
-	uint32_t numClear;           // occupancy grids allocated / re-used by this batch's splits: k_insert clears them (list at offClear)
-	uint32_t unused1;
-	uint32_t numWork;            // spill-copy work items appended so far in this batch (by k_count's tail)
-	uint32_t pad1;
-	uint32_t unused2[4];
+	uint32_t errors, abortBatch, rebuildLeafChunks, debugFlags;   // rebuildLeafChunks: this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
+	uint32_t processed, unused0[3];    // batches completed in this launch
 	uint64_t startNs;
 	uint32_t statCounters[8];
-	unsigned long long reserve;        // k_expand: nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves both or neither
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
-	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (split, barrier, copy, recount, barrier, rounds, calls; tools/kprof.py), [7] = spilled points so far (bench.py)
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
-	// Per-batch state that the VOXEL TAIL of a batch (k_alloc / k_insert part 1) still reads while the next batch's k_count and k_expand
-	// are already running on the caller's stream (launch_construct): two copies, indexed by the batch's ordinal & 1.  the end-of-batch bookkeeping prepares
-	// the next batch in the other copy.  The arrays behind them (emit list, work items, chunk directory) exist once: the next batch
-	// first writes them in its k_alloc part 0, which waits for the tail.
-	uint32_t numVoxItems[2];           // k_alloc (points): (leaf, sample range) pieces for k_voxelize
-	uint32_t numEmits[2];              // k_voxelize: samples that colour at least one new voxel (entries of the emit list)
-	uint32_t numVoxSmall[2];           // k_alloc (points): leaves with few new samples, for the wave-per-leaf path of k_voxelize (they fill the item array from its end)
-	uint32_t dirCountOf[2];            // chunk directory entries in use (point entries of k_alloc part 0, then voxel entries of part 1)
-	uint32_t activeOf[2], tagOf[2];    // the batch is being processed; its tag (batch index + 1) in NodeDir
-	uint32_t nodesOf[2];               // Stats.numNodes after the batch's k_expand: part 1 must not look at nodes the NEXT batch's k_expand is creating
+	uint64_t unused1[4];
+	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
+	BatchCtl batch[2];
 };
+static_assert(offsetof(Ctl, expandNs) == 152, "bench.py / tools read Ctl.expandNs at byte 152");
+static_assert(sizeof(Ctl) <= 4096, "control block");
 
 struct BuildArgs {
 	SimlodPoint* ring;
@@ -82,7 +82,7 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offEmit, offVoxItems, offSpilled;
+	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offEmit, offVoxItems, offSpilled;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap;
 };
 
@@ -172,17 +172,33 @@ __device__ __forceinline__ SimlodOccupancyGrid* path_grid(uint8_t* pers, unsigne
 __device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
 template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
 
+// the per-batch state of batch #ordinal of this launch, or nullptr when that batch does not exist (the copy of its parity may still
+// hold an earlier batch: the launch enqueues kernels for 20 batches whether they exist or not)
+__device__ __forceinline__ BatchCtl* batch_of(Ctl* ctl, uint32_t ordinal) {
+	BatchCtl* bc = &ctl->batch[ordinal & 1u];
+	return bc->active != 0u && bc->ordinal == ordinal ? bc : nullptr;
+}
+
 __device__ __forceinline__ void raise(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); }
 // conditions after which the batch cannot be completed: the rest of the chain does nothing, Stats.dbg keeps the bit until a reset
 __device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); ctl->abortBatch = 1; ctl->stop = 1; }
 
-// Make batch #ordinal of this launch current, or deactivate (progressive_octree_voxels.cu:890-912).
+// Worst case of what the voxel half of a batch can still add to the persistent buffer (voxel chunks: every sample can colour one voxel per
+// level, every inner node can start one more chunk).  The memory guard of voxels.cu:896-912 looks at the allocator after the WHOLE previous
+// batch; here the next batch is prepared while the previous one's voxel half may still be running, so within this distance of the guard a
+// launch takes one batch only: the next launch's k_begin runs after everything and decides exactly.
+__device__ __forceinline__ unsigned long long voxel_half_slack(const BuildArgs& a, const BatchCtl* prev) {
+	const unsigned long long samples = (unsigned long long)prev->batchSize + prev->numSpilled;
+	return (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + a.stats->numNodes + 1ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk));
+}
+
+// Make batch #ordinal of this launch current (in the copy of its parity), or leave it inactive (progressive_octree_voxels.cu:890-912).
 __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
-	const uint32_t par = ordinal & 1u;
-	ctl->active = 0;
-	ctl->activeOf[par] = 0;
+	BatchCtl* bc = &ctl->batch[ordinal & 1u];
+	bc->active = 0;
 	if (ordinal >= ctl->numBatches || ctl->stop) return;
 	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
+	if (ordinal > 0u && alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + voxel_half_slack(a, &ctl->batch[(ordinal - 1u) & 1u]) >= a.persCapacity) { ctl->stop = 1; return; }
 	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
 	a.stats->memCapacityReached = full ? 1 : 0;
 	if (full) { ctl->stop = 1; return; }
@@ -190,23 +206,25 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	const uint32_t slot = batchIndex % SIMLOD_BATCH_STREAM_SIZE;
 	uint32_t size = a.batchSizes[slot];
 	if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
-	ctl->batchIndex = batchIndex;
-	ctl->ringSlot = slot;
-	ctl->batchSize = size;
-	ctl->ordinal = ordinal;
-	ctl->numClear = 0;
-	ctl->numWork = 0;
-	ctl->numSpilled = 0;
-	ctl->reserve = (unsigned long long)a.stats->numNodes << 32;
-	ctl->dirCountOf[par] = 0;
-	ctl->numVoxItems[par] = 0;
-	ctl->numVoxSmall[par] = 0;
-	ctl->numEmits[par] = 0;
-	ctl->tagOf[par] = batchIndex + 1u;
-	ctl->abortBatch = 0;
-	ctl->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
-	ctl->active = 1;
-	ctl->activeOf[par] = 1;
+	bc->batchIndex = batchIndex;
+	bc->ringSlot = slot;
+	bc->batchSize = size;
+	bc->ordinal = ordinal;
+	bc->tag = batchIndex + 1u;
+	bc->slotsRound0 = 0;
+	bc->numSpilled = 0;
+	bc->numWork = 0;
+	bc->numClear = 0;
+	bc->numTouched = 0;
+	bc->allocDone = 0;
+	bc->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
+	bc->nodes = 0;
+	bc->numVoxItems = 0;
+	bc->numVoxSmall = 0;
+	bc->numEmits = 0;
+	bc->dirCount = 0;
+	bc->reserve = (unsigned long long)a.stats->numNodes << 32;
+	bc->active = 1;
 }
 
 // ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
@@ -216,7 +234,9 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
 	ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
 	ctl->stop = (momentaryTooSmall || fatal) ? 1u : 0u;
-	ctl->pad1 = debugFlags;
+	ctl->abortBatch = 0;
+	ctl->processed = 0;
+	ctl->debugFlags = debugFlags;
 	ctl->startNs = wall_ns();
 	*a.frameStart = ctl->startNs;
 	// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
@@ -229,10 +249,10 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	ctl->uploaded = uploaded;
 	ctl->firstBatch = first;
 	ctl->numBatches = n;
-	ctl->barrierCount = 0;
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
 	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers) ? 1u : 0u;
 	ctl->tableMagic = 0;                        // valid again once k_finish has run
+	ctl->batch[1].active = 0;
 	prepare_batch(a, ctl, 0);
 }
 
@@ -299,19 +319,22 @@ __device__ __forceinline__ uint32_t bin_of(uint32_t X, uint32_t Y, uint32_t Z, u
 	return b;
 }
 
-// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  Returns true for exactly one caller per leaf and batch: the one
+// One arrival-counter update for `cnt` samples (voxels.cu:203-218).  Returns CROSSED for exactly one caller per leaf and batch: the one
 // that has to queue the leaf for splitting — whoever sees its counter cross the limit, or, if it is already over the limit because
 // an earlier batch could not split it (spill space, node array or slots exhausted: the split is deferred, nothing is lost), whoever
-// touches it first in this batch.  The exchange on the per-node tag decides.
-__device__ __forceinline__ bool count_into(const BuildArgs& a, Ctl* ctl, uint32_t leafIdx, uint32_t cnt) {
+// touches it first in this batch; the exchange on the per-node tag decides.  And FIRST for exactly one caller per leaf and batch too:
+// the one that found the counter where the last batch left it (== numPoints: everything counted has been stored) — that caller puts
+// the leaf on the batch's list of leaves with new samples, together with the number of points it held (k_insert allocates their chunks from
+// that list while its other workgroups are already advancing numPoints).
+static constexpr uint32_t CROSSED = 1u, FIRST = 2u;
+__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCtl* bc, uint32_t leafIdx, uint32_t cnt, uint32_t& stored) {
 	SimlodNode* leaf = a.nodes + leafIdx;
+	stored = leaf->numPoints;                            // (a leaf queued for splitting meanwhile reads 0 here: it is no leaf any more when the list is used)
 	const uint32_t old = atomicAdd(&leaf->counter, cnt);
+	uint32_t flags = old == stored ? FIRST : 0u;
 	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
-	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH) {
-		const uint32_t tag = ctl->batchIndex + 1u;
-		return atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, tag) != tag;
-	}
-	return false;
+	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, bc->tag) != bc->tag) flags |= CROSSED;
+	return flags;
 }
 
 struct SpillWork {
@@ -324,17 +347,17 @@ struct SpillWork {
 // << 32 | spill in use), before anything is modified: a leaf that cannot be served now stays a leaf — too full, but intact — and is
 // queued again by a later batch.
 static constexpr int RSV_SLOT_SHIFT = 52;
-__device__ __forceinline__ uint32_t slots_in_use(const Ctl* ctl) {
-	return (uint32_t)(__hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> RSV_SLOT_SHIFT);
+__device__ __forceinline__ uint32_t slots_in_use(const BatchCtl* bc) {
+	return (uint32_t)(__hip_atomic_load(&bc->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> RSV_SLOT_SHIFT);
 }
-__device__ __forceinline__ bool reserve(const BuildArgs& a, Ctl* ctl, uint32_t slots, uint32_t nodes, uint32_t spill, uint32_t& slotBase, uint32_t& nodeBase, uint32_t& spillBase) {
-	unsigned long long cur = __hip_atomic_load(&ctl->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ bool reserve(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t slots, uint32_t nodes, uint32_t spill, uint32_t& slotBase, uint32_t& nodeBase, uint32_t& spillBase) {
+	unsigned long long cur = __hip_atomic_load(&bc->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	for (;;) {
 		slotBase = (uint32_t)(cur >> RSV_SLOT_SHIFT); nodeBase = (uint32_t)(cur >> 32) & 0xfffffu; spillBase = (uint32_t)cur;
 		if (slotBase + slots > SLOT_CAP) { raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); return false; }     // more leaves cross the limit at once than a batch has slots for
 		if (nodeBase + nodes > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); return false; }
 		if ((unsigned long long)spillBase + spill > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); return false; }
-		const unsigned long long prev = atomicCAS(&ctl->reserve, cur, cur + ((unsigned long long)slots << RSV_SLOT_SHIFT) + ((unsigned long long)nodes << 32) + spill);
+		const unsigned long long prev = atomicCAS(&bc->reserve, cur, cur + ((unsigned long long)slots << RSV_SLOT_SHIFT) + ((unsigned long long)nodes << 32) + spill);
 		if (prev == cur) { atomicAdd(&a.stats->numNodes, nodes); return true; }       // voxels.cu:317
 		cur = prev;
 	}
@@ -349,9 +372,9 @@ __device__ __forceinline__ void note_clear(const BuildArgs& a, uint32_t c, Simlo
 		for (uint32_t i = 0; i < SIMLOD_GRID_NUM_WORDS / 4; i++) w[i] = make_uint4(0, 0, 0, 0);
 	}
 }
-__device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& a, Ctl* ctl) {
+__device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& a, BatchCtl* bc) {
 	SimlodOccupancyGrid* g = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
-	note_clear(a, atomicAdd(&ctl->numClear, 1u), g);
+	note_clear(a, atomicAdd(&bc->numClear, 1u), g);
 	return g;
 }
 
@@ -359,7 +382,7 @@ __device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& 
 // with it a histogram), eight node slots and the spill space for the stored points together, the occupancy grid.  Then the leaf's
 // chunk list becomes spill-copy work items (chunk k comes from the leaf chunk table, not from a walk) and goes back to the recycle
 // stack (voxels.cu:346-357; nothing pops before k_alloc).  (voxels.cu:308-383 doSplitting, first half)
-__device__ void queue_split(const BuildArgs& a, Ctl* ctl, uint32_t nodeIdx) {
+__device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t nodeIdx) {
 	const uint32_t lane = (uint32_t)lane_id();
 	SimlodNode* node = a.nodes + nodeIdx;
 	uint32_t ok = 0, slot = 0, spillBase = 0, stored = 0, level = 0, w0 = 0;
@@ -372,21 +395,21 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, uint32_t nodeIdx) {
 		// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
 		numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
 		uint32_t childBase = 0;
-		if (reserve(a, ctl, 1u, 8u, stored, slot, childBase, spillBase)) {
+		if (reserve(a, ctl, bc, 1u, 8u, stored, slot, childBase, spillBase)) {
 			ok = 1;
 			// (four independent atomics with a return value: issued together, one round trip)
 			SimlodAllocatorGlobal* alloc = reinterpret_cast<SimlodAllocatorGlobal*>(a.pers);
 			const unsigned long long gridAt = grid == nullptr ? atomicAdd(reinterpret_cast<unsigned long long*>(&alloc->offset), (unsigned long long)SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid))) : 0ull;   // voxels.cu:363-365
-			const uint32_t c = atomicAdd(&ctl->numClear, 1u);
+			const uint32_t c = atomicAdd(&bc->numClear, 1u);
 			if (numChunks > 0) {
-				w0 = atomicAdd(&ctl->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
+				w0 = atomicAdd(&bc->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
 				top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
 			}
-			atomicAdd(&ctl->numSpilled, stored);
+			atomicAdd(&bc->numSpilled, stored);
 			if (grid == nullptr) { grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + gridAt); node->grid = grid; }
 			note_clear(a, c, grid);
 			at<SlotRec>(a, a.offSlots)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, 0u, 0u, 0u};
-			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)(ctl->ordinal + 1u) << 32) | (level << 16) | slot;
+			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)(bc->ordinal + 1u) << 32) | (level << 16) | slot;
 		}
 	}
 	ok = __shfl(ok, 0);
@@ -436,26 +459,38 @@ static constexpr uint32_t CPT = 8;
 static constexpr uint32_t CPB = TPB * CPT;
 static constexpr uint32_t CROSS_CAP = 128;         // leaves one workgroup can see cross the limit in one batch
 
-__global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
+static constexpr uint32_t TOUCH_CAP = 512;         // leaves one workgroup can be the first to touch in one batch (more: appended one by one)
+
+__global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->active) return;
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr) return;
 	__shared__ BlockTable tbl;
 	__shared__ uint32_t sh_cross[CROSS_CAP];
-	__shared__ uint32_t sh_numCross;
-	const uint32_t n = ctl->batchSize;
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	__shared__ uint2 sh_touch[TOUCH_CAP];
+	__shared__ uint32_t sh_numCross, sh_numTouch, sh_touchBase;
+	const uint32_t n = bc->batchSize;
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	uint2* touched = at<uint2>(a, a.offTouched);           // {leaf, points it held when the batch began}
 	const uint32_t numChunks = (n + CPB - 1) / CPB;
 	if (blockIdx.x >= numChunks) return;
-	auto crossed = [&](uint32_t leafIdx) {
-		const uint32_t k = atomicAdd(&sh_numCross, 1u);
-		if (k < CROSS_CAP) sh_cross[k] = leafIdx;
-		else { at<uint32_t>(a, a.offRetryTag)[leafIdx] = 0u; raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); }   // deferred: a later batch queues it again
+	auto counted = [&](uint32_t leafIdx, uint32_t flags, uint32_t stored) {
+		if ((flags & FIRST) != 0u) {
+			const uint32_t k = atomicAdd(&sh_numTouch, 1u);
+			if (k < TOUCH_CAP) sh_touch[k] = make_uint2(leafIdx, stored);
+			else touched[atomicAdd(&bc->numTouched, 1u)] = make_uint2(leafIdx, stored);       // (at most one entry per node and batch: the list has room for every node)
+		}
+		if ((flags & CROSSED) != 0u) {
+			const uint32_t k = atomicAdd(&sh_numCross, 1u);
+			if (k < CROSS_CAP) sh_cross[k] = leafIdx;
+			else { at<uint32_t>(a, a.offRetryTag)[leafIdx] = 0u; raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); }   // deferred: a later batch queues it again
+		}
 	};
 	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
 	// other's slowest descent; one flush at the end.
 	table_init(tbl);
-	if (threadIdx.x == 0) sh_numCross = 0;
+	if (threadIdx.x == 0) { sh_numCross = 0; sh_numTouch = 0; }
 	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		float4 p[CPT];
@@ -481,21 +516,25 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 			const uint32_t leafIdx = cur[j];
 			leafOf[i] = leafIdx;
 			uint32_t rank;
-			if (table_add(tbl, leafIdx, 1u, &rank) < 0 && count_into(a, ctl, leafIdx, 1u)) crossed(leafIdx);
+			if (table_add(tbl, leafIdx, 1u, &rank) < 0) { uint32_t stored; const uint32_t f = count_into(a, bc, leafIdx, 1u, stored); counted(leafIdx, f, stored); }
 		}
 	}
 	__syncthreads();
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY && count_into(a, ctl, key, tbl.vals[e])) crossed(key);
+		if (key != TBL_EMPTY) { uint32_t stored; const uint32_t f = count_into(a, bc, key, tbl.vals[e], stored); counted(key, f, stored); }
 	}
 	__syncthreads();
-	// the leaves this workgroup saw cross the limit: reserved, listed and emptied here, wave by wave, so that k_expand starts with
-	// the histogram pass right away
+	// the leaves this workgroup was the first to touch in this batch go on the batch's list (one reservation per workgroup)
+	const uint32_t numTouch = min(sh_numTouch, TOUCH_CAP);
+	if (threadIdx.x == 0 && numTouch != 0u) sh_touchBase = atomicAdd(&bc->numTouched, numTouch);
+	// the leaves this workgroup saw cross the limit: reserved, listed and emptied here, wave by wave, so that k_hist finds their work items
 	const uint32_t numCross = min(sh_numCross, CROSS_CAP);
 	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if k_expand's grid barrier had given up, before anything is modified (tests the abort path)
-	if (numCross != 0u && (ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += TPB / 64u) queue_split(a, ctl, sh_cross[e]);
+	if (numCross != 0u && (ctl->debugFlags & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += TPB / 64u) queue_split(a, ctl, bc, sh_cross[e]);
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < numTouch; e += TPB) touched[sh_touchBase + e] = sh_touch[e];
 }
 
 // ---- hist: round 0 of the split cascade's histograms (voxels.cu:245-289) ---------------------------------------------------------
@@ -504,11 +543,12 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a) {
 // (voxels.cu:253-289) — then the batch's samples.  Whatever lies in a queued leaf is added to the leaf's histogram (per workgroup in LDS
 // first, one global add per workgroup and bin) and its cached-leaf word is relabelled FLAG | slot | bin.  Exits at once when k_count
 // queued nothing.
-__global__ __launch_bounds__(TPB) void k_hist(BuildArgs a) {
+__global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->active) return;
-	const uint32_t slots0 = slots_in_use(ctl);
-	if (blockIdx.x == 0 && threadIdx.x == 0) ctl->slotsRound0 = slots0;
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch) return;
+	const uint32_t slots0 = slots_in_use(bc);
+	if (blockIdx.x == 0 && threadIdx.x == 0) bc->slotsRound0 = slots0;
 	if (slots0 == 0u) return;
 	__shared__ BlockTable tbl;
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
@@ -516,10 +556,10 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a) {
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const uint32_t n = ctl->batchSize;
-	const uint32_t tag = ctl->ordinal + 1u;
-	const uint32_t moved = min(ctl->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const uint32_t n = bc->batchSize;
+	const uint32_t tag = bc->ordinal + 1u;
+	const uint32_t moved = min(bc->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
 	const uint32_t total = moved + n;
 	const uint32_t numChunks = (total + CPB - 1) / CPB;
 	if (blockIdx.x >= numChunks) return;
@@ -613,13 +653,14 @@ __device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, u
 // local node number t of a slot -> depth below the slot's node (1..3) and the octants chosen on the way
 __device__ __forceinline__ uint32_t local_depth(uint32_t t) { return t < 8u ? 1u : t < 72u ? 2u : 3u; }
 
-__global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
+__global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->active) return;
-	if (ctl->slotsRound0 == 0u) return;         // slots handed out by k_count's tail, as k_hist found them: stable while this kernel hands out more
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch) return;
+	if (bc->slotsRound0 == 0u) return;         // slots handed out by k_count's tail, as k_hist found them: stable while this kernel hands out more
 	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if the grid barrier had given up (tests the abort path); either way the octree is
 	// not to be trusted any more (k_count's tail has already emptied the queued leaves): fatal, sticky until a reset
-	if ((ctl->pad1 & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+	if ((ctl->debugFlags & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
@@ -628,15 +669,16 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	uint32_t* map = at<uint32_t>(a, a.offMap);        // (not the histogram's words: other workgroups may still be peeking at those)
 	const float4* spilled = at<const float4>(a, a.offSpilled);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
-	const uint32_t n = ctl->batchSize;
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const uint32_t n = bc->batchSize;
+	uint2* touched = at<uint2>(a, a.offTouched);
 	uint32_t generation = 0;
 
 	__shared__ ExpandShared sh;
 	const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
 	if (timer) ctl->expandNs[6] += 1;
 
-	uint32_t sb = 0, se = min(ctl->slotsRound0, SLOT_CAP);
+	uint32_t sb = 0, se = min(bc->slotsRound0, SLOT_CAP);
 	for (uint32_t round = 0; round < SIMLOD_MAX_EXPAND_ROUNDS && sb < se; ++round) {
 		uint64_t t0 = timer ? wall_ns() : 0, t1;
 		// -- H: histograms (round 0: k_hist has built them) --------------------------------------------------------------------------
@@ -648,7 +690,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			// the batch's samples and the moved points, eight per thread at a time, stage by stage: the cached-leaf words are in flight
 			// together, then the map words of those that were relabelled, then the points of those whose node was queued again
 			const uint32_t stride = gridDim.x * ETPB;
-			const uint32_t total = n + min(ctl->numSpilled, a.spilledCap);
+			const uint32_t total = n + min(bc->numSpilled, a.spilledCap);
 			constexpr uint32_t U = 8;
 			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < total; first += U * stride) {
 				uint32_t idx[U], v[U], ent[U];
@@ -689,7 +731,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				if (key != TBL_EMPTY) atomicAdd(hist + key, sh.vals[e]);
 			}
 			if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
-			if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+			if (!grid_barrier(&bc->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 			if (timer) { t1 = wall_ns(); ctl->expandNs[1] += t1 - t0; t0 = t1; }
 		}
 
@@ -737,7 +779,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				uint32_t extraBase = 0;
 				if (t == 0 && n1 + n2 > 0u) {
 					uint32_t noSlot, noSpill;
-					if (!reserve(a, ctl, 0u, 8u * (n1 + n2), 0u, noSlot, extraBase, noSpill)) extraBase = NONE;    // no room for the cascade: the children stay too full (deferred)
+					if (!reserve(a, ctl, bc, 0u, 8u * (n1 + n2), 0u, noSlot, extraBase, noSpill)) extraBase = NONE;    // no room for the cascade: the children stay too full (deferred)
 				}
 				extraBase = __shfl(extraBase, 0);
 				if (extraBase == NONE) { mask1 = 0; mask2 = 0ull; n1 = 0; n2 = 0; }
@@ -755,11 +797,11 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 			auto indexOf = [&](uint32_t u) { return u < 8u ? rec.childBase + u : u < 72u ? sh.base2[(u - 8u) >> 3] + ((u - 8u) & 7u) : sh.base3[(u - 72u) >> 3] + ((u - 72u) & 7u); };
 			if (t < LOCAL_NODES && exists(t)) {
 				const uint32_t level = l + local_depth(t);
-				if (splits(t)) sh.grid[t] = grid_for_split(a, ctl);
+				if (splits(t)) sh.grid[t] = grid_for_split(a, bc);
 				else if (countOf(t) > SIMLOD_MAX_POINTS_PER_NODE && level < (uint32_t)SIMLOD_MAX_DEPTH && local_depth(t) == 3u) {
 					// still too full after three levels: a slot of its own for the next round (its eight children reserved now, no stored points)
 					uint32_t slot = 0, childBase = 0, dummy;
-					if (reserve(a, ctl, 1u, 8u, 0u, slot, childBase, dummy)) {
+					if (reserve(a, ctl, bc, 1u, 8u, 0u, slot, childBase, dummy)) {
 						uint4* h = reinterpret_cast<uint4*>(hist + (uint64_t)slot * HIST_BINS);
 						for (uint32_t i = 0; i < HIST_BINS / 4; i++) h[i] = make_uint4(0, 0, 0, 0);
 						slots[slot] = SlotRec{indexOf(t), level, childBase, 0u, 0u, 0u, 0u, 0u};
@@ -792,7 +834,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				c.grid = split ? sh.grid[t] : nullptr; c.points = nullptr; c.voxelChunks = nullptr;
 				c.numVoxels = 0; c.numVoxelsStored = 0;
 				if (nextRound) {                                                   // (its grid: like a queued leaf's, before its children exist)
-					c.grid = grid_for_split(a, ctl);
+					c.grid = grid_for_split(a, bc);
 				}
 				// parent, and the ancestor path: parent first, ..., then L, then L's own ancestors
 				const uint32_t parentLocal = depth == 1u ? NONE : depth == 2u ? (t - 8u) >> 3 : 8u + ((t - 72u) >> 3);
@@ -810,6 +852,19 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 				}
 				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
 			}
+			{
+				// the nodes of the cascade that hold samples go on the batch's list of leaves with new samples (those that were queued again are no
+				// leaves when k_insert reads the list): one reservation per wave
+				const bool mine = t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u;
+				const unsigned long long m = __ballot(mine);
+				if (m != 0ull) {
+					const uint32_t lane = (uint32_t)lane_id();
+					uint32_t base = 0;
+					if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&bc->numTouched, (uint32_t)__popcll(m));
+					base = __shfl(base, __ffsll((long long)m) - 1, 64);
+					if (mine) touched[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(indexOf(t), 0u);
+				}
+			}
 			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
 			if (t < HIST_BINS) {
 				const uint32_t j = t >> 6, jk = t >> 3;
@@ -820,10 +875,10 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a) {
 		}
 		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; ctl->expandNs[5] += 1; }
 		if (!more) break;
-		if (!grid_barrier(&ctl->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+		if (!grid_barrier(&bc->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 		if (timer) { t1 = wall_ns(); ctl->expandNs[3] += t1 - t0; }
 		sb = se;
-		se = min(slots_in_use(ctl), SLOT_CAP);
+		se = min(slots_in_use(bc), SLOT_CAP);
 	}
 }
 
@@ -905,8 +960,8 @@ __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t 
 // the ancestor, so Node.numVoxels takes one add per (leaf, level, step).  The waves of k_voxelize's workgroups do this after their
 // pieces.  (Measured: without this path the uniformly scattered
 // 350 M-point replay of the C++ harness, 40 000 leaves touched per batch, took 408 ms of kernel time instead of 157 ms.)
-__device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, const uint32_t wave, const uint32_t numWaves, const uint32_t par, const bool rootOnly) {
-	const uint32_t numSmall = min(ctl->numVoxSmall[par], a.voxItemCap - VOX_BIG_ITEMS);
+__device__ __forceinline__ void voxelize_small(const BuildArgs& a, BatchCtl* bc, const uint32_t wave, const uint32_t numWaves) {
+	const uint32_t numSmall = min(bc->numVoxSmall, a.voxItemCap - VOX_BIG_ITEMS);
 	if (numSmall == 0u) return;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -926,7 +981,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 #pragma unroll
 		for (uint32_t u = 0; u < U; u++) {
 			const uint32_t leafIdx = it[u].leaf & 0xffffffu;
-			count[u] = k0 + u < numSmall && (leafIdx == 0u) == rootOnly ? it[u].s1 - it[u].s0 : 0u;   // a root that is still a leaf: the other launch's
+			count[u] = k0 + u < numSmall ? it[u].s1 - it[u].s0 : 0u;
 			// the leaf's path, one entry per lane (entry d - 1 = ancestor d; a root that is still a leaf samples itself, voxels.cu:449-463)
 			mine[u] = 0ull;
 			if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; if (lane == 0u && g != nullptr) mine[u] = path_pack(a.pers, 0u, 0u, g); }
@@ -991,7 +1046,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 			}
 			if (total != 0u) {
 				uint32_t at0 = 0;
-				if (lane == 0u) at0 = atomicAdd(&ctl->numEmits[par], total);
+				if (lane == 0u) at0 = atomicAdd(&bc->numEmits, total);
 				at0 = __shfl(at0, 0, 64);
 #pragma unroll
 				for (uint32_t u = 0; u < U; u++) if (levels[u] != 0u) emits[at0 + before[u]] = emit_pack(itemIndex[u], base + lane, levels[u]);
@@ -1001,33 +1056,31 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, con
 }
 
 // ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
-// One thread; rides in the rootOnly launch of k_voxelize, the last kernel of a batch on the caller's stream (nothing that launch or
-// the voxel half on the side stream reads is touched here: they know their batch by `par`).
-__device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
-	if (ctl->active && ctl->abortBatch) ctl->stop = 1;       // scratch overflow: this batch is lost, report through Stats.dbg
-	if (ctl->active && !ctl->abortBatch) {
+// One thread of k_insert part 0, the last kernel of a batch on the caller's stream, once the batch's chunk allocations are complete
+// (nothing the rest of that launch or the voxel half on the side stream reads is touched here: they know their batch by its parity copy).
+__device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
+	if (ctl->abortBatch) { ctl->stop = 1; }                   // scratch overflow: this batch is lost, report through Stats.dbg
+	else {
 		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
 		a.stats->batchletIndex += 1;
-		a.stats->numPointsProcessed += ctl->batchSize;
-		ctl->expandNs[7] += min(ctl->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
+		a.stats->numPointsProcessed += bc->batchSize;
+		ctl->processed += 1;
+		ctl->expandNs[7] += min(bc->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
 		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
 		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
 	}
-	prepare_batch(a, ctl, ordinal + 1);
+	prepare_batch(a, ctl, bc->ordinal + 1u);
 }
 
-// Launched twice per batch.  rootOnly = 0, on the library's side stream, while the next batch is already counted and split on the
-// caller's: everything except the samples of a root that is still a leaf.  rootOnly = 1, on the caller's stream: only those (the
-// whole octree holds fewer than 50 000 points then; the launch returns at once otherwise) — the next batch's k_expand may split that
-// root and CLEAR its grid (voxels.cu:371-382), which must not happen under a sampling pass that is still setting bits in it.  No
-// other grid is touched by both: a leaf that k_expand splits gets a NEW grid, and nothing samples into a leaf's own grid.
-__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, uint32_t rootOnly, uint32_t ordinal) {
+// On the library's side stream, while the next batch is already counted and split on the caller's.  A root that is still a leaf (the whole
+// octree holds fewer than 50 000 points) is sampled here like every other leaf — into its own grid: the next batch may split that root, but
+// the grid is cleared by that batch's k_insert (voxels.cu:371-382), which waits for this kernel.  No other grid is touched by both: a leaf
+// that k_expand splits gets a NEW grid, and nothing samples into a leaf's own grid.
+__global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	const bool mine = ctl->activeOf[par] != 0u && ctl->abortBatch == 0u;          // read before the bookkeeping below moves on to the next batch
-	if (rootOnly != 0u && blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, ordinal);
-	if (!mine) return;
-	if (rootOnly != 0u && !node_is_leaf(a.nodes)) return;
-	const uint32_t numItems = min(ctl->numVoxItems[par], VOX_BIG_ITEMS);
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch) return;
+	const uint32_t numItems = min(bc->numVoxItems, VOX_BIG_ITEMS);
 	__shared__ VoxShared sh;
 	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
@@ -1038,7 +1091,6 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, ui
 		// path; chunk addresses + cube words; the samples; the write-back atomics; the emit reservation.
 		VoxItem it = items[item];
 		it.leaf &= 0xffffffu;                                  // (the level in the top byte is for k_insert)
-		if ((it.leaf == 0u) != (rootOnly != 0u)) continue;     // whole workgroup
 		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
@@ -1210,7 +1262,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, ui
 			for (uint32_t j = 0; j < VOX_SPT; j++) mineEmits += levels[j] != 0u ? 1u : 0u;
 			uint32_t at0 = mineEmits != 0u ? atomicAdd(&sh.emitCount, mineEmits) : 0u;
 			__syncthreads();
-			if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&ctl->numEmits[par], sh.emitCount);
+			if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&bc->numEmits, sh.emitCount);
 			__syncthreads();
 			if (mineEmits != 0u) {
 				at0 += sh.emitBase;
@@ -1223,81 +1275,109 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t par, ui
 		}
 	}
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
-	voxelize_small(a, ctl, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u, par, rootOnly != 0u);
+	voxelize_small(a, bc, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
 }
 
 // ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
 // (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
 __device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
 
-// part 0 (before k_insert): the point chunks of leaves, and k_voxelize's work list; part 1 (after k_voxelize, when Node.numVoxels is
-// final for this batch): the voxel chunks of inner nodes
-__device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_t i, uint32_t part, uint32_t par) {
-	SimlodNode* node = a.nodes + i;
+// sum over the wave and the sum of the lanes below (every lane of the wave calls)
+__device__ __forceinline__ uint32_t wave_exclusive(uint32_t v, uint32_t& total) {
+	const uint32_t lane = (uint32_t)lane_id();
+	uint32_t x = v;
+#pragma unroll
+	for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
+	total = (uint32_t)__shfl((int)x, 63, 64);
+	return x - v;
+}
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+}
+
+// The point chunks of a leaf with new samples and its share of k_voxelize's work list (voxels.cu:485-538): one leaf per lane, a WHOLE
+// WAVE calls (i == NONE: nothing to do for this lane).  The reservations of the wave's leaves — chunk directory entries, chunks off the
+// recycle stack (voxels.cu:505-516), work items, chunks the stack cannot serve — are summed over the wave and made with ONE atomic each:
+// the words they advance are shared by every leaf of the batch, and device-scope atomics on one word retire at ~88 M/s here.
+__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t i, uint32_t stored) {
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
-	const uint32_t tag = ctl->tagOf[par];
-	if (part == 0u) node->countIteration = tag;
-
-	// -- points of leaves -------------------------------------------------------------------------------------
-	const uint32_t counter = node->counter, stored = node->numPoints;
-	if (part == 0u && stored < counter && node_is_leaf(node)) {
-		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
-		const uint32_t entries = required - first;
-		const uint32_t additional = required - existing;
-		const uint32_t fresh = counter - stored;
-		// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
-		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
-		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
-		const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
-		// the three reservations travel together (each is a returning device-scope atomic: one round trip instead of three): chunk
-		// directory entries, chunks (recycle stack first, voxels.cu:505-516), work items
-		const uint32_t base = atomicAdd(&ctl->dirCountOf[par], entries);
-		const unsigned long long firstIdx = additional > 0u ? atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)additional) : 0ull;
-		uint32_t itemAt = 0;
-		if (pieces != 0u) itemAt = atomicAdd(&ctl->numVoxItems[par], pieces);
-		else {
-			// one reservation per wave: a scattered batch has tens of thousands of these, and one returning atomic each on one word was 0.4 ms
-			const unsigned long long peers = __ballot(1);                                    // the lanes that are here with me
-			const int leader = __ffsll((long long)peers) - 1;
-			if (lane_id() == leader) itemAt = atomicAdd(&ctl->numVoxSmall[par], (uint32_t)__popcll(peers));
-			itemAt = VOX_BIG_ITEMS + __shfl(itemAt, leader, 64) + (uint32_t)__popcll(peers & ((1ull << lane_id()) - 1ull));
-		}
-		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by end_of_batch
-		SimlodChunk* head = node->points;
-		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
-		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
-		if (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt >= a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }   // a batch + moved points beyond 33 M samples
-		uint32_t e = 0;
-		if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
-		if (additional > 0) {
-			// pop from the recycle stack, allocate what the stack cannot serve
-			const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
-			uint8_t* mem = additional > fromPool ? persistent_alloc(a.pers, sizeof(SimlodChunk), additional - fromPool) : nullptr;
-			for (uint32_t k = 0; k < additional; k++) {
-				SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
-				                              : reinterpret_cast<SimlodChunk*>(mem + (uint64_t)(k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-				c->next = nullptr;
-				if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
-				tail = c;
-				chunkDir[base + e++] = c;
-				if (existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;
-			}
-			tail_of(head) = tail;
-		}
-		NodeDir& d = nodeDir[i];
-		d.ptBase = base; d.ptFirst = first; d.ptTag = tag;
-		VoxItem* items = at<VoxItem>(a, a.offVoxItems);
-		if (pieces == 0u) items[itemAt] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
-		else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
+	const uint32_t lane = (uint32_t)lane_id();
+	SimlodNode* node = a.nodes + (i != NONE ? i : 0u);
+	// (`stored` comes with the list entry: Node.numPoints is already being advanced by the other workgroups of k_insert)
+	uint32_t counter = 0;
+	bool need = false;
+	if (i != NONE) { counter = node->counter; need = stored < counter && node_is_leaf(node); }
+	const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+	const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+	const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
+	const uint32_t entries = need ? required - first : 0u;
+	const uint32_t additional = need ? required - existing : 0u;
+	const uint32_t fresh = need ? counter - stored : 0u;
+	// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
+	// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
+	// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
+	const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
+	const uint32_t small = need && pieces == 0u ? 1u : 0u;
+	uint32_t totEntries, totAdditional, totPieces, totSmall;
+	const uint32_t exEntries = wave_exclusive(entries, totEntries), exAdditional = wave_exclusive(additional, totAdditional);
+	const uint32_t exPieces = wave_exclusive(pieces, totPieces), exSmall = wave_exclusive(small, totSmall);
+	if (totEntries == 0u) return;                                  // (whole wave)
+	uint32_t dirBase = 0, itemBase = 0, smallBase = 0;
+	unsigned long long chunkBase = 0;
+	if (lane == 0u) {                                              // (four independent atomics with a return value: one round trip)
+		dirBase = atomicAdd(&bc->dirCount, totEntries);
+		if (totAdditional != 0u) chunkBase = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)totAdditional);
+		if (totPieces != 0u) itemBase = atomicAdd(&bc->numVoxItems, totPieces);
+		if (totSmall != 0u) smallBase = atomicAdd(&bc->numVoxSmall, totSmall);
 	}
-	if (part == 0u) return;
+	dirBase = (uint32_t)__shfl((int)dirBase, 0, 64); itemBase = (uint32_t)__shfl((int)itemBase, 0, 64); smallBase = (uint32_t)__shfl((int)smallBase, 0, 64);
+	chunkBase = shfl64(chunkBase, 0);
+	const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by end_of_batch, after every allocation of the batch
+	// pop from the recycle stack, allocate what the stack cannot serve
+	const unsigned long long firstIdx = chunkBase + exAdditional;
+	const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
+	uint32_t totNew;
+	const uint32_t exNew = wave_exclusive(additional - fromPool, totNew);
+	unsigned long long mem = 0;
+	if (lane == 0u && totNew != 0u) mem = (unsigned long long)persistent_alloc(a.pers, sizeof(SimlodChunk), totNew);
+	mem = shfl64(mem, 0);
+	if (!need) return;
+	const uint32_t base = dirBase + exEntries;
+	const uint32_t itemAt = pieces != 0u ? itemBase + exPieces : VOX_BIG_ITEMS + smallBase + exSmall;
+	if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
+	if (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt >= a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }   // a batch + moved points beyond 33 M samples
+	SimlodChunk* head = node->points;
+	SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
+	uint32_t e = 0;
+	if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
+	if (additional > 0) {
+		for (uint32_t k = 0; k < additional; k++) {
+			SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
+			                              : reinterpret_cast<SimlodChunk*>(mem + (uint64_t)(exNew + k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+			c->next = nullptr;
+			if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
+			tail = c;
+			chunkDir[base + e++] = c;
+			if (existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;
+		}
+		tail_of(head) = tail;
+	}
+	NodeDir& d = nodeDir[i];
+	d.ptBase = base; d.ptFirst = first; d.ptTag = bc->tag;
+	VoxItem* items = at<VoxItem>(a, a.offVoxItems);
+	if (pieces == 0u) items[itemAt] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
+	else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
+}
 
-	// -- voxels of inner nodes (and of the root while it is still a leaf) --------------------------------------
+// the voxel chunks of a node whose numVoxels grew in this batch (voxels.cu:641-672): after k_voxelize, when Node.numVoxels is final
+__device__ __forceinline__ void alloc_voxels(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t i) {
+	SimlodNode* node = a.nodes + i;
+	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
+	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
 	if (numVoxels > voxStored) {
 		const uint32_t required = (numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
@@ -1306,7 +1386,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t entries = required - first;
 		// (both reservations in one round trip)
-		const uint32_t base = atomicAdd(&ctl->dirCountOf[par], entries);
+		const uint32_t base = atomicAdd(&bc->dirCount, entries);
 		uint8_t* fresh = required > existing ? persistent_alloc(a.pers, sizeof(SimlodChunk), required - existing) : nullptr;   // voxel chunks never come from the pool
 		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
 		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
@@ -1314,7 +1394,7 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 		if (first < existing) chunkDir[base + e++] = tail;
 		if (required > existing) {
 			const uint32_t additional = required - existing;
-			// (never the root: this part may run while the NEXT batch's k_expand splits a root that was still a leaf and reads its row)
+			// (never the root: this part may run while the NEXT batch's k_count / k_expand split a root that was still a leaf and read its row)
 			const bool inner = i != 0u && !node_is_leaf(node);
 			for (uint32_t k = 0; k < additional; k++) {
 				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
@@ -1327,19 +1407,18 @@ __device__ __forceinline__ void alloc_node(const BuildArgs& a, Ctl* ctl, uint32_
 			tail_of(head) = tail;
 		}
 		NodeDir& d = nodeDir[i];
-		d.voxBase = base; d.voxFirst = first; d.voxTag = tag;
+		d.voxBase = base; d.voxFirst = first; d.voxTag = bc->tag;
 	}
 }
 
-// A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
-// part 0 runs in the batch's own sequence; part 1 may run on the library's side stream while the next batch has begun: it knows its
-// batch by `par` (ordinal & 1), not by the control block's current-batch fields
-__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a, uint32_t part, uint32_t par) {
+// The voxel chunks: on the library's side stream, after k_voxelize, while the next batch has begun — it knows its batch by `par`
+// (ordinal & 1).  A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
+__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->activeOf[par] || ctl->abortBatch) return;
-	if (part == 0u && blockIdx.x == 0 && threadIdx.x == 0) ctl->nodesOf[par] = min(a.stats->numNodes, a.nodeCapacity);
-	const uint32_t numNodes = part == 0u ? min(a.stats->numNodes, a.nodeCapacity) : ctl->nodesOf[par];
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_node(a, ctl, i, part, par);
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch) return;
+	const uint32_t numNodes = bc->nodes;
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_voxels(a, ctl, bc, i);
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -1373,15 +1452,33 @@ __device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32
 	return v;
 }
 
-// part 0: the points (before k_voxelize, which reads them back leaf by leaf); part 1: the voxels of k_voxelize's emit list
-__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint32_t par) {
+// part 0: the points (before k_voxelize, which reads them back leaf by leaf), and with them what used to be kernels of their own — the
+// chunks of the leaves that receive them, the clearing of the grids of the nodes this batch split, the end-of-batch bookkeeping;
+// part 1: the voxels of k_voxelize's emit list.
+//
+// Part 0 in steps: (0) the first ceil(numTouched / 256) workgroups allocate the chunks of the batch's leaves with new samples (one leaf
+// per lane, alloc_points) and say so; (1) everybody counts its samples per leaf in an LDS table — a relabelled sample finds its leaf in
+// its slot's map — and (2) reserves one slot range per (workgroup, leaf) with one global atomic each; neither needs the chunks;
+// (3) wait for the allocators (they have the lowest workgroup numbers, run first and wait for nobody), then store: the slot inside the
+// range comes from an LDS cursor.  Barriers are paid per workgroup, not per chunk.
+__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
-	if (!ctl->activeOf[par] || ctl->abortBatch) return;
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr) return;
+	if (ctl->abortBatch) {                                  // an earlier kernel — or an allocator of this one — gave up: the batch is not counted (Stats.dbg says why)
+		if (part == 0u && threadIdx.x == 0) {
+			const uint32_t allocBlocks = (min(bc->numTouched, a.nodeCapacity) + TPB - 1) / TPB;       // (whoever still waits for the allocators must not wait for this workgroup)
+			for (uint32_t blk = blockIdx.x; blk < allocBlocks; blk += gridDim.x) __hip_atomic_fetch_add(&bc->allocDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (blockIdx.x == 0) end_of_batch(a, ctl, bc);
+		}
+		return;
+	}
 	__shared__ InsertShared sh;
-	const uint32_t n = ctl->batchSize;
-	const uint32_t total = part == 0u ? n + min(ctl->numSpilled, a.spilledCap) : ctl->numEmits[par];
-	if (total == 0u) return;
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)ctl->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	__shared__ uint32_t sh_go;
+	const uint32_t n = bc->batchSize;
+	const uint32_t total = part == 0u ? n + min(bc->numSpilled, a.spilledCap) : bc->numEmits;
+	if (part != 0u && total == 0u) return;
+	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	const Emit* emits = at<const Emit>(a, a.offEmit);
@@ -1389,90 +1486,125 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
 	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
-	const uint32_t tag = ctl->tagOf[par];
+	const uint32_t tag = bc->tag;
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
-	// Three workgroup-wide steps, each over ALL chunks this workgroup owns, so that barriers are paid per workgroup and not
-	// per chunk: (1) count the samples per leaf in the LDS table, (2) reserve one slot range per (workgroup, leaf) with one
-	// global atomic each, (3) store — the slot inside the range comes from an LDS cursor.
 
 	if (part == 0u) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) bc->nodes = min(a.stats->numNodes, a.nodeCapacity);
+		// (0) chunks for the leaves with new samples (voxels.cu:485-538); whoever is done says so with a release
+		const uint32_t numTouched = min(bc->numTouched, a.nodeCapacity);
+		const uint32_t allocBlocks = (numTouched + TPB - 1) / TPB;
+		const uint2* touched = at<const uint2>(a, a.offTouched);
+		for (uint32_t blk = blockIdx.x; blk < allocBlocks; blk += gridDim.x) {
+			const uint32_t k = blk * TPB + threadIdx.x;
+			const uint2 entry = k < numTouched ? touched[k] : make_uint2(NONE, 0u);
+			alloc_points(a, ctl, bc, entry.x, entry.y);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_fetch_add(&bc->allocDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
 		// k_voxelize samples into them (voxels.cu:371-382) — 256 KB each, the stores ride along with the loads below
-		const uint32_t numClear = min(ctl->numClear, a.clearCap);
+		const uint32_t numClear = min(bc->numClear, a.clearCap);
 		SimlodOccupancyGrid* const* clearList = at<SimlodOccupancyGrid*>(a, a.offClear);
 		constexpr uint32_t W4 = SIMLOD_GRID_NUM_WORDS / 4;
 		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numClear * W4; i += gridDim.x * TPB)
 			reinterpret_cast<uint4*>(clearList[i / W4]->values)[i % W4] = make_uint4(0, 0, 0, 0);
+		if (blockIdx.x >= numChunks && blockIdx.x != 0u) return;       // (workgroup 0 stays for the bookkeeping even when the batch is empty)
+
+		// (1) samples per leaf
+		table_init(sh.tbl);
+		__syncthreads();
+		const uint32_t* map = at<const uint32_t>(a, a.offMap);
+		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+			uint32_t v[PPT];
+#pragma unroll
+			for (uint32_t j = 0; j < PPT; j++) {
+				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+				v[j] = t < total ? leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] : NONE;
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < PPT; j++) {
+				// a sample that k_hist / k_expand relabelled (slot, bin): its leaf is one word of the slot's map
+				if (v[j] == NONE || (v[j] & LEAF_FLAG) == 0u) continue;
+				uint32_t e = map[v[j] & 0x1fffffu];
+				if ((e & MAP_LISTED) != 0u) e = at<const SlotRec>(a, a.offSlots)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
+				v[j] = e;
+				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+				leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] = e;
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < PPT; j++) {
+				if (v[j] == NONE) continue;
+				uint32_t rank;
+				(void)table_add(sh.tbl, v[j], 1u, &rank);
+			}
+		}
+		__syncthreads();
+		// (2) one slot range per (workgroup, leaf)
+		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+			const uint32_t key = sh.tbl.keys[e];
+			if (key == TBL_EMPTY) continue;
+			sh.base[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);                      // voxels.cu:593
+			sh.tbl.vals[e] = 0;                                                                    // becomes the cursor
+		}
+		// (3) the chunks have to be there now
+		if (threadIdx.x == 0) {
+			int good = 1;
+			const uint64_t t0 = wall_clock64();
+			while (__hip_atomic_load(&bc->allocDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < allocBlocks) {
+				__builtin_amdgcn_s_sleep(4);
+				if (wall_clock64() - t0 > 200000000ull) { good = 0; break; }   // 2 s at 100 MHz: a guard against a broken device (the allocators wait for nobody)
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			if (!good) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT);
+			sh_go = (good && __hip_atomic_load(&ctl->abortBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? 1u : 0u;   // (an allocator may have run out of directory space)
+			if (blockIdx.x == 0) end_of_batch(a, ctl, bc);
+		}
+		__syncthreads();
+		if (!sh_go) return;
+		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+			const uint32_t key = sh.tbl.keys[e];
+			if (key == TBL_EMPTY) continue;
+			const NodeDir d = nodeDir[key];
+			sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
+			sh.dirFirst[e] = d.ptFirst;
+		}
+		__syncthreads();
+		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+			float4 p[PPT];
+#pragma unroll
+			for (uint32_t j = 0; j < PPT; j++) {
+				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+				p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? pts[t] : spilled[t - n]);
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < PPT; j++) {
+				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
+				if (t >= total) continue;
+				const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+				const int e = table_find(sh.tbl, leafIdx);
+				uint32_t slot, base, first;
+				if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
+				else {                                                                                // table had no room for this leaf
+					const NodeDir d = nodeDir[leafIdx];
+					slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u); base = d.ptTag == tag ? d.ptBase : 0xffffffffu; first = d.ptFirst;
+				}
+				if (base == 0xffffffffu) { raise(ctl, SIMLOD_ERR_NULL_CHUNK); continue; }           // voxels.cu:599-604
+				SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
+				reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p[j];
+			}
+		}
+		return;
 	}
+
 	if (blockIdx.x >= numChunks) return;
-	// ======== points ========
 	table_init(sh.tbl);
 	__syncthreads();
-	if (part == 0u) {
-	const uint32_t* map = at<const uint32_t>(a, a.offMap);
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		uint32_t v[PPT];
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			v[j] = t < total ? leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] : NONE;
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			// a sample that k_expand relabelled (slot, bin): its leaf is one word of the slot's map
-			if (v[j] == NONE || (v[j] & LEAF_FLAG) == 0u) continue;
-			uint32_t e = map[v[j] & 0x1fffffu];
-			if ((e & MAP_LISTED) != 0u) e = at<const SlotRec>(a, a.offSlots)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
-			v[j] = e;
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] = e;
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			if (v[j] == NONE) continue;
-			uint32_t rank;
-			(void)table_add(sh.tbl, v[j], 1u, &rank);
-		}
-	}
-	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-		const uint32_t key = sh.tbl.keys[e];
-		if (key == TBL_EMPTY) continue;
-		const NodeDir d = nodeDir[key];
-		sh.base[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);                      // voxels.cu:593
-		sh.tbl.vals[e] = 0;                                                                    // becomes the cursor
-		sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
-		sh.dirFirst[e] = d.ptFirst;
-	}
-	__syncthreads();
-	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		float4 p[PPT];
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? pts[t] : spilled[t - n]);
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < PPT; j++) {
-			const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-			if (t >= total) continue;
-			const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
-			const int e = table_find(sh.tbl, leafIdx);
-			uint32_t slot, base, first;
-			if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
-			else {                                                                                // table had no room for this leaf
-				const NodeDir d = nodeDir[leafIdx];
-				slot = atomicAdd(&a.nodes[leafIdx].numPoints, 1u); base = d.ptTag == tag ? d.ptBase : 0xffffffffu; first = d.ptFirst;
-			}
-			if (base == 0xffffffffu) { raise(ctl, SIMLOD_ERR_NULL_CHUNK); continue; }           // voxels.cu:599-604
-			SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
-			reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p[j];
-		}
-	}
-
-	return;
-	}
-
 	// ======== voxels: the samples on k_voxelize's emit list regenerate their voxel(s) ========
 	for (int pass = 0; pass < 2; pass++) {
 		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
@@ -1547,7 +1679,9 @@ __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};   // inner, leaves, nonempty, points, voxels, chunksP, chunksV
 	if (i < numNodes) {
-		const SimlodNode* n = a.nodes + i;
+		SimlodNode* n = a.nodes + i;
+		// voxels.cu:298-300: every counting pass stamps every node with (index of the batch + 1); what the host can see is the last stamp
+		if (ctl->processed != 0u) n->countIteration = a.stats->batchletIndex;
 		if (node_is_leaf(n)) {
 			v[1] = 1; v[3] = n->numPoints; v[5] = (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 			v[2] = n->numPoints > 0 ? 1u : 0u;
@@ -1592,7 +1726,7 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	uint64_t off = 4096;                                                       // Ctl
 	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	off += align_up((uint64_t)SLOT_CAP * sizeof(SlotRec), 256) + 2 * align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256) + align_up(65536ull * 8, 256);
-	off += 4 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf
+	off += 6 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf, touched list (8 B)
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
 	off += align_up((uint64_t)dirCap * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
@@ -1610,6 +1744,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offMap = off;      off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
 	a.clearCap = 65536;
 	a.offClear = off;    off += align_up((uint64_t)a.clearCap * 8, 256);
+	a.offTouched = off;  off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
@@ -1712,22 +1847,19 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
 		for (uint32_t b = 0; b < limit; b++) {
-			const uint32_t par = b & 1u;
-			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a);
-			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a);
+			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a, b);
+			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a, b);
+			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a, 0u, par);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u, par);
-			SIMLOD_LAUNCH(k_voxelize, dim3(dev.numCUs * 2), dim3(VTPB), stream, a, par, 1u, b);   // a root that is still a leaf: here (else: only the end-of-batch bookkeeping)
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u, b);             // chunks, points, end-of-batch bookkeeping
 			hipStream_t tail = stream;
 			if (side != nullptr) {
 				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
 				tail = side->stream;
 			}
-			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, par, 0u, b);
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, 1u, par);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), tail, a, 1u, par);
+			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, b);
+			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, b);
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), tail, a, 1u, b);
 			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
 		}
 		if (side != nullptr && limit > 0 && hipStreamWaitEvent(stream, side->tailDone[limit - 1], 0) != hipSuccess) return (int)hipGetLastError();

@@ -2,6 +2,7 @@
 // CudaModularProgram / cuLaunchCooperativeKernel shaped surface of the reference host
 // (include/CudaModularProgram.h:140-264, modules/progressive_octree/main_progressive_octree.cpp:333-546).
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -25,6 +26,16 @@ uint32_t batch_limit() { return g_batchLimit.load(); }
 int tune(const char* envName, int dflt) {
 	const char* v = std::getenv(envName);
 	return v ? std::atoi(v) : dflt;
+}
+
+bool debug_sync() {
+	static const bool on = tune("SIMLOD_DEBUG_SYNC", 0) != 0;
+	return on;
+}
+void debug_synced(const char* kernelName) {
+	const hipError_t e = hipDeviceSynchronize();
+	std::fprintf(stderr, "[simlod] %s -> %d\n", kernelName, (int)e);
+	std::fflush(stderr);
 }
 
 const DeviceInfo& device_info() {

@@ -137,7 +137,10 @@ void profile_close(hipStream_t stream);                           // records the
 	do {                                                                          \
 		if (::simlod::profile_enabled()) ::simlod::profile_mark(#kernel, stream); \
 		hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);          \
+		if (::simlod::debug_sync()) ::simlod::debug_synced(#kernel);              \
 	} while (0)
+bool debug_sync();                           // SIMLOD_DEBUG_SYNC=1: synchronise the device after every kernel and name it on stderr (fault hunting)
+void debug_synced(const char* kernelName);
 uint32_t node_capacity();
 uint32_t ingest_mode();                      // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
 uint32_t batch_limit();                      // host hint: at most this many batches are pending (<= 20)
