@@ -67,7 +67,9 @@ struct Ctl {
 	uint64_t unused1[4];
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
 	BatchCtl batch[2];
+	uint64_t phaseNs[48];              // byte 408: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
 };
+static_assert(offsetof(Ctl, phaseNs) == 408, "tools/probe.py reads Ctl.phaseNs at byte 408");
 static_assert(offsetof(Ctl, expandNs) == 152, "bench.py / tools read Ctl.expandNs at byte 152");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
@@ -178,6 +180,19 @@ __device__ __forceinline__ BatchCtl* batch_of(Ctl* ctl, uint32_t ordinal) {
 	BatchCtl* bc = &ctl->batch[ordinal & 1u];
 	return bc->active != 0u && bc->ordinal == ordinal ? bc : nullptr;
 }
+
+// phase timer of ONE thread of one workgroup per kernel: adds the time since `t` to slot k and restarts `t`
+struct Phase {
+	Ctl* ctl; bool on; uint64_t t;
+	__device__ __forceinline__ Phase(Ctl* c, bool who) : ctl(c), on(who && threadIdx.x == 0), t(on ? wall_ns() : 0) {}
+	__device__ __forceinline__ void mark(uint32_t k) { if (on) { const uint64_t n = wall_ns(); ctl->phaseNs[k] += n - t; t = n; } }
+};
+
+// The chunk directory and k_voxelize's work items of a batch exist twice, by the parity of the batch's ordinal: batch b + 1's are filled
+// (k_hist, k_expand) while the voxel half of batch b is still reading its own on the side stream.
+struct VoxItem;
+__device__ __forceinline__ SimlodChunk** chunk_dir(const BuildArgs& a, const BatchCtl* bc) { return at<SimlodChunk*>(a, a.offChunkDir) + (uint64_t)(bc->ordinal & 1u) * a.dirCap; }
+__device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl* bc);
 
 __device__ __forceinline__ void raise(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->errors, bit); }
 // conditions after which the batch cannot be completed: the rest of the chain does nothing, Stats.dbg keeps the bit until a reset
@@ -456,12 +471,14 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 // k_count takes more points per thread than k_insert (PPT): its cost is the flush of the per-workgroup counts into a few dozen
 // hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
 static constexpr uint32_t CPT = 8;
-static constexpr uint32_t CPB = TPB * CPT;
+static constexpr uint32_t CPB = TPB * CPT;         // (k_hist)
 static constexpr uint32_t CROSS_CAP = 128;         // leaves one workgroup can see cross the limit in one batch
 
 static constexpr uint32_t TOUCH_CAP = 512;         // leaves one workgroup can be the first to touch in one batch (more: appended one by one)
 
-__global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
+template <uint32_t BT>
+__global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
+	constexpr uint32_t CPB = BT * CPT;
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr) return;
@@ -475,6 +492,7 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
 	uint2* touched = at<uint2>(a, a.offTouched);           // {leaf, points it held when the batch began}
 	const uint32_t numChunks = (n + CPB - 1) / CPB;
 	if (blockIdx.x >= numChunks) return;
+	Phase ph(ctl, blockIdx.x == 0);
 	auto counted = [&](uint32_t leafIdx, uint32_t flags, uint32_t stored) {
 		if ((flags & FIRST) != 0u) {
 			const uint32_t k = atomicAdd(&sh_numTouch, 1u);
@@ -496,7 +514,7 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
 		float4 p[CPT];
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
-			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
+			const uint32_t i = chunk * CPB + j * BT + threadIdx.x;
 			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
 		}
 		// the eight descents of a thread in lockstep, one level per step: eight L2 round trips in flight instead of eight chains of 5-8
@@ -506,12 +524,12 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
 			X[j] = quantize(F_GRID, p[j].x, a.minx, a.size); Y[j] = quantize(F_GRID, p[j].y, a.miny, a.size); Z[j] = quantize(F_GRID, p[j].z, a.minz, a.size);
-			cur[j] = 0u; level[j] = 0u; walking[j] = chunk * CPB + j * TPB + threadIdx.x < n;
+			cur[j] = 0u; level[j] = 0u; walking[j] = chunk * CPB + j * BT + threadIdx.x < n;
 		}
 		descend_lockstep<(int)CPT>(a.nodes, cur, level, X, Y, Z, walking);
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
-			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x;
+			const uint32_t i = chunk * CPB + j * BT + threadIdx.x;
 			if (i >= n) continue;
 			const uint32_t leafIdx = cur[j];
 			leafOf[i] = leafIdx;
@@ -520,11 +538,13 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
 		}
 	}
 	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
+	ph.mark(0);
+	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += BT) {
 		const uint32_t key = tbl.keys[e];
 		if (key != TBL_EMPTY) { uint32_t stored; const uint32_t f = count_into(a, bc, key, tbl.vals[e], stored); counted(key, f, stored); }
 	}
 	__syncthreads();
+	ph.mark(1);
 	// the leaves this workgroup was the first to touch in this batch go on the batch's list (one reservation per workgroup)
 	const uint32_t numTouch = min(sh_numTouch, TOUCH_CAP);
 	if (threadIdx.x == 0 && numTouch != 0u) sh_touchBase = atomicAdd(&bc->numTouched, numTouch);
@@ -532,9 +552,158 @@ __global__ __launch_bounds__(TPB) void k_count(BuildArgs a, uint32_t ordinal) {
 	const uint32_t numCross = min(sh_numCross, CROSS_CAP);
 	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if k_expand's grid barrier had given up, before anything is modified (tests the abort path)
 	if (numCross != 0u && (ctl->debugFlags & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += TPB / 64u) queue_split(a, ctl, bc, sh_cross[e]);
+	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += BT / 64u) queue_split(a, ctl, bc, sh_cross[e]);
 	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < numTouch; e += TPB) touched[sh_touchBase + e] = sh_touch[e];
+	ph.mark(2);
+	for (uint32_t e = threadIdx.x; e < numTouch; e += BT) touched[sh_touchBase + e] = sh_touch[e];
+	if (ph.on) ctl->phaseNs[3] += 1;
+}
+
+// ---- k_voxelize's work items (filled by the chunk allocation below) -----------------------------------------------------
+static constexpr uint32_t VTPB = 1024;
+static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
+static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
+static constexpr uint32_t VOX_BIG_ITEMS = 65536;                // entries of the item array for k_voxelize's pieces; the rest: one small item per leaf
+static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with fewer new samples than this takes the wave-per-leaf path
+static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
+static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
+struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; its chunk directory, its coordinates; leaf = node index | level << 24
+__device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl* bc) { return at<VoxItem>(a, a.offVoxItems) + (uint64_t)(bc->ordinal & 1u) * a.voxItemCap; }
+// emit-list entry, one per sample that colours at least one new voxel: work item (20 bits) << 44 | index inside the item's range
+// (13 bits) << 20 | levels (bit L = the sample colours a new voxel of its level-L ancestor, L < 20)
+typedef unsigned long long Emit;
+__device__ __forceinline__ Emit emit_pack(uint32_t item, uint32_t rel, uint32_t levels) { return ((Emit)item << 44) | ((Emit)rel << 20) | levels; }
+static_assert(VOX_PIECE <= (1u << 13), "Emit: 13 bits for the index inside a piece");
+
+// ---- chunks for the leaves with new samples ----------------------------------------------------------------------------
+__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
+// sum over the wave and the sum of the lanes below (every lane of the wave calls)
+__device__ __forceinline__ uint32_t wave_exclusive(uint32_t v, uint32_t& total) {
+	const uint32_t lane = (uint32_t)lane_id();
+	uint32_t x = v;
+#pragma unroll
+	for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
+	total = (uint32_t)__shfl((int)x, 63, 64);
+	return x - v;
+}
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+}
+
+// The point chunks of the leaves with new samples and their share of k_voxelize's work list (voxels.cu:485-538), for ALLOC_LEAVES entries
+// of the batch's list: ONE WORKGROUP.
+//   phase 1, wave 0, one leaf per lane: how many chunks, directory entries and work items each leaf needs; the reservations of the wave's
+//     leaves — directory entries, chunks off the recycle stack (voxels.cu:505-516), work items, memory for the chunks the stack cannot
+//     serve — are summed over the wave and made with ONE atomic each (the words they advance are shared by every leaf of the batch, and
+//     device-scope atomics on one word retire at ~88 M/s here);
+//   phase 2, all waves, one NEW CHUNK per lane: fetch it (stack or fresh memory), link it, enter it in the chunk directory and the leaf
+//     chunk table.  A leaf the batch has filled from nothing needs 50 chunks; taken one after the other by the leaf's lane that was 50
+//     dependent round trips (the whole of the former k_alloc: 13 us), taken side by side it is two.
+static constexpr uint32_t ALLOC_LEAVES = 64;
+struct AllocRec {
+	uint32_t node, existing, additional, fromPool;
+	uint32_t dirNew, prefix;                                // directory entry of the leaf's first new chunk | new chunks of the lanes below
+	unsigned long long firstIdx, mem;                       // recycle-stack index of the first new chunk | memory of the first one the stack could not serve
+	SimlodChunk* head; SimlodChunk* tail;                   // the list as it is (nullptr: empty)
+};
+struct AllocShared { AllocRec rec[ALLOC_LEAVES]; uint32_t total; };
+
+// `entries` (global memory or LDS): {leaf, points it held when the batch began}; entry k is taken when firstEntry + lane < numEntries.
+__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint2* entries, uint32_t firstEntry, uint32_t numEntries) {
+	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
+	SimlodChunk** chunkDir = chunk_dir(a, bc);
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	if (threadIdx.x < 64u) {
+		const uint32_t lane = threadIdx.x;
+		// (the points the leaf held when the batch began come with the list entry: Node.numPoints is already being advanced by the other
+		// workgroups of k_insert)
+		const uint2 entry = firstEntry + lane < numEntries ? entries[firstEntry + lane] : make_uint2(NONE, 0u);
+		const uint32_t i = entry.x, stored = entry.y;
+		SimlodNode* node = a.nodes + (i != NONE ? i : 0u);
+		uint32_t counter = 0;
+		bool need = false;
+		SimlodChunk* head = nullptr;
+		if (i != NONE) {
+			// (a leaf that k_count's tail has queued for splitting still looks like a leaf until k_expand gives it children: not this one's business)
+			const bool queued = (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[i] >> 32) == bc->ordinal + 1u;
+			counter = node->counter; head = node->points; need = !queued && stored < counter && node_is_leaf(node);
+		}
+		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		const uint32_t existing = need ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+		const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
+		const uint32_t entries = need ? required - first : 0u;
+		const uint32_t additional = need ? required - existing : 0u;
+		const uint32_t fresh = need ? counter - stored : 0u;
+		SimlodChunk* tail = existing > 0u ? tail_of(head) : nullptr;
+		if (existing == 0u) head = nullptr;
+		// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
+		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
+		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
+		const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
+		const uint32_t small = need && pieces == 0u ? 1u : 0u;
+		uint32_t totEntries, totAdditional, totPieces, totSmall;
+		const uint32_t exEntries = wave_exclusive(entries, totEntries), exAdditional = wave_exclusive(additional, totAdditional);
+		const uint32_t exPieces = wave_exclusive(pieces, totPieces), exSmall = wave_exclusive(small, totSmall);
+		uint32_t dirBase = 0, itemBase = 0, smallBase = 0;
+		unsigned long long chunkBase = 0;
+		if (lane == 0u) {                                              // (four independent atomics with a return value: one round trip)
+			if (totEntries != 0u) dirBase = atomicAdd(&bc->dirCount, totEntries);
+			if (totAdditional != 0u) chunkBase = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)totAdditional);
+			if (totPieces != 0u) itemBase = atomicAdd(&bc->numVoxItems, totPieces);
+			if (totSmall != 0u) smallBase = atomicAdd(&bc->numVoxSmall, totSmall);
+			sh.total = totAdditional;
+		}
+		dirBase = (uint32_t)__shfl((int)dirBase, 0, 64); itemBase = (uint32_t)__shfl((int)itemBase, 0, 64); smallBase = (uint32_t)__shfl((int)smallBase, 0, 64);
+		chunkBase = shfl64(chunkBase, 0);
+		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by end_of_batch, after every allocation of the batch
+		// pop from the recycle stack, allocate what the stack cannot serve
+		const unsigned long long firstIdx = chunkBase + exAdditional;
+		const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
+		uint32_t totNew;
+		const uint32_t exNew = wave_exclusive(additional - fromPool, totNew);
+		unsigned long long mem = 0;
+		if (lane == 0u && totNew != 0u) mem = (unsigned long long)persistent_alloc(a.pers, sizeof(SimlodChunk), totNew);
+		mem = shfl64(mem, 0) + (unsigned long long)exNew * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk));
+		const uint32_t base = dirBase + exEntries;
+		const uint32_t itemAt = pieces != 0u ? itemBase + exPieces : VOX_BIG_ITEMS + smallBase + exSmall;
+		bool ok = need;
+		if (need && base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); ok = false; }
+		if (need && (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt >= a.voxItemCap)) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); ok = false; }   // a batch + moved points beyond 33 M samples
+		uint32_t e = 0;
+		if (ok) {
+			if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
+			NodeDir& d = nodeDir[i];
+			d.ptBase = base; d.ptFirst = first; d.ptTag = bc->tag;
+			VoxItem* items = vox_items(a, bc);
+			if (pieces == 0u) items[itemAt] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
+			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
+		}
+		AllocRec& r = sh.rec[lane];
+		r.node = i; r.existing = existing; r.additional = ok ? additional : 0u; r.fromPool = fromPool; r.dirNew = base + e; r.prefix = exAdditional;
+		r.firstIdx = firstIdx; r.mem = mem; r.head = head; r.tail = tail;
+	}
+	__syncthreads();
+	// phase 2: new chunk q of the workgroup = chunk k of the leaf whose prefix covers q
+	const uint32_t total = sh.total;
+	for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+		uint32_t lo = 0, hi = ALLOC_LEAVES;                              // the last leaf with prefix <= q (leaves without new chunks share their successor's prefix)
+		while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (sh.rec[mid].prefix <= q) lo = mid; else hi = mid; }
+		const AllocRec r = sh.rec[lo];
+		const uint32_t k = q - r.prefix;
+		if (k >= r.additional) continue;                                 // (a leaf that could not be served: its reservation stays unused)
+		auto chunk_at = [&](uint32_t j) -> SimlodChunk* {
+			return j < r.fromPool ? chunkQueue[r.firstIdx + j] : reinterpret_cast<SimlodChunk*>(r.mem + (unsigned long long)(j - r.fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+		};
+		SimlodChunk* c = chunk_at(k);
+		SimlodChunk* next = k + 1u < r.additional ? chunk_at(k + 1u) : nullptr;
+		SimlodChunk* first = r.head != nullptr ? r.head : (k == 0u ? c : (k + 1u == r.additional ? chunk_at(0u) : nullptr));
+		c->next = next;
+		chunkDir[r.dirNew + k] = c;
+		if (r.existing + k < LEAF_SLOTS) leafChunks[(uint64_t)r.node * LEAF_SLOTS + r.existing + k] = c;
+		if (k == 0u) { if (r.tail == nullptr) a.nodes[r.node].points = c; else r.tail->next = c; }
+		if (k + 1u == r.additional) tail_of(first) = c;
+	}
 }
 
 // ---- hist: round 0 of the split cascade's histograms (voxels.cu:245-289) ---------------------------------------------------------
@@ -549,8 +718,21 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	if (bc == nullptr || ctl->abortBatch) return;
 	const uint32_t slots0 = slots_in_use(bc);
 	if (blockIdx.x == 0 && threadIdx.x == 0) bc->slotsRound0 = slots0;
+	__shared__ union { BlockTable tbl; AllocShared alloc; } shared;
+	{
+		// The chunks of the leaves that k_count found new samples for (those that do not split: the nodes of a cascade get theirs from k_expand):
+		// taken care of by the LAST workgroups of the grid, which have no histogram work — 64 leaves each, beside everybody else's histogram pass
+		// and off k_insert's path (voxels.cu:485-538 allocatePointChunks)
+		const uint32_t numTouched = min(bc->numTouched, a.nodeCapacity);
+		const uint32_t allocBlocks = (numTouched + ALLOC_LEAVES - 1) / ALLOC_LEAVES;
+		for (uint32_t blk = gridDim.x - 1u - blockIdx.x; blk < allocBlocks; blk += gridDim.x) {        // list #blk: the blk-th workgroup from the end
+			__syncthreads();
+			alloc_points(a, ctl, bc, shared.alloc, at<const uint2>(a, a.offTouched), blk * ALLOC_LEAVES, numTouched);
+		}
+		__syncthreads();
+	}
 	if (slots0 == 0u) return;
-	__shared__ BlockTable tbl;
+	BlockTable& tbl = shared.tbl;
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
@@ -563,6 +745,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	const uint32_t total = moved + n;
 	const uint32_t numChunks = (total + CPB - 1) / CPB;
 	if (blockIdx.x >= numChunks) return;
+	Phase ph(ctl, blockIdx.x == 0);
 	table_init(tbl);
 	__syncthreads();
 	auto add = [&](uint32_t key) {
@@ -605,10 +788,13 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 		}
 	}
 	__syncthreads();
+	ph.mark(4);
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
 		const uint32_t key = tbl.keys[e];
 		if (key != TBL_EMPTY) atomicAdd(hist + key, tbl.vals[e]);
 	}
+	ph.mark(5);
+	if (ph.on) ctl->phaseNs[6] += 1;
 }
 
 // ---- expand: split the queued leaves, cascades included (voxels.cu:385-415, 245-289, 308-383) ---------------------------
@@ -633,6 +819,9 @@ struct ExpandShared {
 	uint32_t bins[HIST_BINS], c2[64], c1[8];
 	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
 	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
+	uint2 fresh[LOCAL_NODES];                      // the cascade's nodes that hold samples: {node, 0} — they get their chunks before the kernel ends
+	uint32_t numFresh;
+	AllocShared alloc;
 	SimlodOccupancyGrid* grid[8 + 64];             // grids of the children / grandchildren that split here
 	unsigned long long pathL[PATH_WORDS];          // the slot node's own ancestor path
 	uint32_t mask1, extraBase, ok, more;
@@ -671,7 +860,6 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const uint32_t n = bc->batchSize;
-	uint2* touched = at<uint2>(a, a.offTouched);
 	uint32_t generation = 0;
 
 	__shared__ ExpandShared sh;
@@ -764,6 +952,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			if (t < PATH_WORDS) sh.pathL[t] = t + 1 < PATH_WORDS ? paths[(uint64_t)L * PATH_WORDS + t] : 0ull;
 			for (uint32_t i = t; i < LOCAL_NODES; i += ETPB) sh.listed[i] = NONE;
 			if (t < 72u) sh.grid[t] = nullptr;
+			if (t == 0u) sh.numFresh = 0;
 			__syncthreads();
 			if (t < 64u) { uint32_t c = 0; for (uint32_t k = 0; k < 8; k++) c += sh.bins[t * 8 + k]; sh.c2[t] = c; }
 			__syncthreads();
@@ -852,25 +1041,20 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				}
 				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
 			}
-			{
-				// the nodes of the cascade that hold samples go on the batch's list of leaves with new samples (those that were queued again are no
-				// leaves when k_insert reads the list): one reservation per wave
-				const bool mine = t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u;
-				const unsigned long long m = __ballot(mine);
-				if (m != 0ull) {
-					const uint32_t lane = (uint32_t)lane_id();
-					uint32_t base = 0;
-					if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&bc->numTouched, (uint32_t)__popcll(m));
-					base = __shfl(base, __ffsll((long long)m) - 1, 64);
-					if (mine) touched[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(indexOf(t), 0u);
-				}
-			}
+			// the nodes of the cascade that hold samples and stay leaves (one that was queued again is none by the time its chunks would be used)
+			if (t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u && sh.listed[t] == NONE) sh.fresh[atomicAdd(&sh.numFresh, 1u)] = make_uint2(indexOf(t), 0u);
 			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
 			if (t < HIST_BINS) {
 				const uint32_t j = t >> 6, jk = t >> 3;
 				const uint32_t u = ((mask1 >> j) & 1u) == 0u ? j : ((mask2 >> jk) & 1ull) == 0ull ? 8u + jk : 72u + t;
 				const uint32_t ls = sh.listed[u];
 				map[(uint64_t)s * HIST_BINS + t] = ls != NONE ? ls : indexOf(u);
+			}
+			// ... and their chunks, 64 leaves at a time (voxels.cu:485-538; the nodes written above are this workgroup's own stores: visible after the barrier)
+			__syncthreads();
+			for (uint32_t first = 0; first < sh.numFresh; first += ALLOC_LEAVES) {
+				alloc_points(a, ctl, bc, sh.alloc, sh.fresh, first, sh.numFresh);
+				__syncthreads();
 			}
 		}
 		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; ctl->expandNs[5] += 1; }
@@ -904,19 +1088,6 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 //   pass B  every sample: if its cell is still marked won, take the mark: this sample colours the voxel (which sample of a cell does
 //           is scheduling dependent in the reference too).  Samples that took marks go on the emit list
 //           {work item, index in the piece, levels won}; k_insert's second part regenerates their voxels once k_alloc has made room.
-static constexpr uint32_t VTPB = 1024;
-static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
-static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
-static constexpr uint32_t VOX_BIG_ITEMS = 65536;                // entries of the item array for k_voxelize's pieces; the rest: one small item per leaf
-static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with fewer new samples than this takes the wave-per-leaf path
-static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
-static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
-struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; its chunk directory, its coordinates; leaf = node index | level << 24
-// emit-list entry, one per sample that colours at least one new voxel: work item (20 bits) << 44 | index inside the item's range
-// (13 bits) << 20 | levels (bit L = the sample colours a new voxel of its level-L ancestor, L < 20)
-typedef unsigned long long Emit;
-__device__ __forceinline__ Emit emit_pack(uint32_t item, uint32_t rel, uint32_t levels) { return ((Emit)item << 44) | ((Emit)rel << 20) | levels; }
-static_assert(VOX_PIECE <= (1u << 13), "Emit: 13 bits for the index inside a piece");
 struct VoxShared {
 	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row
 	uint32_t fresh[CUBE_WORDS];                                 // pass A: cells this piece set; after the write-back: cells it won
@@ -963,8 +1134,8 @@ __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t 
 __device__ __forceinline__ void voxelize_small(const BuildArgs& a, BatchCtl* bc, const uint32_t wave, const uint32_t numWaves) {
 	const uint32_t numSmall = min(bc->numVoxSmall, a.voxItemCap - VOX_BIG_ITEMS);
 	if (numSmall == 0u) return;
-	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
-	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	const VoxItem* items = vox_items(a, bc);
+	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	Emit* emits = at<Emit>(a, a.offEmit);
 	const uint32_t lane = (uint32_t)lane_id();
 	constexpr uint32_t U = 4;                              // leaves a wave works on together: a scattered batch leaves ~25 samples in each
@@ -1082,8 +1253,8 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	if (bc == nullptr || ctl->abortBatch) return;
 	const uint32_t numItems = min(bc->numVoxItems, VOX_BIG_ITEMS);
 	__shared__ VoxShared sh;
-	const VoxItem* items = at<const VoxItem>(a, a.offVoxItems);
-	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	const VoxItem* items = vox_items(a, bc);
+	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	Emit* emits = at<Emit>(a, a.offEmit);
 	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
@@ -1280,103 +1451,12 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 
 // ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
 // (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
-__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
-
-// sum over the wave and the sum of the lanes below (every lane of the wave calls)
-__device__ __forceinline__ uint32_t wave_exclusive(uint32_t v, uint32_t& total) {
-	const uint32_t lane = (uint32_t)lane_id();
-	uint32_t x = v;
-#pragma unroll
-	for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
-	total = (uint32_t)__shfl((int)x, 63, 64);
-	return x - v;
-}
-__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
-	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
-}
-
-// The point chunks of a leaf with new samples and its share of k_voxelize's work list (voxels.cu:485-538): one leaf per lane, a WHOLE
-// WAVE calls (i == NONE: nothing to do for this lane).  The reservations of the wave's leaves — chunk directory entries, chunks off the
-// recycle stack (voxels.cu:505-516), work items, chunks the stack cannot serve — are summed over the wave and made with ONE atomic each:
-// the words they advance are shared by every leaf of the batch, and device-scope atomics on one word retire at ~88 M/s here.
-__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t i, uint32_t stored) {
-	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
-	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
-	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
-	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
-	const uint32_t lane = (uint32_t)lane_id();
-	SimlodNode* node = a.nodes + (i != NONE ? i : 0u);
-	// (`stored` comes with the list entry: Node.numPoints is already being advanced by the other workgroups of k_insert)
-	uint32_t counter = 0;
-	bool need = false;
-	if (i != NONE) { counter = node->counter; need = stored < counter && node_is_leaf(node); }
-	const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-	const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-	const uint32_t first = stored / SIMLOD_POINTS_PER_CHUNK;       // chunk that receives slot `stored`
-	const uint32_t entries = need ? required - first : 0u;
-	const uint32_t additional = need ? required - existing : 0u;
-	const uint32_t fresh = need ? counter - stored : 0u;
-	// the leaf's new samples [stored, counter) are k_voxelize's work, in pieces one workgroup takes — or, when they are few,
-	// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
-	// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
-	const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
-	const uint32_t small = need && pieces == 0u ? 1u : 0u;
-	uint32_t totEntries, totAdditional, totPieces, totSmall;
-	const uint32_t exEntries = wave_exclusive(entries, totEntries), exAdditional = wave_exclusive(additional, totAdditional);
-	const uint32_t exPieces = wave_exclusive(pieces, totPieces), exSmall = wave_exclusive(small, totSmall);
-	if (totEntries == 0u) return;                                  // (whole wave)
-	uint32_t dirBase = 0, itemBase = 0, smallBase = 0;
-	unsigned long long chunkBase = 0;
-	if (lane == 0u) {                                              // (four independent atomics with a return value: one round trip)
-		dirBase = atomicAdd(&bc->dirCount, totEntries);
-		if (totAdditional != 0u) chunkBase = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)totAdditional);
-		if (totPieces != 0u) itemBase = atomicAdd(&bc->numVoxItems, totPieces);
-		if (totSmall != 0u) smallBase = atomicAdd(&bc->numVoxSmall, totSmall);
-	}
-	dirBase = (uint32_t)__shfl((int)dirBase, 0, 64); itemBase = (uint32_t)__shfl((int)itemBase, 0, 64); smallBase = (uint32_t)__shfl((int)smallBase, 0, 64);
-	chunkBase = shfl64(chunkBase, 0);
-	const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by end_of_batch, after every allocation of the batch
-	// pop from the recycle stack, allocate what the stack cannot serve
-	const unsigned long long firstIdx = chunkBase + exAdditional;
-	const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
-	uint32_t totNew;
-	const uint32_t exNew = wave_exclusive(additional - fromPool, totNew);
-	unsigned long long mem = 0;
-	if (lane == 0u && totNew != 0u) mem = (unsigned long long)persistent_alloc(a.pers, sizeof(SimlodChunk), totNew);
-	mem = shfl64(mem, 0);
-	if (!need) return;
-	const uint32_t base = dirBase + exEntries;
-	const uint32_t itemAt = pieces != 0u ? itemBase + exPieces : VOX_BIG_ITEMS + smallBase + exSmall;
-	if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
-	if (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt >= a.voxItemCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }   // a batch + moved points beyond 33 M samples
-	SimlodChunk* head = node->points;
-	SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
-	uint32_t e = 0;
-	if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
-	if (additional > 0) {
-		for (uint32_t k = 0; k < additional; k++) {
-			SimlodChunk* c = k < fromPool ? chunkQueue[firstIdx + k]
-			                              : reinterpret_cast<SimlodChunk*>(mem + (uint64_t)(exNew + k - fromPool) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-			c->next = nullptr;
-			if (tail == nullptr) { node->points = c; head = c; } else tail->next = c;
-			tail = c;
-			chunkDir[base + e++] = c;
-			if (existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;
-		}
-		tail_of(head) = tail;
-	}
-	NodeDir& d = nodeDir[i];
-	d.ptBase = base; d.ptFirst = first; d.ptTag = bc->tag;
-	VoxItem* items = at<VoxItem>(a, a.offVoxItems);
-	if (pieces == 0u) items[itemAt] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
-	else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
-}
 
 // the voxel chunks of a node whose numVoxels grew in this batch (voxels.cu:641-672): after k_voxelize, when Node.numVoxels is final
 __device__ __forceinline__ void alloc_voxels(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t i) {
 	SimlodNode* node = a.nodes + i;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
-	SimlodChunk** chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	SimlodChunk** chunkDir = chunk_dir(a, bc);
 	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
 	if (numVoxels > voxStored) {
@@ -1465,16 +1545,11 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr) return;
-	if (ctl->abortBatch) {                                  // an earlier kernel — or an allocator of this one — gave up: the batch is not counted (Stats.dbg says why)
-		if (part == 0u && threadIdx.x == 0) {
-			const uint32_t allocBlocks = (min(bc->numTouched, a.nodeCapacity) + TPB - 1) / TPB;       // (whoever still waits for the allocators must not wait for this workgroup)
-			for (uint32_t blk = blockIdx.x; blk < allocBlocks; blk += gridDim.x) __hip_atomic_fetch_add(&bc->allocDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (blockIdx.x == 0) end_of_batch(a, ctl, bc);
-		}
+	if (ctl->abortBatch) {                                  // an earlier kernel gave up: the batch is not counted (Stats.dbg says why)
+		if (part == 0u && blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);
 		return;
 	}
 	__shared__ InsertShared sh;
-	__shared__ uint32_t sh_go;
 	const uint32_t n = bc->batchSize;
 	const uint32_t total = part == 0u ? n + min(bc->numSpilled, a.spilledCap) : bc->numEmits;
 	if (part != 0u && total == 0u) return;
@@ -1482,31 +1557,18 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	const Emit* emits = at<const Emit>(a, a.offEmit);
-	const VoxItem* voxItems = at<const VoxItem>(a, a.offVoxItems);
+	const VoxItem* voxItems = vox_items(a, bc);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
-	SimlodChunk* const* chunkDir = at<SimlodChunk*>(a, a.offChunkDir);
+	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
 	const uint32_t tag = bc->tag;
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
 
 	if (part == 0u) {
+		Phase ph(ctl, blockIdx.x == 0 || blockIdx.x + 1u == numChunks);
+		const uint32_t pb = blockIdx.x == 0 ? 8u : 16u;
 		if (blockIdx.x == 0 && threadIdx.x == 0) bc->nodes = min(a.stats->numNodes, a.nodeCapacity);
-		// (0) chunks for the leaves with new samples (voxels.cu:485-538); whoever is done says so with a release
-		const uint32_t numTouched = min(bc->numTouched, a.nodeCapacity);
-		const uint32_t allocBlocks = (numTouched + TPB - 1) / TPB;
-		const uint2* touched = at<const uint2>(a, a.offTouched);
-		for (uint32_t blk = blockIdx.x; blk < allocBlocks; blk += gridDim.x) {
-			const uint32_t k = blk * TPB + threadIdx.x;
-			const uint2 entry = k < numTouched ? touched[k] : make_uint2(NONE, 0u);
-			alloc_points(a, ctl, bc, entry.x, entry.y);
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__syncthreads();
-			if (threadIdx.x == 0) {
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				__hip_atomic_fetch_add(&bc->allocDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
+		ph.mark(pb + 0);
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
 		// k_voxelize samples into them (voxels.cu:371-382) — 256 KB each, the stores ride along with the loads below
 		const uint32_t numClear = min(bc->numClear, a.clearCap);
@@ -1516,6 +1578,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 			reinterpret_cast<uint4*>(clearList[i / W4]->values)[i % W4] = make_uint4(0, 0, 0, 0);
 		if (blockIdx.x >= numChunks && blockIdx.x != 0u) return;       // (workgroup 0 stays for the bookkeeping even when the batch is empty)
 
+		ph.mark(pb + 1);
 		// (1) samples per leaf
 		table_init(sh.tbl);
 		__syncthreads();
@@ -1545,36 +1608,21 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 			}
 		}
 		__syncthreads();
+		ph.mark(pb + 2);
 		// (2) one slot range per (workgroup, leaf)
 		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
 			const uint32_t key = sh.tbl.keys[e];
 			if (key == TBL_EMPTY) continue;
+			const NodeDir d = nodeDir[key];
 			sh.base[e] = atomicAdd(&a.nodes[key].numPoints, sh.tbl.vals[e]);                      // voxels.cu:593
 			sh.tbl.vals[e] = 0;                                                                    // becomes the cursor
-		}
-		// (3) the chunks have to be there now
-		if (threadIdx.x == 0) {
-			int good = 1;
-			const uint64_t t0 = wall_clock64();
-			while (__hip_atomic_load(&bc->allocDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < allocBlocks) {
-				__builtin_amdgcn_s_sleep(4);
-				if (wall_clock64() - t0 > 200000000ull) { good = 0; break; }   // 2 s at 100 MHz: a guard against a broken device (the allocators wait for nobody)
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			if (!good) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT);
-			sh_go = (good && __hip_atomic_load(&ctl->abortBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? 1u : 0u;   // (an allocator may have run out of directory space)
-			if (blockIdx.x == 0) end_of_batch(a, ctl, bc);
-		}
-		__syncthreads();
-		if (!sh_go) return;
-		for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-			const uint32_t key = sh.tbl.keys[e];
-			if (key == TBL_EMPTY) continue;
-			const NodeDir d = nodeDir[key];
 			sh.dirBase[e] = d.ptTag == tag ? d.ptBase : 0xffffffffu;
 			sh.dirFirst[e] = d.ptFirst;
 		}
 		__syncthreads();
+		ph.mark(pb + 3);
+		if (blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);          // (every chunk of the batch was allocated by k_hist / k_expand)
+		ph.mark(pb + 4);
 		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 			float4 p[PPT];
 #pragma unroll
@@ -1599,6 +1647,9 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 				reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = p[j];
 			}
 		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		ph.mark(pb + 5);
+		if (ph.on) ctl->phaseNs[pb + 6] += 1;
 		return;
 	}
 
@@ -1728,10 +1779,10 @@ uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
 	off += align_up((uint64_t)SLOT_CAP * sizeof(SlotRec), 256) + 2 * align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256) + align_up(65536ull * 8, 256);
 	off += 6 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf, touched list (8 B)
 	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
-	off += align_up((uint64_t)dirCap * 8, 256);
+	off += align_up(2ull * dirCap * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
 	off += align_up((uint64_t)nodeCapacity * PATH_WORDS * 8, 256);
-	off += align_up((uint64_t)(nodeCapacity + 65536) * sizeof(VoxItem), 256);
+	off += align_up(2ull * (nodeCapacity + 65536) * sizeof(VoxItem), 256);
 	return off;
 }
 
@@ -1749,13 +1800,13 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
-	a.offChunkDir = off; off += align_up((uint64_t)a.dirCap * 8, 256);
+	a.offChunkDir = off; off += align_up(2ull * a.dirCap * 8, 256);            // (two copies, by batch parity)
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	const uint64_t fixedEnd = off;
 	// what is left is shared by the per-sample arrays: 4 B leaf + an 8 B emit-list entry for batch and spilled samples, 16 B per spilled sample
 	a.voxItemCap = min(a.nodeCapacity + VOX_BIG_ITEMS, 1u << 20);              // VOX_BIG_ITEMS pieces + one small item per leaf; Emit has 20 bits for the index
-	a.offVoxItems = off; off += align_up((uint64_t)a.voxItemCap * sizeof(VoxItem), 256);
+	a.offVoxItems = off; off += align_up(2ull * a.voxItemCap * sizeof(VoxItem), 256);   // (two copies, by batch parity)
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 12;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
 	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
@@ -1846,8 +1897,11 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
+		const int countTpb = tune("SIMLOD_COUNT_TPB", 256);
 		for (uint32_t b = 0; b < limit; b++) {
-			SIMLOD_LAUNCH(k_count, dim3(gridPoints), dim3(TPB), stream, a, b);
+			if (countTpb == 1024) SIMLOD_LAUNCH(k_count<1024>, dim3(gridPoints / 4), dim3(1024), stream, a, b);
+			else if (countTpb == 512) SIMLOD_LAUNCH(k_count<512>, dim3(gridPoints / 2), dim3(512), stream, a, b);
+			else SIMLOD_LAUNCH(k_count<TPB>, dim3(gridPoints), dim3(TPB), stream, a, b);
 			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a, b);
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
