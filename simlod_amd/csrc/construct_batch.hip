@@ -48,7 +48,7 @@ struct BatchCtl {
 	uint32_t ordinal, tag, slotsRound0, numSpilled;   // tag = batch index + 1 (NodeDir); slotsRound0: slots handed out by k_count's tail, snapshot by k_hist: k_expand's first round
 	uint32_t numWork, numClear, numTouched, allocDone;   // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_insert's allocation list) | allocation workgroups of k_insert that are done
 	uint32_t barrierCount, nodes, numVoxItems, numVoxSmall;   // nodes = Stats.numNodes after the batch's k_expand: the voxel half must not look at nodes the NEXT batch's k_expand is creating
-	uint32_t numEmits, dirCount, pad0, pad1;
+	uint32_t unused0, dirCount, pad0, pad1;
 	unsigned long long reserve;        // split slots << 52 | nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves all or nothing
 	unsigned long long pad2;
 };
@@ -84,8 +84,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offEmit, offVoxItems, offSpilled;
-	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap;
+	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap;
 };
 
 
@@ -142,8 +142,8 @@ static constexpr uint32_t TPB = 256;
 static constexpr float F_GRID = 1048576.0f;      // 2^MAX_DEPTH, progressive_octree_voxels.cu:139
 static constexpr float F_FULL = 268435456.0f;    // MAX_DEPTH_GRIDSIZE, structures.cuh:26
 
-struct NodeDir {          // per node, valid for the batch whose tag it carries
-	uint32_t ptBase, ptFirst, ptTag, voxBase, voxFirst, voxTag, pad0, pad1;
+struct NodeDir {          // per node, valid for the batch whose tag it carries: where the leaf's chunks stand in the batch's chunk directory
+	uint32_t ptBase, ptFirst, ptTag, pad0;
 };
 
 // Leaf chunk table: slot k of leaf i's point list -> chunk, LEAF_SLOTS entries per node.  A leaf that can still split stores
@@ -236,7 +236,6 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	bc->nodes = 0;
 	bc->numVoxItems = 0;
 	bc->numVoxSmall = 0;
-	bc->numEmits = 0;
 	bc->dirCount = 0;
 	bc->reserve = (unsigned long long)a.stats->numNodes << 32;
 	bc->active = 1;
@@ -569,11 +568,6 @@ static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d =
 static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
 struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; its chunk directory, its coordinates; leaf = node index | level << 24
 __device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl* bc) { return at<VoxItem>(a, a.offVoxItems) + (uint64_t)(bc->ordinal & 1u) * a.voxItemCap; }
-// emit-list entry, one per sample that colours at least one new voxel: work item (20 bits) << 44 | index inside the item's range
-// (13 bits) << 20 | levels (bit L = the sample colours a new voxel of its level-L ancestor, L < 20)
-typedef unsigned long long Emit;
-__device__ __forceinline__ Emit emit_pack(uint32_t item, uint32_t rel, uint32_t levels) { return ((Emit)item << 44) | ((Emit)rel << 20) | levels; }
-static_assert(VOX_PIECE <= (1u << 13), "Emit: 13 bits for the index inside a piece");
 
 // ---- chunks for the leaves with new samples ----------------------------------------------------------------------------
 __device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
@@ -1066,6 +1060,127 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	}
 }
 
+// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
+__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
+	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
+	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
+	const uint32_t nsh = 28u - (uint32_t)level;
+	// masked to `level` bits: a coordinate exactly on the max face quantises to 2^20 (2^28 here) and the reference's descent, which
+	// looks at bits 19..0 only, files it under node coordinate 0 on that axis (voxels.cu:171-179) — the voxel sits at the LOW face
+	const uint32_t nmask = (1u << (uint32_t)level) - 1u;
+	const uint32_t nX = (pX >> nsh) & nmask, nY = (pY >> nsh) & nmask, nZ = (pZ >> nsh) & nmask;
+	const float nodeSize = a.size / exp2_int((uint32_t)level);
+	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
+	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
+	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
+	float4 v;
+	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
+	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
+	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
+	v.w = colorBits;                       // colour of the claiming point
+	return v;
+}
+
+// ---- voxel chunks, on demand (voxels.cu:641-698 allocateVoxelChunks + insertVoxels in one pass) ------------------------------------------
+// A reservation in a node's voxel list is the return value of the add to Node.numVoxels (voxels.cu:101): slots [old, old + n).  Whoever
+// holds slot k * 1000 allocates chunk k of the list (voxel chunks never come from the recycle stack, voxels.cu:656-659), publishes it in
+// a hash directory of the batch ((node, k) -> chunk) and links it behind its predecessor; whoever holds another slot of chunk k looks it up —
+// or takes the list's old tail, if the chunk existed when the batch began (Node.numVoxelsStored and the tail pointer in the head chunk stay
+// as they were until k_voxdone).  An allocator publishes everything it owns BEFORE it waits for anybody (its predecessor's allocator, whose
+// add came first and who is therefore already running), so every wait ends.
+struct DirEntry { unsigned long long key; SimlodChunk* ptr; };
+static constexpr unsigned long long DIR_BUSY = 1ull << 62;
+__device__ __forceinline__ unsigned long long dir_key(uint32_t tag, uint32_t node, uint32_t k) {
+	return (1ull << 63) | ((unsigned long long)(tag & 0xfffffu) << 42) | ((unsigned long long)node << 22) | (k & 0x3fffffu);
+}
+__device__ __forceinline__ uint32_t dir_tag(unsigned long long key) { return (uint32_t)(key >> 42) & 0xfffffu; }
+__device__ __forceinline__ uint32_t dir_hash(const BuildArgs& a, unsigned long long key) {
+	key ^= key >> 29; key *= 0x9e3779b97f4a7c15ull; key ^= key >> 32;
+	return (uint32_t)key & (a.hashCap - 1u);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ void dir_insert(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t node, uint32_t k, SimlodChunk* c) {
+	DirEntry* dir = at<DirEntry>(a, a.offHashDir);
+	const unsigned long long key = dir_key(tag, node, k);
+	uint32_t h = dir_hash(a, key);
+	for (uint32_t probe = 0; probe < a.hashCap; probe++, h = (h + 1u) & (a.hashCap - 1u)) {
+		unsigned long long cur = ld_agent(&dir[h].key);
+		while (cur == 0ull || ((cur >> 63) != 0ull && dir_tag(cur) != (tag & 0xfffffu))) {           // free, or left over from an earlier batch
+			const unsigned long long prev = atomicCAS(&dir[h].key, cur, DIR_BUSY);
+			if (prev == cur) {
+				// pointer first, key second: a reader that sees the key must see the pointer (write-through stores, drained in between)
+				__hip_atomic_store(reinterpret_cast<unsigned long long*>(&dir[h].ptr), (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(&dir[h].key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			cur = prev;
+		}
+	}
+	panic(ctl, SIMLOD_ERR_DIRECTORY_FULL);
+}
+// non-blocking lookup; nullptr when the entry is not (yet) there
+__device__ SimlodChunk* dir_find(const BuildArgs& a, uint32_t tag, uint32_t node, uint32_t k) {
+	const DirEntry* dir = at<const DirEntry>(a, a.offHashDir);
+	const unsigned long long key = dir_key(tag, node, k);
+	uint32_t h = dir_hash(a, key);
+	for (uint32_t probe = 0; probe < a.hashCap; probe++, h = (h + 1u) & (a.hashCap - 1u)) {
+		const unsigned long long cur = ld_agent(&dir[h].key);
+		if (cur == key) return reinterpret_cast<SimlodChunk*>(ld_agent(reinterpret_cast<const unsigned long long*>(&dir[h].ptr)));
+		if (cur == 0ull) return nullptr;
+		if ((cur >> 63) != 0ull && dir_tag(cur) != (tag & 0xfffffu)) return nullptr;
+	}
+	return nullptr;
+}
+// blocking lookup (see above: it ends; the bound is a guard against a broken device)
+__device__ SimlodChunk* dir_wait(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t node, uint32_t k) {
+	for (uint32_t spin = 0;; spin++) {
+		SimlodChunk* c = dir_find(a, tag, node, k);
+		if (c != nullptr) return c;
+		__builtin_amdgcn_s_sleep(2);
+		if ((spin & 255u) == 255u && __hip_atomic_load(&ctl->abortBatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return nullptr;
+		if (spin > (1u << 22)) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return nullptr; }
+	}
+}
+// chunk k of node's voxel list exists from now on (the caller holds slot k * 1000)
+__device__ __forceinline__ void vox_chunk_publish(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t node, uint32_t k, SimlodChunk* c) {
+	// an inner node's row of the leaf chunk table lists its voxel chunks: the rasteriser reads the list from there (render.hip r_visible) — never
+	// the root's: its row may still be read as a LEAF's by the next batch's k_count, which splits a root that was still a leaf
+	if (k < LEAF_SLOTS && node != 0u) at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)node * LEAF_SLOTS + k] = c;
+	dir_insert(a, ctl, tag, node, k, c);
+}
+// ... and hangs behind its predecessor: the head pointer, the old tail, or a chunk of this batch (which may have to be waited for).
+// Every `next` field has ONE writer per kernel — the allocator of the chunk behind it, or, for the list's last chunk, k_voxdone (the L2s of
+// the eight XCDs are not coherent with each other for plain stores: an allocator that cleared its own chunk's `next` could overwrite, at
+// write-back time, the link its successor's allocator has made from another XCD).
+__device__ __forceinline__ void vox_chunk_link(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t node, uint32_t k, uint32_t existing, SimlodChunk* oldTail, SimlodChunk* c) {
+	if (k == 0u) a.nodes[node].voxelChunks = c;
+	else {
+		SimlodChunk* pred = k - 1u < existing ? oldTail : dir_wait(a, ctl, tag, node, k - 1u);
+		if (pred != nullptr) pred->next = c;
+	}
+}
+// A wave stores one voxel per `go` lane: lane's slot in `node`'s voxel list (lanes may name different nodes).  All allocations of the
+// wave come before any of its waits (a lane may wait for a chunk another lane of the same wave opens).
+__device__ __forceinline__ void store_voxels_wave(const BuildArgs& a, Ctl* ctl, uint32_t tag, bool go, uint32_t node, uint32_t slot, const float4& vox) {
+	const uint32_t k = slot / SIMLOD_POINTS_PER_CHUNK, r = slot % SIMLOD_POINTS_PER_CHUNK;
+	const uint32_t existing = go ? (a.nodes[node].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+	SimlodChunk* mine = nullptr;
+	if (go && r == 0u) {
+		mine = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), 1));
+		vox_chunk_publish(a, ctl, tag, node, k, mine);             // (its `next`: see vox_chunk_link)
+	}
+	if (go) {
+		SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[node].voxelChunks) : nullptr;
+		if (mine != nullptr) vox_chunk_link(a, ctl, tag, node, k, existing, oldTail, mine);
+		SimlodChunk* c = mine != nullptr ? mine : k < existing ? oldTail : dir_wait(a, ctl, tag, node, k);
+		if (c != nullptr) reinterpret_cast<float4*>(c->points)[r] = vox;
+	}
+}
+
 // ---- voxelize: 128^3 occupancy test-and-set on every inner node of the root-to-leaf path (voxels.cu:50-121, 417-483) ----------------
 // The reference offers every sample to the grid of EVERY node of its path, root first.  Two properties make that cheap here:
 //  * Occupancy is hierarchical: a cell of a node covers exactly 2x2x2 cells of the child below it, and every sample that ever set a bit
@@ -1088,13 +1203,16 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 //   pass B  every sample: if its cell is still marked won, take the mark: this sample colours the voxel (which sample of a cell does
 //           is scheduling dependent in the reference too).  Samples that took marks go on the emit list
 //           {work item, index in the piece, levels won}; k_insert's second part regenerates their voxels once k_alloc has made room.
+static constexpr uint32_t VOX_CHUNKS = VOX_PIECE / SIMLOD_POINTS_PER_CHUNK + 2;   // chunks a piece's voxels of one ancestor can span
 struct VoxShared {
 	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row
 	uint32_t fresh[CUBE_WORDS];                                 // pass A: cells this piece set; after the write-back: cells it won
 	uint32_t hiOcc[PATH_WORDS], hiFresh[PATH_WORDS];            // ancestors d >= 8: the ONE cell the whole leaf falls into
 	unsigned long long anc[PATH_WORDS];
 	uint32_t cnt[PATH_WORDS];
-	uint32_t emitCount, emitBase;
+	uint32_t first[PATH_WORDS], rank[PATH_WORDS];               // the slots this piece reserved in ancestor d's voxel list: [first, first + cnt); how many of them are taken
+	SimlodChunk* chunkOf[PATH_WORDS][VOX_CHUNKS];               // ... and the chunks they lie in, from chunk first / 1000 on
+	float color[VOX_PIECE];                                     // the samples' colours (coordinates stay in registers)
 };
 __device__ __forceinline__ uint32_t cube_offset(uint32_t d) {          // word offset of cube d in VoxShared::occ / fresh
 	return d == 1u ? 0u : d == 2u ? 8192u : d == 3u ? 9216u : d == 4u ? 9472u : d == 5u ? 9536u : d == 6u ? 9552u : 9556u;
@@ -1131,12 +1249,12 @@ __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t 
 // the ancestor, so Node.numVoxels takes one add per (leaf, level, step).  The waves of k_voxelize's workgroups do this after their
 // pieces.  (Measured: without this path the uniformly scattered
 // 350 M-point replay of the C++ harness, 40 000 leaves touched per batch, took 408 ms of kernel time instead of 157 ms.)
-__device__ __forceinline__ void voxelize_small(const BuildArgs& a, BatchCtl* bc, const uint32_t wave, const uint32_t numWaves) {
+__device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, const uint32_t wave, const uint32_t numWaves) {
 	const uint32_t numSmall = min(bc->numVoxSmall, a.voxItemCap - VOX_BIG_ITEMS);
 	if (numSmall == 0u) return;
 	const VoxItem* items = vox_items(a, bc);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
-	Emit* emits = at<Emit>(a, a.offEmit);
+	const uint32_t tag = bc->tag;
 	const uint32_t lane = (uint32_t)lane_id();
 	constexpr uint32_t U = 4;                              // leaves a wave works on together: a scattered batch leaves ~25 samples in each
 	for (uint32_t k0 = wave * U; k0 < numSmall; k0 += numWaves * U) {
@@ -1165,7 +1283,8 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, BatchCtl* bc,
 			maxCount = max(maxCount, count[u]); maxDepth = max(maxDepth, depth[u]);
 		}
 		for (uint32_t base = 0; base < maxCount; base += 64u) {
-			uint32_t pX[U], pY[U], pZ[U], levels[U];
+			uint32_t pX[U], pY[U], pZ[U];
+			float color[U];
 			bool go[U];
 			{
 				float4 p[U];
@@ -1178,7 +1297,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, BatchCtl* bc,
 #pragma unroll
 				for (uint32_t u = 0; u < U; u++) {
 					pX[u] = quantize(F_FULL, p[u].x, a.minx, a.size); pY[u] = quantize(F_FULL, p[u].y, a.miny, a.size); pZ[u] = quantize(F_FULL, p[u].z, a.minz, a.size);
-					levels[u] = 0u;
+					color[u] = p[u].w;
 				}
 			}
 			for (uint32_t d = 1; d <= maxDepth; d++) {                                   // bottom-up, the whole wave one level at a time
@@ -1202,25 +1321,16 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, BatchCtl* bc,
 #pragma unroll
 				for (uint32_t u = 0; u < U; u++) {
 					go[u] = go[u] && ((seen[u] >> bit[u]) & 1u) == 0u;                  // lost: the winner climbs on
-					if (go[u]) levels[u] |= 1u << level[u];
-					const uint32_t winners = (uint32_t)__popcll(__ballot(go[u]));        // they share the ancestor: one add per (leaf, level)
-					if (lane == 0u && winners != 0u) atomicAdd(&a.nodes[path_node(ent[u])].numVoxels, winners);       // voxels.cu:101
+					// the winners share the ancestor: one add per (leaf, level) reserves their slots in its voxel list (voxels.cu:101), and each stores
+					// its voxel — the cell's centre in the sample's colour (voxels.cu:103-114, 674-698) — right away
+					const unsigned long long wm = __ballot(go[u]);
+					if (wm == 0ull) continue;
+					const uint32_t node = path_node(ent[u]);
+					uint32_t first = 0;
+					if (lane == 0u) first = atomicAdd(&a.nodes[node].numVoxels, (uint32_t)__popcll(wm));
+					first = (uint32_t)__shfl((int)first, 0, 64);
+					store_voxels_wave(a, ctl, tag, go[u], node, first + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull)), voxel_of(a, (int)level[u], pX[u], pY[u], pZ[u], color[u]));
 				}
-			}
-			// the samples that colour voxels go on the emit list: one reservation per step
-			uint32_t before[U], total = 0;
-#pragma unroll
-			for (uint32_t u = 0; u < U; u++) {
-				const unsigned long long m = __ballot(levels[u] != 0u);
-				before[u] = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-				total += (uint32_t)__popcll(m);
-			}
-			if (total != 0u) {
-				uint32_t at0 = 0;
-				if (lane == 0u) at0 = atomicAdd(&bc->numEmits, total);
-				at0 = __shfl(at0, 0, 64);
-#pragma unroll
-				for (uint32_t u = 0; u < U; u++) if (levels[u] != 0u) emits[at0 + before[u]] = emit_pack(itemIndex[u], base + lane, levels[u]);
 			}
 		}
 	}
@@ -1255,13 +1365,14 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	__shared__ VoxShared sh;
 	const VoxItem* items = vox_items(a, bc);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
-	Emit* emits = at<Emit>(a, a.offEmit);
+	const uint32_t tag = bc->tag;
 	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
 		// Global memory is touched in six steps, each one round trip with everything it needs in flight together: the item; the leaf's
-		// path; chunk addresses + cube words; the samples; the write-back atomics; the emit reservation.
+		// path; chunk addresses + cube words; the samples; the write-back atomics; the slot reservations and voxel chunks.
 		VoxItem it = items[item];
-		it.leaf &= 0xffffffu;                                  // (the level in the top byte is for k_insert)
+		const uint32_t leafLevel = it.leaf >> 24;
+		it.leaf &= 0xffffffu;
 		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
@@ -1271,9 +1382,8 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 			unsigned long long e;
 			if (it.leaf == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; e = (threadIdx.x == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
 			else e = threadIdx.x < PATH_WORDS - 1 ? rec[threadIdx.x] : 0ull;
-			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0;
+			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0; sh.rank[threadIdx.x] = 0;
 		}
-		if (threadIdx.x == 0) sh.emitCount = 0;
 		const SimlodChunk* chunk[VOX_SPT];
 		bool live[VOX_SPT];
 #pragma unroll
@@ -1323,6 +1433,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 #pragma unroll
 			for (uint32_t j = 0; j < VOX_SPT; j++) {
 				pX[j] = quantize(F_FULL, p[j].x, a.minx, a.size); pY[j] = quantize(F_FULL, p[j].y, a.miny, a.size); pZ[j] = quantize(F_FULL, p[j].z, a.minz, a.size);
+				sh.color[j * VTPB + threadIdx.x] = p[j].w;
 				levels[j] = 0u;
 			}
 
@@ -1402,8 +1513,38 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 				}
 			}
 			__syncthreads();
-			if (threadIdx.x >= 1u && threadIdx.x <= depth && sh.cnt[threadIdx.x] != 0u)
-				atomicAdd(&a.nodes[path_node(sh.anc[threadIdx.x - 1u])].numVoxels, sh.cnt[threadIdx.x]);         // voxels.cu:101
+			// The cells this piece won in ancestor d become voxels: the add to Node.numVoxels (voxels.cu:101) reserves their slots in d's voxel
+			// list, and the chunks those slots lie in are made or found here (see "voxel chunks, on demand") — one lane per ancestor, all in
+			// wave 0: first every lane allocates and publishes what it owns, then every lane links / looks up (which may wait for another piece).
+			{
+				const uint32_t d = threadIdx.x;
+				const bool mineD = d >= 1u && d <= depth && sh.cnt[d] != 0u;
+				uint32_t node = 0, first = 0, existing = 0, kFirst = 0, ownFirst = 0, own = 0;
+				SimlodChunk* mem = nullptr;
+				if (mineD) {
+					node = path_node(sh.anc[d - 1u]);
+					const uint32_t cnt = sh.cnt[d];
+					first = atomicAdd(&a.nodes[node].numVoxels, cnt);
+					existing = (a.nodes[node].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+					kFirst = first / SIMLOD_POINTS_PER_CHUNK;
+					const uint32_t kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
+					ownFirst = first % SIMLOD_POINTS_PER_CHUNK == 0u ? kFirst : kFirst + 1u;           // chunk k is this piece's to make when it holds slot k * 1000
+					own = kLast + 1u > ownFirst ? kLast + 1u - ownFirst : 0u;
+					if (own != 0u) mem = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), own));   // voxel chunks never come from the pool (voxels.cu:656-659)
+					for (uint32_t q = 0; q < own; q++) {
+						SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+						if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));   // (the last one's: vox_chunk_link)
+						vox_chunk_publish(a, ctl, tag, node, ownFirst + q, c);
+						sh.chunkOf[d][ownFirst + q - kFirst] = c;
+					}
+					sh.first[d] = first;
+				}
+				if (mineD) {
+					SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[node].voxelChunks) : nullptr;
+					if (own != 0u) vox_chunk_link(a, ctl, tag, node, ownFirst, existing, oldTail, mem);
+					if (ownFirst != kFirst) sh.chunkOf[d][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, node, kFirst);
+				}
+			}
 
 			// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
 			uint32_t levelsWithNew = 0;
@@ -1427,78 +1568,46 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 					}
 				}
 			}
-			// the samples that colour voxels go on the emit list: one reservation per piece
-			uint32_t mineEmits = 0;
-#pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) mineEmits += levels[j] != 0u ? 1u : 0u;
-			uint32_t at0 = mineEmits != 0u ? atomicAdd(&sh.emitCount, mineEmits) : 0u;
+			// ... and stores the voxel: the cell's centre in its own colour (voxels.cu:103-114, 674-698), in the next free slot of the piece's range
 			__syncthreads();
-			if (threadIdx.x == 0 && sh.emitCount != 0u) sh.emitBase = atomicAdd(&bc->numEmits, sh.emitCount);
-			__syncthreads();
-			if (mineEmits != 0u) {
-				at0 += sh.emitBase;
 #pragma unroll
-				for (uint32_t j = 0; j < VOX_SPT; j++) {
-					if (levels[j] == 0u) continue;
-					emits[at0++] = emit_pack(item, j * VTPB + threadIdx.x, levels[j]);                // never more entries than samples: no overflow to handle
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				for (uint32_t left = levels[j]; left != 0u; left &= left - 1u) {
+					const uint32_t level = (uint32_t)__ffs((int)left) - 1u;
+					const uint32_t d = it.leaf == 0u ? 1u : leafLevel - level;                      // ancestor d sits d levels above the leaf (a root that is still a leaf: itself)
+					const uint32_t slot = sh.first[d] + atomicAdd(&sh.rank[d], 1u);
+					SimlodChunk* c = sh.chunkOf[d][slot / SIMLOD_POINTS_PER_CHUNK - sh.first[d] / SIMLOD_POINTS_PER_CHUNK];
+					if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, (int)level, pX[j], pY[j], pZ[j], sh.color[j * VTPB + threadIdx.x]);
 				}
 			}
 		}
 	}
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
-	voxelize_small(a, bc, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
+	voxelize_small(a, ctl, bc, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
 }
 
 // ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
 // (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
 
-// the voxel chunks of a node whose numVoxels grew in this batch (voxels.cu:641-672): after k_voxelize, when Node.numVoxels is final
-__device__ __forceinline__ void alloc_voxels(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t i) {
-	SimlodNode* node = a.nodes + i;
-	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
-	SimlodChunk** chunkDir = chunk_dir(a, bc);
-	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
-	const uint32_t numVoxels = node->numVoxels, voxStored = node->numVoxelsStored;
-	if (numVoxels > voxStored) {
-		const uint32_t required = (numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-		SimlodChunk* head = node->voxelChunks;
-		const uint32_t existing = head == nullptr ? 0u : max(1u, (voxStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK);
-		const uint32_t first = voxStored / SIMLOD_POINTS_PER_CHUNK;
-		const uint32_t entries = required - first;
-		// (both reservations in one round trip)
-		const uint32_t base = atomicAdd(&bc->dirCount, entries);
-		uint8_t* fresh = required > existing ? persistent_alloc(a.pers, sizeof(SimlodChunk), required - existing) : nullptr;   // voxel chunks never come from the pool
-		SimlodChunk* tail = existing > 0 ? tail_of(head) : nullptr;
-		if (base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); return; }
-		uint32_t e = 0;
-		if (first < existing) chunkDir[base + e++] = tail;
-		if (required > existing) {
-			const uint32_t additional = required - existing;
-			// (never the root: this part may run while the NEXT batch's k_count / k_expand split a root that was still a leaf and read its row)
-			const bool inner = i != 0u && !node_is_leaf(node);
-			for (uint32_t k = 0; k < additional; k++) {
-				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(fresh + (uint64_t)k * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-				c->next = nullptr;
-				if (tail == nullptr) { node->voxelChunks = c; head = c; } else tail->next = c;
-				tail = c;
-				chunkDir[base + e++] = c;
-				if (inner && existing + k < LEAF_SLOTS) leafChunks[(uint64_t)i * LEAF_SLOTS + existing + k] = c;   // an inner node's row lists its voxel chunks
-			}
-			tail_of(head) = tail;
-		}
-		NodeDir& d = nodeDir[i];
-		d.voxBase = base; d.voxFirst = first; d.voxTag = bc->tag;
-	}
-}
-
-// The voxel chunks: on the library's side stream, after k_voxelize, while the next batch has begun — it knows its batch by `par`
-// (ordinal & 1).  A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
-__global__ __launch_bounds__(TPB) void k_alloc(BuildArgs a, uint32_t ordinal) {
+// ---- voxdone: the voxel lists are complete (voxels.cu:674-698: numVoxelsStored catches up with numVoxels) -------------------------------------
+// After k_voxelize, on the side stream.  A node whose list grew gets its new tail (the head chunk remembers it: O(1) append next time).
+// A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
+__global__ __launch_bounds__(TPB) void k_voxdone(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr || ctl->abortBatch) return;
-	const uint32_t numNodes = bc->nodes;
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) alloc_voxels(a, ctl, bc, i);
+	const uint32_t numNodes = bc->nodes;                    // (not the nodes the NEXT batch's k_expand is creating meanwhile)
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
+		SimlodNode* node = a.nodes + i;
+		const uint32_t numVoxels = node->numVoxels, stored = node->numVoxelsStored;
+		if (numVoxels == stored) continue;
+		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK, last = (numVoxels - 1u) / SIMLOD_POINTS_PER_CHUNK;
+		if (last >= existing) {
+			SimlodChunk* tail = dir_find(a, bc->tag, i, last);
+			if (tail != nullptr) { tail->next = nullptr; tail_of(node->voxelChunks) = tail; } else raise(ctl, SIMLOD_ERR_NULL_CHUNK);
+		}
+		node->numVoxelsStored = numVoxels;
+	}
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -1509,62 +1618,31 @@ struct InsertShared {
 	uint32_t dirFirst[TBL_CAP];
 };
 
-// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
-__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
-	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
-	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
-	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
-	const uint32_t nsh = 28u - (uint32_t)level;
-	// masked to `level` bits: a coordinate exactly on the max face quantises to 2^20 (2^28 here) and the reference's descent, which
-	// looks at bits 19..0 only, files it under node coordinate 0 on that axis (voxels.cu:171-179) — the voxel sits at the LOW face
-	const uint32_t nmask = (1u << (uint32_t)level) - 1u;
-	const uint32_t nX = (pX >> nsh) & nmask, nY = (pY >> nsh) & nmask, nZ = (pZ >> nsh) & nmask;
-	const float nodeSize = a.size / exp2_int((uint32_t)level);
-	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
-	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
-	const float nminz = ((float)nZ + 0.0f) * nodeSize + a.minz;
-	float4 v;
-	v.x = nminx + (nodeSize * ((float)cx + 0.5f)) / 128.0f;
-	v.y = nminy + (nodeSize * ((float)cy + 0.5f)) / 128.0f;
-	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
-	v.w = colorBits;                       // colour of the claiming point
-	return v;
-}
-
-// part 0: the points (before k_voxelize, which reads them back leaf by leaf), and with them what used to be kernels of their own — the
-// chunks of the leaves that receive them, the clearing of the grids of the nodes this batch split, the end-of-batch bookkeeping;
-// part 1: the voxels of k_voxelize's emit list.
-//
-// Part 0 in steps: (0) the first ceil(numTouched / 256) workgroups allocate the chunks of the batch's leaves with new samples (one leaf
-// per lane, alloc_points) and say so; (1) everybody counts its samples per leaf in an LDS table — a relabelled sample finds its leaf in
-// its slot's map — and (2) reserves one slot range per (workgroup, leaf) with one global atomic each; neither needs the chunks;
-// (3) wait for the allocators (they have the lowest workgroup numbers, run first and wait for nobody), then store: the slot inside the
-// range comes from an LDS cursor.  Barriers are paid per workgroup, not per chunk.
-__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint32_t ordinal) {
+// The points go into their leaves (before k_voxelize, which reads them back leaf by leaf), and with them what used to be kernels of their
+// own: the clearing of the grids of the nodes this batch split, the end-of-batch bookkeeping.  The chunks are there already (k_hist,
+// k_expand).  In steps: (1) everybody counts its samples per leaf in an LDS table — a relabelled sample finds its leaf in its slot's map —
+// (2) reserves one slot range per (workgroup, leaf) with one global atomic each, (3) stores: the slot inside the range comes from an
+// LDS cursor.  Barriers are paid per workgroup, not per chunk.
+__global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr) return;
 	if (ctl->abortBatch) {                                  // an earlier kernel gave up: the batch is not counted (Stats.dbg says why)
-		if (part == 0u && blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);
+		if (blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);
 		return;
 	}
 	__shared__ InsertShared sh;
 	const uint32_t n = bc->batchSize;
-	const uint32_t total = part == 0u ? n + min(bc->numSpilled, a.spilledCap) : bc->numEmits;
-	if (part != 0u && total == 0u) return;
+	const uint32_t total = n + min(bc->numSpilled, a.spilledCap);
 	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	const Emit* emits = at<const Emit>(a, a.offEmit);
-	const VoxItem* voxItems = vox_items(a, bc);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
-	const unsigned long long* paths = at<const unsigned long long>(a, a.offPaths);
 	const uint32_t tag = bc->tag;
 	const uint32_t numChunks = (total + PPB - 1) / PPB;
 
-	if (part == 0u) {
+	{
 		Phase ph(ctl, blockIdx.x == 0 || blockIdx.x + 1u == numChunks);
 		const uint32_t pb = blockIdx.x == 0 ? 8u : 16u;
 		if (blockIdx.x == 0 && threadIdx.x == 0) bc->nodes = min(a.stats->numNodes, a.nodeCapacity);
@@ -1650,71 +1728,6 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t part, uint
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		ph.mark(pb + 5);
 		if (ph.on) ctl->phaseNs[pb + 6] += 1;
-		return;
-	}
-
-	if (blockIdx.x >= numChunks) return;
-	table_init(sh.tbl);
-	__syncthreads();
-	// ======== voxels: the samples on k_voxelize's emit list regenerate their voxel(s) ========
-	for (int pass = 0; pass < 2; pass++) {
-		// pass 0 counts the new voxels per (workgroup, node); pass 1 stores them behind the reserved base
-		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-#pragma unroll
-			for (uint32_t j = 0; j < PPT; j++) {
-				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-				if (t >= total) continue;
-				const Emit em = emits[t];
-				uint32_t left = (uint32_t)em & 0xfffffu;
-				if (left == 0u) continue;
-				const VoxItem vi = voxItems[(uint32_t)(em >> 44)];
-				const uint32_t leafIdx = vi.leaf & 0xffffffu, leafLevel = vi.leaf >> 24;
-				const unsigned long long* rec = paths + (uint64_t)leafIdx * PATH_WORDS;
-				float4 p = make_float4(0, 0, 0, 0);
-				uint32_t pX = 0, pY = 0, pZ = 0;
-				if (pass == 1) {
-					const uint32_t index = vi.s0 + ((uint32_t)(em >> 20) & 0x1fffu);                   // the sample itself: in the leaf's chunks since part 0
-					p = reinterpret_cast<const float4*>(chunkDir[vi.ptBase + (index / SIMLOD_POINTS_PER_CHUNK - vi.ptFirst)]->points)[index % SIMLOD_POINTS_PER_CHUNK];
-					pX = quantize(F_FULL, p.x, a.minx, a.size); pY = quantize(F_FULL, p.y, a.miny, a.size); pZ = quantize(F_FULL, p.z, a.minz, a.size);
-				}
-				for (; left != 0u; left &= left - 1u) {
-					// the level-L ancestor is entry (leaf level - 1 - L) of the leaf's path; a root that is still a leaf samples itself
-					const int level = __ffs((int)left) - 1;
-					const unsigned long long ent = leafIdx == 0u ? PATH_VALID : rec[leafLevel - 1u - (uint32_t)level];
-					const uint32_t curIdx = path_node(ent);
-					if (pass == 0) {
-						uint32_t rank;
-						(void)table_add(sh.tbl, curIdx, 1u, &rank);
-					} else {
-						const int e = table_find(sh.tbl, curIdx);
-						uint32_t slot, base, first;
-						if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
-						else {
-							const NodeDir d = nodeDir[curIdx];
-							slot = atomicAdd(&a.nodes[curIdx].numVoxelsStored, 1u); base = d.voxTag == tag ? d.voxBase : 0xffffffffu; first = d.voxFirst;
-						}
-						if (base == 0xffffffffu) raise(ctl, SIMLOD_ERR_NULL_CHUNK);
-						else {
-							SimlodChunk* c = chunkDir[base + (slot / SIMLOD_POINTS_PER_CHUNK - first)];
-							reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, level, pX, pY, pZ, p.w);
-						}
-					}
-				}
-			}
-		}
-		__syncthreads();
-		if (pass == 0) {
-			for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
-				const uint32_t key = sh.tbl.keys[e];
-				if (key == TBL_EMPTY) continue;
-				const NodeDir d = nodeDir[key];
-				sh.base[e] = atomicAdd(&a.nodes[key].numVoxelsStored, sh.tbl.vals[e]);            // voxels.cu:685
-				sh.tbl.vals[e] = 0;
-				sh.dirBase[e] = d.voxTag == tag ? d.voxBase : 0xffffffffu;
-				sh.dirFirst[e] = d.voxFirst;
-			}
-			__syncthreads();
-		}
 	}
 }
 
@@ -1773,19 +1786,6 @@ __global__ void k_finish(BuildArgs a, uint32_t fits) {
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-uint64_t construct_fixed_bytes(uint32_t nodeCapacity, uint32_t dirCap) {
-	uint64_t off = 4096;                                                       // Ctl
-	off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
-	off += align_up((uint64_t)SLOT_CAP * sizeof(SlotRec), 256) + 2 * align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256) + align_up(65536ull * 8, 256);
-	off += 6 * align_up((uint64_t)nodeCapacity * 4, 256);                      // split records (8 B), retryTag, parentOf, touched list (8 B)
-	off += align_up((uint64_t)nodeCapacity * sizeof(NodeDir), 256);
-	off += align_up(2ull * dirCap * 8, 256);
-	off += align_up((uint64_t)nodeCapacity * LEAF_SLOTS * 8, 256);
-	off += align_up((uint64_t)nodeCapacity * PATH_WORDS * 8, 256);
-	off += align_up(2ull * (nodeCapacity + 65536) * sizeof(VoxItem), 256);
-	return off;
-}
-
 bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.dirCap = 2 * a.nodeCapacity + 65536;
 	uint64_t off = 4096;
@@ -1796,28 +1796,28 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.clearCap = 65536;
 	a.offClear = off;    off += align_up((uint64_t)a.clearCap * 8, 256);
 	a.offTouched = off;  off += align_up((uint64_t)a.nodeCapacity * 8, 256);
+	// (cleared by the host-enqueued memset of every launch, offSplitTag .. offParent: split records, retry tags, the hash directory of voxel chunks)
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.hashCap = 1u << 17;
+	a.offHashDir = off;  off += align_up((uint64_t)a.hashCap * sizeof(DirEntry), 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up(2ull * a.dirCap * 8, 256);            // (two copies, by batch parity)
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
-	const uint64_t fixedEnd = off;
-	// what is left is shared by the per-sample arrays: 4 B leaf + an 8 B emit-list entry for batch and spilled samples, 16 B per spilled sample
-	a.voxItemCap = min(a.nodeCapacity + VOX_BIG_ITEMS, 1u << 20);              // VOX_BIG_ITEMS pieces + one small item per leaf; Emit has 20 bits for the index
+	a.voxItemCap = min(a.nodeCapacity + VOX_BIG_ITEMS, 1u << 20);              // VOX_BIG_ITEMS pieces + one small item per leaf
 	a.offVoxItems = off; off += align_up(2ull * a.voxItemCap * sizeof(VoxItem), 256);   // (two copies, by batch parity)
-	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 12;
+	// what is left is shared by the per-sample arrays: the 4-byte cached-leaf word of batch and moved samples, 16 B per moved point
+	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 4;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
 	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
-	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (28 * 1000 + 32);   // + one 32-byte work item per 1000 spilled points
+	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
 	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
 	a.spilledCap = (uint32_t)cap;
-	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 spilled points + one partial chunk per split
+	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 moved points + one partial chunk per split
 	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
-	(void)fixedEnd;
 	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
-	a.offEmit = off;     off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * sizeof(Emit), 256);
 	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
 	a.scratchBytes = off;
 	return off <= capacity;
@@ -1897,7 +1897,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
-		const int countTpb = tune("SIMLOD_COUNT_TPB", 256);
+		const int countTpb = tune("SIMLOD_COUNT_TPB", 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
 		for (uint32_t b = 0; b < limit; b++) {
 			if (countTpb == 1024) SIMLOD_LAUNCH(k_count<1024>, dim3(gridPoints / 4), dim3(1024), stream, a, b);
 			else if (countTpb == 512) SIMLOD_LAUNCH(k_count<512>, dim3(gridPoints / 2), dim3(512), stream, a, b);
@@ -1905,15 +1905,14 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a, b);
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, 0u, b);             // chunks, points, end-of-batch bookkeeping
+			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, b);                 // grid clears, points, end-of-batch bookkeeping
 			hipStream_t tail = stream;
 			if (side != nullptr) {
 				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
 				tail = side->stream;
 			}
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, b);
-			SIMLOD_LAUNCH(k_alloc, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, b);
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), tail, a, 1u, b);
+			SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, b);
 			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
 		}
 		if (side != nullptr && limit > 0 && hipStreamWaitEvent(stream, side->tailDone[limit - 1], 0) != hipSuccess) return (int)hipGetLastError();
