@@ -67,9 +67,10 @@ struct Ctl {
 	uint64_t unused1[4];
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
 	BatchCtl batch[2];
+	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 408 + 384: k_voxelize of batch #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
 	uint64_t phaseNs[48];              // byte 408: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
 };
-static_assert(offsetof(Ctl, phaseNs) == 408, "tools/probe.py reads Ctl.phaseNs at byte 408");
+static_assert(offsetof(Ctl, voxT) == 408 && offsetof(Ctl, phaseNs) == 408 + 480, "tools/probe.py reads Ctl.voxT at byte 408, Ctl.phaseNs behind it");
 static_assert(offsetof(Ctl, expandNs) == 152, "bench.py / tools read Ctl.expandNs at byte 152");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
@@ -267,6 +268,7 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers) ? 1u : 0u;
 	ctl->tableMagic = 0;                        // valid again once k_finish has run
 	ctl->batch[1].active = 0;
+	for (uint32_t i = 0; i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++) { ctl->voxT[i][0] = ~0ull; ctl->voxT[i][1] = 0; ctl->voxT[i][2] = 0; }
 	prepare_batch(a, ctl, 0);
 }
 
@@ -563,7 +565,8 @@ static constexpr uint32_t VTPB = 1024;
 static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
 static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
 static constexpr uint32_t VOX_BIG_ITEMS = 65536;                // entries of the item array for k_voxelize's pieces; the rest: one small item per leaf
-static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with fewer new samples than this takes the wave-per-leaf path
+static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with fewer new samples than this takes the wave-per-leaf path ...
+static constexpr uint32_t VOX_SMALL_PIECE = 128;                // ... in items of at most this many samples (two steps of a wave)
 static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
 static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
 struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; its chunk directory, its coordinates; leaf = node index | level << 24
@@ -635,7 +638,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
 		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
 		const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
-		const uint32_t small = need && pieces == 0u ? 1u : 0u;
+		const uint32_t small = need && pieces == 0u ? (fresh + VOX_SMALL_PIECE - 1) / VOX_SMALL_PIECE : 0u;
 		uint32_t totEntries, totAdditional, totPieces, totSmall;
 		const uint32_t exEntries = wave_exclusive(entries, totEntries), exAdditional = wave_exclusive(additional, totAdditional);
 		const uint32_t exPieces = wave_exclusive(pieces, totPieces), exSmall = wave_exclusive(small, totSmall);
@@ -663,14 +666,14 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		const uint32_t itemAt = pieces != 0u ? itemBase + exPieces : VOX_BIG_ITEMS + smallBase + exSmall;
 		bool ok = need;
 		if (need && base + entries > a.dirCap) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); ok = false; }
-		if (need && (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt >= a.voxItemCap)) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); ok = false; }   // a batch + moved points beyond 33 M samples
+		if (need && (pieces != 0u ? itemAt + pieces > VOX_BIG_ITEMS : itemAt + small > a.voxItemCap)) { panic(ctl, SIMLOD_ERR_DIRECTORY_FULL); ok = false; }   // a batch + moved points beyond 33 M samples
 		uint32_t e = 0;
 		if (ok) {
 			if (first < existing) chunkDir[base + e++] = tail;          // the partially filled tail chunk
 			NodeDir& d = nodeDir[i];
 			d.ptBase = base; d.ptFirst = first; d.ptTag = bc->tag;
 			VoxItem* items = vox_items(a, bc);
-			if (pieces == 0u) items[itemAt] = VoxItem{i | node->level << 24, stored, counter, base, first, node->X, node->Y, node->Z};
+			if (pieces == 0u) for (uint32_t q = 0; q < small; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_SMALL_PIECE, min(stored + (q + 1u) * VOX_SMALL_PIECE, counter), base, first, node->X, node->Y, node->Z};
 			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
 		}
 		AllocRec& r = sh.rec[lane];
@@ -1256,8 +1259,9 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, Bat
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
 	const uint32_t lane = (uint32_t)lane_id();
-	constexpr uint32_t U = 4;                              // leaves a wave works on together: a scattered batch leaves ~25 samples in each
-	for (uint32_t k0 = wave * U; k0 < numSmall; k0 += numWaves * U) {
+	constexpr uint32_t U = 4;                              // items a wave works on together when there are more items than waves: a scattered batch leaves ~25 samples in each of tens of thousands of leaves
+	const uint32_t per = numSmall > numWaves ? U : 1u;
+	for (uint32_t k0 = wave * per; k0 < numSmall; k0 += numWaves * per) {
 		VoxItem it[U];
 		unsigned long long mine[U];
 		uint32_t itemIndex[U], count[U], depth[U];
@@ -1270,7 +1274,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, Bat
 #pragma unroll
 		for (uint32_t u = 0; u < U; u++) {
 			const uint32_t leafIdx = it[u].leaf & 0xffffffu;
-			count[u] = k0 + u < numSmall ? it[u].s1 - it[u].s0 : 0u;
+			count[u] = u < per && k0 + u < numSmall ? it[u].s1 - it[u].s0 : 0u;
 			// the leaf's path, one entry per lane (entry d - 1 = ancestor d; a root that is still a leaf samples itself, voxels.cu:449-463)
 			mine[u] = 0ull;
 			if (leafIdx == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; if (lane == 0u && g != nullptr) mine[u] = path_pack(a.pers, 0u, 0u, g); }
@@ -1367,6 +1371,9 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
 	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
+	Phase ph(ctl, blockIdx.x == 0);
+	const bool clocked = (ctl->debugFlags & 2u) != 0u;       // SIMLOD_DEBUG_VOXELIZE_CLOCK (tools/probe.py): when the first workgroup came, the last piece was done, the last workgroup left
+	if (clocked && blockIdx.x == 0 && threadIdx.x == 0) ctl->voxT[ordinal][0] = wall_ns();
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
 		// Global memory is touched in six steps, each one round trip with everything it needs in flight together: the item; the leaf's
 		// path; chunk addresses + cube words; the samples; the write-back atomics; the slot reservations and voxel chunks.
@@ -1393,6 +1400,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 			chunk[j] = live[j] ? chunkDir[it.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - it.ptFirst)] : nullptr;
 		}
 		__syncthreads();
+		ph.mark(24);
 		uint32_t depth = 0;
 		while (depth < PATH_WORDS - 1 && sh.anc[depth] != 0ull) depth++;
 		// voxels.cu:449: the traverse loop samples levels 0..19 only — an ancestor is at level 19 at most (leaves are at most at 20)
@@ -1428,6 +1436,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 			}
 			if (hiMine) sh.hiOcc[threadIdx.x] = hi;
 			__syncthreads();
+			ph.mark(25);
 			// (the samples stay in registers: coordinates and the levels they end up colouring)
 			uint32_t pX[VOX_SPT], pY[VOX_SPT], pZ[VOX_SPT], levels[VOX_SPT];
 #pragma unroll
@@ -1483,6 +1492,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 				}
 			}
 			__syncthreads();
+			ph.mark(26);
 
 			// write-back: the grids learn the new cells and tell which of them are new for everybody (pieces of one leaf share the cubes):
 			// every thread's atomics are in flight together
@@ -1513,6 +1523,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 				}
 			}
 			__syncthreads();
+			ph.mark(27);
 			// The cells this piece won in ancestor d become voxels: the add to Node.numVoxels (voxels.cu:101) reserves their slots in d's voxel
 			// list, and the chunks those slots lie in are made or found here (see "voxel chunks, on demand") — one lane per ancestor, all in
 			// wave 0: first every lane allocates and publishes what it owns, then every lane links / looks up (which may wait for another piece).
@@ -1545,6 +1556,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 					if (ownFirst != kFirst) sh.chunkOf[d][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, node, kFirst);
 				}
 			}
+			ph.mark(28);
 
 			// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
 			uint32_t levelsWithNew = 0;
@@ -1570,6 +1582,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 			}
 			// ... and stores the voxel: the cell's centre in its own colour (voxels.cu:103-114, 674-698), in the next free slot of the piece's range
 			__syncthreads();
+			ph.mark(29);
 #pragma unroll
 			for (uint32_t j = 0; j < VOX_SPT; j++) {
 				for (uint32_t left = levels[j]; left != 0u; left &= left - 1u) {
@@ -1580,10 +1593,14 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 					if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, (int)level, pX[j], pY[j], pZ[j], sh.color[j * VTPB + threadIdx.x]);
 				}
 			}
+			ph.mark(30);
+			if (ph.on) ctl->phaseNs[31] += 1;
 		}
 	}
+	if (clocked && threadIdx.x == 0 && blockIdx.x < numItems) atomicMax(reinterpret_cast<unsigned long long*>(&ctl->voxT[ordinal][1]), (unsigned long long)wall_ns());
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
 	voxelize_small(a, ctl, bc, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
+	if (clocked) { __syncthreads(); if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&ctl->voxT[ordinal][2]), (unsigned long long)wall_ns()); }
 }
 
 // ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
@@ -1806,7 +1823,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offChunkDir = off; off += align_up(2ull * a.dirCap * 8, 256);            // (two copies, by batch parity)
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
-	a.voxItemCap = min(a.nodeCapacity + VOX_BIG_ITEMS, 1u << 20);              // VOX_BIG_ITEMS pieces + one small item per leaf
+	a.voxItemCap = min(a.nodeCapacity + 2u * VOX_BIG_ITEMS, 1u << 20);         // VOX_BIG_ITEMS pieces + small items: a leaf has one more than its new samples / 128, and 65 536 x 128 = 8 M samples
 	a.offVoxItems = off; off += align_up(2ull * a.voxItemCap * sizeof(VoxItem), 256);   // (two copies, by batch parity)
 	// what is left is shared by the per-sample arrays: the 4-byte cached-leaf word of batch and moved samples, 16 B per moved point
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 4;
@@ -1867,7 +1884,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	const DeviceInfo& dev = device_info();
 
 	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(stats));
-	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, (uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u);
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u) | (tune("SIMLOD_DEBUG_VOXELIZE_CLOCK", 0) != 0 ? 2u : 0u));
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
 		if (e != hipSuccess) return (int)e;
