@@ -389,8 +389,10 @@ __device__ __forceinline__ void note_clear(const BuildArgs& a, uint32_t c, Simlo
 	}
 }
 __device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& a, BatchCtl* bc) {
-	SimlodOccupancyGrid* g = reinterpret_cast<SimlodOccupancyGrid*>(persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1));
-	note_clear(a, atomicAdd(&bc->numClear, 1u), g);
+	uint8_t* mem = persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1);          // (two independent atomics with a return value: one round trip)
+	const uint32_t c = atomicAdd(&bc->numClear, 1u);
+	SimlodOccupancyGrid* g = reinterpret_cast<SimlodOccupancyGrid*>(mem);
+	note_clear(a, c, g);
 	return g;
 }
 
@@ -606,7 +608,8 @@ struct AllocRec {
 struct AllocShared { AllocRec rec[ALLOC_LEAVES]; uint32_t total; };
 
 // `entries` (global memory or LDS): {leaf, points it held when the batch began}; entry k is taken when firstEntry + lane < numEntries.
-__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint2* entries, uint32_t firstEntry, uint32_t numEntries) {
+// `fresh`: the entries are empty leaves a cascade has just made, entry.y = their counter (nothing about them has to be read back).
+__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint2* entries, uint32_t firstEntry, uint32_t numEntries, bool fresh_leaves = false) {
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = chunk_dir(a, bc);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
@@ -616,12 +619,13 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		// (the points the leaf held when the batch began come with the list entry: Node.numPoints is already being advanced by the other
 		// workgroups of k_insert)
 		const uint2 entry = firstEntry + lane < numEntries ? entries[firstEntry + lane] : make_uint2(NONE, 0u);
-		const uint32_t i = entry.x, stored = entry.y;
+		const uint32_t i = entry.x, stored = fresh_leaves ? 0u : entry.y;
 		SimlodNode* node = a.nodes + (i != NONE ? i : 0u);
 		uint32_t counter = 0;
 		bool need = false;
 		SimlodChunk* head = nullptr;
-		if (i != NONE) {
+		if (i != NONE && fresh_leaves) { counter = entry.y; need = counter != 0u; }
+		else if (i != NONE) {
 			// (a leaf that k_count's tail has queued for splitting still looks like a leaf until k_expand gives it children: not this one's business)
 			const bool queued = (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[i] >> 32) == bc->ordinal + 1u;
 			counter = node->counter; head = node->points; need = !queued && stored < counter && node_is_leaf(node);
@@ -715,21 +719,8 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	if (bc == nullptr || ctl->abortBatch) return;
 	const uint32_t slots0 = slots_in_use(bc);
 	if (blockIdx.x == 0 && threadIdx.x == 0) bc->slotsRound0 = slots0;
-	__shared__ union { BlockTable tbl; AllocShared alloc; } shared;
-	{
-		// The chunks of the leaves that k_count found new samples for (those that do not split: the nodes of a cascade get theirs from k_expand):
-		// taken care of by the LAST workgroups of the grid, which have no histogram work — 64 leaves each, beside everybody else's histogram pass
-		// and off k_insert's path (voxels.cu:485-538 allocatePointChunks)
-		const uint32_t numTouched = min(bc->numTouched, a.nodeCapacity);
-		const uint32_t allocBlocks = (numTouched + ALLOC_LEAVES - 1) / ALLOC_LEAVES;
-		for (uint32_t blk = gridDim.x - 1u - blockIdx.x; blk < allocBlocks; blk += gridDim.x) {        // list #blk: the blk-th workgroup from the end
-			__syncthreads();
-			alloc_points(a, ctl, bc, shared.alloc, at<const uint2>(a, a.offTouched), blk * ALLOC_LEAVES, numTouched);
-		}
-		__syncthreads();
-	}
 	if (slots0 == 0u) return;
-	BlockTable& tbl = shared.tbl;
+	__shared__ BlockTable tbl;
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
@@ -816,7 +807,7 @@ struct ExpandShared {
 	uint32_t bins[HIST_BINS], c2[64], c1[8];
 	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
 	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
-	uint2 fresh[LOCAL_NODES];                      // the cascade's nodes that hold samples: {node, 0} — they get their chunks before the kernel ends
+	uint2 fresh[LOCAL_NODES];                      // the cascade's nodes that hold samples: {node, samples} — they get their chunks before the kernel ends
 	uint32_t numFresh;
 	AllocShared alloc;
 	SimlodOccupancyGrid* grid[8 + 64];             // grids of the children / grandchildren that split here
@@ -843,6 +834,19 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr || ctl->abortBatch) return;
+	__shared__ ExpandShared sh;
+	{
+		// The chunks of the leaves that k_count found new samples for and that do not split (voxels.cu:485-538 allocatePointChunks; the nodes of
+		// a cascade get theirs below, from the workgroup that builds them): 64 leaves per list, list #k to the k-th workgroup FROM THE END —
+		// the first workgroups are the ones that build the cascades — beside the cascade and off k_insert's path.
+		const uint32_t numTouched = min(bc->numTouched, a.nodeCapacity);
+		const uint32_t allocBlocks = (numTouched + ALLOC_LEAVES - 1) / ALLOC_LEAVES;
+		for (uint32_t blk = gridDim.x - 1u - blockIdx.x; blk < allocBlocks; blk += gridDim.x) {
+			__syncthreads();
+			alloc_points(a, ctl, bc, sh.alloc, at<const uint2>(a, a.offTouched), blk * ALLOC_LEAVES, numTouched);
+		}
+		__syncthreads();
+	}
 	if (bc->slotsRound0 == 0u) return;         // slots handed out by k_count's tail, as k_hist found them: stable while this kernel hands out more
 	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if the grid barrier had given up (tests the abort path); either way the octree is
 	// not to be trusted any more (k_count's tail has already emptied the queued leaves): fatal, sticky until a reset
@@ -859,7 +863,6 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	const uint32_t n = bc->batchSize;
 	uint32_t generation = 0;
 
-	__shared__ ExpandShared sh;
 	const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
 	if (timer) ctl->expandNs[6] += 1;
 
@@ -1039,7 +1042,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
 			}
 			// the nodes of the cascade that hold samples and stay leaves (one that was queued again is none by the time its chunks would be used)
-			if (t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u && sh.listed[t] == NONE) sh.fresh[atomicAdd(&sh.numFresh, 1u)] = make_uint2(indexOf(t), 0u);
+			if (t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u && sh.listed[t] == NONE) sh.fresh[atomicAdd(&sh.numFresh, 1u)] = make_uint2(indexOf(t), countOf(t));
 			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
 			if (t < HIST_BINS) {
 				const uint32_t j = t >> 6, jk = t >> 3;
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			// ... and their chunks, 64 leaves at a time (voxels.cu:485-538; the nodes written above are this workgroup's own stores: visible after the barrier)
 			__syncthreads();
 			for (uint32_t first = 0; first < sh.numFresh; first += ALLOC_LEAVES) {
-				alloc_points(a, ctl, bc, sh.alloc, sh.fresh, first, sh.numFresh);
+				alloc_points(a, ctl, bc, sh.alloc, sh.fresh, first, sh.numFresh, true);
 				__syncthreads();
 			}
 		}
@@ -1662,7 +1665,9 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 	{
 		Phase ph(ctl, blockIdx.x == 0 || blockIdx.x + 1u == numChunks);
 		const uint32_t pb = blockIdx.x == 0 ? 8u : 16u;
-		if (blockIdx.x == 0 && threadIdx.x == 0) bc->nodes = min(a.stats->numNodes, a.nodeCapacity);
+		// The end-of-batch bookkeeping needs nothing this kernel produces (the batch's chunks were allocated by k_expand, the counters it folds
+		// into Stats are final): the LAST workgroup of the grid, which as a rule has no samples to store, does it right away.
+		if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) { bc->nodes = min(a.stats->numNodes, a.nodeCapacity); end_of_batch(a, ctl, bc); }
 		ph.mark(pb + 0);
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
 		// k_voxelize samples into them (voxels.cu:371-382) — 256 KB each, the stores ride along with the loads below
@@ -1671,7 +1676,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 		constexpr uint32_t W4 = SIMLOD_GRID_NUM_WORDS / 4;
 		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numClear * W4; i += gridDim.x * TPB)
 			reinterpret_cast<uint4*>(clearList[i / W4]->values)[i % W4] = make_uint4(0, 0, 0, 0);
-		if (blockIdx.x >= numChunks && blockIdx.x != 0u) return;       // (workgroup 0 stays for the bookkeeping even when the batch is empty)
+		if (blockIdx.x >= numChunks) return;
 
 		ph.mark(pb + 1);
 		// (1) samples per leaf
@@ -1716,8 +1721,6 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 		}
 		__syncthreads();
 		ph.mark(pb + 3);
-		if (blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);          // (every chunk of the batch was allocated by k_hist / k_expand)
-		ph.mark(pb + 4);
 		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 			float4 p[PPT];
 #pragma unroll
