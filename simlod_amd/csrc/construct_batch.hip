@@ -1610,24 +1610,27 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 // (voxels.cu:485-538 allocatePointChunks, :641-672 allocateVoxelChunks, :298-300 countIteration stamp)
 
 // ---- voxdone: the voxel lists are complete (voxels.cu:674-698: numVoxelsStored catches up with numVoxels) -------------------------------------
-// After k_voxelize, on the side stream.  A node whose list grew gets its new tail (the head chunk remembers it: O(1) append next time).
-// A few thousand nodes exist, the array has room for 263 157: a small grid strides over the nodes that are there.
-__global__ __launch_bounds__(TPB) void k_voxdone(BuildArgs a, uint32_t ordinal) {
-	Ctl* ctl = ctl_of(a);
-	BatchCtl* bc = batch_of(ctl, ordinal);
-	if (bc == nullptr || ctl->abortBatch) return;
-	const uint32_t numNodes = bc->nodes;                    // (not the nodes the NEXT batch's k_expand is creating meanwhile)
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
+// After a batch's k_voxelize.  A node whose list grew gets its new tail: the last chunk's `next` is cleared and the head chunk remembers it
+// (O(1) append next time).  `tag`: the batch whose hash directory names the new chunks.  Runs as part of the NEXT batch's k_insert (the
+// first kernel on the caller's stream that has waited for the side stream; some workgroups at the end of its grid, which have no samples)
+// and once more, as a kernel of its own, at the end of the launch.  Nodes the next batch has created meanwhile have no voxels: skipped.
+__device__ void voxdone_nodes(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t numNodes, uint32_t first, uint32_t stride) {
+	for (uint32_t i = first; i < numNodes; i += stride) {
 		SimlodNode* node = a.nodes + i;
 		const uint32_t numVoxels = node->numVoxels, stored = node->numVoxelsStored;
 		if (numVoxels == stored) continue;
 		const uint32_t existing = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK, last = (numVoxels - 1u) / SIMLOD_POINTS_PER_CHUNK;
 		if (last >= existing) {
-			SimlodChunk* tail = dir_find(a, bc->tag, i, last);
+			SimlodChunk* tail = dir_find(a, tag, i, last);
 			if (tail != nullptr) { tail->next = nullptr; tail_of(node->voxelChunks) = tail; } else raise(ctl, SIMLOD_ERR_NULL_CHUNK);
 		}
 		node->numVoxelsStored = numVoxels;
 	}
+}
+__global__ __launch_bounds__(TPB) void k_voxdone(BuildArgs a) {
+	Ctl* ctl = ctl_of(a);
+	if (ctl->processed == 0u || ctl->abortBatch) return;
+	voxdone_nodes(a, ctl, a.stats->batchletIndex, min(a.stats->numNodes, a.nodeCapacity), blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB);   // (tag of the last batch = its index + 1)
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -1668,6 +1671,13 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 		// The end-of-batch bookkeeping needs nothing this kernel produces (the batch's chunks were allocated by k_expand, the counters it folds
 		// into Stats are final): the LAST workgroup of the grid, which as a rule has no samples to store, does it right away.
 		if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) { bc->nodes = min(a.stats->numNodes, a.nodeCapacity); end_of_batch(a, ctl, bc); }
+		// ... and the 32 before it close the voxel lists of the previous batch (voxdone_nodes: this kernel has waited for its k_voxelize)
+		{
+			constexpr uint32_t DONE_WGS = 32;
+			const uint32_t back = gridDim.x - 1u - blockIdx.x;
+			if (back >= 1u && back <= DONE_WGS && bc->ordinal != 0u)
+				voxdone_nodes(a, ctl, tag - 1u, min(a.stats->numNodes, a.nodeCapacity), (back - 1u) * TPB + threadIdx.x, DONE_WGS * TPB);
+		}
 		ph.mark(pb + 0);
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
 		// k_voxelize samples into them (voxels.cu:371-382) — 256 KB each, the stores ride along with the loads below
@@ -1932,10 +1942,10 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 				tail = side->stream;
 			}
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, b);
-			SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), tail, a, b);
 			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
 		}
 		if (side != nullptr && limit > 0 && hipStreamWaitEvent(stream, side->tailDone[limit - 1], 0) != hipSuccess) return (int)hipGetLastError();
+		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
 	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
