@@ -1234,6 +1234,15 @@ __device__ __forceinline__ void cube_cell(uint32_t d, uint32_t cell, uint32_t& w
 	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
 	else { word = cube_offset(d) + row; bit = lx; }
 }
+// the same for a sample, straight from its 28-bit coordinates: `level` = the ancestor's (its grid cell is coordinate >> (21 - level), voxels.cu:78-92);
+// the low bits of the cell index are the position inside the leaf's cube (the cube is aligned to its side).  A dozen integer operations —
+// the two passes over the samples are bound by instruction issue (16 waves share four SIMDs), not by LDS.
+__device__ __forceinline__ void cube_cell_of(uint32_t d, uint32_t level, uint32_t pX, uint32_t pY, uint32_t pZ, uint32_t& word, uint32_t& bit) {
+	const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level, m = (128u >> d) - 1u;
+	const uint32_t lx = (pX >> shf) & m, row = ((pY >> shf) & m) + (((pZ >> shf) & m) << (7u - d));
+	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
+	else { word = cube_offset(d) + row; bit = lx; }
+}
 // LDS word w of the cubes -> which ancestor's grid word it mirrors: d (0: none), the word's index in that grid, the bit offset of the
 // cube's row inside the word, and the row's mask
 __device__ __forceinline__ uint32_t cube_word(uint32_t w, uint32_t LX, uint32_t LY, uint32_t LZ, uint32_t& gridWord, uint32_t& shift, uint32_t& mask) {
@@ -1464,7 +1473,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 					if (d <= ldsDepth) {
 						uint32_t word[VOX_SPT], bit[VOX_SPT], old[VOX_SPT];
 #pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word[j], bit[j]); old[j] = go[j] ? sh.occ[word[j]] : 0xffffffffu; }
+						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell_of(d, level, pX[j], pY[j], pZ[j], word[j], bit[j]); old[j] = go[j] ? sh.occ[word[j]] : 0xffffffffu; }
 #pragma unroll
 						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) old[j] = atomicOr(&sh.occ[word[j]], 1u << bit[j]); }   // voxels.cu:93-96
 #pragma unroll
@@ -1571,7 +1580,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 					if (d <= ldsDepth) {
 						uint32_t word[VOX_SPT], bit[VOX_SPT], cur[VOX_SPT];
 #pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell(d, grid_cell(level, pX[j], pY[j], pZ[j]), word[j], bit[j]); cur[j] = live[j] ? sh.fresh[word[j]] : 0u; }
+						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell_of(d, level, pX[j], pY[j], pZ[j], word[j], bit[j]); cur[j] = live[j] ? sh.fresh[word[j]] : 0u; }
 #pragma unroll
 						for (uint32_t j = 0; j < VOX_SPT; j++) cur[j] = ((cur[j] >> bit[j]) & 1u) != 0u ? atomicAnd(&sh.fresh[word[j]], ~(1u << bit[j])) : 0u;   // take the mark
 #pragma unroll
