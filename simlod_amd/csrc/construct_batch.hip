@@ -58,7 +58,7 @@ struct BatchCtl {
 struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
 	uint32_t errors, abortBatch, rebuildLeafChunks, debugFlags;   // rebuildLeafChunks: this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
-	uint32_t processed, unused0[3];    // batches completed in this launch
+	uint32_t processed, budgetUs, unused0[2];    // batches completed in this launch | the launch's time budget (voxels.cu:22 MAX_PROCESSING_TIME = 10 ms; SIMLOD_DEBUG_BUDGET_US overrides)
 	uint64_t startNs;
 	uint32_t statCounters[8];
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
@@ -243,7 +243,7 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 }
 
 // ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
-__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags) {
+__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
 	const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
@@ -252,6 +252,7 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	ctl->abortBatch = 0;
 	ctl->processed = 0;
 	ctl->debugFlags = debugFlags;
+	ctl->budgetUs = budgetUs != 0u ? budgetUs : (uint32_t)(SIMLOD_MAX_PROCESSING_MS * 1000.0f);
 	ctl->startNs = wall_ns();
 	*a.frameStart = ctl->startNs;
 	// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
@@ -1364,7 +1365,7 @@ __device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
 		ctl->processed += 1;
 		ctl->expandNs[7] += min(bc->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
 		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
-		if (elapsedMs > SIMLOD_MAX_PROCESSING_MS) ctl->stop = 1;
+		if (elapsedMs > (float)ctl->budgetUs / 1000.0f) ctl->stop = 1;                 // voxels.cu:936-949
 	}
 	prepare_batch(a, ctl, bc->ordinal + 1u);
 }
@@ -1906,7 +1907,8 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	const DeviceInfo& dev = device_info();
 
 	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(stats));
-	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u) | (tune("SIMLOD_DEBUG_VOXELIZE_CLOCK", 0) != 0 ? 2u : 0u));
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u) | (tune("SIMLOD_DEBUG_VOXELIZE_CLOCK", 0) != 0 ? 2u : 0u),
+	              (uint32_t)std::max(0, tune("SIMLOD_DEBUG_BUDGET_US", 0)));
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
 		if (e != hipSuccess) return (int)e;

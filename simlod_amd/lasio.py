@@ -99,9 +99,12 @@ def las_records(xyz_int, rgb16, fmt, bytes_per_point=None, seed=0):
     return rec
 
 
-def write_las(path, records, fmt, scale, offset, mins, maxs, version=(1, 2), header_size=None, vlr_bytes=0):
-    """Minimal LAS file: public header block (227 B for 1.2, 375 B for 1.4), `vlr_bytes` of filler, the point records."""
+def write_las(path, records, fmt, scale, offset, mins, maxs, version=(1, 2), header_size=None, vlr_bytes=0, num_points=None):
+    """Minimal LAS file: public header block (227 B for 1.2, 375 B for 1.4), `vlr_bytes` of filler, the point records
+    (`num_points`: the count the header announces when the records are appended later)."""
     n, bpp = records.shape
+    if num_points is not None:
+        n = num_points
     major, minor = version
     hs = header_size if header_size is not None else (375 if minor >= 4 else 227)
     b = bytearray(hs)
@@ -125,14 +128,19 @@ def write_las(path, records, fmt, scale, offset, mins, maxs, version=(1, 2), hea
         f.write(records.tobytes())
 
 
-def points_to_las(path, points, box_size, fmt=2, scale=0.001, world_min=(0.0, 0.0, 0.0), version=(1, 2), seed=0):
-    """Synthetic LAS file whose decoded (translated) positions are close to `points`: X = round((x + world_min) / scale)."""
+def points_to_las(path, points, box_size, fmt=2, scale=0.001, world_min=(0.0, 0.0, 0.0), version=(1, 2), seed=0, chunk=4_000_000):
+    """Synthetic LAS file whose decoded (translated) positions are close to `points`: X = round((x + world_min) / scale).
+    Written `chunk` records at a time (a 350 M-point file is 9 GB; its records never exist in memory all at once)."""
     wm = np.asarray(world_min, dtype=np.float64)
-    xyz = np.stack([points["x"], points["y"], points["z"]], axis=1).astype(np.float64) + wm
-    xyz_int = np.rint(xyz / scale).astype(np.int64).astype(np.int32)
-    c = points["color"]
-    rgb8 = np.stack([c & 255, (c >> 8) & 255, (c >> 16) & 255], axis=1).astype(np.uint16)
-    rgb16 = rgb8 * np.uint16(256) + rgb8                       # 16-bit colour as scanners write it; decodes back to rgb8
-    rec = las_records(xyz_int, rgb16, fmt, seed=seed)
-    write_las(path, rec, fmt, (scale,) * 3, (0.0, 0.0, 0.0), wm, wm + np.asarray(box_size, dtype=np.float64), version=version)
+    n = len(points)
+    write_las(path, np.zeros((0, FORMAT_BYTES[fmt]), dtype=np.uint8), fmt, (scale,) * 3, (0.0, 0.0, 0.0), wm, wm + np.asarray(box_size, dtype=np.float64), version=version, num_points=n)
+    with open(path, "ab") as f:
+        for i in range(0, n, chunk):
+            p = points[i:i + chunk]
+            xyz = np.stack([p["x"], p["y"], p["z"]], axis=1).astype(np.float64) + wm
+            xyz_int = np.rint(xyz / scale).astype(np.int64).astype(np.int32)
+            c = p["color"]
+            rgb8 = np.stack([c & 255, (c >> 8) & 255, (c >> 16) & 255], axis=1).astype(np.uint16)
+            rgb16 = rgb8 * np.uint16(256) + rgb8                   # 16-bit colour as scanners write it; decodes back to rgb8
+            f.write(las_records(xyz_int, rgb16, fmt, seed=seed + i // chunk).tobytes())
     return load_header(path)

@@ -274,6 +274,116 @@ def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs, chain):
         assert hs == np.uint64(d["pointsSum"].sum()) and hx == np.bitwise_xor.reduce(d["pointsXor"])
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_time_budget_stops_launches_early_without_changing_the_octree(built_libs, overlap, monkeypatch):
+    """voxels.cu:22, 936-949: a launch stops taking batches once it has run for 10 ms; the host launches again next frame.  With the
+    budget forced down to 150 us (SIMLOD_DEBUG_BUDGET_US) every launch stops after a batch or two — with the voxel half of the stopped
+    batch still on the side stream (overlap 1) or behind it on the caller's (overlap 0) — and 60 batches take dozens of launches.  The
+    octree and every counter must be what the restatement builds without ever running out of time."""
+    monkeypatch.setenv("SIMLOD_OVERLAP_TAIL", overlap)
+    monkeypatch.setenv("SIMLOD_DEBUG_BUDGET_US", "150")
+    n, batch = 6_000_000, 100_000
+    pts, box = synthetic.terrain(n, seed=21)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(ring_slots=50)
+    u = dev.uniforms(W, H, T, box)
+    dev.reset(u)
+    launches = 0
+    for i in range(0, n, batch):
+        if dev.uploaded_host - dev.processed() >= dev.ring_slots:
+            launches += dev.drain(u)
+        dev.upload(pts[i:i + batch])
+    launches += dev.drain(u)
+    assert launches >= 20, f"the budget was meant to cut the launches short ({launches} launches for 60 batches)"
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=50)
+    ref.reset(u)
+    ref.add_points(u, pts, batch)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "budget")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "budget")
+
+
+def test_deferred_splits_catch_up_to_the_oracles_octree(built_libs):
+    """The regime BASELINE config 3's adversarial replay enters (Stats.dbg bit 0x2): with too little spill space hundreds of leaves grow past
+    50 000 instead of splitting.  Once space is plentiful and every such leaf is touched again, the late splits must produce the octree
+    the restatement builds without ever deferring: same topology, per-node multisets, occupancy bitsets, voxel positions and counts
+    (everything that does not depend on WHEN a leaf split; the allocator / chunk-pool counters do)."""
+    from simlod_amd.runtime import lib
+    n = 6_000_000
+    pts, box = synthetic.uniform_cube(n + 2_000_000, seed=99)
+    pts["z"] *= np.float32(0.02)                                  # a slab: ~2-D density, leaves fill up together
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    small = int(lib().simlod_construct_buffer_min_bytes()) + 6_000_000
+    dev = _device(ring_slots=8, momentary_bytes=300_000_000)
+    u = dev.uniforms(W, H, T, box)
+    us = u.copy()
+    us["momentaryBufferCapacity"] = small                         # phase 1: room for ~250 k moved points per batch
+    dev.reset(us)
+    for i in range(0, n, 1_000_000):
+        dev.upload(pts[i:i + 1_000_000])
+        dev.drain(us)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) & 0x2 and int(ds["dbg"]) & ~0x2 == 0, f"phase 1 was meant to exhaust the spill space only ({int(ds['dbg']):#x})"
+    nodes, pers, nn = host_image_of(dev)
+    d = oracle.dump_image(nodes, nn)
+    assert (d["numPoints"][d["isLeaf"] == 1] > abi.MAX_POINTS_PER_NODE).any(), "expected leaves whose split is pending"
+    for i in range(n, n + 2_000_000, 1_000_000):                  # phase 2: the full buffer; 2 M more points over the same slab touch every leaf
+        dev.upload(pts[i:i + 1_000_000])
+        dev.drain(u)
+    ds = dev.read_stats()
+    nodes, pers, nn = host_image_of(dev)
+    got = oracle.dump_image(nodes, nn)
+    assert not (got["numPoints"][got["isLeaf"] == 1] > abi.MAX_POINTS_PER_NODE).any(), "a deferred split is still pending"
+    ref = oracle.HostOctree("port", persistent_bytes=2 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts, 1_000_000)
+    want = ref.dump()
+    got, want = got[np.argsort(got["key"])], want[np.argsort(want["key"])]
+    assert len(got) == len(want)
+    for f in GRANULARITY_FREE_FIELDS:
+        assert np.array_equal(got[f], want[f]), f
+    assert_stats_equal(ds, ref.stats[0], ["numNodes", "numInner", "numLeaves", "numNonemptyLeaves", "numPoints", "numVoxels", "numChunksPoints", "numChunksVoxels",
+                                          "batchletIndex", "numPointsProcessed"], "deferred")
+    assert voxel_colors_are_member(nodes, nn, pts, box) == int(nodes["numVoxelsStored"][:nn].sum())
+
+
+def test_las_stream_of_60m_points_wraps_the_ring_and_equals_the_oracle(built_libs, tmp_path):
+    """BASELINE config 3's path at a size the serial restatement finishes in seconds: a scan-ordered LAS 1.4 file of 60 M points is read in
+    1 M-point batches, decoded on the device into the 50-slot ring (which wraps), and ingested incrementally; the full octree dump and
+    Stats must equal the restatement's on the oracle-decoded points.  Stats.dbg must stay 0 (no deferred split on this input)."""
+    from simlod_amd import lasio
+    n = 60_000_000
+    pts0, box = synthetic.terrain_scan(n, seed=7)
+    path = str(tmp_path / "scan60m.las")
+    h = lasio.points_to_las(path, pts0, box, fmt=2, scale=0.001, world_min=(694000.0, 3915000.0, -3.0), version=(1, 4))
+    del pts0
+    tr = tuple(-m for m in h.min)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(persistent_bytes=6 << 30)
+    u = dev.uniforms(W, H, T, box)
+    dev.reset(u)
+    dev.add_las(u, path)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0 and int(ds["numPoints"]) == n and int(ds["batchletIndex"]) == 60
+    ref = oracle.HostOctree("port", persistent_bytes=6 << 30, ring_slots=50)
+    uh = u.copy()
+    uh["persistentBufferCapacity"] = 6 << 30
+    ref.reset(uh)
+    for first, count in lasio.batches(h, abi.MAX_BATCH_SIZE):
+        if int(ref.num_uploaded[0]) - int(ref.stats["batchletIndex"][0]) >= 50:
+            while int(ref.stats["batchletIndex"][0]) < int(ref.num_uploaded[0]):
+                ref.construct(uh)
+        ref.upload(oracle.decode_las_port(lasio.read_records(path, h, first, count), h.bytesPerPoint, h.format, h.scale, lasio.decode_offset(h, tr)))
+    while int(ref.stats["batchletIndex"][0]) < int(ref.num_uploaded[0]):
+        ref.construct(uh)
+    assert ref.last_error() == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "las 60 M")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "las 60 M")
+
+
 # ---- render --------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("hqs", [False, True])
