@@ -44,9 +44,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=36_000_000)
+    ap.add_argument("--points", type=int, default=None, help="points per GPU (default: 36 M resident in the ring at N=1 = BASELINE config 2; 500 M streamed through the ring at N>1 = config 4)")
+    ap.add_argument("--stream", action="store_true", help="N=1 too: device-generated points streamed through the 50-slot ring with the reference's back-pressure (config 4's per-rank path)")
     ap.add_argument("--frames", type=int, default=20)
-    ap.add_argument("--cpu-points", type=int, default=6_000_000, help="bounded sample for the CPU baseline")
+    ap.add_argument("--cpu-points", type=int, default=36_000_000, help="bounded sample for the CPU baseline (the port finishes all 36 M in a few seconds)")
+    ap.add_argument("--b0-points", type=int, default=36_000_000, help="how much of the same terrain B0 — the reference's own sources as host code — is given (it stops after 25 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--coalesce", action="store_true", help="opt-in coalesced ingest (simlod_set_ingest_mode(1)): all pending batches of a launch as one")
@@ -54,6 +56,8 @@ def parse():
     ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
                     help="record order of the synthetic terrain: shuffled inside 250 m tiles (default, the harder case) or scan-line order as in a LAS file")
     a = ap.parse_args()
+    if a.points is None:
+        a.points = 36_000_000 if a.gpus == 1 and not a.stream else 500_000_000
     if a.momentary_mb is None:
         a.momentary_mb = 700 if a.coalesce else 300      # coalesced groups of 20 batches want room for 20 M waiting samples + moved points
     return a
@@ -113,9 +117,11 @@ def main():
     n_points = args.points
     batch = abi.MAX_BATCH_SIZE
     partition = None
-    if not use_dist:
+    source = None                          # N>1 / --stream: the rank's points, resident on the device, streamed through the ring every step
+    persistent_bytes = max(8 << 30, 48 * n_points)
+    if not use_dist and not args.stream:
         n_batches = (n_points + batch - 1) // batch
-        assert n_batches <= abi.BATCH_STREAM_SIZE, "the workload must fit the 50-slot ring (resident input)"
+        assert n_batches <= abi.BATCH_STREAM_SIZE, "the resident workload must fit the 50-slot ring (use --stream for more)"
         gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
         pts, box = gen(n_points, seed=7)
         dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
@@ -131,33 +137,43 @@ def main():
         tiles_y = (world + tiles_x - 1) // tiles_x
         tile_extent = (6000.0, 4000.0, 400.0)
         box = np.array([tiles_x * tile_extent[0], tiles_y * tile_extent[1], tile_extent[2]], dtype=np.float32)
-        dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
+        dev = DeviceOctree(f"cuda:{local}", persistent_bytes=persistent_bytes, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
         L = lib()
         generated = torch.empty(n_points * 16, dtype=torch.uint8, device=dev.device)
         dev.generate_terrain(generated, rank * n_points, n_points, 7, tiles_x, tile_extent)       # rank r makes tile r of the global stream
         torch.cuda.synchronize(); barrier()
-        t0 = time.perf_counter()
-        codes = distributed.cell_codes(generated, box, 3)
-        owner, counts = distributed.balanced_owners(codes, world, 3)
-        mine, recv = distributed.route_points(generated, codes, owner)
-        torch.cuda.synchronize(); barrier()
-        t_part = time.perf_counter() - t0
-        load = np.array([int(counts[owner.cpu().numpy() == r].sum()) for r in range(world)])
+        if use_dist:
+            t0 = time.perf_counter()
+            chunk = 64_000_000                                                                    # (cell codes in slices: the int64 temporaries of 500 M points are not small)
+            codes = torch.cat([distributed.cell_codes(generated[i * 16: (i + chunk) * 16], box, 3) for i in range(0, n_points, chunk)])
+            owner, counts = distributed.balanced_owners(codes, world, 3)
+            mine, recv = distributed.route_points(generated, codes, owner)
+            torch.cuda.synchronize(); barrier()
+            t_part = time.perf_counter() - t0
+            load = np.array([int(counts[owner.cpu().numpy() == r].sum()) for r in range(world)])
+            partition = {"level": 3, "cells_occupied": int((counts > 0).sum()), "per_rank_points": load.tolist(), "max_over_mean": float(load.max() / load.mean()),
+                         "histogram_assign_route_ms": t_part * 1e3, "kept_local": int(recv[rank]), "what": "all-reduce of 512-cell histograms, greedy by count, one all_to_all_single of the records"}
+            del generated, codes
+        else:
+            mine = generated.reshape(-1, 16)
         my_points = int(mine.shape[0])
         n_batches = (my_points + batch - 1) // batch
-        assert n_batches <= abi.BATCH_STREAM_SIZE, f"rank {rank} owns {my_points} points: more than the 50-slot ring holds resident"
-        dev.ring.view(torch.uint8)[: my_points * 16].copy_(mine.reshape(-1))
-        partition = {"level": 3, "cells_occupied": int((counts > 0).sum()), "per_rank_points": load.tolist(), "max_over_mean": float(load.max() / load.mean()),
-                     "histogram_assign_route_ms": t_part * 1e3, "kept_local": int(recv[rank]), "what": "all-reduce of 512-cell histograms, greedy by count, one all_to_all_single of the records"}
-        del generated, mine, codes
+        source = mine.reshape(-1)
         pts = None
     sizes = torch.tensor([min(batch, my_points - i * batch) for i in range(n_batches)], dtype=torch.int32, device=dev.device)
+    # "Morro Bay - bird" and "Morro Bay - close" (main_progressive_octree.cpp:1314-1328), scaled to the stand-in's box: the bird looks at the
+    # middle of the terrain from 3.9 km, the close one at the surface point under the reference's target from 94 m
     T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886 * float(box[0]) / 6000.0, (box[0] / 2, box[1] / 2, 0.35 * box[2])),
                                camera.perspective(aspect=W / H))
+    cx, cy = 2750.218 * float(box[0]) / 6000.0, 974.775 * float(box[1]) / 4000.0
+    T_close = camera.world_view_proj(camera.orbit_view(-11.270, -0.225, 93.982, (cx, cy, synthetic.terrain_height(cx, cy, seed=7, box=tuple(float(v) for v in box)) if not use_dist and source is None else 0.35 * float(box[2]))),
+                                     camera.perspective(aspect=W / H))
     u = dev.uniforms(W, H, T, box, hqs=True)
 
     def ingest_step():
         dev.reset(u)
+        if source is not None:                        # config 4: through the 50-slot ring, uploader + back-pressure + one launch per frame
+            return dev.stream(u, source, my_points)
         dev.batch_sizes[:n_batches] = sizes           # what the uploader's cuMemsetD32Async pair publishes
         dev.num_uploaded.fill_(n_batches)
         dev.uploaded_host = n_batches
@@ -184,20 +200,21 @@ def main():
     # ---- raster ------------------------------------------------------------------------------------------------
     from simlod_amd import distributed
 
-    def frame():
-        """One frame: a single launch on one GPU; across ranks the exact composition of distributed.render_frame —
-        HQS: all-reduce(MIN) of the depth plane and all-reduce(SUM) of the colour sums between the passes; plain: all-reduce(MIN)
-        of the uint64 framebuffer; plus the all-gather of the visible-node records."""
-        if use_dist:
-            distributed.render_frame(dev, u)
-        else:
-            dev.render(u)
-
     raster = {}
-    tfile = os.path.join(ROOT, "profiles", "traffic_r02.json")
-    rtraffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
-    for name, hqs in (("hqs", 1), ("plain", 0)):
-        u["useHighQualityShading"] = hqs
+    tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("traffic_r03.json", "traffic_r02.json")) if os.path.exists(f)), None)
+    rtraffic = json.load(open(tfile)) if tfile else {}
+    for name, hqs, Tcam in (("hqs", 1, T), ("plain", 0, T), ("hqs_close", 1, T_close), ("plain_close", 0, T_close)):
+        uc = dev.uniforms(W, H, Tcam, box, hqs=bool(hqs))
+
+        def frame():
+            """One frame: a single launch on one GPU; across ranks the exact composition of distributed.render_frame —
+            HQS: all-reduce(MIN) of the depth plane and all-reduce(SUM) of the colour sums between the passes; plain: all-reduce(MIN)
+            of the uint64 framebuffer; plus the all-gather of the visible-node records."""
+            if use_dist:
+                distributed.render_frame(dev, uc)
+            else:
+                dev.render(uc)
+
         for _ in range(2):
             frame()
         torch.cuda.synchronize(); barrier()
@@ -215,17 +232,24 @@ def main():
         vs = float(samples.item())
         # plain 24 B/sample (16 B read + 8 B framebuffer RMW) + 20 B/px (8 clear + 12 output); HQS 32 B/sample (two
         # reads) + 4 B depth RMW per sample + 48 B/px (20 clear + 28 resolve) — the 16 B colour RMW per ACCEPTED sample is left out
-        # (the kernels do not count acceptances), so the HQS figure is a lower bound
+        # (the kernels do not count acceptances), so the HQS figure is a lower bound.  `frac` prices the frame by THAT definition; with
+        # per-item LDS tiles the framebuffer RMW never reaches HBM, so `frac_by_traffic` prices the same frame by the bytes the PMC
+        # counters saw the whole frame move (profiles/traffic_r0x.json, bird preset; None for the other preset / without the file).
         rb = (32.0 + 4.0) * vs + 48.0 * W * H if hqs else 24.0 * vs + 20.0 * W * H
+        fkeys = (["r_clear", "r_visible", "r_draw<MODE_DEPTH>", "r_draw<MODE_COLOR>", "r_resolve", "r_output"] if hqs else ["r_clear", "r_visible", "r_draw<MODE_MIN64>", "r_output"])
+        ftraffic = sum(rtraffic.get(k, 0.0) for k in fkeys) if (rtraffic and name in ("hqs", "plain") and "r_draw<MODE_MIN64>" in rtraffic) else None
         raster[name] = {"value": vs / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,
+                        "camera": "Morro Bay - close (main_progressive_octree.cpp:1323-1328)" if "close" in name else "Morro Bay - bird (:1314-1320)",
                         "visible_samples": int(vs), "visible_nodes": int(st["numVisibleNodes"]),
                         "roofline": {"bound": "hbm", "achieved": rb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes_per_frame": rb,
-                                     "traffic": (rtraffic["r_draw<MODE_DEPTH>"] + rtraffic["r_draw<MODE_COLOR>"] if hqs else rtraffic["r_draw<MODE_MIN64>"]) if "r_draw<MODE_MIN64>" in rtraffic else None,
-                                     "traffic_source": "profiles/traffic_r02.json: draw kernels of one frame (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if rtraffic else None}}
-    u["useHighQualityShading"] = 1
+                                     "traffic": ftraffic, "frac_by_traffic": (ftraffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ftraffic else None,
+                                     "traffic_source": (os.path.relpath(tfile, ROOT) + ": all kernels of one frame (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)") if ftraffic else None}}
 
-    # ---- per-kernel attribution with HIP events on the launch stream (separate, untimed pass) --------------------
+    # ---- per-kernel attribution (separate, untimed pass) ------------------------------------------------------------------
+    # Two sources, both in the JSON: (1) HIP events recorded between the launches of one more ingest — that needs everything on ONE
+    # stream, so the voxel half does not overlap the next batch as it does in the headline run ("measured_with"); (2) the rocprofv3
+    # kernel trace of the headline configuration (overlap on) that profiles/r03/ holds, when it is there ("rocprof_overlap_on").
     roofline, chain, kernels = None, None, {}
     bulk_chain = args.coalesce or os.environ.get("SIMLOD_EXACT_CHAIN") == "bulk"
     # measurement aids in the control block at byte 0 of the momentary buffer: construct_bulk.hip Ctl {spilledTotal, pendingTotal,
@@ -245,31 +269,41 @@ def main():
         st = dev.read_stats()
         new_voxels = int(st["numVoxels"])
         kernels = {k: {"launches": n, "total_ms": ms, "avg_ms": ms / max(n, 1)} for k, (n, ms) in {**prof_c, **prof_r}.items()}
+        kernels["_measured_with"] = "HIP events between launches, ONE stream: the side-stream overlap of the headline run is off in this pass"
+        rocprof = {}
+        kpath = os.path.join(ROOT, "profiles", "r03", "kernel_stats.csv")
+        if os.path.exists(kpath):
+            import csv
+            for row in csv.DictReader(open(kpath)):
+                nm = row["Name"].split("(")[0].replace("void ", "").replace("simlod::batch::", "").replace("simlod::", "")
+                rocprof[nm] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
         chain_ms = sum(ms for k, (n, ms) in prof_c.items())
-        chain_bytes = 32.0 * n_points + 16.0 * new_voxels                  # 32 B/point + 16 B/new voxel
-        chain = {"bound": "hbm", "achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms, "what": "whole kernel_construct chain, one 36 M ingest"}
+        chain_bytes = 32.0 * my_points + 16.0 * new_voxels                 # 32 B/point + 16 B/new voxel
+        chain = {"bound": "hbm", "achieved": chain_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": chain_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": ms_per_step, "algorithmic_bytes": chain_bytes,
+                 "what": "whole kernel_construct chain over the headline's own ms_per_step (reset + launches + Stats readbacks included)",
+                 "one_stream_event_pass_ms": chain_ms}
         # Algorithmic bytes per kernel for one whole ingest.
-        #  batch chain: k_count reads every point (16 B); k_insert reads and stores it (32 B; moved points too), and in its second part reads
-        #    the sample of every new voxel and stores the voxel (32 B each); k_voxelize reads every stored sample back (16 B; the cube words
-        #    it loads and writes, ~40 KB per 8192 samples, are not counted); k_expand reads a moved point and writes it to the spill buffer (32 B);
-        #  bulk chain: k_ingest reads every point, stores the ones it places itself and their voxels; k_place reads and stores the samples of
-        #    overflowing leaves and the moved points; k_voxelize reads them back twice and stores their voxels; k_expand as above plus one
-        #    read of every waiting sample per split round (lower bound: one round).
+        #  batch chain: k_count reads every point (16 B); k_hist reads a moved point and writes it to the spill buffer (32 B; the samples of the
+        #    splitting leaves it also reads are not counted: lower bound); k_insert reads and stores every point, moved ones too (32 B);
+        #    k_voxelize reads every stored sample back (16 B; the cube words it loads and writes, ~40 KB per 8192 samples, are not counted) and
+        #    stores a voxel per new cell (16 B);  k_expand moves no bulk data (decisions from histograms, node records, chunk links);
+        #  bulk chain (coalesced mode): k_ingest reads every point, stores the ones it places itself and their voxels; k_place reads and stores
+        #    the samples of overflowing leaves and the moved points; k_voxelize reads them back twice and stores their voxels; k_expand reads a
+        #    moved point and writes it to the spill buffer plus one read of every waiting sample per split round (lower bound: one round).
         if bulk_chain:
-            per_ingest = {"k_ingest": 16.0 * n_points + 16.0 * (n_points - placed) + 16.0 * (new_voxels - place_voxels), "k_place": 32.0 * (placed + moved),
+            per_ingest = {"k_ingest": 16.0 * my_points + 16.0 * (my_points - placed) + 16.0 * (new_voxels - place_voxels), "k_place": 32.0 * (placed + moved),
                           "k_voxelize": 32.0 * (placed + moved) + 16.0 * place_voxels, "k_expand": 32.0 * moved + 16.0 * placed}
         else:
-            per_ingest = {"k_count": 16.0 * n_points, "k_voxelize": 16.0 * (n_points + moved), "k_insert": 32.0 * (n_points + moved) + 32.0 * new_voxels, "k_expand": 32.0 * moved}
+            per_ingest = {"k_count": 16.0 * my_points, "k_hist": 32.0 * moved, "k_insert": 32.0 * (my_points + moved), "k_voxelize": 16.0 * (my_points + moved) + 16.0 * new_voxels}
         base = lambda k: k.split("<")[0]                                     # k_ingest<4> -> k_ingest
         dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
-        per_batch = 2 if (not bulk_chain and dom in ("k_insert", "k_alloc")) else 1        # the batch chain runs these twice per batch (points, voxels)
-        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], per_batch * n_batches, bulk_chain and args.coalesce)))
+        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, bulk_chain and args.coalesce)))
         bytes_per_launch = per_ingest[dom] / active
         avg_ms = prof_c[dom_full][1] / active
         traffic, traffic_src = None, None
-        for tname in ("traffic_r02.json", "traffic_r01.json"):               # rocprofv3 --pmc passes of THIS command, folded by tools/summarize_profile.py
+        for tname in ("traffic_r03.json", "traffic_r02.json"):               # rocprofv3 --pmc passes of THIS command, folded by tools/fold_profiles.py
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and dom in json.load(open(tpath)):
                 traffic, traffic_src = json.load(open(tpath)).get(dom), "profiles/" + tname
@@ -277,7 +311,12 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
-                    "moved_points": moved, "placed_by_k_place": placed, "voxels_by_k_place": place_voxels}
+                    "measured_with": "HIP events on one stream (overlap off); rocprof_overlap_on = the same kernel in the headline configuration",
+                    "rocprof_overlap_on": rocprof.get(dom_full) or rocprof.get(dom),
+                    "moved_points": moved, "new_voxels": new_voxels, "per_kernel_algorithmic_bytes_per_ingest": per_ingest,
+                    "placed_by_k_place": placed, "voxels_by_k_place": place_voxels}
+        if rocprof:
+            kernels["_rocprof_overlap_on"] = {k: v for k, v in rocprof.items() if k.startswith(("k_", "r_"))}
 
     # ---- loader row: LAS format-2 records (26 B) -> Points (16 B) on the device, one 1 M-point batch ----
     loader = None
@@ -381,6 +420,25 @@ def main():
                     del h1
                 cpu["config1_reference_B0"] = {"what": "BASELINE config 1 (1 M uniform points, single batch, 512x512 plain frame), 1 thread: oracle/_ref = the reference's .cu files "
                                                        "compiled as host C++ (clang -O2) vs the restatement", "kind": "reference", **res}
+                # ... and on a prefix of THIS workload (its list walks are quadratic in a leaf's chunk count: the whole 36 M would take hours)
+                mb0 = min(args.b0_points, n_points)
+                if mb0 > 0:
+                    hb = oracle.HostOctree("ref", persistent_bytes=4 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+                    ub = abi.make_uniforms(W, H, T, box, persistent_capacity=4 << 30, momentary_capacity=oracle.REF_MOMENTARY_BYTES, hqs=True)
+                    hb.reset(ub)
+                    tb, done = 0.0, 0
+                    for i in range(0, mb0, batch):                               # batch by batch, as long as 25 s allow
+                        hb.upload(pts[i:i + batch])
+                        t0 = time.perf_counter()
+                        hb.construct(ub)
+                        tb += time.perf_counter() - t0
+                        done = min(i + batch, mb0)
+                        if tb > 25.0:
+                            break
+                    cpu["workload_prefix_reference_B0"] = {"kind": "reference", "value": done / tb / 1e6, "unit": "M points/s inserted", "cores": 1,
+                                                           "sample": f"first {done} points ({(done + batch - 1) // batch} batches, one per kernel_construct call) of the same terrain through oracle/_ref "
+                                                                     f"(stopped after 25 s)" if done < mb0 else f"all {done} points of the same terrain through oracle/_ref, one batch per kernel_construct call", "seconds": tb}
+                    del hb
         except Exception as e:                     # the baseline must never take the bench down
             cpu["config1_reference_B0"] = {"error": repr(e)}
         finally:
@@ -427,8 +485,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+u32 (fp32 quantise/project, fp64 pixel coordinate, integer octree/atomics)", "data": "synthetic",
             "ingest_mode": "coalesced" if args.coalesce else "exact",
-            "config": {"workload": f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M "
-                                   f"ring batches resident in HBM, reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
+            "config": {"workload": (f"BASELINE config 4 shape: tiled fractal terrain, {n_points} device-generated XYZRGBA points (16 B) per GPU, resident in HBM, "
+                                    f"STREAMED through the 50-slot ring ({n_batches} x 1M batches: uploader stream + back-pressure, main_progressive_octree.cpp:1005-1050), "
+                                    if source is not None else
+                                    f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M ring batches resident in HBM, ") +
+                                   f"reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
                                    f"(<= 20 batches and <= 10 ms each, Stats read back between launches); "
                                    f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order if not use_dist else "device-generated tiles, swath order",
                        "parallelism": f"one global cube, level-3 cells dealt to {world} rank(s) by point count"},

@@ -63,10 +63,13 @@ def exchange_points(points, owners, group=None):
 
 def cell_codes(points, box_size, level):
     """Level-`level` cell code (x<<2|y<<1|z per level, as cell_of) of every 16-byte record of a torch tensor, on the tensor's
-    device (CUDA for RCCL jobs, CPU under gloo): the builder's quantisation X = uint32(2^20 * p / size), boxMin = 0."""
+    device (CUDA for RCCL jobs, CPU under gloo): the builder's quantisation X = uint32((2^20 * p) / size), boxMin = 0, bits 19..0 —
+    so that every rank receives exactly the points the builder files under the cells it owns (also on cell boundaries and the max faces)."""
     xyz = points.reshape(-1, 16)[:, :12].contiguous().view(torch.float32).reshape(-1, 3)
-    size = float(np.float32(max(box_size)))
-    q = (xyz * (float(2 ** 20) / size)).to(torch.int64).clamp_(0, 2 ** 20 - 1)
+    size = torch.tensor(float(np.float32(max(box_size))), dtype=torch.float32, device=points.device)
+    # exactly the builder's arithmetic (simlod_device.hpp quantize / child_index): (2^20 * p) / size in fp32, left to right, truncated
+    # (negative -> 0 as v_cvt_u32_f32 saturates), and only bits 19..0 are looked at — a coordinate on the max face wraps to cell 0
+    q = ((xyz * torch.tensor(float(2 ** 20), dtype=torch.float32, device=points.device)) / size).clamp_(min=0.0).to(torch.int64) & (2 ** 20 - 1)
     code = torch.zeros(q.shape[0], dtype=torch.int64, device=points.device)
     for lv in range(level):
         s = 19 - lv

@@ -327,6 +327,40 @@ class DeviceOctree:
                                   f"memCapacityReached={int(st['memCapacityReached'])})")
         return launches
 
+    def stream(self, uniforms, source, num_points, batch=abi.MAX_BATCH_SIZE):
+        """Feed `num_points` 16-byte records that are RESIDENT on the device (`source`: uint8 tensor) through the ring the way the reference
+        host does (main_progressive_octree.cpp:1005-1050, :364-428): an uploader fills free ring slots on its own stream — copy, then
+        batchSizes[slot], then numBatchesUploaded, in stream order — but never runs more than a ring ahead of what the host has seen
+        processed (back-pressure, :1012); every frame launches kernel_construct once (<= 20 batches, <= 10 ms) and reads Stats back.
+        Returns the number of launches.  Arbitrarily long inputs go through 50 slots."""
+        nb = (num_points + batch - 1) // batch
+        base = self.uploaded_host
+        main = torch.cuda.current_stream()
+        src = source.reshape(-1)
+        uploaded, processed, launches = 0, 0, 0
+        while processed < nb:
+            if uploaded < nb and uploaded - processed < self.ring_slots:
+                with torch.cuda.stream(self.upload_stream):
+                    while uploaded < nb and uploaded - processed < self.ring_slots:
+                        slot = (base + uploaded) % abi.BATCH_STREAM_SIZE
+                        n = min(batch, num_points - uploaded * batch)
+                        self.ring[slot * abi.MAX_BATCH_SIZE * 16: slot * abi.MAX_BATCH_SIZE * 16 + n * 16].copy_(src[uploaded * batch * 16: (uploaded * batch + n) * 16], non_blocking=True)
+                        self.batch_sizes[slot: slot + 1].fill_(n)
+                        uploaded += 1
+                        self.num_uploaded.fill_(base + uploaded)
+                    published = self.upload_stream.record_event()
+                main.wait_event(published)        # (the frame that follows sees every batch published so far; the reference's sees whatever has arrived)
+            self.uploaded_host = base + uploaded
+            before = processed
+            self.construct(uniforms)
+            launches += 1
+            processed = self.processed() - base
+            if processed == before:
+                st = self.read_stats()
+                raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, memCapacityReached={int(st['memCapacityReached'])})")
+        self.processed_host = self.uploaded_host
+        return launches
+
     def add_points(self, uniforms, points, batch=abi.MAX_BATCH_SIZE):
         """Upload `points` batch by batch; ingest whenever the ring would overflow and at the end."""
         for i in range(0, len(points), batch):

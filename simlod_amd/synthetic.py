@@ -44,6 +44,11 @@ def _height(x, y, rng, box):
     return h * np.float32(box[2] * 0.9) + np.float32(box[2] * 0.02)
 
 
+def terrain_height(x, y, seed=7, box=(6000.0, 4000.0, 400.0)):
+    """Height of terrain()/terrain_scan()'s surface (same seed) at one position: where a camera preset should look."""
+    return float(_height(np.asarray([x], dtype=np.float32), np.asarray([y], dtype=np.float32), np.random.RandomState(seed + 1), np.asarray(box, dtype=np.float64))[0])
+
+
 def terrain(n=36_000_000, seed=7, box=(6000.0, 4000.0, 400.0), tile=250.0, chunk=4_000_000):
     """Stand-in for Morro Bay (BASELINE config 2/3): a fractal height field over a 6 km x 4 km x 0.4 km box,
     emitted swath by swath (serpentine tiles of `tile` metres with uneven density) so that a 1 M-point batch is
