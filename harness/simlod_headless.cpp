@@ -320,8 +320,9 @@ int main(int argc, char** argv) {
 
 	// SIMLOD_HARNESS_PINNED=1: the point array itself is page-locked, as if the loader threads had already read every batch into its
 	// pinned slot (main.cpp:846-935) — the uploader then issues the H2D copy straight from it and the staging memcpy disappears.
-	const bool sourcePinned = std::getenv("SIMLOD_HARNESS_PINNED") != nullptr && points.size() > 0 &&
-	                          hipHostRegister(points.data(), points.size() * sizeof(Point), hipHostRegisterDefault) == hipSuccess;
+	const bool sourcePinned = std::getenv("SIMLOD_HARNESS_PINNED") != nullptr &&
+	                          ((points.size() > 0 && hipHostRegister(points.data(), points.size() * sizeof(Point), hipHostRegisterDefault) == hipSuccess) ||
+	                           (lasRecords.size() > 0 && hipHostRegister(lasRecords.data(), lasRecords.size(), hipHostRegisterDefault) == hipSuccess));
 
 	// ---- spawnUploader (main.cpp:963-1063): ITS OWN THREAD, its own stream.  It publishes batchSizes[slot] and numBatchesUploaded
 	// with stream-ordered memsets WHILE kernel_construct launches run on the frame thread's stream; the frame thread
@@ -347,8 +348,9 @@ int main(int argc, char** argv) {
 			if (isLas) {
 				// the loader thread's job shrinks to moving bytes: raw records -> pinned slot -> device, decoded into the ring slot there
 				const size_t bytes = (size_t)count * lasBytesPerPoint;
-				std::memcpy(pinned[slot], lasRecords.data() + first * lasBytesPerPoint, bytes);
-				cuMemcpyHtoDAsync(lasStage[slot], pinned[slot], bytes, stream_upload);
+				const void* src = lasRecords.data() + first * lasBytesPerPoint;
+				if (!sourcePinned) { std::memcpy(pinned[slot], src, bytes); src = pinned[slot]; }
+				cuMemcpyHtoDAsync(lasStage[slot], src, bytes, stream_upload);
 				simlod_decode_las((const void*)(uintptr_t)lasStage[slot], count, lasBytesPerPoint, lasFormat, lasScale, lasOffset,
 				                  (SimlodPoint*)(uintptr_t)cptr_points_ring[uploadRingIndex], (void*)stream_upload);
 			} else {

@@ -166,6 +166,11 @@ int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPer
  * surface over all tiles; a pure function of (seed, index), so every rank of a multi-GPU job can generate any part of the stream. */
 int simlod_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed,
                             uint32_t tilesX, const float tileExtent[3], void* stream);
+/* The same stream with flight lines: inside a tile the points come in strips of `swathWidth` metres (along x), each strip row by row —
+ * what an airborne scanner with a finite swath writes (BASELINE config 3's stand-in file; simlod_amd/synthetic.terrain_scan is the host
+ * twin).  swathWidth <= 0 or >= the tile's width: one strip, i.e. simlod_generate_terrain. */
+int simlod_generate_terrain_scan(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed,
+                                 uint32_t tilesX, const float tileExtent[3], float swathWidth, void* stream);
 
 /* Version / build info string (static storage). */
 const char* simlod_build_info(void);

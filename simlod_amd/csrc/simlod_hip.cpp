@@ -255,7 +255,12 @@ uint64_t simlod_colorfilter_buffer_min_bytes(void) { return colorfilter_min_byte
 
 int simlod_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
                             const float tileExtent[3], void* stream) {
-	return launch_generate_terrain(out, numPoints, firstIndex, pointsPerTile, seed, tilesX, tileExtent, (hipStream_t)stream);
+	return launch_generate_terrain(out, numPoints, firstIndex, pointsPerTile, seed, tilesX, tileExtent, 0.0f, (hipStream_t)stream);
+}
+
+int simlod_generate_terrain_scan(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
+                                 const float tileExtent[3], float swathWidth, void* stream) {
+	return launch_generate_terrain(out, numPoints, firstIndex, pointsPerTile, seed, tilesX, tileExtent, swathWidth, (hipStream_t)stream);
 }
 
 int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms, SimlodNode* nodes, uint32_t* colorbuffer,

@@ -153,7 +153,7 @@ int launch_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPer
 int launch_colorfilter(const SimlodUniforms* u, uint32_t* buffer, SimlodNode* nodes, const uint32_t* numNodes, SimlodStats* stats, hipStream_t stream);
 uint64_t colorfilter_min_bytes(uint32_t nodeCapacity);
 int launch_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
-                            const float tileExtent[3], hipStream_t stream);
+                            const float tileExtent[3], float swathWidth, hipStream_t stream);
 enum : uint32_t { RENDER_FIRST = 1u, RENDER_COLOR = 2u, RENDER_RESOLVE = 4u, RENDER_OUTPUT = 8u, RENDER_ALL = 15u };
 int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
                   uint64_t* frameStart, hipStream_t stream, uint32_t parts);

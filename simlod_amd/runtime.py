@@ -66,6 +66,7 @@ def lib():
         L.simlod_launch_colorfilter.argtypes = [vp] * 6
         L.simlod_colorfilter_buffer_min_bytes.restype = u64
         L.simlod_generate_terrain.argtypes = [vp, u64, u64, u64, u32, u32, ctypes.POINTER(ctypes.c_float), vp]
+        L.simlod_generate_terrain_scan.argtypes = [vp, u64, u64, u64, u32, u32, ctypes.POINTER(ctypes.c_float), ctypes.c_float, vp]
         _lib = L
     return _lib
 
@@ -77,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
     "simlod_octree_image_replaced",
-    "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
+    "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_generate_terrain_scan", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 
 
@@ -228,13 +229,13 @@ class DeviceOctree:
         u, up = self._u(uu)
         _check(self.L.simlod_launch_colorfilter(up, self._p(self.render_buffer), self._p(self.nodes), None, self._p(self.stats), self._stream()), "colorfilter kernel")
 
-    def generate_terrain(self, out, first_index, points_per_tile, seed, tiles_x, tile_extent):
+    def generate_terrain(self, out, first_index, points_per_tile, seed, tiles_x, tile_extent, swath_width=0.0):
         """BASELINE config 4's input made on the device: points first_index .. first_index + len(out)/16 - 1 of the tiled-terrain stream
-        into the uint8 device tensor `out` (simlod_generate_terrain)."""
+        into the uint8 device tensor `out` (simlod_generate_terrain; with swath_width > 0: in flight lines of that width, simlod_generate_terrain_scan)."""
         n = out.numel() // 16
         ext = (ctypes.c_float * 3)(*[float(v) for v in tile_extent])
-        _check(self.L.simlod_generate_terrain(self._p(out), ctypes.c_uint64(n), ctypes.c_uint64(first_index), ctypes.c_uint64(points_per_tile),
-                                              ctypes.c_uint32(seed), ctypes.c_uint32(tiles_x), ext, self._stream()), "simlod_generate_terrain")
+        _check(self.L.simlod_generate_terrain_scan(self._p(out), ctypes.c_uint64(n), ctypes.c_uint64(first_index), ctypes.c_uint64(points_per_tile),
+                                                   ctypes.c_uint32(seed), ctypes.c_uint32(tiles_x), ext, ctypes.c_float(swath_width), self._stream()), "simlod_generate_terrain_scan")
 
     def construct(self, uniforms):
         u, up = self._u(uniforms)
