@@ -251,10 +251,8 @@ def main():
     # stream, so the voxel half does not overlap the next batch as it does in the headline run ("measured_with"); (2) the rocprofv3
     # kernel trace of the headline configuration (overlap on) that profiles/r03/ holds, when it is there ("rocprof_overlap_on").
     roofline, chain, kernels = None, None, {}
-    bulk_chain = args.coalesce or os.environ.get("SIMLOD_EXACT_CHAIN") == "bulk"
-    # measurement aids in the control block at byte 0 of the momentary buffer: construct_bulk.hip Ctl {spilledTotal, pendingTotal,
-    # placeVoxels} at byte 176; construct_batch.hip Ctl.expandNs[7] (stored points moved by splits) at byte 208
-    CTL_COUNTERS = slice(176, 200) if bulk_chain else slice(208, 216)
+    # measurement aid in the control block at byte 0 of the momentary buffer: construct.hip Ctl.expandNs[7] (stored points moved by splits) at byte 208
+    CTL_COUNTERS = slice(208, 216)
     if rank == 0 and not args.no_profile:
         L.simlod_profile_enable(1)
         dev.momentary[CTL_COUNTERS].zero_()
@@ -262,7 +260,6 @@ def main():
         prof_c = collect_profile(L)
         counters = [int(v) for v in dev.momentary[CTL_COUNTERS].cpu().numpy().view(np.uint64)]
         moved = counters[0]
-        placed, place_voxels = (counters[1], counters[2]) if bulk_chain else (0, 0)
         dev.render(u)
         prof_r = collect_profile(L)
         L.simlod_profile_enable(0)
@@ -275,7 +272,7 @@ def main():
         if os.path.exists(kpath):
             import csv
             for row in csv.DictReader(open(kpath)):
-                nm = row["Name"].split("(")[0].replace("void ", "").replace("simlod::batch::", "").replace("simlod::", "")
+                nm = row["Name"].split("(")[0].replace("void ", "").replace("simlod::build::", "").replace("simlod::", "")
                 rocprof[nm] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
         chain_ms = sum(ms for k, (n, ms) in prof_c.items())
         chain_bytes = 32.0 * my_points + 16.0 * new_voxels                 # 32 B/point + 16 B/new voxel
@@ -283,23 +280,16 @@ def main():
                  "frac": chain_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": ms_per_step, "algorithmic_bytes": chain_bytes,
                  "what": "whole kernel_construct chain over the headline's own ms_per_step (reset + launches + Stats readbacks included)",
                  "one_stream_event_pass_ms": chain_ms}
-        # Algorithmic bytes per kernel for one whole ingest.
-        #  batch chain: k_count reads every point (16 B); k_hist reads a moved point and writes it to the spill buffer (32 B; the samples of the
-        #    splitting leaves it also reads are not counted: lower bound); k_insert reads and stores every point, moved ones too (32 B);
-        #    k_voxelize reads every stored sample back (16 B; the cube words it loads and writes, ~40 KB per 8192 samples, are not counted) and
-        #    stores a voxel per new cell (16 B);  k_expand moves no bulk data (decisions from histograms, node records, chunk links);
-        #  bulk chain (coalesced mode): k_ingest reads every point, stores the ones it places itself and their voxels; k_place reads and stores
-        #    the samples of overflowing leaves and the moved points; k_voxelize reads them back twice and stores their voxels; k_expand reads a
-        #    moved point and writes it to the spill buffer plus one read of every waiting sample per split round (lower bound: one round).
-        if bulk_chain:
-            per_ingest = {"k_ingest": 16.0 * my_points + 16.0 * (my_points - placed) + 16.0 * (new_voxels - place_voxels), "k_place": 32.0 * (placed + moved),
-                          "k_voxelize": 32.0 * (placed + moved) + 16.0 * place_voxels, "k_expand": 32.0 * moved + 16.0 * placed}
-        else:
-            per_ingest = {"k_count": 16.0 * my_points, "k_hist": 32.0 * moved, "k_insert": 32.0 * (my_points + moved), "k_voxelize": 16.0 * (my_points + moved) + 16.0 * new_voxels}
+        # Algorithmic bytes per kernel for one whole ingest: k_count reads every point (16 B); k_hist reads a moved point and writes
+        # it to the spill buffer (32 B; the samples of the splitting leaves it also reads are not counted: lower bound); k_insert reads and stores
+        # every point, moved ones too (32 B); k_voxelize reads every stored sample back (16 B; the cube words it loads and writes, ~40 KB per 8192
+        # samples, are not counted) and stores a voxel per new cell (16 B); k_expand moves no bulk data (decisions from histograms, node records,
+        # chunk links).  The coalesced mode runs the same kernels on groups of batches.
+        per_ingest = {"k_count": 16.0 * my_points, "k_hist": 32.0 * moved, "k_insert": 32.0 * (my_points + moved), "k_voxelize": 16.0 * (my_points + moved) + 16.0 * new_voxels}
         base = lambda k: k.split("<")[0]                                     # k_ingest<4> -> k_ingest
         dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
         dom = base(dom_full)
-        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, bulk_chain and args.coalesce)))
+        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, args.coalesce)))
         bytes_per_launch = per_ingest[dom] / active
         avg_ms = prof_c[dom_full][1] / active
         traffic, traffic_src = None, None
@@ -313,8 +303,7 @@ def main():
                     "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
                     "measured_with": "HIP events on one stream (overlap off); rocprof_overlap_on = the same kernel in the headline configuration",
                     "rocprof_overlap_on": rocprof.get(dom_full) or rocprof.get(dom),
-                    "moved_points": moved, "new_voxels": new_voxels, "per_kernel_algorithmic_bytes_per_ingest": per_ingest,
-                    "placed_by_k_place": placed, "voxels_by_k_place": place_voxels}
+                    "moved_points": moved, "new_voxels": new_voxels, "per_kernel_algorithmic_bytes_per_ingest": per_ingest}
         if rocprof:
             kernels["_rocprof_overlap_on"] = {k: v for k, v in rocprof.items() if k.startswith(("k_", "r_"))}
 
@@ -472,7 +461,7 @@ def main():
             ok = int(st2["numPoints"]) == n_points and int(st2["dbg"]) == 0 and all(int(st2[k]) == int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels"))
             coalesced = {"value": n_points / (ms2 * 1e-3) / 1e6, "unit": "M points/s", "ms_per_step": ms2, "launches_per_step": l2 / args.steps, "momentary_mb": mb,
                          "same_octree_content_counts_as_exact": bool(ok),
-                         "what": "simlod_set_ingest_mode(1): all pending batches of a launch as one group (construct_bulk.hip); topology, multisets, bitsets and voxels "
+                         "what": "simlod_set_ingest_mode(1): the pending batches of a launch in groups (the same kernels, construct.hip); topology, multisets, bitsets and voxels "
                                  "equal the exact mode's, the allocator / chunk-pool counters of Stats do not"}
             del dev2
         finally:

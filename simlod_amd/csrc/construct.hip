@@ -36,10 +36,8 @@
 #include "simlod_internal.hpp"
 
 namespace simlod {
-namespace batch {
+namespace build {
 
-// Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
-// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
 // Per-batch state, one copy per parity of the batch's ordinal in the launch: the voxel half of batch b (library's side stream) still
 // reads its copy while k_count .. k_expand of batch b + 1 work on the other, and the last kernel of batch b on the caller's stream
 // (k_insert part 0) prepares the copy of batch b + 1 — which is the copy of batch b - 1, whose voxel half k_insert has waited for.
@@ -48,7 +46,10 @@ struct BatchCtl {
 	uint32_t ordinal, tag, slotsRound0, numSpilled;   // tag = batch index + 1 (NodeDir); slotsRound0: slots handed out by k_count's tail, snapshot by k_hist: k_expand's first round
 	uint32_t numWork, numClear, numTouched, allocDone;   // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_insert's allocation list) | allocation workgroups of k_insert that are done
 	uint32_t barrierCount, nodes, numVoxItems, numVoxSmall;   // nodes = Stats.numNodes after the batch's k_expand: the voxel half must not look at nodes the NEXT batch's k_expand is creating
-	uint32_t unused0, dirCount, pad0, pad1;
+	uint32_t groupBatches, dirCount, pad0, pad1;      // ring batches taken together: 1 in exact mode, up to groupMax in coalesced mode; batchSize = all their samples
+	uint32_t start[SIMLOD_MAX_BATCHES_PER_LAUNCH + 1];   // sample index of the first sample of batch k of the group (start[groupBatches] = batchSize)
+	uint32_t slot[SIMLOD_MAX_BATCHES_PER_LAUNCH];        // its ring slot
+	uint32_t pad3;
 	unsigned long long reserve;        // split slots << 52 | nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves all or nothing
 	unsigned long long pad2;
 };
@@ -58,7 +59,7 @@ struct BatchCtl {
 struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
 	uint32_t errors, abortBatch, rebuildLeafChunks, debugFlags;   // rebuildLeafChunks: this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
-	uint32_t processed, budgetUs, unused0[2];    // batches completed in this launch | the launch's time budget (voxels.cu:22 MAX_PROCESSING_TIME = 10 ms; SIMLOD_DEBUG_BUDGET_US overrides)
+	uint32_t processed, budgetUs, consumed, groupMax;   // groups completed in this launch | its time budget in us (voxels.cu:22: 10 ms; SIMLOD_DEBUG_BUDGET_US overrides) | ring batches taken so far | batches per group (1: exact mode)
 	uint64_t startNs;
 	uint32_t statCounters[8];
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
@@ -66,11 +67,12 @@ struct Ctl {
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
 	uint64_t unused1[4];
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
+	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 216: k_voxelize of group #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
+	uint64_t phaseNs[48];              // byte 696: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
 	BatchCtl batch[2];
-	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 408 + 384: k_voxelize of batch #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
-	uint64_t phaseNs[48];              // byte 408: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
+	uint32_t tagOf[SIMLOD_MAX_BATCHES_PER_LAUNCH];     // tag of group #ordinal of this launch (whoever closes a group's voxel lists later needs it: its parity copy is recycled by then)
 };
-static_assert(offsetof(Ctl, voxT) == 408 && offsetof(Ctl, phaseNs) == 408 + 480, "tools/probe.py reads Ctl.voxT at byte 408, Ctl.phaseNs behind it");
+static_assert(offsetof(Ctl, voxT) == 216 && offsetof(Ctl, phaseNs) == 696, "tools/probe.py reads Ctl.voxT at byte 216, Ctl.phaseNs at byte 696");
 static_assert(offsetof(Ctl, expandNs) == 152, "bench.py / tools read Ctl.expandNs at byte 152");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
@@ -86,7 +88,7 @@ struct BuildArgs {
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
 	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir;
-	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
 };
 
 
@@ -208,25 +210,37 @@ __device__ __forceinline__ unsigned long long voxel_half_slack(const BuildArgs& 
 	return (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + a.stats->numNodes + 1ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk));
 }
 
-// Make batch #ordinal of this launch current (in the copy of its parity), or leave it inactive (progressive_octree_voxels.cu:890-912).
+// Make group #ordinal of this launch current (in the copy of its parity), or leave it inactive (progressive_octree_voxels.cu:890-912).
+// Exact mode: a group is ONE ring batch, the reference's granularity.  Coalesced mode (simlod_set_ingest_mode(1)): the next groupMax
+// pending batches are counted, split, stored and voxelized as one; the memory guard is looked at once per group.
 __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	BatchCtl* bc = &ctl->batch[ordinal & 1u];
 	bc->active = 0;
-	if (ordinal >= ctl->numBatches || ctl->stop) return;
+	if (ordinal >= SIMLOD_MAX_BATCHES_PER_LAUNCH || ctl->consumed >= ctl->numBatches || ctl->stop) return;
 	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
 	if (ordinal > 0u && alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + voxel_half_slack(a, &ctl->batch[(ordinal - 1u) & 1u]) >= a.persCapacity) { ctl->stop = 1; return; }
 	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
 	a.stats->memCapacityReached = full ? 1 : 0;
 	if (full) { ctl->stop = 1; return; }
 	const uint32_t batchIndex = a.stats->batchletIndex;
-	const uint32_t slot = batchIndex % SIMLOD_BATCH_STREAM_SIZE;
-	uint32_t size = a.batchSizes[slot];
-	if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
+	const uint32_t take = min(ctl->groupMax, ctl->numBatches - ctl->consumed);
+	uint32_t total = 0;
+	for (uint32_t k = 0; k < take; k++) {
+		const uint32_t slot = (batchIndex + k) % SIMLOD_BATCH_STREAM_SIZE;
+		uint32_t size = a.batchSizes[slot];
+		if (size > SIMLOD_MAX_BATCH_SIZE) size = SIMLOD_MAX_BATCH_SIZE;
+		bc->start[k] = total; bc->slot[k] = slot;
+		total += size;
+	}
+	bc->start[take] = total;
+	ctl->consumed += take;
+	bc->groupBatches = take;
 	bc->batchIndex = batchIndex;
-	bc->ringSlot = slot;
-	bc->batchSize = size;
+	bc->ringSlot = bc->slot[0];
+	bc->batchSize = total;
 	bc->ordinal = ordinal;
 	bc->tag = batchIndex + 1u;
+	ctl->tagOf[ordinal] = bc->tag;
 	bc->slotsRound0 = 0;
 	bc->numSpilled = 0;
 	bc->numWork = 0;
@@ -242,8 +256,26 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	bc->active = 1;
 }
 
+// The samples of the current group: batch k of the group holds samples [start[k], start[k + 1]) in its ring slot (a batch holds at most
+// 1 000 000 samples, so batch i / 1 000 000 is the first candidate).  Exact mode — one batch per group — is a plain array.
+// (SINGLE: the kernel was launched for exact mode — the host knows — and carries no trace of the group lookup)
+template <bool SINGLE>
+struct Samples {
+	const float4* ring; const float4* only; const BatchCtl* bc; uint32_t batches;
+	__device__ __forceinline__ Samples(const BuildArgs& a, const BatchCtl* b) : ring(reinterpret_cast<const float4*>(a.ring)), bc(b), batches(b->groupBatches) {
+		only = ring + (size_t)b->ringSlot * SIMLOD_MAX_BATCH_SIZE;
+	}
+	__device__ __forceinline__ const float4* ptr(uint32_t i) const {
+		if (SINGLE || batches == 1u) return only + i;
+		uint32_t k = min(i / SIMLOD_MAX_BATCH_SIZE, batches - 1u);
+		while (k + 1u < batches && i >= bc->start[k + 1u]) k++;
+		return ring + (size_t)bc->slot[k] * SIMLOD_MAX_BATCH_SIZE + (i - bc->start[k]);
+	}
+	__device__ __forceinline__ float4 operator[](uint32_t i) const { return *ptr(i); }
+};
+
 // ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
-__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs) {
+__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs, uint32_t groupMax) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
 	const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
@@ -251,6 +283,8 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	ctl->stop = (momentaryTooSmall || fatal) ? 1u : 0u;
 	ctl->abortBatch = 0;
 	ctl->processed = 0;
+	ctl->consumed = 0;
+	ctl->groupMax = groupMax;
 	ctl->debugFlags = debugFlags;
 	ctl->budgetUs = budgetUs != 0u ? budgetUs : (uint32_t)(SIMLOD_MAX_PROCESSING_MS * 1000.0f);
 	ctl->startNs = wall_ns();
@@ -480,7 +514,7 @@ static constexpr uint32_t CROSS_CAP = 128;         // leaves one workgroup can s
 
 static constexpr uint32_t TOUCH_CAP = 512;         // leaves one workgroup can be the first to touch in one batch (more: appended one by one)
 
-template <uint32_t BT>
+template <uint32_t BT, bool SINGLE>
 __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	constexpr uint32_t CPB = BT * CPT;
 	Ctl* ctl = ctl_of(a);
@@ -491,7 +525,7 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	__shared__ uint2 sh_touch[TOUCH_CAP];
 	__shared__ uint32_t sh_numCross, sh_numTouch, sh_touchBase;
 	const uint32_t n = bc->batchSize;
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const Samples<SINGLE> pts(a, bc);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	uint2* touched = at<uint2>(a, a.offTouched);           // {leaf, points it held when the batch began}
 	const uint32_t numChunks = (n + CPB - 1) / CPB;
@@ -714,6 +748,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 // (voxels.cu:253-289) — then the batch's samples.  Whatever lies in a queued leaf is added to the leaf's histogram (per workgroup in LDS
 // first, one global add per workgroup and bin) and its cached-leaf word is relabelled FLAG | slot | bin.  Exits at once when k_count
 // queued nothing.
+template <bool SINGLE>
 __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
@@ -727,7 +762,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const Samples<SINGLE> pts(a, bc);
 	const uint32_t n = bc->batchSize;
 	const uint32_t tag = bc->ordinal + 1u;
 	const uint32_t moved = min(bc->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
@@ -761,7 +796,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 			if (v[j] == NONE) continue;
 			const uint32_t e = chunk * CPB + j * TPB + threadIdx.x;
 			const unsigned long long info = slotOf[v[j]];
-			if ((uint32_t)(info >> 32) == tag) { ent[j] = (uint32_t)info; src[j] = pts + (e - moved); dst[j] = e - moved; }
+			if ((uint32_t)(info >> 32) == tag) { ent[j] = (uint32_t)info; src[j] = pts.ptr(e - moved); dst[j] = e - moved; }
 		}
 		float4 p[CPT];
 #pragma unroll
@@ -771,7 +806,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 			if (ent[j] == NONE) continue;
 			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
 			const uint32_t key = ((ent[j] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[j] >> 16);
-			if (v[j] == NONE) { spilled[dst[j]] = p[j]; leafOf[SIMLOD_MAX_BATCH_SIZE + dst[j]] = LEAF_FLAG | key; }      // a stored point moves
+			if (v[j] == NONE) { spilled[dst[j]] = p[j]; leafOf[a.groupCap + dst[j]] = LEAF_FLAG | key; }      // a stored point moves
 			else leafOf[dst[j]] = LEAF_FLAG | key;
 			add(key);
 		}
@@ -860,7 +895,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	uint32_t* map = at<uint32_t>(a, a.offMap);        // (not the histogram's words: other workgroups may still be peeking at those)
 	const float4* spilled = at<const float4>(a, a.offSpilled);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const Samples<false> pts(a, bc);
 	const uint32_t n = bc->batchSize;
 	uint32_t generation = 0;
 
@@ -887,7 +922,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 #pragma unroll
 				for (uint32_t q = 0; q < U; q++) {
 					const uint32_t t = first + q * stride;
-					idx[q] = t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n);
+					idx[q] = t < n ? t : a.groupCap + (t - n);
 					v[q] = t < total ? leafOf[idx[q]] : 0u;
 				}
 #pragma unroll
@@ -1360,7 +1395,7 @@ __device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
 	if (ctl->abortBatch) { ctl->stop = 1; }                   // scratch overflow: this batch is lost, report through Stats.dbg
 	else {
 		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
-		a.stats->batchletIndex += 1;
+		a.stats->batchletIndex += bc->groupBatches;
 		a.stats->numPointsProcessed += bc->batchSize;
 		ctl->processed += 1;
 		ctl->expandNs[7] += min(bc->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
@@ -1640,7 +1675,7 @@ __device__ void voxdone_nodes(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32
 __global__ __launch_bounds__(TPB) void k_voxdone(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (ctl->processed == 0u || ctl->abortBatch) return;
-	voxdone_nodes(a, ctl, a.stats->batchletIndex, min(a.stats->numNodes, a.nodeCapacity), blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB);   // (tag of the last batch = its index + 1)
+	voxdone_nodes(a, ctl, ctl->tagOf[ctl->processed - 1u], min(a.stats->numNodes, a.nodeCapacity), blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB);   // (the launch's last group)
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -1656,6 +1691,7 @@ struct InsertShared {
 // k_expand).  In steps: (1) everybody counts its samples per leaf in an LDS table — a relabelled sample finds its leaf in its slot's map —
 // (2) reserves one slot range per (workgroup, leaf) with one global atomic each, (3) stores: the slot inside the range comes from an
 // LDS cursor.  Barriers are paid per workgroup, not per chunk.
+template <bool SINGLE>
 __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
@@ -1667,7 +1703,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 	__shared__ InsertShared sh;
 	const uint32_t n = bc->batchSize;
 	const uint32_t total = n + min(bc->numSpilled, a.spilledCap);
-	const float4* pts = reinterpret_cast<const float4*>(a.ring + (size_t)bc->ringSlot * SIMLOD_MAX_BATCH_SIZE);
+	const Samples<SINGLE> pts(a, bc);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
 	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
@@ -1686,7 +1722,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 			constexpr uint32_t DONE_WGS = 32;
 			const uint32_t back = gridDim.x - 1u - blockIdx.x;
 			if (back >= 1u && back <= DONE_WGS && bc->ordinal != 0u)
-				voxdone_nodes(a, ctl, tag - 1u, min(a.stats->numNodes, a.nodeCapacity), (back - 1u) * TPB + threadIdx.x, DONE_WGS * TPB);
+				voxdone_nodes(a, ctl, ctl->tagOf[bc->ordinal - 1u], min(a.stats->numNodes, a.nodeCapacity), (back - 1u) * TPB + threadIdx.x, DONE_WGS * TPB);
 		}
 		ph.mark(pb + 0);
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
@@ -1708,7 +1744,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 #pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-				v[j] = t < total ? leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] : NONE;
+				v[j] = t < total ? leafOf[t < n ? t : a.groupCap + (t - n)] : NONE;
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
@@ -1718,7 +1754,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 				if ((e & MAP_LISTED) != 0u) e = at<const SlotRec>(a, a.offSlots)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
 				v[j] = e;
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-				leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)] = e;
+				leafOf[t < n ? t : a.groupCap + (t - n)] = e;
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
@@ -1752,7 +1788,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 			for (uint32_t j = 0; j < PPT; j++) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				if (t >= total) continue;
-				const uint32_t leafIdx = leafOf[t < n ? t : SIMLOD_MAX_BATCH_SIZE + (t - n)];
+				const uint32_t leafIdx = leafOf[t < n ? t : a.groupCap + (t - n)];
 				const int e = table_find(sh.tbl, leafIdx);
 				uint32_t slot, base, first;
 				if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
@@ -1826,7 +1862,7 @@ __global__ void k_finish(BuildArgs a, uint32_t fits) {
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-bool layout_construct(BuildArgs& a, uint64_t capacity) {
+bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce) {
 	a.dirCap = 2 * a.nodeCapacity + 65536;
 	uint64_t off = 4096;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
@@ -1848,16 +1884,22 @@ bool layout_construct(BuildArgs& a, uint64_t capacity) {
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	a.voxItemCap = min(a.nodeCapacity + 2u * VOX_BIG_ITEMS, 1u << 20);         // VOX_BIG_ITEMS pieces + small items: a leaf has one more than its new samples / 128, and 65 536 x 128 = 8 M samples
 	a.offVoxItems = off; off += align_up(2ull * a.voxItemCap * sizeof(VoxItem), 256);   // (two copies, by batch parity)
-	// what is left is shared by the per-sample arrays: the 4-byte cached-leaf word of batch and moved samples, 16 B per moved point
+	// what is left is shared by the per-sample arrays: the 4-byte cached-leaf word of the group's and of the moved samples, 16 B per moved point.
+	// Exact mode: a group is one ring batch.  Coalesced mode: as many batches per group (up to 20) as leave room for a million moved points
+	// per batch (with the reference host's 300 MB that is 2-3 batches; the mode wants ~700 MB for groups of 20).
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 4;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
+	a.groupMax = 1; a.groupCap = SIMLOD_MAX_BATCH_SIZE;
 	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
-	uint64_t cap = (capacity - off - perBatch - fixedWork - 4096) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
-	if (cap > 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE) cap = 0x7fffffffull - SIMLOD_MAX_BATCH_SIZE;
+	const uint64_t freeBytes = capacity - off - fixedWork - 4096;
+	if (coalesce) a.groupMax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(SIMLOD_MAX_BATCHES_PER_LAUNCH, freeBytes / (perBatch + 20ull * SIMLOD_MAX_BATCH_SIZE)));
+	a.groupCap = a.groupMax * SIMLOD_MAX_BATCH_SIZE;
+	uint64_t cap = (freeBytes - a.groupMax * perBatch) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
+	if (cap > 0x7fffffffull - a.groupCap) cap = 0x7fffffffull - a.groupCap;
 	a.spilledCap = (uint32_t)cap;
 	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 moved points + one partial chunk per split
 	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
-	a.offLeafOf = off;   off += align_up(((uint64_t)SIMLOD_MAX_BATCH_SIZE + a.spilledCap) * 4, 256);
+	a.offLeafOf = off;   off += align_up(((uint64_t)a.groupCap + a.spilledCap) * 4, 256);
 	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
 	a.scratchBytes = off;
 	return off <= capacity;
@@ -1898,7 +1940,8 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.persCapacity = u->persistentBufferCapacity;
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = node_capacity();
-	const bool fits = layout_construct(a, u->momentaryBufferCapacity);
+	const bool coalesce = ingest_mode() != 0u;
+	const bool fits = layout_construct(a, u->momentaryBufferCapacity, coalesce);
 	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
 		note_leaf_table(LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
@@ -1908,7 +1951,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 
 	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(stats));
 	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u) | (tune("SIMLOD_DEBUG_VOXELIZE_CLOCK", 0) != 0 ? 2u : 0u),
-	              (uint32_t)std::max(0, tune("SIMLOD_DEBUG_BUDGET_US", 0)));
+	              (uint32_t)std::max(0, tune("SIMLOD_DEBUG_BUDGET_US", 0)), a.groupMax);
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
 		if (e != hipSuccess) return (int)e;
@@ -1921,7 +1964,8 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// (with the previous batch's voxel half running beside it on the side stream: one per FOUR CUs — 256: 8.3 ms per ingest, 128: 7.8,
 		// 96: 7.5, 64: 7.2, 48: 7.3, 32: 7.5)
 		const bool overlap = tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled();
-		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
+		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
+		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		// The VOXEL HALF of a batch — k_voxelize, then k_alloc / k_insert part 1: ~80 us + three kernel boundaries — touches nothing the next
 		// batch's k_count and k_expand read or write (occupancy grids of nodes that are already inner, voxel chunks, numVoxels*, the
@@ -1939,14 +1983,21 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
 		const int countTpb = tune("SIMLOD_COUNT_TPB", 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
-		for (uint32_t b = 0; b < limit; b++) {
-			if (countTpb == 1024) SIMLOD_LAUNCH(k_count<1024>, dim3(gridPoints / 4), dim3(1024), stream, a, b);
-			else if (countTpb == 512) SIMLOD_LAUNCH(k_count<512>, dim3(gridPoints / 2), dim3(512), stream, a, b);
-			else SIMLOD_LAUNCH(k_count<TPB>, dim3(gridPoints), dim3(TPB), stream, a, b);
-			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a, b);
+		const bool single = a.groupMax == 1u;
+		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
+		for (uint32_t b = 0; b < numGroups; b++) {
+			if (single) {
+				if (countTpb == 256) SIMLOD_LAUNCH((k_count<TPB, true>), dim3(gridPoints), dim3(TPB), stream, a, b);
+				else SIMLOD_LAUNCH((k_count<512, true>), dim3(gridPoints / 2), dim3(512), stream, a, b);
+				SIMLOD_LAUNCH(k_hist<true>, dim3(gridPoints), dim3(TPB), stream, a, b);
+			} else {
+				SIMLOD_LAUNCH((k_count<512, false>), dim3(gridPoints / 2), dim3(512), stream, a, b);
+				SIMLOD_LAUNCH(k_hist<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
+			}
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
-			SIMLOD_LAUNCH(k_insert, dim3(gridPoints), dim3(TPB), stream, a, b);                 // grid clears, points, end-of-batch bookkeeping
+			if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), stream, a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
+			else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
 			hipStream_t tail = stream;
 			if (side != nullptr) {
 				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
@@ -1955,7 +2006,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, b);
 			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
 		}
-		if (side != nullptr && limit > 0 && hipStreamWaitEvent(stream, side->tailDone[limit - 1], 0) != hipSuccess) return (int)hipGetLastError();
+		if (side != nullptr && numGroups > 0 && hipStreamWaitEvent(stream, side->tailDone[numGroups - 1], 0) != hipSuccess) return (int)hipGetLastError();
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
@@ -1970,9 +2021,9 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 uint64_t construct_min_bytes() {
 	BuildArgs a{};
 	a.nodeCapacity = node_capacity();
-	layout_construct(a, 0);
+	layout_construct(a, 0, false);
 	return a.scratchBytes + 4096 + 26ull * 65536;   // the smallest capacity layout_construct accepts, plus a page of slack
 }
 
-}  // namespace batch
+}  // namespace build
 }  // namespace simlod

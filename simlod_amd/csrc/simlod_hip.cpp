@@ -196,14 +196,7 @@ uint64_t simlod_render_framebuffer_offset(void) {
 
 uint64_t simlod_render_buffer_bytes(uint32_t width, uint32_t height) { return render_buffer_bytes(width, height); }
 
-// exact mode runs the batch chain (construct_batch.hip) unless SIMLOD_EXACT_CHAIN=bulk asks for the bulk chain one batch at a time
-static bool use_bulk_chain() {
-	if (ingest_mode() != 0u) return true;
-	const char* v = std::getenv("SIMLOD_EXACT_CHAIN");
-	return v != nullptr && std::strcmp(v, "bulk") == 0;
-}
-
-uint64_t simlod_construct_buffer_min_bytes(void) { return use_bulk_chain() ? bulk::construct_min_bytes() : batch::construct_min_bytes(); }
+uint64_t simlod_construct_buffer_min_bytes(void) { return build::construct_min_bytes(); }
 
 int simlod_set_ingest_mode(uint32_t mode) {
 	if (mode > 1u) return (int)hipErrorInvalidValue;
@@ -235,10 +228,7 @@ int simlod_launch_construct(const SimlodUniforms* uniforms, SimlodPoint* points,
 	(void)cudaprint;
 	if (!uniforms || !points || !buffer || !buffer_persistent || !nodes || !stats || !frameStartTimestamp ||
 	    !numBatchesUploaded_volatile || !batchSizes) return (int)hipErrorInvalidValue;
-	return use_bulk_chain() ? bulk::launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp,
-	                                                 numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream)
-	                        : batch::launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp,
-	                                                  numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
+	return build::launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp, numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
 }
 
 int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double scale[3],

@@ -12,82 +12,13 @@ namespace simlod {
 static constexpr uint32_t CHUNK_QUEUE_CAPACITY = 1000000u;   // progressive_octree_voxels.cu:856
 static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octree_voxels.cu:847
 
-namespace bulk {   // construct_bulk.hip: the chain of the coalesced ingest mode
-
-// One entry of a split round's work list: the leaf that has to split, the eight node slots reserved for its children and — for
-// leaves that hold stored points (round 0 only: nodes created inside a cascade are empty) — where those points go in the spill buffer.
-struct SpillEntry {
-	uint32_t leaf, childBase, spillBase, stored;
-};
-
-// Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
-// (the recycle stack behind it, like the reference's chunkQueue, must survive between launches; so does the leaf chunk table).
-struct Ctl {
-	uint32_t uploaded, firstBatch, numBatches, stop;      // launch: snapshot of the upload counter, first batch, batches to take
-	uint32_t consumed;           // batches of this launch already ingested
-	uint32_t active;             // the current group exists
-	uint32_t ordinal;            // group number inside this launch (tags)
-	uint32_t batchIndex;         // Stats.batchletIndex of the group's first batch
-	uint32_t groupBatches;       // 1 in exact mode, up to 20 in coalesced mode
-	uint32_t groupPoints;
-	uint32_t numPending;         // samples waiting for the place pass (their leaf overflowed, or is the root, or the LDS table was full)
-	uint32_t numSpilling;        // round-0 list length (written by k_ingest, never modified by k_expand: stable early-exit test)
-	uint32_t dirUsed;            // chunks published in the hash directory by this group
-	uint32_t numVoxLeaves;       // leaves that k_place stored samples in: k_voxelize's work list
-	uint32_t errors, abortBatch, panic;
-	uint32_t barrierCount[2];    // one monotonic counter per k_expand launch of a group (round 0 | the later rounds)
-	uint32_t rebuildLeafChunks;  // this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer)
-	uint32_t roundSpill[2];      // list length of rounds >= 1: round r appends to roundSpill[r & 1]
-	uint32_t coalesce, debugFlags;
-	uint32_t nodesAtStart;       // Stats.numNodes when the group began
-	uint32_t treeModified;       // k_expand has started to build nodes in this group
-	uint64_t startNs;
-	uint32_t statCounters[8];
-	unsigned long long reserve;  // nodes in use << 32 | spill space in use — ONE word, so a split reserves both or neither
-	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
-	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
-	uint64_t spilledTotal;       // byte 176: measurement aid — stored points moved by splits since the host last cleared it (bench.py)
-	uint64_t pendingTotal;       // byte 184: samples that went through k_place (their leaf overflowed) ...
-	uint64_t placeVoxels;        // byte 192: ... and the voxels k_place created, since the host last cleared them
-	uint64_t expandNs[8];        // byte 200: k_expand phase times of workgroup 0 (hist, barrier, decide, barrier; rounds; calls)
-	uint32_t batchSize[SIMLOD_MAX_BATCHES_PER_LAUNCH], batchSlot[SIMLOD_MAX_BATCHES_PER_LAUNCH];
-	uint64_t tableSig;           // table_signature() of the Stats the table belongs to (k_finish)
-	uint64_t phaseNs[24];        // SIMLOD_PHASE_TIMERS=1 — wall time per phase summed over workgroups: k_ingest [0..7], k_place [8..15], k_voxelize [16..23]
-};
-static_assert(offsetof(Ctl, spilledTotal) == 176, "bench.py reads Ctl.spilledTotal at byte 176");
-static_assert(offsetof(Ctl, phaseNs) == 432, "tools/phases.py reads Ctl.phaseNs at byte 432");
-static_assert(sizeof(Ctl) <= 4096, "control block");
-
-struct BuildArgs {
-	SimlodPoint* ring;
-	uint8_t*     mom;
-	uint8_t*     pers;
-	SimlodNode*  nodes;
-	SimlodStats* stats;
-	uint64_t*    frameStart;
-	uint32_t*    numBatchesUploaded;
-	uint32_t*    batchSizes;
-	float        minx, miny, minz, size;
-	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSpillA, offSpillB, offSplitTag, offRetryTag, offEst, offPlacedTag, offParent, offPtStart, offVoxStart, offLeafChunks, offPaths, offHist, offDir,
-	             offPendIdx, offPendLeaf, offSpMeta, offSpilled, offVoxList;
-	uint32_t     nodeCapacity, spilledCap, pendCap, histCap, dirCap, groupMax, voxListCap;
-};
-
-bool layout_construct(BuildArgs& a, uint64_t capacity);
-int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
-                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
-uint64_t construct_min_bytes();
-
-}  // namespace bulk
-
-namespace batch {  // construct_batch.hip: exact mode, one ring batch at a time
+namespace build {  // construct.hip: kernel_construct — one ring batch at a time (exact mode) or groups of pending batches (coalesced mode)
 
 int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
                      SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
 uint64_t construct_min_bytes();
 
-}  // namespace batch
+}  // namespace build
 
 // The builder's leaf chunk table, as the rasteriser may use it (render.hip r_visible): row i holds the first chunks of node i's list in order (a leaf: points; an inner node: voxels).
 // The three stamp words live in the builder's control block on the device; the table describes the octree `nodes` as it is NOW only

@@ -56,14 +56,12 @@ def _oracle_render(nodes, nn, u):
     return fb, col, stats[0]
 
 
-@pytest.fixture(params=["batch", "bulk"])
+@pytest.fixture(params=["exact"])
 def chain(request):
-    """Exact mode runs the batch chain (construct_batch.hip); SIMLOD_EXACT_CHAIN=bulk runs the chain of the coalesced mode
-    (construct_bulk.hip) one batch at a time instead — it must be exactly as exact."""
-    if request.param == "bulk":
-        os.environ["SIMLOD_EXACT_CHAIN"] = "bulk"
+    """kernel_construct in exact mode (one ring batch at a time, the reference's granularity: every Stats counter after every batch is the
+    reference's).  The opt-in coalesced mode runs the same kernels on groups of batches; its contract is tested separately
+    (test_coalesced_ingest_builds_the_same_octree_content)."""
     yield request.param
-    os.environ.pop("SIMLOD_EXACT_CHAIN", None)
 
 
 # ---- construct ---------------------------------------------------------------------------------------------------------
@@ -1137,15 +1135,13 @@ def test_colorfilter_equals_the_reference_kernel_on_the_same_octree(built_libs, 
 
 
 # ---- the rasteriser reads chunk lists through the builder's chunk table ------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["batch", "bulk", "coalesced"])
+@pytest.mark.parametrize("mode", ["exact", "coalesced"])
 def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(built_libs, mode):
     """render.hip r_visible takes a visible node's chunk addresses from the builder's table (leaf rows: point chunks, inner rows: voxel
     chunks) while the table's stamp says it describes the octree as it is now.  After every drain of a growing octree, after a reset and
     a rebuild with other points in the same buffers, and for an image uploaded behind the builder's back: the frame equals the oracle's
     rasteriser on the same image, and equals the frame drawn with the table switched off (SIMLOD_RASTER_LEAF_TABLE=0)."""
     from simlod_amd.runtime import lib
-    if mode == "bulk":
-        os.environ["SIMLOD_EXACT_CHAIN"] = "bulk"
     box = (3000.0, 2000.0, 200.0)
     T = camera.lookat_transform((1.2 * box[0], -0.6 * box[1], 1.1 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
     try:
@@ -1194,7 +1190,6 @@ def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(b
         dev.upload_image(nodes, pers, nn)
         frames(f"{mode} uploaded image", False)
     finally:
-        os.environ.pop("SIMLOD_EXACT_CHAIN", None)
         os.environ.pop("SIMLOD_RASTER_LEAF_TABLE", None)
         lib().simlod_set_ingest_mode(0)
 

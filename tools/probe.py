@@ -58,7 +58,7 @@ for var in args.variants:
     step()
     torch.cuda.synchronize()
     dev.momentary[152:216].zero_()
-    dev.momentary[888:888 + 48 * 8].zero_()
+    dev.momentary[696:696 + 48 * 8].zero_()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -70,12 +70,12 @@ for var in args.variants:
     print(f"{var or 'default':60s} {ms:7.3f} ms/ingest  {args.points / ms / 1e3:7.0f} M pts/s  dbg={int(st['dbg'])} nodes={int(st['numNodes'])} | "
           f"k_expand wg0 per call us: H {c[0] / 1e3 / calls:5.1f} bar {c[1] / 1e3 / calls:5.1f} D {c[2] / 1e3 / calls:5.1f} bar2 {c[3] / 1e3 / calls:5.1f} "
           f"rounds/call {rounds / calls:4.2f} calls {int(c[6])}", flush=True)
-    vt = dev.momentary[408:888].cpu().numpy().view(np.uint64).reshape(20, 3).astype(np.float64)
+    vt = dev.momentary[216:696].cpu().numpy().view(np.uint64).reshape(20, 3).astype(np.float64)
     vt = vt[vt[:, 2] > 0]
     if len(vt):
         print(f"    k_voxelize of the last launch, us from the first workgroup in: last piece done {np.mean(vt[:, 1] - vt[:, 0]) / 1e3:5.1f} (max {np.max(vt[:, 1] - vt[:, 0]) / 1e3:5.1f}), "
               f"last wave out {np.mean(vt[:, 2] - vt[:, 0]) / 1e3:5.1f} (max {np.max(vt[:, 2] - vt[:, 0]) / 1e3:5.1f}); batches {len(vt)}")
-    ph = dev.momentary[888:888 + 48 * 8].cpu().numpy().view(np.uint64).astype(np.float64)
+    ph = dev.momentary[696:696 + 48 * 8].cpu().numpy().view(np.uint64).astype(np.float64)
     f = lambda lo, n, cnt: " ".join(f"{ph[lo + i] / 1e3 / max(ph[cnt], 1):5.1f}" for i in range(n))
     print(f"    us per call, one workgroup: k_count [main loop, flush, queue_split] {f(0, 3, 3)} | k_hist [loop, flush] {f(4, 2, 6)} | k_insert wg0 [alloc, clear, count, reserve, wait, store] {f(8, 6, 14)}"
           f" | k_insert last wg {f(16, 6, 22)} | k_voxelize wg0 per piece [item+path+chunks, cubes+samples, pass A, write-back, reserve+chunks, pass B, store] {f(24, 7, 31)}", flush=True)

@@ -10,6 +10,6 @@ counts = [i for i, r in enumerate(rows) if "k_count" in r["Kernel_Name"]]
 i0, i1 = counts[skip], counts[skip + 1]
 t0 = int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i1 + 1]:
-    name = r["Kernel_Name"].split("(")[0].replace("simlod::batch::", "").replace("void ", "")
+    name = r["Kernel_Name"].split("(")[0].replace("simlod::build::", "").replace("void ", "")
     print("%-14s q%-3s start %7.1f us  end %7.1f us  (%5.1f us)" % (name, r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                                (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
