@@ -34,6 +34,7 @@ struct FilterArgs {
 	const uint32_t* numNodesPtr;
 	uint32_t nodeCapacity;
 	float cubeSize, minx, miny, minz;
+	float octreeSizeX, octreeSizeY, octreeSizeZ;          // (boxMin + cubeSize) - boxMin per axis, colorfilter.cu:75-79
 	uint64_t offHeights, offGrids, offAccepted;
 };
 
@@ -77,9 +78,10 @@ __device__ void cf_sample(const FilterArgs& a, FilterShared& sh, const SimlodNod
 		if (chunk == nullptr) break;
 		const SimlodPoint p = chunk->points[pointIndex % SIMLOD_POINTS_PER_CHUNK];
 		// :116-128 — integer coordinate relative to the root at 2^24, then the node's 128-cell grid, then the child's 64-cell octant
-		const uint32_t pXf = (uint32_t)((16777216.0f * (p.x - a.minx)) / a.cubeSize);
-		const uint32_t pYf = (uint32_t)((16777216.0f * (p.y - a.miny)) / a.cubeSize);
-		const uint32_t pZf = (uint32_t)((16777216.0f * (p.z - a.minz)) / a.cubeSize);
+		// (divided per axis by octreeSize = (boxMin + cubeSize) - boxMin, colorfilter.cu:75-79, 117-119: not cubeSize itself when boxMin != 0 in fp32)
+		const uint32_t pXf = (uint32_t)((16777216.0f * (p.x - a.minx)) / a.octreeSizeX);
+		const uint32_t pYf = (uint32_t)((16777216.0f * (p.y - a.miny)) / a.octreeSizeY);
+		const uint32_t pZf = (uint32_t)((16777216.0f * (p.z - a.minz)) / a.octreeSizeZ);
 		const uint32_t sh17 = 17u - level;
 		const float pX = (float)((pXf >> sh17) % CF_SIDE), pY = (float)((pYf >> sh17) % CF_SIDE), pZ = (float)((pZf >> sh17) % CF_SIDE);
 		uint32_t voxelIndex = (uint32_t)(pX + pY * (float)CF_SIDE + pZ * (float)(CF_SIDE * CF_SIDE));
@@ -164,11 +166,12 @@ int launch_colorfilter(const SimlodUniforms* u, uint32_t* buffer, SimlodNode* no
 	const float bx = u->boxMax.x - u->boxMin.x, by = u->boxMax.y - u->boxMin.y, bz = u->boxMax.z - u->boxMin.z;
 	a.cubeSize = fmaxf(fmaxf(bx, by), bz);
 	a.minx = u->boxMin.x; a.miny = u->boxMin.y; a.minz = u->boxMin.z;
+	a.octreeSizeX = (a.minx + a.cubeSize) - a.minx; a.octreeSizeY = (a.miny + a.cubeSize) - a.miny; a.octreeSizeZ = (a.minz + a.cubeSize) - a.minz;
 	a.offHeights = 4096;
 	a.offGrids = (a.offHeights + a.nodeCapacity + 255) / 256 * 256;
 	const uint64_t perWg = (uint64_t)CF_CELLS * 8 + (uint64_t)CF_ACCEPTED * 4;
 	if (u->momentaryBufferCapacity < a.offGrids + perWg) return (int)hipErrorInvalidValue;
-	const uint32_t wgs = (uint32_t)std::min<uint64_t>(device_info().numCUs / 4, (u->momentaryBufferCapacity - a.offGrids) / perWg);
+	const uint32_t wgs = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1u, device_info().numCUs / 4), (u->momentaryBufferCapacity - a.offGrids) / perWg);
 	a.offAccepted = a.offGrids + (uint64_t)wgs * CF_CELLS * 8;
 	hipError_t e = hipMemsetAsync(a.mom + a.offGrids, 0, (size_t)wgs * CF_CELLS * 8, stream);      // :222-226
 	if (e != hipSuccess) return (int)e;

@@ -142,8 +142,11 @@ __device__ __forceinline__ int tab_find(const Tab<BITS>& t, uint32_t key) {
 // ---- grid barrier (expand loop only) --------------------------------------------------------------------------
 // One monotonic device-scope counter, zeroed by the host-enqueued prologue of every launch.  Producer side: every
 // wave drains its stores, the block syncs, lane 0 issues the agent-scope release (L2 write-back), arrives, polls
-// relaxed, then ONE agent-scope acquire (L1 invalidate) and a block sync.  The kernel that uses it is launched cooperatively
-// (all workgroups resident), so the 2 s bound on the poll is a guard against a broken device, not a scheduling hazard.
+// relaxed, then ONE agent-scope acquire (L1 invalidate) and a block sync.  The kernel that uses it (k_expand) is an ORDINARY launch of at
+// most one 1024-thread workgroup per CU: a workgroup that waits here waits only for workgroups of its own launch, and nothing those need
+// is held by a waiting workgroup — kernels of other streams (the voxel half of the previous batch fills whole CUs) can delay their
+// becoming resident, not prevent it, because they end on their own.  hipLaunchCooperativeKernel would add the residency check at launch
+// time and ~20 us per launch (measured); the 2 s bound on the poll is the guard against a broken device instead.
 __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t& generation, uint32_t numBlocks, bool forceTimeout = false) {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();

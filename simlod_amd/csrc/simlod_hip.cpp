@@ -101,11 +101,18 @@ static constexpr uint32_t NOTHING_SEEN = 0xffffffffu;
 static LaunchHistory* history_of(const void* stats, bool create) {
 	for (LaunchHistory& h : g_history) if (h.stats == stats) return &h;
 	if (!create) return nullptr;
-	void* pinned = nullptr;
-	if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-	volatile uint32_t* seen = static_cast<volatile uint32_t*>(pinned);
+	volatile uint32_t* seen = nullptr;
+	if (g_history.size() >= 64) {
+		// the oldest entry makes room — its page-locked words are handed on, never freed: a copy enqueued by an earlier launch may still
+		// be on its way into them (what arrives late is at worst a stale hint for the new owner: one launch with too many or too few groups)
+		seen = g_history.front().seen;
+		g_history.erase(g_history.begin());
+	} else {
+		void* pinned = nullptr;
+		if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		seen = static_cast<volatile uint32_t*>(pinned);
+	}
 	seen[0] = NOTHING_SEEN; seen[1] = NOTHING_SEEN;
-	if (g_history.size() >= 64) { (void)hipHostFree(const_cast<uint32_t*>(g_history.front().seen)); g_history.erase(g_history.begin()); }
 	g_history.push_back(LaunchHistory{stats, seen, 0u, false});
 	return &g_history.back();
 }
@@ -126,13 +133,10 @@ uint32_t groups_for_launch(const SimlodStats* stats) {
 
 int note_launch_end(const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream) {
 	if (tune("SIMLOD_ADAPTIVE_GROUPS", 1) == 0) return 0;
-	volatile uint32_t* seen;
-	{
-		std::lock_guard<std::mutex> hold(g_historyLock);
-		LaunchHistory* h = history_of(stats, true);
-		if (h == nullptr) return 0;
-		seen = h->seen;
-	}
+	std::lock_guard<std::mutex> hold(g_historyLock);           // (held across the enqueue: the slot cannot change hands in between)
+	LaunchHistory* h = history_of(stats, true);
+	if (h == nullptr) return 0;
+	volatile uint32_t* seen = h->seen;
 	hipError_t e = hipMemcpyAsync(const_cast<uint32_t*>(seen), &stats->batchletIndex, 4, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint32_t*>(seen) + 1, numBatchesUploaded, 4, hipMemcpyDeviceToHost, stream);
 	return (int)e;
