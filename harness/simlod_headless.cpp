@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <deque>
+#include <iterator>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -78,7 +80,8 @@ struct {
 	int pointSize = 1;
 	bool benchmarkRendering = false;
 } settings;   // main.cpp:123-139
-static bool requestBenchmark = true, requestStep = false;      // "benchmark mode": kernel durations are accumulated (main.cpp:411-422)
+static bool requestBenchmark = true;                           // "benchmark mode": kernel durations are accumulated (main.cpp:411-422)
+static std::atomic_bool requestStep = false;
 static double kernelUpdateDuration = 0, minKernelUpdateDuration = 1e30, maxKernelUpdateDuration = 0, avgKernelUpdateDuration = 0, cntKernelUpdateDuration = 0;
 static double kernelRenderDuration = 0, minKernelRenderDuration = 1e30, maxKernelRenderDuration = 0, avgKernelRenderDuration = 0, cntKernelRenderDuration = 0;
 static float renderingDuration = 0;
@@ -96,6 +99,38 @@ static void initCuda() {   // main.cpp:272-281
 }
 
 static Uniforms getUniforms(shared_ptr<GLRenderer> renderer);
+
+#ifdef SIMLOD_REF_UPLOADER_EXTRACT
+// ---- SIMLOD_REF_UPLOADER_EXTRACT: the reference's own PinnedMemorySlot / PinnedMemPool (main.cpp:48-55, 141-222), reset() (:775-809) and
+// spawnUploader() (:963-1063) — the code that races with kernel_construct — cut out of the checkout at build time like the
+// four host functions.  What they need around them is declared here the way main.cpp declares it (:67-93, :225-262); the loader threads
+// (spawnLoader :811-958) and reload() (:644-773) are restated further down: they read files, the uploader and the kernels never see how.
+constexpr uint64_t PINNED_MEM_POOL_SIZE = 200;
+static CUstream stream_download;
+#include SIMLOD_REF_TYPES_EXTRACT     // PinnedMemorySlot, PinnedMemPool
+struct PointBatch {                   // main.cpp:67-75 (file / LAS header: the restated loader keeps them to itself)
+	int first = 0;
+	int count = 0;
+	PinnedMemorySlot pinnedMem;
+};
+static deque<PointBatch> batchesInPinnedMemory;
+static deque<PinnedMemorySlot> pinnedMemoryInUpload;
+static atomic_bool resetInProgress;
+static mutex mtx_uploader;
+static vector<unique_ptr<mutex>> mtx_loader;
+static mutex mtx_batchesInPinnedMemory;
+static mutex mtx_pinnedMemoryInUpload;
+static int batchStreamUploadIndex = 0;
+static bool requestReset = false;
+static atomic_bool requestStepthrough = false;
+static uint32_t numPointsUploaded = 0;
+static int numBatchesTotal = 0;
+static bool lastBatchFinishedDevice = false;
+static PinnedMemPool pinnedMemPool;
+static void reload();
+void resetCUDA(shared_ptr<GLRenderer> renderer);      // (defined by the host-function extract)
+template <class T> static void setThreadPriorityHigh(T&) {}   // unsuck.hpp: a Windows scheduling hint
+#endif
 
 #ifdef SIMLOD_REF_HOST_EXTRACT
 #include SIMLOD_REF_HOST_EXTRACT      // resetCUDA, updateOctree, renderCUDA, initCudaProgram: the reference's own lines
@@ -217,6 +252,20 @@ static void renderCUDA(shared_ptr<GLRenderer> renderer) {   // main.cpp:465-546
 }
 #endif
 
+#ifdef SIMLOD_REF_UPLOADER_EXTRACT
+#include SIMLOD_REF_UPLOADER_EXTRACT  // reset(), spawnUploader(): the reference's own lines
+// reload() (main.cpp:644-773), what is left of it without files to list: the counters the uploader and the frame loop look at (:764-772)
+static uint64_t reloadNumBatches = 0;
+static void reload() {
+	numBatchesTotal = (int)reloadNumBatches;
+	stats = Stats();
+	numPointsUploaded = 0;
+	numBatchesProcessed = 0;
+	lastBatchFinishedDevice = false;
+	batchStreamUploadIndex = 0;
+}
+#endif
+
 // ---- camera: OrbitControls::update (include/OrbitControls.h:140-159) + glm::perspective + main.cpp:286-298 ------------------
 static void mul4(const double a[16], const double b[16], double out[16]) {
 	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j]; out[4 * i + j] = s; }
@@ -310,6 +359,56 @@ int main(int argc, char** argv) {
 	setCamera(-0.207, -0.797, 1.1 * std::max(boxSize.x, std::max(boxSize.y, boxSize.z)), target);
 	resetCUDA(renderer);
 
+#ifdef SIMLOD_REF_UPLOADER_EXTRACT
+	// ---- the reference's uploader thread (spawnUploader, its own text) fed by a restated loader thread (spawnLoader, main.cpp:811-958):
+	// acquire a pinned slot from the reference's pool, fill it with the batch's points — a LAS batch is parsed on the CPU here, as
+	// loadLasNative does (LasLoader.cpp:169-227) — and queue it; the uploader copies it into the ring and publishes it (H10)
+	const bool sourcePinned = false;
+	pinnedMemPool.reserveSlots(24);
+	mtx_loader.push_back(make_unique<mutex>());
+	reloadNumBatches = numBatchesTotal;
+	spawnUploader(renderer);                                     // idles until reload() announces batches
+	reset(renderer);                                             // locks everybody out, resetCUDA, Stats read-back, reload()
+	std::atomic<bool> quitUploader{false};
+	std::thread uploader([&]() {                                 // (the loader; the variable keeps its name for the code below)
+		for (uint64_t index = 0; index < numBatchesTotal && !quitUploader.load(); index++) {
+			for (;;) {                                           // MAX_LOADQUEUE_SIZE, main.cpp:37: do not run ahead of the uploader without bound
+				lock_guard<mutex> lock(mtx_batchesInPinnedMemory);
+				if (batchesInPinnedMemory.size() < 16) break;
+				std::this_thread::sleep_for(std::chrono::microseconds(50));
+			}
+			lock_guard<mutex> lock_loader(*mtx_loader[0]);
+			PinnedMemorySlot slot = pinnedMemPool.acquire();
+			Point* dst = (Point*)slot.memLocation;
+			const uint64_t first = index * MAX_BATCH_SIZE;
+			const uint32_t count = (uint32_t)std::min<uint64_t>(MAX_BATCH_SIZE, numPointsTotal - first);
+			if (isLas) {
+				const uint32_t rgbOffset = lasFormat == 2 ? 20u : (lasFormat == 3 || lasFormat == 5) ? 28u : lasFormat == 7 ? 30u : 0u;   // LasLoader.cpp:177-185
+				for (uint32_t i = 0; i < count; i++) {
+					const uint8_t* rec = lasRecords.data() + (first + i) * lasBytesPerPoint;
+					int32_t X, Y, Z;
+					std::memcpy(&X, rec, 4); std::memcpy(&Y, rec + 4, 4); std::memcpy(&Z, rec + 8, 4);
+					double x = (double)X * lasScale[0]; x = x + lasOffset[0];          // LasLoader.cpp:212-214 (offset and translation added up front)
+					double y = (double)Y * lasScale[1]; y = y + lasOffset[1];
+					double z = (double)Z * lasScale[2]; z = z + lasOffset[2];
+					Point p; p.x = (float)x; p.y = (float)y; p.z = (float)z;
+					uint32_t color = 0xff000000u;
+					if (rgbOffset > 0) {                                               // LasLoader.cpp:216-221
+						uint16_t c[3]; std::memcpy(c, rec + rgbOffset, 6);
+						color |= (uint32_t)(c[0] > 255 ? c[0] / 256 : c[0]) | ((uint32_t)(c[1] > 255 ? c[1] / 256 : c[1]) << 8) | ((uint32_t)(c[2] > 255 ? c[2] / 256 : c[2]) << 16);
+					}
+					p.color = color;
+					dst[i] = p;
+				}
+			} else std::memcpy(dst, points.data() + first, (size_t)count * sizeof(Point));
+			PointBatch batch;
+			batch.first = (int)first; batch.count = (int)count; batch.pinnedMem = slot;
+			lock_guard<mutex> lock(mtx_batchesInPinnedMemory);
+			batchesInPinnedMemory.push_back(batch);
+		}
+	});
+	std::atomic<uint64_t> numPointsProcessedSeen{0};             // (the reference's uploader reads stats.numPointsProcessed itself)
+#else
 	// pinned staging slots, as the reference's pinnedMemPool (main.cpp:141-222)
 	void* pinned[4];
 	CUevent uploadEnd[4];
@@ -366,7 +465,10 @@ int main(int argc, char** argv) {
 		}
 	});
 
+#endif
+#ifndef SIMLOD_REF_UPLOADER_EXTRACT
 	bool lastBatchFinishedDevice = false;
+#endif
 	const double loadStart = now();
 	while (!lastBatchFinishedDevice) {
 		// ---- frame (main.cpp:1159-1226): render first, then update, then the Stats copy

@@ -904,17 +904,20 @@ def test_headless_cpp_host_replay_octree_dump_equals_oracle(built_libs, tmp_path
     oracle.check_invariants(nodes, nn)
 
 
+@pytest.mark.parametrize("host", ["ref_host_replay", "ref_uploader_replay"])
 @pytest.mark.parametrize("kind", ["simlod", "las"])
-def test_reference_host_functions_drive_the_library(built_libs, tmp_path, kind):
+def test_reference_host_functions_drive_the_library(built_libs, tmp_path, kind, host):
     """harness/_ref/ref_host_replay = the headless host with the REFERENCE'S OWN resetCUDA / updateOctree / renderCUDA / initCudaProgram
     (cut out of main_progressive_octree.cpp at build time where the reference exists; the binary travels with the snapshot).  Uploader on
-    its own thread and stream while kernel_construct runs.  The octree it leaves must be the oracle's, node by node."""
+    its own thread and stream while kernel_construct runs.  ref_uploader_replay: that uploader, the pinned-memory pool
+    and reset() are the reference's own text as well (main.cpp:141-222, 775-809, 963-1063).  The octree either leaves must be the
+    oracle's, node by node."""
     import subprocess
     from simlod_amd import lasio
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "harness", "_ref", "ref_host_replay")
+    exe = os.path.join(root, "harness", "_ref", host)
     if not os.path.exists(exe):
-        pytest.skip("harness/_ref/ref_host_replay was not built (no reference checkout where the snapshot was made)")
+        pytest.skip(f"harness/_ref/{host} was not built (no reference checkout where the snapshot was made)")
     pts0, box = synthetic.terrain(2_700_000, seed=19, box=(1500.0, 1000.0, 100.0), tile=125.0)
     dump = str(tmp_path / "octree.bin")
     if kind == "simlod":
