@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=None, help="points per GPU (default: 36 M resident in the ring at N=1 = BASELINE config 2; 500 M streamed through the ring at N>1 = config 4)")
+    ap.add_argument("--raster-presets", default="bird,close", help="camera presets of the raster half (tools/profile.sh collects counters for the bird preset alone)")
     ap.add_argument("--stream", action="store_true", help="N=1 too: device-generated points streamed through the 50-slot ring with the reference's back-pressure (config 4's per-rank path)")
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--cpu-points", type=int, default=36_000_000, help="bounded sample for the CPU baseline (the port finishes all 36 M in a few seconds)")
@@ -203,7 +204,8 @@ def main():
     raster = {}
     tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("traffic_r03.json", "traffic_r02.json")) if os.path.exists(f)), None)
     rtraffic = json.load(open(tfile)) if tfile else {}
-    for name, hqs, Tcam in (("hqs", 1, T), ("plain", 0, T), ("hqs_close", 1, T_close), ("plain_close", 0, T_close)):
+    presets = args.raster_presets.split(",")
+    for name, hqs, Tcam in [m for m in (("hqs", 1, T), ("plain", 0, T), ("hqs_close", 1, T_close), ("plain_close", 0, T_close)) if ("close" if "close" in m[0] else "bird") in presets]:
         uc = dev.uniforms(W, H, Tcam, box, hqs=bool(hqs))
 
         def frame():

@@ -3,7 +3,7 @@ the per-launch figures bench.py quotes as `roofline.traffic`.      usage: python
 import glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 n_ingests, n_batches, frames = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (3, 36, 6)   # bench.py --steps 2 --warmup 1 --frames 4
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -16,7 +16,7 @@ for mode, suffix in (("", ""), ("_coalesced", "_coalesced")):
         stats.sort(key=os.path.getmtime)
         shutil.copy(stats[-1], os.path.join(dst, f"kernel_stats{suffix}.csv"))
 summ = json.load(open(os.path.join(dst, "rocprofv3_summary.json")))
-per_batch = {"k_insert": 2, "k_alloc": 2}      # the exact chain runs these twice per batch (points, voxels)
+per_batch = {}                                 # every kernel of the chain runs once per batch
 out = {"_comment": "HBM bytes per ACTIVE launch of the ingest kernels (a launch that had a 1 M-point batch to process: %d ingests x %d batches; the chain also "
                    "launches early-exiting instances, which move nothing) and per frame for the draw kernels (%d frames per mode), from two separate "
                    "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 2 --warmup 1 --frames 4`.  FETCH_SIZE doubled as MI355X_MICROARCH.md "
@@ -27,7 +27,7 @@ names = {"r_draw<0>": "r_draw<MODE_MIN64>", "r_draw<1>": "r_draw<MODE_DEPTH>", "
 for k, v in summ["hbm_traffic"].items():
     total = v["fetch_bytes_x2"] + v["write_bytes"]
     base = k.split("<")[0]
-    if k.startswith("k_") and base not in ("k_begin", "k_finish", "k_stats", "k_parents", "k_paths", "k_reset", "k_end"):
+    if k.startswith("k_") and base not in ("k_begin", "k_finish", "k_stats", "k_parents", "k_paths", "k_reset", "k_end", "k_voxdone"):
         out[base] = total / (n_ingests * n_batches * per_batch.get(base, 1))
     elif k in names:
         out[names[k]] = total / frames

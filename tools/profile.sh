@@ -4,12 +4,12 @@
 # FETCH_SIZE costs 3, WRITE_SIZE 2; SQ has 8).
 # Usage: tools/profile.sh <tag> [bench flags]      outputs land in gpurun_out/prof_<tag>/, the folded summary in gpurun_out/profile_summary_<tag>.json
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --frames 4 --no-cpu-baseline --no-profile $*"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --frames 4 --no-cpu-baseline --no-profile --raster-presets bird $*"
 cd /tmp
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err

@@ -12,7 +12,7 @@ def find(pattern):
 
 def short(name):
     n = name.split("(")[0]
-    n = n.replace("simlod::", "").replace("batch::", "").replace("bulk::", "").replace("void ", "")
+    n = n.replace("simlod::", "").replace("build::", "").replace("batch::", "").replace("bulk::", "").replace("void ", "")
     return n.strip()
 
 summary = {}
