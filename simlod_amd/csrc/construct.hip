@@ -41,11 +41,14 @@ namespace build {
 // Per-batch state, one copy per parity of the batch's ordinal in the launch: the voxel half of batch b (library's side stream) still
 // reads its copy while k_count .. k_expand of batch b + 1 work on the other, and the last kernel of batch b on the caller's stream
 // (k_insert part 0) prepares the copy of batch b + 1 — which is the copy of batch b - 1, whose voxel half k_insert has waited for.
+static constexpr uint32_t SLOT_CAP_GRIDS = 256;  // (memory guard's slack: grids one group's splits may allocate; more than that many splits per group and the guard is a group late)
+static constexpr uint32_t BATCH_COPIES = 4;      // per-batch state of batch b lives in copy b & 3: the front half of batch b + 1 (count .. expand) and the back halves of
+                                                 // batches b and b - 1 (insert, voxelize) are under way together, and batch b + 2 is being prepared
 struct BatchCtl {
 	uint32_t active, batchSize, ringSlot, batchIndex;
 	uint32_t ordinal, tag, slotsRound0, numSpilled;   // tag = batch index + 1 (NodeDir); slotsRound0: slots handed out by k_count's tail, snapshot by k_hist: k_expand's first round
-	uint32_t numWork, numClear, numTouched, allocDone;   // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_insert's allocation list) | allocation workgroups of k_insert that are done
-	uint32_t barrierCount, nodes, numVoxItems, numVoxSmall;   // nodes = Stats.numNodes after the batch's k_expand: the voxel half must not look at nodes the NEXT batch's k_expand is creating
+	uint32_t numWork, numClear, numTouched, numCross;    // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_expand allocates their chunks) | leaves k_count saw cross the limit (k_queue)
+	uint32_t barrierCount, unused0, numVoxItems, numVoxSmall;
 	uint32_t groupBatches, dirCount, pad0, pad1;      // ring batches taken together: 1 in exact mode, up to groupMax in coalesced mode; batchSize = all their samples
 	uint32_t start[SIMLOD_MAX_BATCHES_PER_LAUNCH + 1];   // sample index of the first sample of batch k of the group (start[groupBatches] = batchSize)
 	uint32_t slot[SIMLOD_MAX_BATCHES_PER_LAUNCH];        // its ring slot
@@ -69,7 +72,7 @@ struct Ctl {
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
 	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 216: k_voxelize of group #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
 	uint64_t phaseNs[48];              // byte 696: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
-	BatchCtl batch[2];
+	BatchCtl batch[BATCH_COPIES];
 	uint32_t tagOf[SIMLOD_MAX_BATCHES_PER_LAUNCH];     // tag of group #ordinal of this launch (whoever closes a group's voxel lists later needs it: its parity copy is recycled by then)
 };
 static_assert(offsetof(Ctl, voxT) == 216 && offsetof(Ctl, phaseNs) == 696, "tools/probe.py reads Ctl.voxT at byte 216, Ctl.phaseNs at byte 696");
@@ -87,8 +90,8 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir;
-	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
+	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, leafOfStride;
+	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax, crossCap;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
 };
 
 
@@ -180,7 +183,7 @@ template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t
 // the per-batch state of batch #ordinal of this launch, or nullptr when that batch does not exist (the copy of its parity may still
 // hold an earlier batch: the launch enqueues kernels for 20 batches whether they exist or not)
 __device__ __forceinline__ BatchCtl* batch_of(Ctl* ctl, uint32_t ordinal) {
-	BatchCtl* bc = &ctl->batch[ordinal & 1u];
+	BatchCtl* bc = &ctl->batch[ordinal % BATCH_COPIES];
 	return bc->active != 0u && bc->ordinal == ordinal ? bc : nullptr;
 }
 
@@ -191,8 +194,8 @@ struct Phase {
 	__device__ __forceinline__ void mark(uint32_t k) { if (on) { const uint64_t n = wall_ns(); ctl->phaseNs[k] += n - t; t = n; } }
 };
 
-// The chunk directory and k_voxelize's work items of a batch exist twice, by the parity of the batch's ordinal: batch b + 1's are filled
-// (k_hist, k_expand) while the voxel half of batch b is still reading its own on the side stream.
+// The chunk directory, k_voxelize's work items and the cached-leaf words of a batch exist twice, by the parity of the batch's ordinal: batch
+// b + 1's are written by its front half (k_count .. k_expand) while the back half of batch b (k_insert, k_voxelize) is still reading its own.
 struct VoxItem;
 __device__ __forceinline__ SimlodChunk** chunk_dir(const BuildArgs& a, const BatchCtl* bc) { return at<SimlodChunk*>(a, a.offChunkDir) + (uint64_t)(bc->ordinal & 1u) * a.dirCap; }
 __device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl* bc);
@@ -203,26 +206,32 @@ __device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->e
 
 // Worst case of what the voxel half of a batch can still add to the persistent buffer (voxel chunks: every sample can colour one voxel per
 // level, every inner node can start one more chunk).  The memory guard of voxels.cu:896-912 looks at the allocator after the WHOLE previous
-// batch; here the next batch is prepared while the previous one's voxel half may still be running, so within this distance of the guard a
-// launch takes one batch only: the next launch's k_begin runs after everything and decides exactly.
+// batch; here a batch is prepared while the voxel halves of the TWO batches before it may still be running, so within this distance of the
+// guard a launch takes one batch only: the next launch's k_begin runs after everything and decides exactly.
 __device__ __forceinline__ unsigned long long voxel_half_slack(const BuildArgs& a, const BatchCtl* prev) {
 	const unsigned long long samples = (unsigned long long)prev->batchSize + prev->numSpilled;
-	return (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + a.stats->numNodes + 1ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk));
+	// (+ the point chunks and grids the group before has yet to allocate: its k_expand runs after this look at the allocator)
+	return (2ull * (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + a.stats->numNodes + 1ull) + samples / SIMLOD_POINTS_PER_CHUNK + 4096ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk))
+	       + (unsigned long long)SLOT_CAP_GRIDS * SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid));
 }
 
-// Make group #ordinal of this launch current (in the copy of its parity), or leave it inactive (progressive_octree_voxels.cu:890-912).
+// Make group #ordinal of this launch current (in copy ordinal & 3), or leave it inactive (progressive_octree_voxels.cu:890-912).  Runs on the
+// FRONT stream: k_begin for the first group, one thread of k_hist of the group before for the others (so that k_count can follow k_expand
+// without a kernel in between; what depends on that k_expand — the node array's fill, the chunk pool's high-water mark — is set by
+// k_count's first workgroup).
 // Exact mode: a group is ONE ring batch, the reference's granularity.  Coalesced mode (simlod_set_ingest_mode(1)): the next groupMax
 // pending batches are counted, split, stored and voxelized as one; the memory guard is looked at once per group.
 __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
-	BatchCtl* bc = &ctl->batch[ordinal & 1u];
+	BatchCtl* bc = &ctl->batch[ordinal % BATCH_COPIES];
 	bc->active = 0;
-	if (ordinal >= SIMLOD_MAX_BATCHES_PER_LAUNCH || ctl->consumed >= ctl->numBatches || ctl->stop) return;
+	if (ordinal >= SIMLOD_MAX_BATCHES_PER_LAUNCH || ctl->consumed >= ctl->numBatches) return;
+	if (__hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // (set by the back half of an earlier group: time budget, abort)
 	const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
-	if (ordinal > 0u && alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + voxel_half_slack(a, &ctl->batch[(ordinal - 1u) & 1u]) >= a.persCapacity) { ctl->stop = 1; return; }
+	if (ordinal > 0u && alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + voxel_half_slack(a, &ctl->batch[(ordinal - 1u) % BATCH_COPIES]) >= a.persCapacity) { ctl->stop = 1; return; }
 	const bool full = alloc->offset + SIMLOD_MEM_SAFETY_MARGIN >= a.persCapacity;
 	a.stats->memCapacityReached = full ? 1 : 0;
 	if (full) { ctl->stop = 1; return; }
-	const uint32_t batchIndex = a.stats->batchletIndex;
+	const uint32_t batchIndex = ctl->firstBatch + ctl->consumed;       // (Stats.batchletIndex itself is advanced by the back half, which may lag)
 	const uint32_t take = min(ctl->groupMax, ctl->numBatches - ctl->consumed);
 	uint32_t total = 0;
 	for (uint32_t k = 0; k < take; k++) {
@@ -246,13 +255,12 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	bc->numWork = 0;
 	bc->numClear = 0;
 	bc->numTouched = 0;
-	bc->allocDone = 0;
+	bc->numCross = 0;
 	bc->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
-	bc->nodes = 0;
 	bc->numVoxItems = 0;
 	bc->numVoxSmall = 0;
 	bc->dirCount = 0;
-	bc->reserve = (unsigned long long)a.stats->numNodes << 32;
+	bc->reserve = 0;           // (k_count's first workgroup: the node array as k_expand of the group before leaves it)
 	bc->active = 1;
 }
 
@@ -302,7 +310,7 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
 	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers) ? 1u : 0u;
 	ctl->tableMagic = 0;                        // valid again once k_finish has run
-	ctl->batch[1].active = 0;
+	for (uint32_t i = 0; i < BATCH_COPIES; i++) ctl->batch[i].active = 0;
 	for (uint32_t i = 0; i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++) { ctl->voxT[i][0] = ~0ull; ctl->voxT[i][1] = 0; ctl->voxT[i][2] = 0; }
 	prepare_batch(a, ctl, 0);
 }
@@ -352,12 +360,21 @@ static constexpr uint32_t PPB = TPB * PPT;         // points per workgroup chunk
 // decided from the histogram alone (k_expand), three levels per round.  Afterwards the same 512 words are the slot's MAP: bin ->
 // the node that bin's samples ended up in.  A sample of a slot is relabelled by rewriting its cached-leaf word as
 // LEAF_FLAG | slot << 9 | bin: whoever needs its leaf later (k_insert, the next round) reads ONE word of the map.
+// the cached-leaf words of a group: one per sample of the group (two copies by the group's parity — k_count of the next group fills
+// its copy while k_insert of this one still reads) and one per moved point (one copy: k_hist writes them after k_insert of the group before)
+struct LeafWords {
+	uint32_t* grp; uint32_t* mov; uint32_t cap;
+	__device__ __forceinline__ LeafWords(const BuildArgs& a, uint32_t ordinal)
+		: grp(at<uint32_t>(a, a.offLeafOf) + (uint64_t)(ordinal & 1u) * a.leafOfStride), mov(at<uint32_t>(a, a.offLeafOf) + 2 * a.leafOfStride), cap(a.groupCap) {}
+	__device__ __forceinline__ uint32_t& operator[](uint32_t i) const { return i < cap ? grp[i] : mov[i - cap]; }     // i: sample of the group, or groupCap + moved point
+};
 static constexpr uint32_t SLOT_CAP = 2048;                  // slots per batch (12 bits of a relabelled word and of the reservation word)
 static constexpr uint32_t HIST_BINS = 512;
 static constexpr uint32_t LEAF_FLAG = 0x80000000u;          // cached-leaf word: FLAG | slot << 9 | bin   (else: a node index)
 static constexpr uint32_t MAP_LISTED = 0x80000000u;         // map entry: LISTED | level << 16 | slot of the NEXT round   (else: a node index)
 static constexpr uint32_t NONE = 0xffffffffu;
 struct SlotRec { uint32_t node, level, childBase, spillBase, stored, pad0, pad1, pad2; };   // node == NONE: nothing could be reserved, the leaf stays as it is
+__device__ __forceinline__ SlotRec* slot_recs(const BuildArgs& a, uint32_t ordinal) { return at<SlotRec>(a, a.offSlots) + (uint64_t)(ordinal & 1u) * SLOT_CAP; }   // (by parity, as the clear list)
 
 // the three child choices below a node at `level`, most significant first (levels beyond MAX_DEPTH contribute zero bits)
 __device__ __forceinline__ uint32_t bin_of(uint32_t X, uint32_t Y, uint32_t Z, uint32_t level) {
@@ -373,19 +390,26 @@ __device__ __forceinline__ uint32_t bin_of(uint32_t X, uint32_t Y, uint32_t Z, u
 // One arrival-counter update for `cnt` samples (voxels.cu:203-218).  Returns CROSSED for exactly one caller per leaf and batch: the one
 // that has to queue the leaf for splitting — whoever sees its counter cross the limit, or, if it is already over the limit because
 // an earlier batch could not split it (spill space, node array or slots exhausted: the split is deferred, nothing is lost), whoever
-// touches it first in this batch; the exchange on the per-node tag decides.  And FIRST for exactly one caller per leaf and batch too:
-// the one that found the counter where the last batch left it (== numPoints: everything counted has been stored) — that caller puts
-// the leaf on the batch's list of leaves with new samples, together with the number of points it held (k_insert allocates their chunks from
-// that list while its other workgroups are already advancing numPoints).
+// touches it first in this batch; the exchange on the per-node tag decides.  And FIRST for exactly one caller per leaf and batch too
+// (another per-node tag): that caller puts the leaf on the batch's list of leaves with new samples (k_expand allocates their chunks from it).
+// Node.numPoints is NOT looked at: the back half of the batch before (k_insert) may still be advancing it.  What the leaf held when this
+// batch began — its counter before anybody's add — is the smallest `old` any caller sees: kept per node as tag << 32 | ~old under an
+// atomic max (a newer batch's tag beats an older one, a smaller `old` a larger one).
 static constexpr uint32_t CROSSED = 1u, FIRST = 2u;
-__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCtl* bc, uint32_t leafIdx, uint32_t cnt, uint32_t& stored) {
+__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCtl* bc, uint32_t leafIdx, uint32_t cnt) {
 	SimlodNode* leaf = a.nodes + leafIdx;
-	stored = leaf->numPoints;                            // (a leaf queued for splitting meanwhile reads 0 here: it is no leaf any more when the list is used)
 	const uint32_t old = atomicAdd(&leaf->counter, cnt);
-	uint32_t flags = old == stored ? FIRST : 0u;
+	const uint32_t before = atomicExch(at<uint32_t>(a, a.offTouchTag) + leafIdx, bc->tag);
+	atomicMax(at<unsigned long long>(a, a.offStartOf) + leafIdx, ((unsigned long long)bc->tag << 32) | (0xffffffffu - old));
+	uint32_t flags = before != bc->tag ? FIRST : 0u;
 	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
 	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, bc->tag) != bc->tag) flags |= CROSSED;
 	return flags;
+}
+// what a leaf held when batch `tag` began (valid once the batch's k_count is complete)
+__device__ __forceinline__ uint32_t stored_at_start(const BuildArgs& a, uint32_t tag, uint32_t leafIdx) {
+	const unsigned long long v = at<const unsigned long long>(a, a.offStartOf)[leafIdx];
+	return (uint32_t)(v >> 32) == tag ? 0xffffffffu - (uint32_t)v : 0u;
 }
 
 struct SpillWork {
@@ -416,8 +440,10 @@ __device__ __forceinline__ bool reserve(const BuildArgs& a, Ctl* ctl, BatchCtl* 
 
 // the occupancy grid of a node that splits in this batch: allocated if the node has none (voxels.cu:363-365), cleared in any case
 // (:371-382, also the root's, which has one from the reset on) — by k_insert, through this list; the grids are first read by k_voxelize
-__device__ __forceinline__ void note_clear(const BuildArgs& a, uint32_t c, SimlodOccupancyGrid* g) {
-	if (c < a.clearCap) at<SimlodOccupancyGrid*>(a, a.offClear)[c] = g;
+// (two copies of the list, by the batch's parity: k_queue of the next batch fills its list while k_insert of this one is still clearing)
+__device__ __forceinline__ SimlodOccupancyGrid** clear_list(const BuildArgs& a, uint32_t ordinal) { return at<SimlodOccupancyGrid*>(a, a.offClear) + (uint64_t)(ordinal & 1u) * a.clearCap; }
+__device__ __forceinline__ void note_clear(const BuildArgs& a, const BatchCtl* bc, uint32_t c, SimlodOccupancyGrid* g) {
+	if (c < a.clearCap) clear_list(a, bc->ordinal)[c] = g;
 	else {                                                        // (never: the list holds a grid per node slot a batch can create)
 		uint4* w = reinterpret_cast<uint4*>(g->values);
 		for (uint32_t i = 0; i < SIMLOD_GRID_NUM_WORDS / 4; i++) w[i] = make_uint4(0, 0, 0, 0);
@@ -427,11 +453,11 @@ __device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& 
 	uint8_t* mem = persistent_alloc(a.pers, sizeof(SimlodOccupancyGrid), 1);          // (two independent atomics with a return value: one round trip)
 	const uint32_t c = atomicAdd(&bc->numClear, 1u);
 	SimlodOccupancyGrid* g = reinterpret_cast<SimlodOccupancyGrid*>(mem);
-	note_clear(a, c, g);
+	note_clear(a, bc, c, g);
 	return g;
 }
 
-// Queue leaf `nodeIdx` for splitting: ONE WAVE.  Everything the split needs is reserved here, before anything is modified: a slot (and
+// Queue leaf `nodeIdx` for splitting: ONE WAVE (k_queue).  Everything the split needs is reserved here, before anything is modified: a slot (and
 // with it a histogram), eight node slots and the spill space for the stored points together, the occupancy grid.  Then the leaf's
 // chunk list becomes spill-copy work items (chunk k comes from the leaf chunk table, not from a walk) and goes back to the recycle
 // stack (voxels.cu:346-357; nothing pops before k_alloc).  (voxels.cu:308-383 doSplitting, first half)
@@ -443,7 +469,9 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 	uint32_t numChunks = 0;
 	SimlodChunk* head = nullptr;
 	if (lane == 0) {
-		stored = node->numPoints; level = node->level; head = node->points;
+		// (not Node.numPoints, which the back half of the group before may still be advancing — and which is reset, with the list's head,
+		// by k_expand, after that back half: this kernel runs beside it)
+		stored = stored_at_start(a, bc->tag, nodeIdx); level = node->level; head = node->points;
 		SimlodOccupancyGrid* grid = node->grid;
 		// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
 		numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
@@ -460,8 +488,8 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 			}
 			atomicAdd(&bc->numSpilled, stored);
 			if (grid == nullptr) { grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + gridAt); node->grid = grid; }
-			note_clear(a, c, grid);
-			at<SlotRec>(a, a.offSlots)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, 0u, 0u, 0u};
+			note_clear(a, bc, c, grid);
+			slot_recs(a, bc->ordinal)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, 0u, 0u, 0u};
 			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)(bc->ordinal + 1u) << 32) | (level << 16) | slot;
 		}
 	}
@@ -501,8 +529,6 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 			beyond->next = nullptr;
 			beyond = next;
 		}
-		node->numPoints = 0;
-		node->points = nullptr;
 	}
 }
 
@@ -510,7 +536,6 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 // hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
 static constexpr uint32_t CPT = 8;
 static constexpr uint32_t CPB = TPB * CPT;         // (k_hist)
-static constexpr uint32_t CROSS_CAP = 128;         // leaves one workgroup can see cross the limit in one batch
 
 static constexpr uint32_t TOUCH_CAP = 512;         // leaves one workgroup can be the first to touch in one batch (more: appended one by one)
 
@@ -521,32 +546,38 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr) return;
 	__shared__ BlockTable tbl;
-	__shared__ uint32_t sh_cross[CROSS_CAP];
-	__shared__ uint2 sh_touch[TOUCH_CAP];
-	__shared__ uint32_t sh_numCross, sh_numTouch, sh_touchBase;
+	__shared__ uint32_t sh_touch[TOUCH_CAP];
+	__shared__ uint32_t sh_numTouch, sh_touchBase;
 	const uint32_t n = bc->batchSize;
 	const Samples<SINGLE> pts(a, bc);
-	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
-	uint2* touched = at<uint2>(a, a.offTouched);           // {leaf, points it held when the batch began}
+	const LeafWords leafOf(a, ordinal);
+	uint32_t* touched = at<uint32_t>(a, a.offTouched);
+	uint32_t* crossList = at<uint32_t>(a, a.offCross);
 	const uint32_t numChunks = (n + CPB - 1) / CPB;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		// what had to wait for k_expand of the group before: voxels.cu:535-537 — the chunk pool's high-water mark follows that group's
+		// allocations, before this one recycles or takes a chunk — and the node array's fill, where this group's reservations start (k_queue)
+		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
+		bc->reserve = (unsigned long long)a.stats->numNodes << 32;
+	}
 	if (blockIdx.x >= numChunks) return;
 	Phase ph(ctl, blockIdx.x == 0);
-	auto counted = [&](uint32_t leafIdx, uint32_t flags, uint32_t stored) {
+	auto counted = [&](uint32_t leafIdx, uint32_t flags) {
 		if ((flags & FIRST) != 0u) {
 			const uint32_t k = atomicAdd(&sh_numTouch, 1u);
-			if (k < TOUCH_CAP) sh_touch[k] = make_uint2(leafIdx, stored);
-			else touched[atomicAdd(&bc->numTouched, 1u)] = make_uint2(leafIdx, stored);       // (at most one entry per node and batch: the list has room for every node)
+			if (k < TOUCH_CAP) sh_touch[k] = leafIdx;
+			else touched[atomicAdd(&bc->numTouched, 1u)] = leafIdx;       // (at most one entry per node and batch: the list has room for every node)
 		}
-		if ((flags & CROSSED) != 0u) {
-			const uint32_t k = atomicAdd(&sh_numCross, 1u);
-			if (k < CROSS_CAP) sh_cross[k] = leafIdx;
+		if ((flags & CROSSED) != 0u) {                                     // (rare: a handful per batch) k_queue reserves, lists and empties them
+			const uint32_t k = atomicAdd(&bc->numCross, 1u);
+			if (k < a.crossCap) crossList[k] = leafIdx;
 			else { at<uint32_t>(a, a.offRetryTag)[leafIdx] = 0u; raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); }   // deferred: a later batch queues it again
 		}
 	};
-	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the four waves never wait for each
+	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the waves never wait for each
 	// other's slowest descent; one flush at the end.
 	table_init(tbl);
-	if (threadIdx.x == 0) { sh_numCross = 0; sh_numTouch = 0; }
+	if (threadIdx.x == 0) sh_numTouch = 0;
 	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		float4 p[CPT];
@@ -570,31 +601,42 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 			const uint32_t i = chunk * CPB + j * BT + threadIdx.x;
 			if (i >= n) continue;
 			const uint32_t leafIdx = cur[j];
-			leafOf[i] = leafIdx;
+			leafOf.grp[i] = leafIdx;
 			uint32_t rank;
-			if (table_add(tbl, leafIdx, 1u, &rank) < 0) { uint32_t stored; const uint32_t f = count_into(a, bc, leafIdx, 1u, stored); counted(leafIdx, f, stored); }
+			if (table_add(tbl, leafIdx, 1u, &rank) < 0) counted(leafIdx, count_into(a, bc, leafIdx, 1u));
 		}
 	}
 	__syncthreads();
 	ph.mark(0);
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += BT) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) { uint32_t stored; const uint32_t f = count_into(a, bc, key, tbl.vals[e], stored); counted(key, f, stored); }
+		if (key != TBL_EMPTY) counted(key, count_into(a, bc, key, tbl.vals[e]));
 	}
 	__syncthreads();
 	ph.mark(1);
 	// the leaves this workgroup was the first to touch in this batch go on the batch's list (one reservation per workgroup)
 	const uint32_t numTouch = min(sh_numTouch, TOUCH_CAP);
 	if (threadIdx.x == 0 && numTouch != 0u) sh_touchBase = atomicAdd(&bc->numTouched, numTouch);
-	// the leaves this workgroup saw cross the limit: reserved, listed and emptied here, wave by wave, so that k_hist finds their work items
-	const uint32_t numCross = min(sh_numCross, CROSS_CAP);
-	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if k_expand's grid barrier had given up, before anything is modified (tests the abort path)
-	if (numCross != 0u && (ctl->debugFlags & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
-	for (uint32_t e = threadIdx.x / 64u; e < numCross; e += BT / 64u) queue_split(a, ctl, bc, sh_cross[e]);
 	__syncthreads();
-	ph.mark(2);
 	for (uint32_t e = threadIdx.x; e < numTouch; e += BT) touched[sh_touchBase + e] = sh_touch[e];
 	if (ph.on) ctl->phaseNs[3] += 1;
+}
+
+// ---- queue: the leaves k_count saw cross the limit are reserved, listed and emptied (voxels.cu:308-383 doSplitting, first half) -------------
+// One wave per leaf.  Runs beside the back half of the batch BEFORE (whose k_insert may still be storing points into these very leaves): it
+// reads what k_count and the allocator know — the counter at batch start, the chunk table — and writes only chunk links, the recycle stack
+// and reservations; k_hist, which moves the points, is the kernel that waits for that k_insert.
+__global__ __launch_bounds__(TPB) void k_queue(BuildArgs a, uint32_t ordinal) {
+	Ctl* ctl = ctl_of(a);
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch) return;
+	const uint32_t numCross = min(bc->numCross, a.crossCap);
+	if (numCross == 0u) return;
+	// SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT: behave as if k_expand's grid barrier had given up, before anything is modified (tests the abort path)
+	if ((ctl->debugFlags & 1u) != 0u) { if (blockIdx.x == 0 && threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
+	const uint32_t* crossList = at<const uint32_t>(a, a.offCross);
+	const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) / 64u, numWaves = gridDim.x * TPB / 64u;
+	for (uint32_t e = wave; e < numCross; e += numWaves) queue_split(a, ctl, bc, crossList[e]);
 }
 
 // ---- k_voxelize's work items (filled by the chunk allocation below) -----------------------------------------------------
@@ -642,19 +684,21 @@ struct AllocRec {
 };
 struct AllocShared { AllocRec rec[ALLOC_LEAVES]; uint32_t total; };
 
-// `entries` (global memory or LDS): {leaf, points it held when the batch began}; entry k is taken when firstEntry + lane < numEntries.
-// `fresh`: the entries are empty leaves a cascade has just made, entry.y = their counter (nothing about them has to be read back).
-__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint2* entries, uint32_t firstEntry, uint32_t numEntries, bool fresh_leaves = false) {
+// Entry k is taken when firstEntry + lane < numEntries.  `touched` (global memory): the leaves k_count found new samples for — what
+// each held when the batch began comes from stored_at_start().  `fresh` (LDS): {node, samples} of the empty leaves a cascade has
+// just made (nothing about them has to be read back).  One of the two lists is given.
+__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint32_t* touched, const uint2* fresh, uint32_t firstEntry, uint32_t numEntries) {
+	const bool fresh_leaves = fresh != nullptr;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = chunk_dir(a, bc);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
 	if (threadIdx.x < 64u) {
 		const uint32_t lane = threadIdx.x;
-		// (the points the leaf held when the batch began come with the list entry: Node.numPoints is already being advanced by the other
-		// workgroups of k_insert)
-		const uint2 entry = firstEntry + lane < numEntries ? entries[firstEntry + lane] : make_uint2(NONE, 0u);
-		const uint32_t i = entry.x, stored = fresh_leaves ? 0u : entry.y;
+		// (Node.numPoints is not looked at: the back half of the batch before may still be advancing it)
+		uint2 entry = make_uint2(NONE, 0u);
+		if (firstEntry + lane < numEntries) entry = fresh_leaves ? fresh[firstEntry + lane] : make_uint2(touched[firstEntry + lane], 0u);
+		const uint32_t i = entry.x, stored = (fresh_leaves || i == NONE) ? 0u : stored_at_start(a, bc->tag, i);
 		SimlodNode* node = a.nodes + (i != NONE ? i : 0u);
 		uint32_t counter = 0;
 		bool need = false;
@@ -692,7 +736,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		}
 		dirBase = (uint32_t)__shfl((int)dirBase, 0, 64); itemBase = (uint32_t)__shfl((int)itemBase, 0, 64); smallBase = (uint32_t)__shfl((int)smallBase, 0, 64);
 		chunkBase = shfl64(chunkBase, 0);
-		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by end_of_batch, after every allocation of the batch
+		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by prepare_batch, between the groups' allocations
 		// pop from the recycle stack, allocate what the stack cannot serve
 		const unsigned long long firstIdx = chunkBase + exAdditional;
 		const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
@@ -746,7 +790,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 // Every CU takes part (an ordinary launch; the rounds that follow, if any, run inside k_expand).  Index space: first the stored points
 // of the queued leaves — element e = point (e % 1000) of work item (e / 1000), one chunk per item: they move into the spill buffer
 // (voxels.cu:253-289) — then the batch's samples.  Whatever lies in a queued leaf is added to the leaf's histogram (per workgroup in LDS
-// first, one global add per workgroup and bin) and its cached-leaf word is relabelled FLAG | slot | bin.  Exits at once when k_count
+// first, one global add per workgroup and bin) and its cached-leaf word is relabelled FLAG | slot | bin.  Exits at once when k_queue
 // queued nothing.
 template <bool SINGLE>
 __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
@@ -755,9 +799,10 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	if (bc == nullptr || ctl->abortBatch) return;
 	const uint32_t slots0 = slots_in_use(bc);
 	if (blockIdx.x == 0 && threadIdx.x == 0) bc->slotsRound0 = slots0;
+	if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) prepare_batch(a, ctl, ordinal + 1u);     // (a workgroup without samples, as a rule)
 	if (slots0 == 0u) return;
 	__shared__ BlockTable tbl;
-	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	const LeafWords leafOf(a, ordinal);
 	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
@@ -879,7 +924,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 		const uint32_t allocBlocks = (numTouched + ALLOC_LEAVES - 1) / ALLOC_LEAVES;
 		for (uint32_t blk = gridDim.x - 1u - blockIdx.x; blk < allocBlocks; blk += gridDim.x) {
 			__syncthreads();
-			alloc_points(a, ctl, bc, sh.alloc, at<const uint2>(a, a.offTouched), blk * ALLOC_LEAVES, numTouched);
+			alloc_points(a, ctl, bc, sh.alloc, at<const uint32_t>(a, a.offTouched), nullptr, blk * ALLOC_LEAVES, numTouched);
 		}
 		__syncthreads();
 	}
@@ -888,10 +933,10 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	// not to be trusted any more (k_count's tail has already emptied the queued leaves): fatal, sticky until a reset
 	if ((ctl->debugFlags & 1u) != 0u) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 
-	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	const LeafWords leafOf(a, ordinal);
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
 	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
-	SlotRec* slots = at<SlotRec>(a, a.offSlots);
+	SlotRec* slots = slot_recs(a, ordinal);
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	uint32_t* map = at<uint32_t>(a, a.offMap);        // (not the histogram's words: other workgroups may still be peeking at those)
 	const float4* spilled = at<const float4>(a, a.offSpilled);
@@ -1077,6 +1122,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				}
 				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
 			}
+			if (t == 0u) { a.nodes[L].numPoints = 0; a.nodes[L].points = nullptr; }          // voxels.cu:359-360 (its points are in the spill buffer, its chunks on the recycle stack: k_queue, k_hist)
 			// the nodes of the cascade that hold samples and stay leaves (one that was queued again is none by the time its chunks would be used)
 			if (t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u && sh.listed[t] == NONE) sh.fresh[atomicAdd(&sh.numFresh, 1u)] = make_uint2(indexOf(t), countOf(t));
 			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
@@ -1089,7 +1135,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			// ... and their chunks, 64 leaves at a time (voxels.cu:485-538; the nodes written above are this workgroup's own stores: visible after the barrier)
 			__syncthreads();
 			for (uint32_t first = 0; first < sh.numFresh; first += ALLOC_LEAVES) {
-				alloc_points(a, ctl, bc, sh.alloc, sh.fresh, first, sh.numFresh, true);
+				alloc_points(a, ctl, bc, sh.alloc, nullptr, sh.fresh, first, sh.numFresh);
 				__syncthreads();
 			}
 		}
@@ -1392,17 +1438,17 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, Bat
 // One thread of k_insert part 0, the last kernel of a batch on the caller's stream, once the batch's chunk allocations are complete
 // (nothing the rest of that launch or the voxel half on the side stream reads is touched here: they know their batch by its parity copy).
 __device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
-	if (ctl->abortBatch) { ctl->stop = 1; }                   // scratch overflow: this batch is lost, report through Stats.dbg
+	if (ctl->abortBatch) __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // scratch overflow: this batch is lost, report through Stats.dbg
 	else {
-		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
 		a.stats->batchletIndex += bc->groupBatches;
 		a.stats->numPointsProcessed += bc->batchSize;
 		ctl->processed += 1;
 		ctl->expandNs[7] += min(bc->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
+		// voxels.cu:936-949: no further batch once the launch has run for 10 ms.  The front half of the next batch (or two) may be under way
+		// already; what has been prepared is completed, nothing more is prepared.
 		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
-		if (elapsedMs > (float)ctl->budgetUs / 1000.0f) ctl->stop = 1;                 // voxels.cu:936-949
+		if (elapsedMs > (float)ctl->budgetUs / 1000.0f) __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	prepare_batch(a, ctl, bc->ordinal + 1u);
 }
 
 // On the library's side stream, while the next batch is already counted and split on the caller's.  A root that is still a leaf (the whole
@@ -1705,7 +1751,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 	const uint32_t total = n + min(bc->numSpilled, a.spilledCap);
 	const Samples<SINGLE> pts(a, bc);
 	const float4* spilled = at<const float4>(a, a.offSpilled);
-	uint32_t* leafOf = at<uint32_t>(a, a.offLeafOf);
+	const LeafWords leafOf(a, ordinal);
 	const NodeDir* nodeDir = at<const NodeDir>(a, a.offNodeDir);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
@@ -1716,7 +1762,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 		const uint32_t pb = blockIdx.x == 0 ? 8u : 16u;
 		// The end-of-batch bookkeeping needs nothing this kernel produces (the batch's chunks were allocated by k_expand, the counters it folds
 		// into Stats are final): the LAST workgroup of the grid, which as a rule has no samples to store, does it right away.
-		if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) { bc->nodes = min(a.stats->numNodes, a.nodeCapacity); end_of_batch(a, ctl, bc); }
+		if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) end_of_batch(a, ctl, bc);
 		// ... and the 32 before it close the voxel lists of the previous batch (voxdone_nodes: this kernel has waited for its k_voxelize)
 		{
 			constexpr uint32_t DONE_WGS = 32;
@@ -1728,7 +1774,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
 		// k_voxelize samples into them (voxels.cu:371-382) — 256 KB each, the stores ride along with the loads below
 		const uint32_t numClear = min(bc->numClear, a.clearCap);
-		SimlodOccupancyGrid* const* clearList = at<SimlodOccupancyGrid*>(a, a.offClear);
+		SimlodOccupancyGrid* const* clearList = clear_list(a, ordinal);
 		constexpr uint32_t W4 = SIMLOD_GRID_NUM_WORDS / 4;
 		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numClear * W4; i += gridDim.x * TPB)
 			reinterpret_cast<uint4*>(clearList[i / W4]->values)[i % W4] = make_uint4(0, 0, 0, 0);
@@ -1751,7 +1797,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 				// a sample that k_hist / k_expand relabelled (slot, bin): its leaf is one word of the slot's map
 				if (v[j] == NONE || (v[j] & LEAF_FLAG) == 0u) continue;
 				uint32_t e = map[v[j] & 0x1fffffu];
-				if ((e & MAP_LISTED) != 0u) e = at<const SlotRec>(a, a.offSlots)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
+				if ((e & MAP_LISTED) != 0u) e = slot_recs(a, ordinal)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
 				v[j] = e;
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				leafOf[t < n ? t : a.groupCap + (t - n)] = e;
@@ -1846,6 +1892,7 @@ __global__ void k_finish(BuildArgs a, uint32_t fits) {
 	s->numVoxels = ctl->statCounters[4];
 	s->numChunksPoints = ctl->statCounters[5];
 	s->numChunksVoxels = ctl->statCounters[6];
+	if (s->numAllocatedChunks > s->chunkPoolSize) s->chunkPoolSize = s->numAllocatedChunks;       // voxels.cu:535-537, for the launch's last group (prepare_batch: the others)
 	s->allocatedBytes_momentary = a.scratchBytes;
 	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
 	s->frameID = (uint32_t)a.frameCounter;
@@ -1866,15 +1913,20 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce) {
 	a.dirCap = 2 * a.nodeCapacity + 65536;
 	uint64_t off = 4096;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
-	a.offSlots = off;    off += align_up((uint64_t)SLOT_CAP * sizeof(SlotRec), 256);
+	a.offSlots = off;    off += align_up((uint64_t)2 * SLOT_CAP * sizeof(SlotRec), 256);
 	a.offHist = off;     off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
 	a.offMap = off;      off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
 	a.clearCap = 65536;
-	a.offClear = off;    off += align_up((uint64_t)a.clearCap * 8, 256);
-	a.offTouched = off;  off += align_up((uint64_t)a.nodeCapacity * 8, 256);
-	// (cleared by the host-enqueued memset of every launch, offSplitTag .. offParent: split records, retry tags, the hash directory of voxel chunks)
+	a.offClear = off;    off += align_up((uint64_t)2 * a.clearCap * 8, 256);
+	a.offTouched = off;  off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.crossCap = 16384;
+	a.offCross = off;    off += align_up((uint64_t)a.crossCap * 4, 256);
+	// (cleared by the host-enqueued memset of every launch, offSplitTag .. offParent: split records, retry / touch tags, the counters at batch
+	// start, the hash directory of voxel chunks)
 	a.offSplitTag = off; off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offTouchTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
+	a.offStartOf = off;  off += align_up((uint64_t)a.nodeCapacity * 8, 256);
 	a.hashCap = 1u << 17;
 	a.offHashDir = off;  off += align_up((uint64_t)a.hashCap * sizeof(DirEntry), 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
@@ -1890,25 +1942,27 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce) {
 	const uint64_t perBatch = (uint64_t)SIMLOD_MAX_BATCH_SIZE * 4;
 	const uint64_t fixedWork = ((uint64_t)SPILLING_CAPACITY + a.nodeCapacity / 8) * 32;
 	a.groupMax = 1; a.groupCap = SIMLOD_MAX_BATCH_SIZE;
-	if (capacity < off + perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + perBatch + fixedWork; return false; }
+	if (capacity < off + 2 * perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + 2 * perBatch + fixedWork; return false; }
 	const uint64_t freeBytes = capacity - off - fixedWork - 4096;
-	if (coalesce) a.groupMax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(SIMLOD_MAX_BATCHES_PER_LAUNCH, freeBytes / (perBatch + 20ull * SIMLOD_MAX_BATCH_SIZE)));
+	if (coalesce) a.groupMax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(SIMLOD_MAX_BATCHES_PER_LAUNCH, freeBytes / (2 * perBatch + 20ull * SIMLOD_MAX_BATCH_SIZE)));
 	a.groupCap = a.groupMax * SIMLOD_MAX_BATCH_SIZE;
-	uint64_t cap = (freeBytes - a.groupMax * perBatch) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
+	// (the group samples' cached-leaf words exist twice, by group parity; 4 + 16 B per moved point)
+	uint64_t cap = (freeBytes - 2ull * a.groupMax * perBatch - 512) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
 	if (cap > 0x7fffffffull - a.groupCap) cap = 0x7fffffffull - a.groupCap;
 	a.spilledCap = (uint32_t)cap;
 	a.workCap = a.spilledCap / SIMLOD_POINTS_PER_CHUNK + a.nodeCapacity / 8 + SPILLING_CAPACITY;   // one item per 1000 moved points + one partial chunk per split
 	a.offWork = off;     off += align_up((uint64_t)a.workCap * 32, 256);
-	a.offLeafOf = off;   off += align_up(((uint64_t)a.groupCap + a.spilledCap) * 4, 256);
+	a.leafOfStride = align_up((uint64_t)a.groupCap * 4, 256) / 4;
+	a.offLeafOf = off;   off += 2 * a.leafOfStride * 4 + align_up((uint64_t)a.spilledCap * 4, 256);
 	a.offSpilled = off;  off += (uint64_t)a.spilledCap * 16;
 	a.scratchBytes = off;
 	return off <= capacity;
 }
 
-// the library's side stream for the voxel tails, and the events that tie it to the caller's stream (one pair per batch of a launch)
+// the library's second stream for the back halves of the batches, and the events that tie it to the caller's stream (one pair per group of a launch)
 struct SideStream {
 	hipStream_t stream;
-	hipEvent_t voxelized[SIMLOD_MAX_BATCHES_PER_LAUNCH], tailDone[SIMLOD_MAX_BATCHES_PER_LAUNCH];
+	hipEvent_t expanded[SIMLOD_MAX_BATCHES_PER_LAUNCH], inserted[SIMLOD_MAX_BATCHES_PER_LAUNCH], tailDone;
 	std::mutex enqueue;          // the events are reused by every launch on the device: one launch's records and waits are enqueued as a block
 };
 static SideStream* side_stream() {
@@ -1922,7 +1976,8 @@ static SideStream* side_stream() {
 		SideStream* s = new SideStream();
 		bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
 		for (uint32_t i = 0; ok && i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++)
-			ok = hipEventCreateWithFlags(&s->voxelized[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->tailDone[i], hipEventDisableTiming) == hipSuccess;
+			ok = hipEventCreateWithFlags(&s->expanded[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->inserted[i], hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&s->tailDone, hipEventDisableTiming) == hipSuccess;
 		if (!ok) { (void)hipGetLastError(); delete s; return nullptr; }     // no side stream: everything stays on the caller's
 		cache[dev] = s;
 	}
@@ -1967,46 +2022,40 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
 		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
-		// The VOXEL HALF of a batch — k_voxelize, then k_alloc / k_insert part 1: ~80 us + three kernel boundaries — touches nothing the next
-		// batch's k_count and k_expand read or write (occupancy grids of nodes that are already inner, voxel chunks, numVoxels*, the
-		// emit list; it reads the batch's samples from their leaf chunks, which k_expand may hand to the recycle stack but nobody
-		// overwrites before the next k_insert), so it runs on a side stream of the library while they run on the caller's: it starts
-		// when k_insert part 0 is done, and the next batch's k_alloc part 0 — the first kernel that reuses the work items, the chunk
-		// directory and, through the recycle stack, those chunks — waits for it.  The per-batch words of the control block it needs exist
-		// twice (Ctl).  One exception stays on the caller's stream: the samples of a root that is still a leaf (k_voxelize, rootOnly).
-		// Measured on the 36 M terrain: 8.46 ms per ingest with everything on one stream, 8.06 with parts 1 on the side, 7.72 with
-		// k_voxelize there too; the two halves are about equally long, but side by side each runs slower (they compete for the CUs'
-		// wave slots: a k_voxelize workgroup fills a CU), and every cross-stream dependency costs ~10 us of its own.  A side stream
-		// restricted to part of the CUs (hipExtStreamCreateWithCUMask) made everything slower (13.9 ms).  Fewer k_voxelize workgroups
-		// (128, 64) made the side the long pole (8.2, 9.4 ms).  Off while per-kernel profiling is on (one stream, one timeline).
+		// A batch has a FRONT half — k_prepare, k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
+		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
+		// the caller's stream, the back half on a second stream of the library, two dependencies per batch between them:
+		//     k_insert(b) after k_expand(b);                 k_hist(b + 1) after k_insert(b)   (it moves points k_insert(b) has stored).
+		// So k_count and k_queue(b + 1) run beside k_insert(b), k_hist and k_expand(b + 1) beside k_voxelize(b), and k_insert(b + 1) follows k_voxelize(b)
+		// by stream order (it overwrites chunks that k_expand(b + 1) recycled and k_voxelize(b) may still be reading).  What the halves share
+		// exists per batch: the control state in copies b & 3, the chunk directory, the work items and the cached-leaf words by parity;
+		// k_count does not look at Node.numPoints (stored_at_start()).  Per batch the chain is as long as its longest cycle — k_insert,
+		// event, k_queue + k_hist + k_expand, event: ~90 us — instead of the sum of all seven kernels (~190 us on one stream).
+		// Off while per-kernel profiling is on (one stream, one timeline) or with SIMLOD_OVERLAP_TAIL=0.
 		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
 		const int countTpb = tune("SIMLOD_COUNT_TPB", 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
 		const bool single = a.groupMax == 1u;
 		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
+		hipStream_t back = side != nullptr ? side->stream : stream;
 		for (uint32_t b = 0; b < numGroups; b++) {
 			if (single) {
 				if (countTpb == 256) SIMLOD_LAUNCH((k_count<TPB, true>), dim3(gridPoints), dim3(TPB), stream, a, b);
 				else SIMLOD_LAUNCH((k_count<512, true>), dim3(gridPoints / 2), dim3(512), stream, a, b);
-				SIMLOD_LAUNCH(k_hist<true>, dim3(gridPoints), dim3(TPB), stream, a, b);
-			} else {
-				SIMLOD_LAUNCH((k_count<512, false>), dim3(gridPoints / 2), dim3(512), stream, a, b);
-				SIMLOD_LAUNCH(k_hist<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
-			}
+			} else SIMLOD_LAUNCH((k_count<512, false>), dim3(gridPoints / 2), dim3(512), stream, a, b);
+			SIMLOD_LAUNCH(k_queue, dim3(16), dim3(TPB), stream, a, b);
+			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->inserted[b - 1], 0) != hipSuccess) return (int)hipGetLastError();
+			if (single) SIMLOD_LAUNCH(k_hist<true>, dim3(gridPoints), dim3(TPB), stream, a, b);
+			else SIMLOD_LAUNCH(k_hist<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
 			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
-			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->tailDone[(b - 1) % SIMLOD_MAX_BATCHES_PER_LAUNCH], 0) != hipSuccess) return (int)hipGetLastError();
-			if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), stream, a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
-			else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
-			hipStream_t tail = stream;
-			if (side != nullptr) {
-				if (hipEventRecord(side->voxelized[b], stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->voxelized[b], 0) != hipSuccess) return (int)hipGetLastError();
-				tail = side->stream;
-			}
-			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), tail, a, b);
-			if (side != nullptr && hipEventRecord(side->tailDone[b], side->stream) != hipSuccess) return (int)hipGetLastError();
+			if (side != nullptr && (hipEventRecord(side->expanded[b], stream) != hipSuccess || hipStreamWaitEvent(back, side->expanded[b], 0) != hipSuccess)) return (int)hipGetLastError();
+			if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
+			else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
+			if (side != nullptr && hipEventRecord(side->inserted[b], back) != hipSuccess) return (int)hipGetLastError();
+			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
 		}
-		if (side != nullptr && numGroups > 0 && hipStreamWaitEvent(stream, side->tailDone[numGroups - 1], 0) != hipSuccess) return (int)hipGetLastError();
+		if (side != nullptr && (hipEventRecord(side->tailDone, back) != hipSuccess || hipStreamWaitEvent(stream, side->tailDone, 0) != hipSuccess)) return (int)hipGetLastError();
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
