@@ -15,6 +15,8 @@
 #include "simlod_device.hpp"
 #include "simlod_hip.h"
 #include "simlod_internal.hpp"
+#include <atomic>
+#include <chrono>
 
 namespace simlod {
 
@@ -39,7 +41,7 @@ struct RenderArgs {
 	uint32_t     numPixels, nodeCapacity, frameCounter;
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
 	uint64_t     offWork, offItems, offDepth, offColor, offOverflow, offDir;
-	uint32_t     itemCap, useTiles;
+	uint32_t     itemCap, useTiles, launchSeq;
 	// the builder's leaf chunk table (simlod_internal.hpp LeafTableRef), or table == nullptr: r_visible walks every list
 	const SimlodChunk* const* leafTable;
 	const uint32_t* leafTableMagic;
@@ -53,16 +55,17 @@ struct RenderArgs {
 static constexpr int WORK_WORDS = 12;
 // Draw items are queued by size, biggest first (longest-processing-time order): the draw workgroups take items from one shared
 // cursor, and a 64 000-sample item taken last would keep one CU busy long after the others ran dry (measured on the bench frame:
-// average workgroup 55 us, slowest 92 us with the items in emission order).  Class of an item = its chunk count: > 32, > 16, > 8, rest;
+// average workgroup 55 us, slowest 92 us with the items in emission order).  Class of an item = its chunk count: > 16, > 8, > 4, rest;
 // class c has its own array (itemCap entries) and counter, position q of the cursor maps to the classes in order.
 static constexpr int ITEM_CLASSES = 4;
-__device__ __forceinline__ uint32_t item_class(uint32_t chunks) { return chunks > 32u ? 0u : (chunks > 16u ? 1u : (chunks > 8u ? 2u : 3u)); }
-// A draw item = up to 64 consecutive chunks (64 000 samples) of one visible node's list: a whole leaf, or a slice of a long voxel list.
+__device__ __forceinline__ uint32_t item_class(uint32_t chunks) { return chunks > 16u ? 0u : (chunks > 8u ? 1u : (chunks > 4u ? 2u : 3u)); }
+// A draw item = up to 32 consecutive chunks (32 000 samples) of one visible node's list (a full leaf is two items; 64 per item: 5 % slower
+// on the bench frame, the biggest item is a fifth of a workgroup's whole share; 16: 10 % slower, twice the tile clears and flushes).
 // ONE workgroup draws an item, accumulating in a 128 x 128-pixel LDS tile laid over the node's screen box: the LOD rule draws a node
 // while its box spans 64..128 pixels (render.cu:893-901), so nearly every sample of a node lands in the tile, pixels that several
 // samples of the node hit (five per pixel on average for a full leaf) cost LDS atomics, and the framebuffer sees one global atomic per
 // TOUCHED pixel and item instead of one per sample.  Samples outside the tile take the global path.
-static constexpr uint32_t ITEM_CHUNKS = 64;
+static constexpr uint32_t ITEM_CHUNKS = 32;
 static constexpr uint32_t DTPB = 1024;              // draw workgroup: 16 waves share one tile (128 KB of LDS: one workgroup per CU)
 
 struct DrawItem {
@@ -79,7 +82,14 @@ __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { re
 enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5 };   // [5]: lists r_visible read through the builder's chunk table
 
 // ---- clear (render.cu:1126-1131, 233-241) ---------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void r_clear(RenderArgs a) {
+// Part of r_visible's launch: the planes are cleared by ALL its workgroups (a thousand, of which the octree's nodes keep a few dozen busy
+// for three dependent memory round trips), the frame's counters by thread 0 of workgroup 0, which then publishes the launch's
+// sequence number; a wave reads that word before its first reservation (by then it has long been there).
+__device__ __forceinline__ uint32_t* frame_ready_word(const RenderArgs& a) { return reinterpret_cast<uint32_t*>(a.mom + a.offWork) + 15; }
+__device__ __forceinline__ void wait_frame_ready(const RenderArgs& a) {
+	while (__hip_atomic_load(frame_ready_word(a), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.launchSeq) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void clear_frame(const RenderArgs& a) {
 	// 16-byte stores (every plane starts 16-byte aligned): the planes are 8, 4, 8 and 16 bytes per pixel
 	const uint32_t stride = gridDim.x * TPB, first = blockIdx.x * TPB + threadIdx.x;
 	auto fill = [&](uint64_t offset, uint64_t bytes, uint4 value, uint64_t tailWord, uint32_t tailBytes) {
@@ -98,14 +108,15 @@ __global__ __launch_bounds__(TPB) void r_clear(RenderArgs a) {
 		fill(a.offColor, (uint64_t)a.numPixels * 8, make_uint4(0, 0, 0, 0), 0ull, 8);
 		fill(a.offOverflow, (uint64_t)a.numPixels * 16, make_uint4(0, 0, 0, 0), 0ull, 8);
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		*a.frameStart = wall_ns();                                    // render.cu:1100-1102
-		for (int k = 0; k < 7; k++) *counter_at(a, k) = 0;
-		uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
-		for (int k = 0; k < WORK_WORDS; k++) work[k] = 0;
-		uint32_t* lines = reinterpret_cast<uint32_t*>(a.mom + R_OFF_LINES);
-		lines[0] = 0;                                                  // lines->count = 0, render.cu:1118
-	}
+}
+__device__ __forceinline__ void clear_counters(const RenderArgs& a) {     // one thread
+	*a.frameStart = wall_ns();                                        // render.cu:1100-1102
+	for (int k = 0; k < 7; k++) *counter_at(a, k) = 0;
+	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
+	for (int k = 0; k < WORK_WORDS; k++) work[k] = 0;
+	uint32_t* lines = reinterpret_cast<uint32_t*>(a.mom + R_OFF_LINES);
+	lines[0] = 0;                                                      // lines->count = 0, render.cu:1118
+	__hip_atomic_store(frame_ready_word(a), a.launchSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- visibility pass 1: screen-space extent + frustum test per node (render.cu:762-901, math.cuh:154-201) --------
@@ -202,12 +213,7 @@ __device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v) {      // exclus
 // (node fields; one reservation per wave; the chunk-table row; stores) instead of three kernels with twelve.
 // Draw items: a lane writes its node's chunk addresses into the frame's directory — copied from the builder's chunk table when that is
 // valid, else by walking the list (the only serial pointer chase left in a frame) — and cuts the list into items of <= 64 chunks.
-__global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	if (blockIdx.x * TPB >= numNodes) return;                                          // whole workgroup: the lanes of a wave reserve together
-	__shared__ float planes[6][4];
-	if (threadIdx.x < 6) frustum_plane(a.transformUpdate, (int)threadIdx.x, planes[threadIdx.x]);
-	__syncthreads();
+__device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (&planes)[6][4], const uint32_t numNodes) {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	const bool active = i < numNodes;
 	SimlodNode* n = a.nodes + (active ? i : 0u);
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
 	uint32_t slot = 0, dirBase = 0, waveBase[ITEM_CLASSES] = {0u, 0u, 0u, 0u};
 	if (lane_id() == 0) {
+		wait_frame_ready(a);
 		slot = atomicAdd(counter_at(a, C_VISIBLE), waveSlots);
 		if (waveChunks != 0u) {
 			dirBase = atomicAdd(work + 4, waveChunks);
@@ -344,6 +351,18 @@ __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
 	}
 	const uint32_t waveTable = wave_sum_u32(throughTable);
 	if (lane_id() == 0 && waveTable != 0u) atomicAdd(counter_at(a, C_TABLE_LISTS), waveTable);
+}
+
+__global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) clear_counters(a);
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	if (blockIdx.x * TPB < numNodes) {                                                 // whole workgroups: the lanes of a wave reserve together
+		__shared__ float planes[6][4];
+		if (threadIdx.x < 6) frustum_plane(a.transformUpdate, (int)threadIdx.x, planes[threadIdx.x]);
+		__syncthreads();
+		visible_nodes(a, planes, numNodes);
+	}
+	clear_frame(a);
 }
 
 // ---- draw ---------------------------------------------------------------------------------------------------------------
@@ -936,8 +955,24 @@ __global__ __launch_bounds__(TPB) void r_unpack(RenderArgs a) {
 }
 
 // ---- output: Stats (render.cu:1244-1252), EDL (:1255-1325, every full 16x16 tile), surface write (:1334-1343) ---------
+// RESOLVE: the HQS resolve of r_resolve in the same pass (whole frames without debug lines: nothing but the resolve writes the
+// framebuffer between the clear and this kernel).  A pixel resolves itself (and stores the word: the pre-EDL framebuffer stays what the
+// reference's is); of its four neighbours EDL wants the depth only, and that is the depth plane's word whenever it is a normal number
+// (its nearest sample passes its own 1 % test, so the pixel has a colour) or +inf (nothing landed: the cleared framebuffer word has the
+// same high half); a denormal depth — whose own sample fails d < d * 1.01f — takes the long way.
+template <bool RESOLVE>
+__device__ __forceinline__ uint32_t resolved_depth_bits(const RenderArgs& a, const uint64_t* fb, int idx) {
+	if (!RESOLVE) return (uint32_t)(fb[idx] >> 32);
+	const uint32_t d = reinterpret_cast<const uint32_t*>(a.mom + a.offDepth)[idx];
+	if (d >= 0x00800000u) return d == 0x7f800000u ? (uint32_t)(fb[idx] >> 32) : d;
+	const unsigned long long pk = reinterpret_cast<const unsigned long long*>(a.mom + a.offColor)[idx];
+	const uint32_t count = reinterpret_cast<const uint4*>(a.mom + a.offOverflow)[idx].w + (uint32_t)(pk >> 42);
+	return count != 0u ? d : (uint32_t)(fb[idx] >> 32);
+}
+
+template <bool RESOLVE>
 __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
-	const uint64_t* fb = reinterpret_cast<const uint64_t*>(a.mom + R_OFF_FB);
+	uint64_t* fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		SimlodStats* s = a.stats;
 		s->numVisibleNodes = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
@@ -952,7 +987,18 @@ __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
 	const int last = (int)a.numPixels - 1;
 	const uint32_t stride = gridDim.x * TPB;
 	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) {
-		const uint64_t enc = fb[i];
+		uint64_t enc;
+		if (RESOLVE) {
+			const unsigned long long pk = reinterpret_cast<const unsigned long long*>(a.mom + a.offColor)[i];
+			uint4 s = reinterpret_cast<const uint4*>(a.mom + a.offOverflow)[i];                 // as r_resolve
+			s.x += (uint32_t)((pk >> 28) & 0x3fffu); s.y += (uint32_t)((pk >> 14) & 0x3fffu); s.z += (uint32_t)(pk & 0x3fffu); s.w += (uint32_t)(pk >> 42);
+			if (s.w == 0u) enc = fb[i];
+			else {
+				const uint32_t rgba = ((s.x / s.w) & 0xffu) | (((s.y / s.w) & 0xffu) << 8) | (((s.z / s.w) & 0xffu) << 16) | (255u << 24);
+				enc = ((uint64_t)reinterpret_cast<const uint32_t*>(a.mom + a.offDepth)[i] << 32) | rgba;
+				fb[i] = enc;
+			}
+		} else enc = fb[i];
 		uint32_t color = (uint32_t)enc;
 		const int x = (int)(i % (uint32_t)a.W), y = (int)(i / (uint32_t)a.W);
 		if (x < edlW && y < edlH) {
@@ -964,7 +1010,7 @@ __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
 			for (int k = 0; k < 4; k++) {
 				int idx = (int)i + offs[k];
 				idx = idx < 0 ? 0 : (idx > last ? last : idx);
-				const float ln = __log2f(__uint_as_float((uint32_t)(fb[idx] >> 32)));
+				const float ln = __log2f(__uint_as_float(resolved_depth_bits<RESOLVE>(a, fb, idx)));
 				const float d = lp - ln;
 				sum = sum + (d > 0.0f ? d : 0.0f);                 // max(NaN, 0) = 0
 			}
@@ -1070,6 +1116,9 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	}
 	a.itemCap = MAX_DRAW_ITEMS;
 	a.useTiles = (uint32_t)tune("SIMLOD_RASTER_LDS_TILES", 1);
+	// (what thread 0 of r_visible publishes once the frame's counters are zero: never the value a stale or poisoned buffer holds)
+	static std::atomic<uint32_t> launchSeq{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
+	a.launchSeq = launchSeq.fetch_add(2u);
 
 	const DeviceInfo& dev = device_info();
 	const uint32_t gridPixels = dev.numCUs * 8;
@@ -1085,7 +1134,6 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 		SIMLOD_LAUNCH(r_lines_raster, dim3((LINE_VERTEX_CAP / 2 + TPB - 1) / TPB), dim3(TPB), stream, a);
 	};
 	if (parts & RENDER_FIRST) {
-		SIMLOD_LAUNCH(r_clear, dim3(gridPixels), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(r_visible, dim3(gridNodes), dim3(TPB), stream, a);
 		if (a.hqs) SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(DTPB), stream, a);
 		else { SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(DTPB), stream, a); lines(); }
@@ -1094,11 +1142,16 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(DTPB), stream, a);
 		if (!whole) SIMLOD_LAUNCH(r_unpack, dim3(gridPixels), dim3(TPB), stream, a);     // ranks all-reduce(SUM) the {R,G,B,count} plane
 	}
-	if (a.hqs && (parts & RENDER_RESOLVE)) {
+	// whole HQS frames without debug lines resolve inside r_output
+	const bool fused = a.hqs && whole && !u->showBoundingBox && colorbuffer != nullptr && tune("SIMLOD_RASTER_FUSED_RESOLVE", 1) != 0;
+	if (a.hqs && (parts & RENDER_RESOLVE) && !fused) {
 		SIMLOD_LAUNCH(r_resolve, dim3(gridPixels), dim3(TPB), stream, a);
 		lines();
 	}
-	if (parts & RENDER_OUTPUT) SIMLOD_LAUNCH(r_output, dim3(gridPixels), dim3(TPB), stream, a);
+	if (parts & RENDER_OUTPUT) {
+		if (fused) SIMLOD_LAUNCH(r_output<true>, dim3(gridPixels), dim3(TPB), stream, a);
+		else SIMLOD_LAUNCH(r_output<false>, dim3(gridPixels), dim3(TPB), stream, a);
+	}
 	if (profile_enabled()) profile_close(stream);
 	return (int)hipGetLastError();
 }

@@ -1,5 +1,10 @@
 """Build the bench octree (36 M terrain), then draw FRAMES plain and FRAMES HQS frames: run under
-`rocprofv3 --kernel-trace --stats` to get the per-kernel times of the rasteriser alone (tools/raster_prof.sh)."""
+`rocprofv3 --kernel-trace --stats` to get the per-kernel times of the rasteriser alone (tools/raster_prof.sh).
+
+    python tools/raster_prof.py [points] [frames] ["NAME=VALUE ..." ...]
+
+Every further argument is one variant: environment settings for the library's tuning knobs (read at every launch), timed one after
+the other on the same octree ("" = defaults)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +20,10 @@ dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, max_pixels=W * H)
 u = dev.uniforms(W, H, T, box, hqs=False)
 dev.reset(u)
 dev.add_points(u, pts)
-for hqs in (0, 1):
+variants = sys.argv[3:] or [""]
+for var, hqs in [(v, h) for v in variants for h in (0, 1)]:
+    for kv in var.split():
+        os.environ[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
     u["useHighQualityShading"] = hqs
     for _ in range(frames):
         dev.render(u)
@@ -25,4 +33,6 @@ for hqs in (0, 1):
     for _ in range(frames):
         dev.render(u)
     t1.record(); torch.cuda.synchronize()
-    print("hqs" if hqs else "plain", "ms/frame", t0.elapsed_time(t1) / frames, "lists through table", dev.lists_read_through_table(), flush=True)
+    for kv in var.split():
+        os.environ.pop(kv.split("=", 1)[0], None)
+    print(f"{var or 'default':40s}", "hqs" if hqs else "plain", "ms/frame", t0.elapsed_time(t1) / frames, "lists through table", dev.lists_read_through_table(), flush=True)
