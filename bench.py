@@ -465,9 +465,10 @@ def main():
                          "same_octree_content_counts_as_exact": bool(ok),
                          "what": "simlod_set_ingest_mode(1): the pending batches of a launch in groups (the same kernels, construct.hip); topology, multisets, bitsets and voxels "
                                  "equal the exact mode's, the allocator / chunk-pool counters of Stats do not"}
+            dev2.close()
             del dev2
         finally:
-            L.simlod_set_ingest_mode(0)
+            pass                              # (the ingest mode belongs to dev2's context: nothing process-wide to restore)
 
     # ---- BASELINE config 3 as stated (350 M-point scan-ordered LAS 1.4 file through the reference's own host functions, device decode in the
     # upload stream): a 9 GB file does not belong in a run that has to finish within minutes, so the object quotes the kept measurement of

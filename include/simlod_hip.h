@@ -41,20 +41,44 @@ extern "C" {
 #define SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW 0x080u /* > 1 000 000 recycled chunks (voxels.cu:856)                        */
 #define SIMLOD_ERR_VISIBLE_OVERFLOW    0x100u /* > 100 000 visible nodes (render.cu:1108)                           */
 
+/* ---- per-octree contexts --------------------------------------------------------------------------------------------------------
+ * The reference host keeps ONE octree per process and its launch signatures carry no handle (main_progressive_octree.cpp:337-345,
+ * :374-382, :499-507).  What this library keeps between launches — ingest mode, node capacity, batch limit, tuning knobs, its second
+ * stream and events, the table registry that links kernel_construct to kernel_render, the launch feedback — lives in a context; a
+ * launch finds its context through the NODE ARRAY it is given.  Node arrays that were never attached share the default context, which
+ * is what the simlod_set_* calls below configure: a host with one octree never needs these six functions.  A host with several octrees
+ * (one per tile, per data set, per thread) makes a context per octree and attaches the octree's node array to it.
+ *
+ * Tuning knobs (SIMLOD_OVERLAP_TAIL, SIMLOD_EXPAND_WGS, SIMLOD_GRID_MULT, SIMLOD_COUNT_TPB, SIMLOD_VOXELIZE_WGS, SIMLOD_ADAPTIVE_GROUPS,
+ * SIMLOD_RASTER_LEAF_TABLE, SIMLOD_RASTER_LDS_TILES, SIMLOD_DRAW_MULT, SIMLOD_RASTER_FUSED_RESOLVE, SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT,
+ * SIMLOD_DEBUG_VOXELIZE_CLOCK, SIMLOD_DEBUG_BUDGET_US) are read from the environment ONCE, when a context is made (the default
+ * context: at its first use); simlod_context_set_knob overrides one by name (set = 0: back to the built-in default),
+ * simlod_context_reload_env reads the environment again.  ctx == NULL means the default context everywhere. */
+typedef struct SimlodContext SimlodContext;
+int simlod_context_create(SimlodContext** out);
+int simlod_context_destroy(SimlodContext* ctx);                               /* waits for the context's second stream; detaches its node arrays */
+int simlod_context_attach(SimlodContext* ctx, const SimlodNode* nodes);       /* launches given `nodes` run in ctx from now on (NULL: default again) */
+int simlod_context_set_node_capacity(SimlodContext* ctx, uint32_t numNodes);
+int simlod_context_set_ingest_mode(SimlodContext* ctx, uint32_t mode);
+int simlod_context_set_construct_batch_limit(SimlodContext* ctx, uint32_t maxBatches);
+int simlod_context_set_knob(SimlodContext* ctx, const char* name, int value, int set);
+int simlod_context_reload_env(SimlodContext* ctx);
+uint64_t simlod_context_construct_buffer_min_bytes(SimlodContext* ctx);
+
 /* Number of Node records the host's node buffer holds (default 263 157 = 40 000 000 / 152,
- * main_progressive_octree.cpp:552).  Process-wide; set before the first reset if the host allocates differently. */
+ * main_progressive_octree.cpp:552).  Default context; set before the first reset if the host allocates differently. */
 int simlod_set_node_capacity(uint32_t numNodes);
 
 /* Ingest granularity of kernel_construct.  0 (default) = EXACT: one ring batch at a time, as progressive_octree_voxels.cu:883-949 does
  * — every Node and Stats field after every batch is the reference's.  1 = COALESCED: all pending batches of a launch (<= 20, as many
  * as the momentary buffer holds) are ingested as one batch.  Topology, per-node sample multisets, occupancy bitsets, voxel positions
  * and counts do not depend on the granularity; the allocator / chunk-pool accounting (Stats.allocatedBytes_persistent,
- * numAllocatedChunks, chunkPoolSize) does: fewer intermediate chunks are ever allocated.  Process-wide. */
+ * numAllocatedChunks, chunkPoolSize) does: fewer intermediate chunks are ever allocated.  Default context. */
 int simlod_set_ingest_mode(uint32_t mode);
 
 /* Optional host hint: no more than `maxBatches` (1..20, default 20) ring batches are pending when kernel_construct is launched, so
  * no more than that many per-batch kernel groups need to be enqueued (the reference host knows its upload counter,
- * main_progressive_octree.cpp:1012-1050).  A launch never ingests more than this many batches.  Process-wide. */
+ * main_progressive_octree.cpp:1012-1050).  A launch never ingests more than this many batches.  Default context. */
 int simlod_set_construct_batch_limit(uint32_t maxBatches);
 
 /* kernel_render reads the chunk lists of visible nodes through a table kernel_construct keeps in ITS momentary buffer (one row of chunk

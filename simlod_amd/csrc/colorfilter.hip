@@ -159,10 +159,10 @@ __global__ __launch_bounds__(CF_TPB) void cf_wave(FilterArgs a, uint32_t height)
 
 uint64_t colorfilter_min_bytes(uint32_t nodeCapacity) { return 4096 + (uint64_t)nodeCapacity + 256 + (uint64_t)CF_CELLS * 8 + (uint64_t)CF_ACCEPTED * 4; }
 
-int launch_colorfilter(const SimlodUniforms* u, uint32_t* buffer, SimlodNode* nodes, const uint32_t* numNodes, SimlodStats* stats, hipStream_t stream) {
+int launch_colorfilter(Context& ctx, const SimlodUniforms* u, uint32_t* buffer, SimlodNode* nodes, const uint32_t* numNodes, SimlodStats* stats, hipStream_t stream) {
 	FilterArgs a{};
 	a.mom = reinterpret_cast<uint8_t*>(buffer); a.nodes = nodes; a.stats = stats; a.numNodesPtr = numNodes;
-	a.nodeCapacity = node_capacity();
+	a.nodeCapacity = ctx.nodeCapacity.load();
 	const float bx = u->boxMax.x - u->boxMin.x, by = u->boxMax.y - u->boxMin.y, bz = u->boxMax.z - u->boxMin.z;
 	a.cubeSize = fmaxf(fmaxf(bx, by), bz);
 	a.minx = u->boxMin.x; a.miny = u->boxMin.y; a.minz = u->boxMin.z;

@@ -1959,32 +1959,39 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce) {
 	return off <= capacity;
 }
 
-// the library's second stream for the back halves of the batches, and the events that tie it to the caller's stream (one pair per group of a launch)
+}  // namespace build
+// a context's second stream for the back halves of the batches, and the events that tie it to the caller's stream (one pair per group of a launch)
 struct SideStream {
 	hipStream_t stream;
 	hipEvent_t expanded[SIMLOD_MAX_BATCHES_PER_LAUNCH], inserted[SIMLOD_MAX_BATCHES_PER_LAUNCH], tailDone;
-	std::mutex enqueue;          // the events are reused by every launch on the device: one launch's records and waits are enqueued as a block
+	std::mutex enqueue;          // the events are reused by every launch of the context: one launch's records and waits are enqueued as a block
 };
-static SideStream* side_stream() {
-	static SideStream* cache[64];
-	static std::mutex lock;
+void destroy_side_stream(SideStream* s) {
+	(void)hipStreamSynchronize(s->stream);
+	for (uint32_t i = 0; i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++) { (void)hipEventDestroy(s->expanded[i]); (void)hipEventDestroy(s->inserted[i]); }
+	(void)hipEventDestroy(s->tailDone);
+	(void)hipStreamDestroy(s->stream);
+	delete s;
+}
+namespace build {
+static SideStream* side_stream(Context& ctx) {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
 	if (dev < 0 || dev >= 64) return nullptr;
-	std::lock_guard<std::mutex> hold(lock);
-	if (cache[dev] == nullptr) {
+	std::lock_guard<std::mutex> hold(ctx.sideLock);
+	if (ctx.side[dev] == nullptr) {
 		SideStream* s = new SideStream();
 		bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
 		for (uint32_t i = 0; ok && i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++)
 			ok = hipEventCreateWithFlags(&s->expanded[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->inserted[i], hipEventDisableTiming) == hipSuccess;
 		ok = ok && hipEventCreateWithFlags(&s->tailDone, hipEventDisableTiming) == hipSuccess;
 		if (!ok) { (void)hipGetLastError(); delete s; return nullptr; }     // no side stream: everything stays on the caller's
-		cache[dev] = s;
+		ctx.side[dev] = s;
 	}
-	return cache[dev];
+	return ctx.side[dev];
 }
 
-int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
                      SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream) {
 	BuildArgs a{};
 	a.ring = points; a.mom = reinterpret_cast<uint8_t*>(buffer); a.pers = pers; a.nodes = nodes; a.stats = stats;
@@ -1994,33 +2001,33 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	a.minx = u->boxMin.x; a.miny = u->boxMin.y; a.minz = u->boxMin.z;
 	a.persCapacity = u->persistentBufferCapacity;
 	a.frameCounter = u->frameCounter;
-	a.nodeCapacity = node_capacity();
-	const bool coalesce = ingest_mode() != 0u;
+	a.nodeCapacity = ctx.nodeCapacity.load();
+	const bool coalesce = ctx.ingestMode.load() != 0u;
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity, coalesce);
 	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
-		note_leaf_table(LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
+		note_leaf_table(ctx, LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
 		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS});
-	} else forget_leaf_table(nodes);
+	} else forget_leaf_table(ctx, nodes);
 	const DeviceInfo& dev = device_info();
 
-	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(batch_limit(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(stats));
-	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 0) & 1u) | (tune("SIMLOD_DEBUG_VOXELIZE_CLOCK", 0) != 0 ? 2u : 0u),
-	              (uint32_t)std::max(0, tune("SIMLOD_DEBUG_BUDGET_US", 0)), a.groupMax);
+	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(ctx.batchLimit.load(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(ctx, stats));
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u),
+	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), a.groupMax);
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
 		if (e != hipSuccess) return (int)e;
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
 		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
-		const uint32_t gridPoints = dev.numCUs * (uint32_t)tune("SIMLOD_GRID_MULT", 8);
+		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
 		// (with the previous batch's voxel half running beside it on the side stream: one per FOUR CUs — 256: 8.3 ms per ingest, 128: 7.8,
 		// 96: 7.5, 64: 7.2, 48: 7.3, 32: 7.5)
-		const bool overlap = tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled();
+		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled();
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
-		const uint32_t expandWgs = (uint32_t)max(1, min(tune("SIMLOD_EXPAND_WGS", a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
+		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		// A batch has a FRONT half — k_prepare, k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
 		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
@@ -2032,10 +2039,10 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 		// k_count does not look at Node.numPoints (stored_at_start()).  Per batch the chain is as long as its longest cycle — k_insert,
 		// event, k_queue + k_hist + k_expand, event: ~90 us — instead of the sum of all seven kernels (~190 us on one stream).
 		// Off while per-kernel profiling is on (one stream, one timeline) or with SIMLOD_OVERLAP_TAIL=0.
-		SideStream* side = (tune("SIMLOD_OVERLAP_TAIL", 1) != 0 && !profile_enabled()) ? side_stream() : nullptr;
+		SideStream* side = (ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled()) ? side_stream(ctx) : nullptr;
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
-		const int countTpb = tune("SIMLOD_COUNT_TPB", 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
+		const int countTpb = ctx.tune(KNOB_COUNT_TPB, 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
 		const bool single = a.groupMax == 1u;
 		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
 		hipStream_t back = side != nullptr ? side->stream : stream;
@@ -2053,7 +2060,7 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 			if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
 			else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
 			if (side != nullptr && hipEventRecord(side->inserted[b], back) != hipSuccess) return (int)hipGetLastError();
-			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)tune("SIMLOD_VOXELIZE_WGS", (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
+			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
 		}
 		if (side != nullptr && (hipEventRecord(side->tailDone, back) != hipSuccess || hipStreamWaitEvent(stream, side->tailDone, 0) != hipSuccess)) return (int)hipGetLastError();
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
@@ -2061,15 +2068,15 @@ int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buf
 	}
 	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
 	if (profile_enabled()) profile_close(stream);
-	if (note_launch_end(stats, numBatchesUploaded, stream) != 0) return (int)hipGetLastError();
+	if (note_launch_end(ctx, stats, numBatchesUploaded, stream) != 0) return (int)hipGetLastError();
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return (int)e;
 	return fits ? 0 : (int)hipErrorInvalidValue;
 }
 
-uint64_t construct_min_bytes() {
+uint64_t construct_min_bytes(uint32_t nodeCapacity) {
 	BuildArgs a{};
-	a.nodeCapacity = node_capacity();
+	a.nodeCapacity = nodeCapacity;
 	layout_construct(a, 0, false);
 	return a.scratchBytes + 4096 + 26ull * 65536;   // the smallest capacity layout_construct accepts, plus a page of slack
 }

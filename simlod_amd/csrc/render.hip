@@ -1065,10 +1065,10 @@ uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * ITEM_CLASSES * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + (uint64_t)MAX_DIR_CHUNKS * 8 + 256;
 }
 
-int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
+int launch_reset(Context& ctx, const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream) {
-	forget_leaf_table(nodes);
-	forget_launch_history(stats);
+	forget_leaf_table(ctx, nodes);
+	forget_launch_history(ctx, stats);
 	SIMLOD_LAUNCH(k_reset, dim3(64), dim3(TPB), stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter);
 	return (int)hipGetLastError();
 }
@@ -1091,7 +1091,7 @@ uint64_t render_sum_planes_offset(uint32_t width, uint32_t height) {
 
 // parts: bit 0 = clear, visibility, draw items and the first pass (plain: the only pass, and the debug lines; HQS: depth)
 //        bit 1 = HQS colour pass, sums unpacked        bit 2 = HQS resolve, then the debug lines        bit 3 = Stats, EDL, RGBA8 output
-int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
+int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
                   uint64_t* frameStart, hipStream_t stream, uint32_t parts) {
 	RenderArgs a{};
 	a.mom = reinterpret_cast<uint8_t*>(buffer); a.nodes = nodes; a.stats = stats; a.colorbuffer = colorbuffer; a.frameStart = frameStart;
@@ -1105,17 +1105,17 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	a.minx = u->boxMin.x; a.miny = u->boxMin.y; a.minz = u->boxMin.z;
 	a.minNodeSize = u->minNodeSize;
 	a.pointSize = u->pointSize;
-	a.nodeCapacity = node_capacity();
+	a.nodeCapacity = ctx.nodeCapacity.load();
 	a.frameCounter = (uint32_t)u->frameCounter;
 	a.showPoints = u->showPoints; a.colorByNode = u->colorByNode; a.colorByLOD = u->colorByLOD; a.hqs = u->useHighQualityShading;
 	render_plane_offsets(a.numPixels, a.offWork, a.offItems, a.offDepth, a.offColor, a.offOverflow, &a.offDir);
 	LeafTableRef lt;
-	if (tune("SIMLOD_RASTER_LEAF_TABLE", 1) && find_leaf_table(nodes, lt)) {
+	if (ctx.tune(KNOB_RASTER_LEAF_TABLE, 1) && find_leaf_table(ctx, nodes, lt)) {
 		a.leafTable = lt.table; a.leafTableMagic = lt.magic; a.leafTableBatch = lt.batch; a.leafTableNodes = lt.tableNodes; a.leafTableSig = lt.sig;
 		a.leafTableMagicValue = lt.magicValue; a.leafTableSlots = lt.slots;
 	}
 	a.itemCap = MAX_DRAW_ITEMS;
-	a.useTiles = (uint32_t)tune("SIMLOD_RASTER_LDS_TILES", 1);
+	a.useTiles = (uint32_t)ctx.tune(KNOB_RASTER_LDS_TILES, 1);
 	// (what thread 0 of r_visible publishes once the frame's counters are zero: never the value a stale or poisoned buffer holds)
 	static std::atomic<uint32_t> launchSeq{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
 	a.launchSeq = launchSeq.fetch_add(2u);
@@ -1126,7 +1126,7 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 	// one draw workgroup per CU: its 128 x 128-pixel tile takes 64-128 KB of the CU's 160 KB of LDS.  The depth pass too, though two of
 	// its 64 KB tiles would fit: the draw loop is ALU-bound, two workgroups per CU each run at half speed, and the last big items then
 	// finish later (HQS frame 0.227 ms against 0.231 ms).
-	const uint32_t gridDraw = dev.numCUs * (uint32_t)tune("SIMLOD_DRAW_MULT", 1);
+	const uint32_t gridDraw = dev.numCUs * (uint32_t)ctx.tune(KNOB_DRAW_MULT, 1);
 	const bool whole = parts == RENDER_ALL;
 	auto lines = [&]() {
 		if (!u->showBoundingBox) return;
@@ -1143,7 +1143,7 @@ int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, 
 		if (!whole) SIMLOD_LAUNCH(r_unpack, dim3(gridPixels), dim3(TPB), stream, a);     // ranks all-reduce(SUM) the {R,G,B,count} plane
 	}
 	// whole HQS frames without debug lines resolve inside r_output
-	const bool fused = a.hqs && whole && !u->showBoundingBox && colorbuffer != nullptr && tune("SIMLOD_RASTER_FUSED_RESOLVE", 1) != 0;
+	const bool fused = a.hqs && whole && !u->showBoundingBox && colorbuffer != nullptr && ctx.tune(KNOB_RASTER_FUSED_RESOLVE, 1) != 0;
 	if (a.hqs && (parts & RENDER_RESOLVE) && !fused) {
 		SIMLOD_LAUNCH(r_resolve, dim3(gridPixels), dim3(TPB), stream, a);
 		lines();

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "simlod_hip.h"
@@ -14,22 +15,39 @@
 
 namespace simlod {
 
-static std::atomic<uint32_t> g_nodeCapacity{263157u};   // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
+const char* const KNOB_NAMES[KNOB_COUNT_] = {
+	"SIMLOD_OVERLAP_TAIL", "SIMLOD_EXPAND_WGS", "SIMLOD_GRID_MULT", "SIMLOD_COUNT_TPB", "SIMLOD_VOXELIZE_WGS", "SIMLOD_ADAPTIVE_GROUPS",
+	"SIMLOD_RASTER_LEAF_TABLE", "SIMLOD_RASTER_LDS_TILES", "SIMLOD_DRAW_MULT", "SIMLOD_RASTER_FUSED_RESOLVE",
+	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US",
+};
 
-static std::atomic<uint32_t> g_ingestMode{0u};
-static std::atomic<uint32_t> g_batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};
+Context::Context() { reload_env(); }
 
-uint32_t node_capacity() { return g_nodeCapacity.load(); }
-uint32_t ingest_mode() { return g_ingestMode.load(); }
-uint32_t batch_limit() { return g_batchLimit.load(); }
+void Context::reload_env() {
+	for (int k = 0; k < KNOB_COUNT_; k++) {
+		const char* v = std::getenv(KNOB_NAMES[k]);
+		knob[k] = v != nullptr && *v != 0 ? std::atoi(v) : KNOB_UNSET;
+	}
+}
 
-int tune(const char* envName, int dflt) {
-	const char* v = std::getenv(envName);
-	return v ? std::atoi(v) : dflt;
+Context::~Context() {
+	for (SideStream*& s : side) { if (s != nullptr) destroy_side_stream(s); s = nullptr; }
+	// (the page-locked feedback words of the launch history stay allocated: a copy of an earlier launch may still be on its way)
+}
+
+// node array -> context (simlod_context_attach); everything else runs in the default context
+static std::mutex g_attachLock;
+static std::vector<std::pair<const void*, Context*>> g_attached;
+static Context& default_context() { static Context* c = new Context(); return *c; }   // (never destroyed: launches may race with process exit)
+
+Context& context_of(const void* nodes) {
+	std::lock_guard<std::mutex> hold(g_attachLock);
+	for (auto& a : g_attached) if (a.first == nodes) return *a.second;
+	return default_context();
 }
 
 bool debug_sync() {
-	static const bool on = tune("SIMLOD_DEBUG_SYNC", 0) != 0;
+	static const bool on = [] { const char* v = std::getenv("SIMLOD_DEBUG_SYNC"); return v != nullptr && std::atoi(v) != 0; }();
 	return on;
 }
 void debug_synced(const char* kernelName) {
@@ -58,25 +76,25 @@ const DeviceInfo& device_info() {
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height);
 
 // ---- builder -> rasteriser: where each octree's leaf chunk table lives (simlod_internal.hpp LeafTableRef) --------
-static std::mutex g_leafTablesLock;
-static std::vector<LeafTableRef> g_leafTables;
-
-void note_leaf_table(const LeafTableRef& ref) {
-	std::lock_guard<std::mutex> hold(g_leafTablesLock);
+void note_leaf_table(Context& ctx, const LeafTableRef& ref) {
+	std::lock_guard<std::mutex> hold(ctx.tablesLock);
+	std::vector<LeafTableRef>& g_leafTables = ctx.tables;
 	for (LeafTableRef& r : g_leafTables)
 		if (r.nodes == ref.nodes) { r = ref; return; }
 	if (g_leafTables.size() >= 64) g_leafTables.erase(g_leafTables.begin());
 	g_leafTables.push_back(ref);
 }
 
-void forget_leaf_table(const void* nodes) {
-	std::lock_guard<std::mutex> hold(g_leafTablesLock);
+void forget_leaf_table(Context& ctx, const void* nodes) {
+	std::lock_guard<std::mutex> hold(ctx.tablesLock);
+	std::vector<LeafTableRef>& g_leafTables = ctx.tables;
 	for (size_t i = 0; i < g_leafTables.size(); i++)
 		if (g_leafTables[i].nodes == nodes) { g_leafTables.erase(g_leafTables.begin() + (long)i); return; }
 }
 
-bool find_leaf_table(const void* nodes, LeafTableRef& ref) {
-	std::lock_guard<std::mutex> hold(g_leafTablesLock);
+bool find_leaf_table(Context& ctx, const void* nodes, LeafTableRef& ref) {
+	std::lock_guard<std::mutex> hold(ctx.tablesLock);
+	std::vector<LeafTableRef>& g_leafTables = ctx.tables;
 	for (size_t i = 0; i < g_leafTables.size(); i++) {
 		if (g_leafTables[i].nodes != nodes) continue;
 		// the host may have freed the construct buffer since: the kernel must not touch an address that is no longer mapped
@@ -93,12 +111,10 @@ bool find_leaf_table(const void* nodes, LeafTableRef& ref) {
 }
 
 // ---- launch feedback: how many batches the recent kernel_construct launches found (simlod_internal.hpp groups_for_launch) ----------
-struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter
-static std::mutex g_historyLock;
-static std::vector<LaunchHistory> g_history;
 static constexpr uint32_t NOTHING_SEEN = 0xffffffffu;
 
-static LaunchHistory* history_of(const void* stats, bool create) {
+static LaunchHistory* history_of(Context& ctx, const void* stats, bool create) {
+	std::vector<LaunchHistory>& g_history = ctx.history;
 	for (LaunchHistory& h : g_history) if (h.stats == stats) return &h;
 	if (!create) return nullptr;
 	volatile uint32_t* seen = nullptr;
@@ -117,10 +133,10 @@ static LaunchHistory* history_of(const void* stats, bool create) {
 	return &g_history.back();
 }
 
-uint32_t groups_for_launch(const SimlodStats* stats) {
-	if (tune("SIMLOD_ADAPTIVE_GROUPS", 1) == 0) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
-	std::lock_guard<std::mutex> hold(g_historyLock);
-	LaunchHistory* h = history_of(stats, false);
+uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
+	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
+	std::lock_guard<std::mutex> hold(ctx.historyLock);
+	LaunchHistory* h = history_of(ctx, stats, false);
 	if (h == nullptr) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
 	const uint32_t index = h->seen[0], uploaded = h->seen[1];
 	if (index == NOTHING_SEEN || uploaded == NOTHING_SEEN) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
@@ -131,10 +147,10 @@ uint32_t groups_for_launch(const SimlodStats* stats) {
 	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want;
 }
 
-int note_launch_end(const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream) {
-	if (tune("SIMLOD_ADAPTIVE_GROUPS", 1) == 0) return 0;
-	std::lock_guard<std::mutex> hold(g_historyLock);           // (held across the enqueue: the slot cannot change hands in between)
-	LaunchHistory* h = history_of(stats, true);
+int note_launch_end(Context& ctx, const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream) {
+	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return 0;
+	std::lock_guard<std::mutex> hold(ctx.historyLock);         // (held across the enqueue: the slot cannot change hands in between)
+	LaunchHistory* h = history_of(ctx, stats, true);
 	if (h == nullptr) return 0;
 	volatile uint32_t* seen = h->seen;
 	hipError_t e = hipMemcpyAsync(const_cast<uint32_t*>(seen), &stats->batchletIndex, 4, hipMemcpyDeviceToHost, stream);
@@ -142,9 +158,9 @@ int note_launch_end(const SimlodStats* stats, const uint32_t* numBatchesUploaded
 	return (int)e;
 }
 
-void forget_launch_history(const SimlodStats* stats) {
-	std::lock_guard<std::mutex> hold(g_historyLock);
-	LaunchHistory* h = history_of(stats, false);
+void forget_launch_history(Context& ctx, const SimlodStats* stats) {
+	std::lock_guard<std::mutex> hold(ctx.historyLock);
+	LaunchHistory* h = history_of(ctx, stats, false);
 	if (h != nullptr) { h->seen[0] = NOTHING_SEEN; h->seen[1] = NOTHING_SEEN; h->havePrev = false; }
 }
 
@@ -187,12 +203,59 @@ using namespace simlod;
 
 extern "C" {
 
-int simlod_set_node_capacity(uint32_t numNodes) {
-	// node indices travel in 19-bit fields (ancestor path entries, split records, claim-set keys: construct.hip)
-	if (numNodes < 9 || numNodes > (1u << 19)) return (int)hipErrorInvalidValue;
-	g_nodeCapacity.store(numNodes);
+struct SimlodContext { simlod::Context ctx; };
+static Context& ctx_or_default(SimlodContext* c) { return c != nullptr ? c->ctx : default_context(); }
+
+int simlod_context_create(SimlodContext** out) {
+	if (!out) return (int)hipErrorInvalidValue;
+	*out = new SimlodContext();
 	return 0;
 }
+
+int simlod_context_destroy(SimlodContext* c) {
+	if (!c) return (int)hipErrorInvalidValue;
+	{
+		std::lock_guard<std::mutex> hold(g_attachLock);
+		for (size_t i = 0; i < g_attached.size();) { if (g_attached[i].second == &c->ctx) g_attached.erase(g_attached.begin() + (long)i); else i++; }
+	}
+	delete c;                                    // (synchronises and destroys the context's second stream)
+	return 0;
+}
+
+int simlod_context_attach(SimlodContext* c, const SimlodNode* nodes) {
+	if (!nodes) return (int)hipErrorInvalidValue;
+	std::lock_guard<std::mutex> hold(g_attachLock);
+	for (size_t i = 0; i < g_attached.size(); i++)
+		if (g_attached[i].first == nodes) { g_attached.erase(g_attached.begin() + (long)i); break; }
+	if (c != nullptr) g_attached.emplace_back(nodes, &c->ctx);           // NULL: back to the default context
+	return 0;
+}
+
+int simlod_context_set_node_capacity(SimlodContext* c, uint32_t numNodes) {
+	// node indices travel in 19-bit fields (ancestor path entries, split records, claim-set keys: construct.hip)
+	if (numNodes < 9 || numNodes > (1u << 19)) return (int)hipErrorInvalidValue;
+	ctx_or_default(c).nodeCapacity.store(numNodes);
+	return 0;
+}
+int simlod_context_set_ingest_mode(SimlodContext* c, uint32_t mode) {
+	if (mode > 1u) return (int)hipErrorInvalidValue;
+	ctx_or_default(c).ingestMode.store(mode);
+	return 0;
+}
+int simlod_context_set_construct_batch_limit(SimlodContext* c, uint32_t maxBatches) {
+	if (maxBatches == 0u) return (int)hipErrorInvalidValue;
+	ctx_or_default(c).batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
+	return 0;
+}
+int simlod_context_set_knob(SimlodContext* c, const char* name, int value, int set) {
+	if (!name) return (int)hipErrorInvalidValue;
+	for (int k = 0; k < KNOB_COUNT_; k++)
+		if (std::strcmp(name, KNOB_NAMES[k]) == 0) { ctx_or_default(c).knob[k] = set ? value : KNOB_UNSET; return 0; }
+	return (int)hipErrorNotFound;
+}
+int simlod_context_reload_env(SimlodContext* c) { ctx_or_default(c).reload_env(); return 0; }
+
+int simlod_set_node_capacity(uint32_t numNodes) { return simlod_context_set_node_capacity(nullptr, numNodes); }
 
 uint64_t simlod_render_framebuffer_offset(void) {
 	return (uint64_t)SIMLOD_MAX_VISIBLE_NODES * sizeof(SimlodNode) + 7 * 16 + 32 + 16000000ull;
@@ -200,22 +263,15 @@ uint64_t simlod_render_framebuffer_offset(void) {
 
 uint64_t simlod_render_buffer_bytes(uint32_t width, uint32_t height) { return render_buffer_bytes(width, height); }
 
-uint64_t simlod_construct_buffer_min_bytes(void) { return build::construct_min_bytes(); }
+uint64_t simlod_construct_buffer_min_bytes(void) { return build::construct_min_bytes(default_context().nodeCapacity.load()); }
+uint64_t simlod_context_construct_buffer_min_bytes(SimlodContext* c) { return build::construct_min_bytes(ctx_or_default(c).nodeCapacity.load()); }
 
-int simlod_set_ingest_mode(uint32_t mode) {
-	if (mode > 1u) return (int)hipErrorInvalidValue;
-	g_ingestMode.store(mode);
-	return 0;
-}
+int simlod_set_ingest_mode(uint32_t mode) { return simlod_context_set_ingest_mode(nullptr, mode); }
 
-int simlod_set_construct_batch_limit(uint32_t maxBatches) {
-	if (maxBatches == 0u) return (int)hipErrorInvalidValue;
-	g_batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
-	return 0;
-}
+int simlod_set_construct_batch_limit(uint32_t maxBatches) { return simlod_context_set_construct_batch_limit(nullptr, maxBatches); }
 
 int simlod_octree_image_replaced(const SimlodNode* nodes) {
-	forget_leaf_table(nodes);
+	forget_leaf_table(context_of(nodes), nodes);
 	return 0;
 }
 
@@ -223,7 +279,7 @@ int simlod_launch_reset(const SimlodUniforms* uniforms, uint8_t* buffer_octree, 
                         void* cudaprint, uint32_t* numBatchesUploaded, uint32_t* batchSizes, void* stream) {
 	(void)cudaprint;   // CudaPrint's device side is a no-op (modules/CudaPrint/CudaPrint.cuh:49-51): accepted, unused
 	if (!uniforms || !buffer_octree || !nodes || !stats || !numBatchesUploaded || !batchSizes) return (int)hipErrorInvalidValue;
-	return launch_reset(uniforms, buffer_octree, nodes, stats, numBatchesUploaded, batchSizes, (hipStream_t)stream);
+	return launch_reset(context_of(nodes), uniforms, buffer_octree, nodes, stats, numBatchesUploaded, batchSizes, (hipStream_t)stream);
 }
 
 int simlod_launch_construct(const SimlodUniforms* uniforms, SimlodPoint* points, uint32_t* buffer, uint8_t* buffer_persistent,
@@ -232,7 +288,7 @@ int simlod_launch_construct(const SimlodUniforms* uniforms, SimlodPoint* points,
 	(void)cudaprint;
 	if (!uniforms || !points || !buffer || !buffer_persistent || !nodes || !stats || !frameStartTimestamp ||
 	    !numBatchesUploaded_volatile || !batchSizes) return (int)hipErrorInvalidValue;
-	return build::launch_construct(uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp, numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
+	return build::launch_construct(context_of(nodes), uniforms, points, buffer, buffer_persistent, nodes, stats, frameStartTimestamp, numBatchesUploaded_volatile, batchSizes, (hipStream_t)stream);
 }
 
 int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double scale[3],
@@ -242,10 +298,10 @@ int simlod_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPer
 
 int simlod_launch_colorfilter(const SimlodUniforms* uniforms, uint32_t* buffer, SimlodNode* nodes, uint32_t* numNodes, SimlodStats* stats, void* stream) {
 	if (!uniforms || !buffer || !nodes || (!numNodes && !stats)) return (int)hipErrorInvalidValue;
-	return launch_colorfilter(uniforms, buffer, nodes, numNodes, stats, (hipStream_t)stream);
+	return launch_colorfilter(context_of(nodes), uniforms, buffer, nodes, numNodes, stats, (hipStream_t)stream);
 }
 
-uint64_t simlod_colorfilter_buffer_min_bytes(void) { return colorfilter_min_bytes(node_capacity()); }
+uint64_t simlod_colorfilter_buffer_min_bytes(void) { return colorfilter_min_bytes(default_context().nodeCapacity.load()); }
 
 int simlod_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
                             const float tileExtent[3], void* stream) {
@@ -261,14 +317,14 @@ int simlod_launch_render(uint32_t* buffer, const SimlodUniforms* uniforms, Simlo
                          SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
 	(void)cudaprint;
 	if (!uniforms || !buffer || !nodes || !stats || !frameStartTimestamp) return (int)hipErrorInvalidValue;
-	return launch_render(buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, RENDER_ALL);
+	return launch_render(context_of(nodes), buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, RENDER_ALL);
 }
 
 int simlod_launch_render_part(uint32_t part, uint32_t* buffer, const SimlodUniforms* uniforms, SimlodNode* nodes, uint32_t* colorbuffer,
                               SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream) {
 	(void)cudaprint;
 	if (!uniforms || !buffer || !nodes || !stats || !frameStartTimestamp || part > 3) return (int)hipErrorInvalidValue;
-	return launch_render(buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, 1u << part);
+	return launch_render(context_of(nodes), buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, 1u << part);
 }
 
 uint64_t simlod_render_depth_plane_offset(uint32_t width, uint32_t height) { return render_depth_plane_offset(width, height); }

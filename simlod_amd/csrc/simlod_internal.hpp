@@ -5,20 +5,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <climits>
+#include <mutex>
+#include <vector>
+
 #include "simlod_abi.h"
 
 namespace simlod {
 
 static constexpr uint32_t CHUNK_QUEUE_CAPACITY = 1000000u;   // progressive_octree_voxels.cu:856
 static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octree_voxels.cu:847
-
-namespace build {  // construct.hip: kernel_construct — one ring batch at a time (exact mode) or groups of pending batches (coalesced mode)
-
-int launch_construct(const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
-                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
-uint64_t construct_min_bytes();
-
-}  // namespace build
 
 // The builder's leaf chunk table, as the rasteriser may use it (render.hip r_visible): row i holds the first chunks of node i's list in order (a leaf: points; an inner node: voxels).
 // The three stamp words live in the builder's control block on the device; the table describes the octree `nodes` as it is NOW only
@@ -38,18 +35,61 @@ struct LeafTableRef {
 __host__ __device__ inline uint64_t table_signature(const SimlodStats* s) {
 	return ((uint64_t)s->numNodes | (uint64_t)s->numPoints << 32) ^ (s->allocatedBytes_persistent * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)s->numVoxels << 20);
 }
-void note_leaf_table(const LeafTableRef& ref);                 // construct chains: after a launch whose layout fits
-void forget_leaf_table(const void* nodes);                     // reset
-bool find_leaf_table(const void* nodes, LeafTableRef& ref);    // false also when the table's buffer is no longer a live device allocation
+// ---- per-octree state (include/simlod_hip.h, simlod_context_*) -----------------------------------------------------------------------------
+// Everything the library keeps between launches belongs to a context: the ingest mode, the node capacity, the host's batch limit, the
+// tuning knobs (read from the environment ONCE, when the context is made; simlod_context_set_knob overrides one), the second stream and
+// its events, the registry of leaf chunk tables, the launch feedback.  The reference's launch signatures carry no handle, so a launch
+// finds its context through the node array it is given (simlod_context_attach); node arrays nobody attached share the default context.
+enum Knob : int {
+	KNOB_OVERLAP_TAIL, KNOB_EXPAND_WGS, KNOB_GRID_MULT, KNOB_COUNT_TPB, KNOB_VOXELIZE_WGS, KNOB_ADAPTIVE_GROUPS,
+	KNOB_RASTER_LEAF_TABLE, KNOB_RASTER_LDS_TILES, KNOB_DRAW_MULT, KNOB_RASTER_FUSED_RESOLVE,
+	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_COUNT_
+};
+static constexpr int KNOB_UNSET = INT_MIN;
+extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...
+
+struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter
+struct SideStream;                                           // construct.hip: the second stream of kernel_construct and its events
+void destroy_side_stream(SideStream* s);
+
+struct Context {
+	std::atomic<uint32_t> nodeCapacity{263157u};             // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
+	std::atomic<uint32_t> ingestMode{0u};                    // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
+	std::atomic<uint32_t> batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};   // host hint: at most this many batches are pending (<= 20)
+	int knob[KNOB_COUNT_];
+	std::mutex sideLock;
+	SideStream* side[64] = {};                               // per device ordinal, made by the first launch that wants it
+	std::mutex tablesLock;
+	std::vector<LeafTableRef> tables;
+	std::mutex historyLock;
+	std::vector<LaunchHistory> history;
+	Context();
+	~Context();
+	void reload_env();
+	int tune(Knob k, int dflt) const { return knob[k] == KNOB_UNSET ? dflt : knob[k]; }
+};
+Context& context_of(const void* nodes);                      // the context `nodes` is attached to, else the default one
+
+namespace build {  // construct.hip: kernel_construct — one ring batch at a time (exact mode) or groups of pending batches (coalesced mode)
+
+int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points, uint32_t* buffer, uint8_t* pers, SimlodNode* nodes,
+                     SimlodStats* stats, uint64_t* frameStart, uint32_t* numBatchesUploaded, uint32_t* batchSizes, hipStream_t stream);
+uint64_t construct_min_bytes(uint32_t nodeCapacity);
+
+}  // namespace build
+
+void note_leaf_table(Context& ctx, const LeafTableRef& ref);                 // kernel_construct: after a launch whose layout fits
+void forget_leaf_table(Context& ctx, const void* nodes);                     // reset
+bool find_leaf_table(Context& ctx, const void* nodes, LeafTableRef& ref);    // false also when the table's buffer is no longer a live device allocation
 
 // How many per-batch kernel groups a kernel_construct launch should enqueue (the host cannot see how many batches are pending: the
 // upload counter lives on the device).  Every launch ends with two 4-byte copies — Stats.batchletIndex and the upload counter — into
 // page-locked host memory; the next launch reads whatever has arrived (no synchronisation) and enqueues what was left pending + what
 // the recent launches processed + 2, at least 2, at most 20.  Unknown octree, or just reset: 20.  An idle frame loop pays for 2
 // groups instead of 20 (0.84 ms -> 0.1 ms per launch on MI355X, tools/idle_launch.py); a burst is picked up one launch late.
-uint32_t groups_for_launch(const SimlodStats* stats);
-int note_launch_end(const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream);
-void forget_launch_history(const SimlodStats* stats);
+uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats);
+int note_launch_end(Context& ctx, const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream);
+void forget_launch_history(Context& ctx, const SimlodStats* stats);
 
 struct DeviceInfo {
 	int      device;
@@ -72,21 +112,17 @@ void profile_close(hipStream_t stream);                           // records the
 	} while (0)
 bool debug_sync();                           // SIMLOD_DEBUG_SYNC=1: synchronise the device after every kernel and name it on stderr (fault hunting)
 void debug_synced(const char* kernelName);
-uint32_t node_capacity();
-uint32_t ingest_mode();                      // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
-uint32_t batch_limit();                      // host hint: at most this many batches are pending (<= 20)
-int tune(const char* envName, int dflt);     // integer tuning knob from the environment (read once per call site)
 
-int launch_reset(const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
+int launch_reset(Context& ctx, const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream);
 int launch_decode_las(const void* records, uint64_t numPoints, uint32_t bytesPerPoint, uint32_t format, const double* scale,
                       const double* offset, SimlodPoint* out, hipStream_t stream);
-int launch_colorfilter(const SimlodUniforms* u, uint32_t* buffer, SimlodNode* nodes, const uint32_t* numNodes, SimlodStats* stats, hipStream_t stream);
+int launch_colorfilter(Context& ctx, const SimlodUniforms* u, uint32_t* buffer, SimlodNode* nodes, const uint32_t* numNodes, SimlodStats* stats, hipStream_t stream);
 uint64_t colorfilter_min_bytes(uint32_t nodeCapacity);
 int launch_generate_terrain(SimlodPoint* out, uint64_t numPoints, uint64_t firstIndex, uint64_t pointsPerTile, uint32_t seed, uint32_t tilesX,
                             const float tileExtent[3], float swathWidth, hipStream_t stream);
 enum : uint32_t { RENDER_FIRST = 1u, RENDER_COLOR = 2u, RENDER_RESOLVE = 4u, RENDER_OUTPUT = 8u, RENDER_ALL = 15u };
-int launch_render(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
+int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
                   uint64_t* frameStart, hipStream_t stream, uint32_t parts);
 uint64_t render_depth_plane_offset(uint32_t width, uint32_t height);
 uint64_t render_sum_planes_offset(uint32_t width, uint32_t height);

@@ -41,6 +41,16 @@ def lib():
         L.simlod_set_ingest_mode.argtypes = [u32]
         L.simlod_set_construct_batch_limit.argtypes = [u32]
         L.simlod_octree_image_replaced.argtypes = [vp]
+        L.simlod_context_create.argtypes = [ctypes.POINTER(vp)]
+        L.simlod_context_destroy.argtypes = [vp]
+        L.simlod_context_attach.argtypes = [vp, vp]
+        L.simlod_context_set_node_capacity.argtypes = [vp, u32]
+        L.simlod_context_set_ingest_mode.argtypes = [vp, u32]
+        L.simlod_context_set_construct_batch_limit.argtypes = [vp, u32]
+        L.simlod_context_set_knob.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        L.simlod_context_reload_env.argtypes = [vp]
+        L.simlod_context_construct_buffer_min_bytes.restype = u64
+        L.simlod_context_construct_buffer_min_bytes.argtypes = [vp]
         L.simlod_render_framebuffer_offset.restype = u64
         L.simlod_render_buffer_bytes.restype = u64
         L.simlod_render_buffer_bytes.argtypes = [u32, u32]
@@ -77,6 +87,8 @@ EXPORTED_SYMBOLS = [
     "simlod_program_create", "simlod_program_destroy", "simlod_program_kernel", "simlod_function_max_active_blocks",
     "simlod_launch_cooperative", "simlod_build_info", "simlod_decode_las", "simlod_launch_render_part",
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
+    "simlod_context_create", "simlod_context_destroy", "simlod_context_attach", "simlod_context_set_node_capacity", "simlod_context_set_ingest_mode",
+    "simlod_context_set_construct_batch_limit", "simlod_context_set_knob", "simlod_context_reload_env", "simlod_context_construct_buffer_min_bytes",
     "simlod_octree_image_replaced",
     "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_generate_terrain_scan", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
@@ -115,14 +127,19 @@ class DeviceOctree:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.max_nodes = max_nodes
-        _check(self.L.simlod_set_node_capacity(max_nodes), "simlod_set_node_capacity")
-        # ingest granularity (process-wide, like the node capacity): exact = the reference's batch-by-batch bookkeeping; coalesced = all
-        # pending batches of a launch as one (same octree content, different allocator / chunk-pool counters, include/simlod_hip.h)
-        _check(self.L.simlod_set_ingest_mode(1 if coalesce else 0), "simlod_set_ingest_mode")
-        _check(self.L.simlod_set_construct_batch_limit(abi.MAX_BATCHES_PER_LAUNCH), "simlod_set_construct_batch_limit")
+        # this octree's own context (include/simlod_hip.h): node capacity, ingest granularity — exact = the reference's batch-by-batch
+        # bookkeeping; coalesced = all pending batches of a launch as one (same octree content, different allocator / chunk-pool
+        # counters) —, batch limit, tuning knobs (from the environment as it is NOW), second stream; launches find it by the node array
+        ctx = ctypes.c_void_p()
+        _check(self.L.simlod_context_create(ctypes.byref(ctx)), "simlod_context_create")
+        self.ctx = ctx
+        _check(self.L.simlod_context_set_node_capacity(ctx, max_nodes), "simlod_context_set_node_capacity")
+        _check(self.L.simlod_context_set_ingest_mode(ctx, 1 if coalesce else 0), "simlod_context_set_ingest_mode")
+        _check(self.L.simlod_context_set_construct_batch_limit(ctx, abi.MAX_BATCHES_PER_LAUNCH), "simlod_context_set_construct_batch_limit")
         z = dict(dtype=torch.uint8, device=self.device)
         # H11: the reference renders before any reset and relies on fresh VRAM reading as zero
         self.nodes = torch.zeros(max_nodes * 152, **z)
+        _check(self.L.simlod_context_attach(ctx, self._p(self.nodes)), "simlod_context_attach")
         self.stats = torch.zeros(112, **z)
         self.persistent = torch.empty(persistent_bytes, **z)
         self.persistent[:1 << 20].zero_()
@@ -140,6 +157,31 @@ class DeviceOctree:
         self.uploaded_host = 0
         self.processed_host = 0
         self.upload_stream = torch.cuda.Stream(device=self.device)
+
+    def close(self):
+        """Give the context back (waits for its second stream).  The buffers go with the object."""
+        ctx, self.ctx = getattr(self, "ctx", None), None
+        if ctx is not None and torch.cuda.is_available():
+            torch.cuda.synchronize(self.device)
+            self.L.simlod_context_attach(None, self._p(self.nodes))
+            self.L.simlod_context_destroy(ctx)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tune(self, name, value=None):
+        """Override one tuning knob of THIS octree's context (name as in the environment, e.g. "SIMLOD_OVERLAP_TAIL"); None: built-in default."""
+        _check(self.L.simlod_context_set_knob(self.ctx, name.encode(), int(value or 0), 0 if value is None else 1), f"simlod_context_set_knob({name})")
+
+    def reload_env(self):
+        """Read the tuning knobs from the environment again (they are read once, when the context is made)."""
+        _check(self.L.simlod_context_reload_env(self.ctx), "simlod_context_reload_env")
+
+    def set_batch_limit(self, max_batches):
+        _check(self.L.simlod_context_set_construct_batch_limit(self.ctx, max_batches), "simlod_context_set_construct_batch_limit")
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def uniforms(self, width, height, transform, box_size, **kw):

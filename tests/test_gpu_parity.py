@@ -586,6 +586,18 @@ def test_full_size_36m_properties(built_libs):
     assert np.array_equal(fh >> np.uint64(32), f1 >> np.uint64(32)), "HQS resolves to the same nearest depth per pixel as the 64-bit min"
     fho, _, _ = _oracle_render(nodes, nn, u)
     assert np.array_equal(fh, fho), f"{int((fh != fho).sum())} HQS pixels differ from the oracle at 1080p (averaged colours incl. the >64-samples-per-pixel path)"
+    # "Morro Bay - close" (main_progressive_octree.cpp:1323-1328, as bench.py scales it): 94 m above the surface, leaves of the deepest levels
+    # on screen next to coarse voxel nodes at the horizon
+    cx, cy = 2750.218 * float(box[0]) / 6000.0, 974.775 * float(box[1]) / 4000.0
+    T_close = camera.world_view_proj(camera.orbit_view(-11.270, -0.225, 93.982, (cx, cy, synthetic.terrain_height(cx, cy, seed=7, box=tuple(float(v) for v in box)))),
+                                     camera.perspective(aspect=Wd / Hd))
+    for hqs in (0, 1):
+        uc = dev.uniforms(Wd, Hd, T_close, box, hqs=bool(hqs))
+        dev.render(uc); fc, rc = dev.framebuffer(Wd, Hd), dev.read_stats()
+        fco, _, sco = _oracle_render(nodes, nn, uc)
+        assert int(rc["numVisibleNodes"]) > 100
+        assert np.array_equal(fc, fco), f"close preset, hqs={hqs}: {int((fc != fco).sum())} of {Wd * Hd} pixels differ from the oracle"
+        assert_stats_equal(rc, sco, STATS_RENDER_FIELDS, f"close preset hqs={hqs}")
 
 
 # ---- the reference host's launch sequence in C++ (harness/simlod_headless.cpp on shim/cuda.h) ------------------------------------
@@ -864,7 +876,7 @@ def test_config5_hotspot_20m_octree_and_frames_match_oracle_with_and_without_lds
     want = {}
     try:
         for tiles in ("1", "0"):
-            os.environ["SIMLOD_RASTER_LDS_TILES"] = tiles
+            dev.tune("SIMLOD_RASTER_LDS_TILES", int(tiles))
             for hqs in (0, 1):
                 u["useHighQualityShading"] = hqs
                 dev.render(u)
@@ -875,7 +887,7 @@ def test_config5_hotspot_20m_octree_and_frames_match_oracle_with_and_without_lds
                 assert_stats_equal(st, so, STATS_RENDER_FIELDS, f"config 5 tiles={tiles} hqs={hqs}")
                 assert np.array_equal(fb, fo), f"tiles={tiles} hqs={hqs}: {int((fb != fo).sum())} pixels differ from the oracle"
     finally:
-        os.environ.pop("SIMLOD_RASTER_LDS_TILES", None)
+        dev.tune("SIMLOD_RASTER_LDS_TILES", None)
 
 
 def test_headless_cpp_host_replay_octree_dump_equals_oracle(built_libs, tmp_path):
@@ -994,13 +1006,13 @@ def test_forced_barrier_timeout_aborts_the_batch_and_stays_fatal_until_reset(bui
     dev.reset(u)
     dev.upload(pts[:40_000])
     dev.drain(u)                                       # 40 000 points: no split yet
-    os.environ["SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT"] = "1"
+    dev.tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", 1)
     try:
         dev.upload(pts[40_000:])                       # crosses the limit: k_expand runs and its barrier "gives up"
         with pytest.raises(SimlodError):
             dev.drain(u)
     finally:
-        os.environ.pop("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", None)
+        dev.tune("SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", None)
     s = dev.read_stats()
     assert int(s["dbg"]) & 0x40 and int(s["batchletIndex"]) == 1 and int(s["numNodes"]) == 1
     with pytest.raises(SimlodError):
@@ -1055,7 +1067,7 @@ def test_coalesced_ingest_builds_the_same_octree_content(built_libs, kind, n):
         assert np.array_equal(dev.framebuffer(W, H), fo)
         assert_stats_equal(dev.read_stats(), so, STATS_RENDER_FIELDS, kind)
     finally:
-        lib().simlod_set_ingest_mode(0)
+        pass                                  # (the ingest mode belongs to the octree's context: nothing process-wide to restore)
 
 
 # ---- BASELINE config 4: tiles generated on the device, one global cube -------------------------------------------------------------------
@@ -1138,6 +1150,64 @@ def test_colorfilter_equals_the_reference_kernel_on_the_same_octree(built_libs, 
     assert int((dev.framebuffer(W, H) != abi.CLEAR_PIXEL).sum()) > 1000
 
 
+# ---- per-octree contexts (include/simlod_hip.h simlod_context_*) -----------------------------------------------------------------------------
+def test_two_octrees_with_their_own_contexts_build_side_by_side(built_libs):
+    """Mode, node capacity, knobs, the second stream and the table registry belong to a context that a launch finds through its node
+    array.  Two octrees in one process — exact with the two-stream pipeline and 263 157 nodes; coalesced on one stream with room for
+    60 000 nodes — take their batches alternately, launch by launch.  Each must end as its own oracle octree (exact: every counter),
+    and each frame must be the oracle's (the rasteriser reads each octree through ITS builder's chunk table)."""
+    from simlod_amd.runtime import SimlodError
+    pa, box_a = synthetic.terrain(3_300_000, seed=3, box=(3000.0, 2000.0, 200.0), tile=125.0)
+    pb, box_b = synthetic.uniform_cube(2_100_000, seed=4)
+    a = _device(ring_slots=abi.BATCH_STREAM_SIZE)
+    b = _device(ring_slots=abi.BATCH_STREAM_SIZE, coalesce=True, momentary_bytes=400_000_000, max_nodes=60_000)
+    b.tune("SIMLOD_OVERLAP_TAIL", 0)
+    Ta = camera.lookat_transform((1.8 * box_a[0], -1.2 * box_a[1], 1.4 * max(box_a)), (0.5 * box_a[0], 0.5 * box_a[1], 0.3 * box_a[2]), W, H)
+    Tb = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    ua, ub = a.uniforms(W, H, Ta, box_a), b.uniforms(W, H, Tb, box_b)
+    a.reset(ua); b.reset(ub)
+    step = 300_000
+    for i in range(0, max(len(pa), len(pb)), step):
+        for dev, u, pts in ((a, ua, pa), (b, ub, pb)):
+            if i < len(pts):
+                if dev.uploaded_host - dev.processed() >= dev.ring_slots:
+                    dev.drain(u)
+                dev.upload(pts[i:i + step])
+                dev.construct(u)                                   # one launch each, in turn: nothing waits in between
+    a.drain(ua); b.drain(ub)
+    sa, sb = a.read_stats(), b.read_stats()
+    assert int(sa["dbg"]) == 0 and int(sb["dbg"]) == 0
+    ra = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE); ra.reset(ua); ra.add_points(ua, pa, step)
+    rb = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE); rb.reset(ub); rb.add_points(ub, pb, step)
+    na, keep_a, nna = host_image_of(a)                # (the node records point into the persistent copies: they must stay alive)
+    nb, keep_b, nnb = host_image_of(b)
+    assert_stats_equal(sa, ra.stats[0], STATS_BUILD_FIELDS, "exact octree")
+    assert_dumps_equal(oracle.dump_image(na, nna), ra.dump(), "exact octree")
+    assert_stats_equal(sb, rb.stats[0], GRANULARITY_FREE_STATS, "coalesced octree")
+    got, want = oracle.dump_image(nb, nnb), rb.dump()
+    assert len(got) == len(want)
+    for f in GRANULARITY_FREE_FIELDS:
+        assert np.array_equal(got[f], want[f]), f
+    for dev, u, nodes, nn in ((a, ua, na, nna), (b, ub, nb, nnb)):
+        for hqs in (0, 1):
+            u["useHighQualityShading"] = hqs
+            dev.render(u)
+            assert dev is b or dev.lists_read_through_table() > 0    # (b's visible nodes at this size are inner nodes with more voxel chunks than a table row holds)
+            fo, _, so = _oracle_render(nodes, nn, u)
+            assert np.array_equal(dev.framebuffer(W, H), fo)
+            assert_stats_equal(dev.read_stats(), so, STATS_RENDER_FIELDS, f"hqs={hqs}")
+    # a knob set on one context is not seen by the other; an unknown name is refused
+    b.tune("SIMLOD_RASTER_LEAF_TABLE", 0)
+    a.render(ua)
+    assert a.lists_read_through_table() > 0
+    a.tune("SIMLOD_RASTER_LEAF_TABLE", 0)
+    a.render(ua)
+    assert a.lists_read_through_table() == 0
+    with pytest.raises(SimlodError):
+        a.tune("SIMLOD_NO_SUCH_KNOB", 1)
+    a.close(); b.close()
+
+
 # ---- the rasteriser reads chunk lists through the builder's chunk table ------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["exact", "coalesced"])
 def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(built_libs, mode):
@@ -1160,9 +1230,9 @@ def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(b
                 dev.render(u)
                 used = dev.lists_read_through_table()
                 f1, s1 = dev.framebuffer(W, H), dev.read_stats()
-                os.environ["SIMLOD_RASTER_LEAF_TABLE"] = "0"
+                dev.tune("SIMLOD_RASTER_LEAF_TABLE", 0)
                 dev.render(u)
-                os.environ.pop("SIMLOD_RASTER_LEAF_TABLE")
+                dev.tune("SIMLOD_RASTER_LEAF_TABLE", None)
                 assert dev.lists_read_through_table() == 0
                 assert np.array_equal(f1, dev.framebuffer(W, H)), f"{tag} hqs={hqs}: table on != table off"
                 assert np.array_equal(f1, fo), f"{tag} hqs={hqs}: {int((f1 != fo).sum())} pixels differ from the oracle"
@@ -1194,8 +1264,7 @@ def test_frames_through_the_builders_chunk_table_equal_frames_by_pointer_chase(b
         dev.upload_image(nodes, pers, nn)
         frames(f"{mode} uploaded image", False)
     finally:
-        os.environ.pop("SIMLOD_RASTER_LEAF_TABLE", None)
-        lib().simlod_set_ingest_mode(0)
+        pass                                  # (knobs and ingest mode belong to the octree's context: nothing process-wide to restore)
 
 
 # ---- bench.py as the driver launches it for N > 1 ---------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ st = dev.read_stats()
 out = {"points": n, "span_px": span_px, "ingest_s_incl_h2d": t_ingest, "dbg": int(st["dbg"]), "numNodes": int(st["numNodes"])}
 fbs = {}
 for tiles in (1, 0):
-    os.environ["SIMLOD_RASTER_LDS_TILES"] = str(tiles)
+    dev.tune("SIMLOD_RASTER_LDS_TILES", tiles)
     for mode, hqs in (("plain", 0), ("hqs", 1)):
         u["useHighQualityShading"] = hqs
         for _ in range(3):

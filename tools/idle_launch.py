@@ -12,9 +12,9 @@ dev = DeviceOctree("cuda:0", persistent_bytes=2 << 30, max_pixels=W * H)
 u = dev.uniforms(W, H, T, box)
 dev.reset(u); dev.add_points(u, pts)
 for limit in (abi.MAX_BATCHES_PER_LAUNCH, 1):
-    dev.L.simlod_set_construct_batch_limit(limit)
+    dev.set_batch_limit(limit)
     for ov in ("1", "0"):
-        os.environ["SIMLOD_OVERLAP_TAIL"] = ov
+        dev.tune("SIMLOD_OVERLAP_TAIL", int(ov))
         for _ in range(5): dev.construct(u)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,4 +22,4 @@ for limit in (abi.MAX_BATCHES_PER_LAUNCH, 1):
         for _ in range(50): dev.construct(u)
         e1.record(); th = time.perf_counter() - t0; torch.cuda.synchronize()
         print("batch limit %2d overlap %s: idle launch %.0f us on the GPU, %.0f us of host time to enqueue" % (limit, ov, e0.elapsed_time(e1) * 1e3 / 50, th * 1e6 / 50))
-dev.L.simlod_set_construct_batch_limit(abi.MAX_BATCHES_PER_LAUNCH)
+dev.set_batch_limit(abi.MAX_BATCHES_PER_LAUNCH)

@@ -5,7 +5,7 @@ k_expand's phase timers of workgroup 0 (construct_batch.hip Ctl.expandNs, byte 1
     python tools/probe.py [--steps 5] [--points 36000000] "SIMLOD_EXPAND_WGS=64" "SIMLOD_EXPAND_WGS=128 SIMLOD_GRID_MULT=4" ...
 
 Every positional argument is one variant: space-separated NAME=VALUE pairs put into the environment for that variant only
-(the library reads its tuning knobs with getenv at every launch).  The empty string "" is the default configuration."""
+(a context reads its tuning knobs from the environment once; DeviceOctree.reload_env() reads them again).  The empty string "" is the default configuration."""
 import argparse
 import os
 import sys
@@ -55,6 +55,7 @@ for var in args.variants:
         k, v = kv.split("=", 1)
         saved[k] = os.environ.get(k)
         os.environ[k] = v
+    dev.reload_env()
     step()
     torch.cuda.synchronize()
     dev.momentary[152:216].zero_()

@@ -3,7 +3,7 @@
 
     python tools/raster_prof.py [points] [frames] ["NAME=VALUE ..." ...]
 
-Every further argument is one variant: environment settings for the library's tuning knobs (read at every launch), timed one after
+Every further argument is one variant: environment settings for the library's tuning knobs (DeviceOctree.reload_env() before each), timed one after
 the other on the same octree ("" = defaults)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +24,7 @@ variants = sys.argv[3:] or [""]
 for var, hqs in [(v, h) for v in variants for h in (0, 1)]:
     for kv in var.split():
         os.environ[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
+    dev.reload_env()
     u["useHighQualityShading"] = hqs
     for _ in range(frames):
         dev.render(u)
