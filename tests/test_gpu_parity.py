@@ -197,6 +197,60 @@ def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs, chain
         lib().simlod_set_node_capacity(263_157)
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_memory_guard_trips_while_launches_take_several_batches_each(built_libs, overlap, monkeypatch):
+    """voxels.cu:896-912 looks at the allocator after the WHOLE previous batch.  Here a batch's front half starts while the back halves of
+    the batches before it are still allocating voxel chunks, so a launch takes further batches only while the allocator is a worst-case
+    voxel half away from the guard, and goes batch by batch from there on (construct.hip voxel_half_slack) — the stopping batch and
+    every counter must still be the reference's.  14 M points in 100 000-point batches against 800 MB: launches of many batches up to
+    ~370 MB, single-batch launches up to 600 MB, then the guard; two-stream pipeline on and off."""
+    import torch
+    from simlod_amd.runtime import SimlodError
+    monkeypatch.setenv("SIMLOD_OVERLAP_TAIL", overlap)
+    n, step, cap = 14_000_000, 100_000, 800_000_000
+    pts, box = synthetic.uniform_cube(n, seed=17)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    dev = _device(ring_slots=abi.BATCH_STREAM_SIZE, persistent_bytes=cap + 4096)
+    dev.persistent[cap:].fill_(0x3C)                              # canary behind the capacity the uniforms announce
+    u = dev.uniforms(W, H, T, box)
+    u["persistentBufferCapacity"] = cap
+    dev.persistent_bytes = cap
+    ref = oracle.HostOctree("port", persistent_bytes=cap, ring_slots=abi.BATCH_STREAM_SIZE)
+    uh = u.copy()
+    dev.reset(u); ref.reset(uh)
+    per_launch = []
+    for i in range(0, n, step):
+        if dev.uploaded_host - dev.processed() >= abi.MAX_BATCHES_PER_LAUNCH:
+            before = dev.processed()
+            dev.construct(u); ref.construct(uh)
+            per_launch.append(dev.processed() - before)
+            if per_launch[-1] == 0:
+                break
+        dev.upload(pts[i:i + step]); ref.upload(pts[i:i + step])
+    while per_launch[-1] != 0:                                    # the frame loop keeps launching until nothing moves any more
+        before = dev.processed()
+        dev.construct(u)
+        per_launch.append(dev.processed() - before)
+    for _ in range(3):
+        dev.construct(u)
+    while True:                                                   # (the restatement takes what its launches let it: until it stands still too)
+        before = int(ref.stats["batchletIndex"][0])
+        ref.construct(uh)
+        if int(ref.stats["batchletIndex"][0]) == before:
+            break
+    torch.cuda.synchronize()
+    ds = dev.read_stats()
+    assert int(ds["memCapacityReached"]) == 1 == int(ref.stats["memCapacityReached"][0])
+    assert max(per_launch) >= 10 and per_launch.count(1) >= 10, f"expected launches of many batches, then of one: {per_launch}"
+    assert 60 < int(ds["batchletIndex"]) < n // step
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "memory guard")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "memory guard")
+    assert (dev.persistent[cap:] == 0x3C).all()
+    with pytest.raises(SimlodError):
+        dev.drain(u)
+
+
 def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs, chain):
     """70 000 identical points force twenty split rounds inside one batch, down to level 20 where a node cannot split any more;
     8 000 points sit exactly on the faces / corners of the bounding box (coordinate == boxMax quantises to 2^20 and, as in the
