@@ -1,35 +1,40 @@
-// construct_batch.hip — incremental octree/LOD builder for MI355X (gfx950): `kernel_construct` in EXACT mode (one ring batch at a time,
-// the reference's granularity; the default).  construct_bulk.hip is the chain of the opt-in coalesced mode.
+// construct.hip — incremental octree/LOD builder for MI355X (gfx950): `kernel_construct`.  ONE builder with two granularities:
+// EXACT (default: a group is one ring batch, the reference's granularity — every Node and Stats field after every batch is the
+// reference's) and COALESCED (simlod_context_set_ingest_mode(1): a group is up to 20 pending batches; same octree content, fewer
+// intermediate chunks).  The kernels are the same; the ones on the sample stream are compiled twice (SINGLE = one batch per group).
 //
-// Replaces modules/progressive_octree/progressive_octree_voxels.cu:804-1010 (one persistent cooperative CUDA
-// kernel with ~40 grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid
-// memory image.  Design:
+// Replaces modules/progressive_octree/progressive_octree_voxels.cu:804-1010 (one persistent cooperative CUDA kernel with ~40
+// grid.sync() per batch) behind the same argument list and the same Node/Chunk/OccupancyGrid memory image.  Design:
 //
-//   * per batch a CHAIN of ordinary launches on the caller's stream — count, expand, alloc + insert (points), voxelize,
-//     alloc + insert (voxels), end — because a dependent kernel boundary costs ~1.5-1.9 us on this chip while a software grid barrier
-//     over 256 CUs / 8 XCDs costs 4-26 us; control flow stays on the device (a control block at byte 0 of the
-//     momentary buffer), inactive kernels exit at once, so the call is fully asynchronous like the reference's;
-//   * every point is read with one coalesced 16-byte load per phase and descends the tree ONCE: the leaf found
-//     by `count` is cached (4 B/point) and only points whose leaf was split re-descend, from that leaf down
-//     (the reference re-descends from the root in three phases and re-scans the batch in every split round);
-//   * per-leaf counters, slot reservations and voxel counters are aggregated per WORKGROUP in LDS hash tables (one global
-//     atomic per workgroup and counter): device-scope atomics on one word retire at ~88 M/s on this chip, and a spatially
-//     compact batch sends most of its points to a few dozen leaves;
-//   * voxel sampling walks the root path BOTTOM-UP (occupancy is hierarchical: a set bit implies the covering bits of all
-//     ancestors), AFTER the insert, leaf by leaf, in LDS copies of the cubes of the ancestors' grids a leaf can touch
-//     (k_voxelize): the grids see one atomicOr per touched word instead of one per sample;
-//   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of every
-//     list remembers its tail (8 spare bytes of Chunk), a per-batch chunk directory gives O(1) slot->chunk, and a leaf chunk
-//     table lets a split read the whole list of a leaf with one wave;
-//   * new voxels are not copied through a 24-byte backlog record: `voxelize` leaves an 8-byte entry per sample that colours
-//     voxels (which sample, which levels), `insert` regenerates the voxels from (level, cell) and the sample;
-//   * no capacity limit loses a point: a split reserves its node slots and spill space in one compare-and-swap or does not
-//     happen yet (the leaf grows and is queued again by a later batch).
+//   * per group a CHAIN of ordinary launches — k_count, k_queue, k_hist, k_expand | k_insert, k_voxelize — because a dependent kernel
+//     boundary costs ~3.7 us on this chip while a software grid barrier over 256 CUs / 8 XCDs costs 4-26 us; control flow stays on the
+//     device (a control block at byte 0 of the momentary buffer), kernels of groups that do not exist exit at once, so the call is fully
+//     asynchronous like the reference's.  The front half (the tree grows, every chunk the group needs is allocated) runs on the caller's
+//     stream, the back half (points stored, voxels sampled and stored) on a second stream of the context, one group behind;
+//   * every sample is read with one coalesced 16-byte load per pass and descends the tree ONCE (k_count): its leaf is cached (4 B/sample),
+//     and when that leaf splits the word becomes (split slot, histogram bin) — the final leaf is one lookup in the slot's map;
+//   * a leaf that crosses 50 000 gets a SLOT with a 512-bin histogram — three octree levels — of everything that lies in it (k_hist:
+//     the group's samples and the leaf's stored points, which move to a spill buffer on the way).  The whole cascade of voxels.cu:245-415
+//     is decided FROM THE COUNTS (k_expand): up to 584 nodes per slot and round, counters filled in, chunks allocated; only a
+//     great-grandchild that is still too full costs another round (another histogram pass over the samples inside k_expand, one grid
+//     barrier).  The reference needs ~8 grid.sync() per LEVEL and re-scans the batch in every one of them;
+//   * per-leaf counters are aggregated per WORKGROUP in LDS hash tables (one global atomic per workgroup and leaf): device-scope
+//     atomics on one word retire at ~88 M/s on this chip, and a spatially compact batch sends most of its samples to a few dozen leaves;
+//   * voxel sampling walks the root path BOTTOM-UP (occupancy is hierarchical: a set bit implies the covering bits of all ancestors),
+//     AFTER the insert, leaf by leaf, in LDS copies of the cubes of the ancestors' grids a leaf can touch (k_voxelize): the grids see one
+//     atomicOr per touched word instead of one per sample.  The same kernel reserves the voxels' slots (one atomic per piece and
+//     ancestor), allocates voxel chunks ON DEMAND (whoever reserves the first slot of a chunk allocates it and publishes it in a hash
+//     directory) and stores the voxels: no second allocation / insertion pass;
+//   * the O(list length) chunk walks of voxels.cu:606-610 / 688-692 / 500-503 are gone: the head chunk of a list remembers its tail (8
+//     spare bytes of Chunk), a per-group chunk directory gives O(1) slot -> chunk, a per-node chunk table (also read by the rasteriser)
+//     lets a split hand a leaf's whole list to the spill copy with one wave;
+//   * no capacity limit loses a point: a split reserves its slot, its node slots and its spill space in ONE compare-and-swap or does
+//     not happen yet (the leaf grows and is queued again by a later batch; Stats.dbg says so).
 //
-// The result after every batch is the reference's: same topology, same per-node sample multisets, same occupancy
-// bitsets, same voxel positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same
-// chunk-pool accounting.  What stays scheduling dependent is what is scheduling dependent in the reference too
-// (SURVEY.md H6): node indices, chunk addresses, sample order inside a node, which point colours a voxel.
+// The result after every batch is the reference's: same topology, same per-node sample multisets, same occupancy bitsets, same voxel
+// positions (bit-exact fp32), same counters in Node and Stats, same allocator offset, same chunk-pool accounting.  What stays
+// scheduling dependent is what is scheduling dependent in the reference too: node indices, chunk addresses, sample
+// order inside a node, which point colours a voxel.
 #include <mutex>
 #include "simlod_device.hpp"
 #include "simlod_hip.h"
@@ -38,9 +43,7 @@
 namespace simlod {
 namespace build {
 
-// Per-batch state, one copy per parity of the batch's ordinal in the launch: the voxel half of batch b (library's side stream) still
-// reads its copy while k_count .. k_expand of batch b + 1 work on the other, and the last kernel of batch b on the caller's stream
-// (k_insert part 0) prepares the copy of batch b + 1 — which is the copy of batch b - 1, whose voxel half k_insert has waited for.
+// Per-group state (BatchCtl), BATCH_COPIES copies in the control block, group #ordinal of a launch in copy ordinal & 3.
 static constexpr uint32_t SLOT_CAP_GRIDS = 256;  // (memory guard's slack: grids one group's splits may allocate; more than that many splits per group and the guard is a group late)
 static constexpr uint32_t BATCH_COPIES = 4;      // per-batch state of batch b lives in copy b & 3: the front half of batch b + 1 (count .. expand) and the back halves of
                                                  // batches b and b - 1 (insert, voxelize) are under way together, and batch b + 2 is being prepared
@@ -154,7 +157,7 @@ struct NodeDir {          // per node, valid for the batch whose tag it carries:
 
 // Leaf chunk table: slot k of leaf i's point list -> chunk, LEAF_SLOTS entries per node.  A leaf that can still split stores
 // at most MAX_POINTS_PER_NODE points between batches (= 50 chunks), so the split reads its whole list from here with all
-// lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by k_alloc; survives between
+// lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by alloc_points (k_expand); survives between
 // launches like the recycle stack does, and is refilled by k_parents whenever k_begin finds its stamp stale.
 static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
 static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
@@ -460,7 +463,7 @@ __device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& 
 // Queue leaf `nodeIdx` for splitting: ONE WAVE (k_queue).  Everything the split needs is reserved here, before anything is modified: a slot (and
 // with it a histogram), eight node slots and the spill space for the stored points together, the occupancy grid.  Then the leaf's
 // chunk list becomes spill-copy work items (chunk k comes from the leaf chunk table, not from a walk) and goes back to the recycle
-// stack (voxels.cu:346-357; nothing pops before k_alloc).  (voxels.cu:308-383 doSplitting, first half)
+// stack (voxels.cu:346-357; nothing pops before alloc_points in k_expand).  (voxels.cu:308-383 doSplitting, first half)
 __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t nodeIdx) {
 	const uint32_t lane = (uint32_t)lane_id();
 	SimlodNode* node = a.nodes + nodeIdx;
@@ -674,7 +677,7 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int s
 //     device-scope atomics on one word retire at ~88 M/s here);
 //   phase 2, all waves, one NEW CHUNK per lane: fetch it (stack or fresh memory), link it, enter it in the chunk directory and the leaf
 //     chunk table.  A leaf the batch has filled from nothing needs 50 chunks; taken one after the other by the leaf's lane that was 50
-//     dependent round trips (the whole of the former k_alloc: 13 us), taken side by side it is two.
+//     dependent round trips (the whole of round 2's allocation kernel: 13 us), taken side by side it is two.
 static constexpr uint32_t ALLOC_LEAVES = 64;
 struct AllocRec {
 	uint32_t node, existing, additional, fromPool;
@@ -1289,8 +1292,9 @@ __device__ __forceinline__ void store_voxels_wave(const BuildArgs& a, Ctl* ctl, 
 //   pass A  every sample: mark its cell in the deepest cube; if the cell was clear, mark `fresh` and climb to the next cube ...
 //   write-back  old = atomicOr(grid word, fresh bits); won = fresh & ~old; Node.numVoxels += popcount(won)   (voxels.cu:96-101)
 //   pass B  every sample: if its cell is still marked won, take the mark: this sample colours the voxel (which sample of a cell does
-//           is scheduling dependent in the reference too).  Samples that took marks go on the emit list
-//           {work item, index in the piece, levels won}; k_insert's second part regenerates their voxels once k_alloc has made room.
+//           is scheduling dependent in the reference too).
+//   reserve  per ancestor with won cells: slot range from atomicAdd(Node.numVoxels); chunks the range starts are allocated here and now
+//   store    every sample that took a mark writes its voxel into slot base + rank (voxels.cu:674-698), through the hash directory of chunks
 static constexpr uint32_t VOX_CHUNKS = VOX_PIECE / SIMLOD_POINTS_PER_CHUNK + 2;   // chunks a piece's voxels of one ancestor can span
 struct VoxShared {
 	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row
@@ -2029,7 +2033,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
 		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
-		// A batch has a FRONT half — k_prepare, k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
+		// A batch has a FRONT half — k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
 		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
 		// the caller's stream, the back half on a second stream of the library, two dependencies per batch between them:
 		//     k_insert(b) after k_expand(b);                 k_hist(b + 1) after k_insert(b)   (it moves points k_insert(b) has stored).

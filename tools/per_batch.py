@@ -28,5 +28,5 @@ for rep in range(2):
         rows.append((b // 1_000_000, int(st["numNodes"]), int(st["numVoxels"]), {k.split("<")[0]: round(ms * 1e3) for k, (c, ms) in p.items() if k.startswith("k_")}))
 prev = 0
 for b, nn, nv, p in rows:
-    print("batch %2d nodes %5d newvox %7d | count %3d expand %4d alloc %3d insert %3d voxelize %4d" % (b, nn, nv - prev, p["k_count"], p["k_expand"], p["k_alloc"], p["k_insert"], p["k_voxelize"]))
+    print("batch %2d nodes %5d newvox %7d | count %3d queue %3d hist %3d expand %4d insert %3d voxelize %4d" % (b, nn, nv - prev, p.get("k_count", 0), p.get("k_queue", 0), p.get("k_hist", 0), p.get("k_expand", 0), p.get("k_insert", 0), p.get("k_voxelize", 0)))
     prev = nv

@@ -1,6 +1,6 @@
 """A/B probe of the exact ingest on the bench workload (36 M terrain, 36 resident ring batches): one terrain, several
 environment settings, each timed like bench.py's step (reset + republish + kernel_construct launches until drained), plus
-k_expand's phase timers of workgroup 0 (construct_batch.hip Ctl.expandNs, byte 152).
+k_expand's phase timers of workgroup 0 (construct.hip Ctl.expandNs, byte 152).
 
     python tools/probe.py [--steps 5] [--points 36000000] "SIMLOD_EXPAND_WGS=64" "SIMLOD_EXPAND_WGS=128 SIMLOD_GRID_MULT=4" ...
 
