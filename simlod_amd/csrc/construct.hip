@@ -1913,7 +1913,7 @@ __global__ void k_finish(BuildArgs a, uint32_t fits) {
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce) {
+bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t groupLimit = SIMLOD_MAX_BATCHES_PER_LAUNCH) {
 	a.dirCap = 2 * a.nodeCapacity + 65536;
 	uint64_t off = 4096;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
@@ -1948,7 +1948,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce) {
 	a.groupMax = 1; a.groupCap = SIMLOD_MAX_BATCH_SIZE;
 	if (capacity < off + 2 * perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + 2 * perBatch + fixedWork; return false; }
 	const uint64_t freeBytes = capacity - off - fixedWork - 4096;
-	if (coalesce) a.groupMax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(SIMLOD_MAX_BATCHES_PER_LAUNCH, freeBytes / (2 * perBatch + 20ull * SIMLOD_MAX_BATCH_SIZE)));
+	if (coalesce) a.groupMax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(groupLimit, SIMLOD_MAX_BATCHES_PER_LAUNCH), freeBytes / (2 * perBatch + 20ull * SIMLOD_MAX_BATCH_SIZE)));
 	a.groupCap = a.groupMax * SIMLOD_MAX_BATCH_SIZE;
 	// (the group samples' cached-leaf words exist twice, by group parity; 4 + 16 B per moved point)
 	uint64_t cap = (freeBytes - 2ull * a.groupMax * perBatch - 512) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
@@ -2007,7 +2007,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = ctx.nodeCapacity.load();
 	const bool coalesce = ctx.ingestMode.load() != 0u;
-	const bool fits = layout_construct(a, u->momentaryBufferCapacity, coalesce);
+	const bool fits = layout_construct(a, u->momentaryBufferCapacity, coalesce, (uint32_t)std::max(1, ctx.tune(KNOB_GROUP_BATCHES, 10)));   // coalesced mode: groups of 10 (36 M terrain: 20: 3.17 ms, 10: 2.95, 5: 3.10, 2: 3.66 — two groups per launch overlap front and back halves)
 	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
 		note_leaf_table(ctx, LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
