@@ -1090,8 +1090,9 @@ GRANULARITY_FREE_STATS = ["numNodes", "numInner", "numLeaves", "numNonemptyLeave
                           "batchletIndex", "numPointsProcessed", "numAllocatedChunks", "memCapacityReached"]
 
 
-@pytest.mark.parametrize("kind,n", [("terrain", 7_300_000), ("hotspot", 5_000_000), ("uniform", 3_000_000)])
-def test_coalesced_ingest_builds_the_same_octree_content(built_libs, kind, n):
+@pytest.mark.parametrize("kind,n,batch", [("terrain", 7_300_000, abi.MAX_BATCH_SIZE), ("terrain", 7_300_000, 300_000), ("hotspot", 5_000_000, abi.MAX_BATCH_SIZE),
+                                          ("uniform", 3_000_000, abi.MAX_BATCH_SIZE)])
+def test_coalesced_ingest_builds_the_same_octree_content(built_libs, kind, n, batch):
     """Opt-in coalesced mode (simlod_set_ingest_mode(1)): all pending batches of a launch as ONE batch.  Everything that does not depend
     on the batch granularity must equal the oracle's batch-by-batch octree; the frame of that image must equal the oracle's rasteriser."""
     from simlod_amd.runtime import lib
@@ -1099,14 +1100,15 @@ def test_coalesced_ingest_builds_the_same_octree_content(built_libs, kind, n):
                 "hotspot": lambda: synthetic.hotspot(n, seed=13, level=4, cell=(5, 9, 6))}[kind]()
     T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
     try:
-        dev = _device(ring_slots=8, coalesce=True, momentary_bytes=400_000_000)
+        # (25 batches of 300 000: a launch takes 20 of them as two groups of 10, the second group's front half beside the first's back half)
+        dev = _device(ring_slots=abi.BATCH_STREAM_SIZE, coalesce=True, momentary_bytes=400_000_000)
         u = dev.uniforms(W, H, T, box)
-        _ingest(dev, u, [pts[i:i + abi.MAX_BATCH_SIZE] for i in range(0, n, abi.MAX_BATCH_SIZE)])
+        _ingest(dev, u, [pts[i:i + batch] for i in range(0, n, batch)])
         ds = dev.read_stats()
         assert int(ds["dbg"]) == 0
-        ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+        ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
         ref.reset(u)
-        ref.add_points(u, pts)
+        ref.add_points(u, pts, batch)
         assert_stats_equal(ds, ref.stats[0], GRANULARITY_FREE_STATS, kind)
         nodes, pers, nn = host_image_of(dev)
         got, want = oracle.dump_image(nodes, nn), ref.dump()
