@@ -353,18 +353,25 @@ class DeviceOctree:
     def processed(self):
         """Stats.batchletIndex as the host sees it after the stream drained (main_progressive_octree.cpp:1201-1216)."""
         torch.cuda.current_stream().synchronize()
-        return int(self.stats[76:80].cpu().numpy().view(np.uint32)[0])
+        self.processed_host = int(self.stats[76:80].cpu().numpy().view(np.uint32)[0])
+        return self.processed_host
 
     def drain(self, uniforms, max_launches=1000):
         """Launch kernel_construct until every uploaded batch is ingested.  One launch takes at most 20 batches and stops
         early once it has run for 10 ms (progressive_octree_voxels.cu:883, :939-949) — the reference host simply launches
         again next frame; so does this loop.  Returns the number of launches."""
         launches = 0
-        while self.processed() < self.uploaded_host and launches < max_launches:
-            before = self.processed()
-            self.construct(uniforms)
-            launches += 1
-            if self.processed() == before:
+        before = self.processed_host              # (what the host last saw: 0 after a reset; too low only costs a launch that exits at once)
+        while before < self.uploaded_host and launches < max_launches:
+            # as many launches as the pending batches need at 20 per launch, enqueued back to back (the reference's frame loop does not wait
+            # for a launch either before it enqueues the next frame's); then ONE look at Stats
+            need = -(-(self.uploaded_host - before) // abi.MAX_BATCHES_PER_LAUNCH)
+            for _ in range(need):
+                self.construct(uniforms)
+            launches += need
+            after = self.processed()
+            stalled, before = after == before, after
+            if stalled:
                 st = self.read_stats()
                 raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, "
                                   f"memCapacityReached={int(st['memCapacityReached'])})")
@@ -425,6 +432,7 @@ class DeviceOctree:
         self.stats.copy_(torch.from_numpy(st.view(np.uint8).reshape(-1)))
         self.momentary[:4096].zero_()          # control block: the builder's side tables describe the previous octree
         _check(self.L.simlod_octree_image_replaced(self.nodes.data_ptr()), "simlod_octree_image_replaced")
+        self.processed_host = int(st["batchletIndex"][0])
 
     def download_image(self):
         """(nodes, persistent, numNodes, device base addresses) — the octree image as host arrays, pointers untouched."""
