@@ -1469,7 +1469,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
 	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
-	Phase ph(ctl, blockIdx.x == 0);
+	Phase ph(ctl, blockIdx.x == ((ctl->debugFlags >> 8) & 0xffffu));     // (SIMLOD_DEBUG_PHASE_WG: whose phase times tools/probe.py prints; default workgroup 0)
 	const bool clocked = (ctl->debugFlags & 2u) != 0u;       // SIMLOD_DEBUG_VOXELIZE_CLOCK (tools/probe.py): when the first workgroup came, the last piece was done, the last workgroup left
 	if (clocked && blockIdx.x == 0 && threadIdx.x == 0) ctl->voxT[ordinal][0] = wall_ns();
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
@@ -2016,7 +2016,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	const DeviceInfo& dev = device_info();
 
 	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(ctx.batchLimit.load(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(ctx, stats));
-	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u),
+	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
 	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), a.groupMax);
 	if (fits) {
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
