@@ -385,29 +385,46 @@ class DeviceOctree:
         Returns the number of launches.  Arbitrarily long inputs go through 50 slots."""
         nb = (num_points + batch - 1) // batch
         base = self.uploaded_host
-        main = torch.cuda.current_stream()
         src = source.reshape(-1)
-        uploaded, processed, launches = 0, 0, 0
+        uploaded, processed, launches, stalls = 0, 0, 0, 0
+
+        def top_up():
+            # the uploader: runs of free ring slots, each run one copy (a run ends where the ring wraps or the batches stop being full), then the
+            # run's batchSizes, then the counter — in stream order on the upload stream, as main_progressive_octree.cpp:1020-1050 publishes them
+            nonlocal uploaded
+            if uploaded >= nb or uploaded - processed >= self.ring_slots:
+                return
+            with torch.cuda.stream(self.upload_stream):
+                while uploaded < nb and uploaded - processed < self.ring_slots:
+                    slot = (base + uploaded) % abi.BATCH_STREAM_SIZE
+                    assert slot < self.ring_slots, "ring smaller than BATCH_STREAM_SIZE"
+                    run = min(nb - uploaded, self.ring_slots - (uploaded - processed), abi.BATCH_STREAM_SIZE - slot, self.ring_slots - slot)
+                    if batch != abi.MAX_BATCH_SIZE or (uploaded + run) * batch > num_points:
+                        run = 1                   # (short batches do not lie back to back in the ring)
+                    n = min(run * batch, num_points - uploaded * batch)
+                    self.ring[slot * abi.MAX_BATCH_SIZE * 16: slot * abi.MAX_BATCH_SIZE * 16 + n * 16].copy_(src[uploaded * batch * 16: uploaded * batch * 16 + n * 16], non_blocking=True)
+                    self.batch_sizes[slot: slot + run].fill_(min(batch, n))
+                    uploaded += run
+                    self.num_uploaded.fill_(base + uploaded)
+
+        self.upload_stream.wait_stream(torch.cuda.current_stream())     # (a reset enqueued just before zeroes batchSizes: the uploader starts behind it)
+        top_up()
         while processed < nb:
-            if uploaded < nb and uploaded - processed < self.ring_slots:
-                with torch.cuda.stream(self.upload_stream):
-                    while uploaded < nb and uploaded - processed < self.ring_slots:
-                        slot = (base + uploaded) % abi.BATCH_STREAM_SIZE
-                        n = min(batch, num_points - uploaded * batch)
-                        self.ring[slot * abi.MAX_BATCH_SIZE * 16: slot * abi.MAX_BATCH_SIZE * 16 + n * 16].copy_(src[uploaded * batch * 16: (uploaded * batch + n) * 16], non_blocking=True)
-                        self.batch_sizes[slot: slot + 1].fill_(n)
-                        uploaded += 1
-                        self.num_uploaded.fill_(base + uploaded)
-                    published = self.upload_stream.record_event()
-                main.wait_event(published)        # (the frame that follows sees every batch published so far; the reference's sees whatever has arrived)
             self.uploaded_host = base + uploaded
-            before = processed
-            self.construct(uniforms)
+            self.construct(uniforms)              # takes what has been published by now (k_begin reads the counter with a device-scope load)
             launches += 1
-            processed = self.processed() - base
-            if processed == before:
+            top_up()                              # ... and the uploader refills behind it while it runs
+            before, processed = processed, self.processed() - base
+            if processed != before:
+                stalls = 0
+                continue
+            # nothing taken: either nothing had been published yet (the uploader is behind: wait for it, once) or the builder refuses
+            stalls += 1
+            self.upload_stream.synchronize()
+            if stalls > 1:
                 st = self.read_stats()
                 raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, memCapacityReached={int(st['memCapacityReached'])})")
+        self.uploaded_host = base + uploaded
         self.processed_host = self.uploaded_host
         return launches
 

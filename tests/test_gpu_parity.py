@@ -437,6 +437,36 @@ def test_las_stream_of_60m_points_wraps_the_ring_and_equals_the_oracle(built_lib
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "las 60 M")
 
 
+@pytest.mark.parametrize("batch,n", [(abi.MAX_BATCH_SIZE, 53_400_000), (130_000, 9_000_000)])
+def test_resident_points_streamed_through_the_ring_by_the_uploader_equal_the_oracle(built_libs, batch, n):
+    """BASELINE config 4's mechanism (bench.py --gpus N / --stream, DeviceOctree.stream): the rank's points lie in device memory; an uploader on
+    its own stream copies runs of them into free ring slots and publishes sizes and counter behind the copies, never more than a ring ahead
+    of what the host has seen processed; kernel_construct is launched once per frame and takes whatever has been published by then.  More
+    batches than the ring has slots (54 of 1 M with a short last one; 70 of 130 000), device-generated terrain: octree and Stats == oracle."""
+    import torch
+    box = (6000.0, 4000.0, 400.0)
+    dev = _device(persistent_bytes=6 << 30)
+    src = torch.empty(n * 16, dtype=torch.uint8, device=dev.device)
+    dev.generate_terrain(src, 0, n, 11, 1, box, swath_width=250.0)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    u = dev.uniforms(W, H, T, box)
+    dev.reset(u)
+    launches = dev.stream(u, src, n, batch=batch)
+    ds = dev.read_stats()
+    nb = (n + batch - 1) // batch
+    assert int(ds["dbg"]) == 0 and int(ds["numPoints"]) == n and int(ds["batchletIndex"]) == nb > abi.BATCH_STREAM_SIZE and launches >= 3
+    pts = src.cpu().numpy().view(abi.point_dtype)
+    ref = oracle.HostOctree("port", persistent_bytes=6 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+    uh = u.copy()
+    uh["persistentBufferCapacity"] = 6 << 30
+    ref.reset(uh)
+    ref.add_points(uh, pts, batch)
+    assert ref.last_error() == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "streamed")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "streamed")
+
+
 # ---- render --------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("hqs", [False, True])
