@@ -178,7 +178,7 @@ def main():
         dev.batch_sizes[:n_batches] = sizes           # what the uploader's cuMemsetD32Async pair publishes
         dev.num_uploaded.fill_(n_batches)
         dev.uploaded_host = n_batches
-        return dev.drain(u)      # relaunch until Stats.batchletIndex == 36, as the reference's frame loop does
+        return dev.drain(u)      # ceil(36 / 20) launches back to back, one look at Stats.batchletIndex; more launches if a time budget cut one short
 
     for _ in range(args.warmup):
         ingest_step()
@@ -493,7 +493,7 @@ def main():
                                     if source is not None else
                                     f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M ring batches resident in HBM, ") +
                                    f"reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
-                                   f"(<= 20 batches and <= 10 ms each, Stats read back between launches); "
+                                   f"(<= 20 batches and <= 10 ms each; " + ("Stats read back after every launch); " if source is not None else "the launches the pending batches need are enqueued back to back, Stats read back after them); ") +
                                    f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order if not use_dist else "device-generated tiles, swath order",
                        "parallelism": f"one global cube, level-3 cells dealt to {world} rank(s) by point count"},
             "coalesced_ingest": coalesced, "config3": config3, "partition": partition, "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu, "loader": loader,
