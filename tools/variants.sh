@@ -11,7 +11,7 @@ import json,sys
 d=json.loads(sys.stdin.read())
 print('value %.0f M pts/s  ms_per_step %.3f' % (d['value'], d['ms_per_step']))
 print({k.split('<')[0]: round(v['total_ms'],2) for k,v in d['kernels'].items() if k.startswith('k_')})
-r=d['roofline']; print('dominant', r['kernel'], 'frac %.4f' % r['frac'], 'moved', r['moved_points'], 'placed', r['placed_by_k_place'])
+r=d['roofline']; print('dominant', r['kernel'], 'frac %.4f' % r['frac'], 'moved', r['moved_points'])
 " >> $OUT 2>&1
 done
 cat $OUT
