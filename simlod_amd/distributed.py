@@ -130,6 +130,12 @@ def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
     hqs = bool(u["useHighQualityShading"][0])
     boxes = bool(u["showBoundingBox"][0])
     renderer.render_part(uniforms, 0)
+    # the visible-node lists are final after part 0: their all-gather is issued now, asynchronously, and runs beside the passes and
+    # reductions that follow (RCCL puts it on its own stream behind part 0; the frame waits for it at the very end)
+    pending = None
+    if hasattr(renderer, "visible_records_early"):
+        vis, n = renderer.visible_records_early()
+        pending = gather_visible(vis, n, group=group, capacity=gather_capacity, async_op=True)
     if hqs:
         dist.all_reduce(renderer.depth_plane(), op=dist.ReduceOp.MIN, group=group)
         renderer.render_part(uniforms, 1)
@@ -138,14 +144,17 @@ def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
     if not hqs or boxes:                       # resolved HQS frames are identical on every rank; only rank-local debug lines differ
         compose_min(renderer.framebuffer_words(), group=group)
     renderer.render_part(uniforms, 3)
+    if pending is not None:
+        return pending()
     vis, n = renderer.visible_records()
     return gather_visible(vis, n, group=group, capacity=gather_capacity)
 
 
-def gather_visible(visible_bytes, count, group=None, capacity=4096):
+def gather_visible(visible_bytes, count, group=None, capacity=4096, async_op=False):
     """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, capacity, 152], counts).
     `count` may be a host int or a one-element tensor on the records' device (then nothing synchronises with the host: the
-    first `capacity` records travel as they are and the gathered counts say how many of them are valid)."""
+    first `capacity` records travel as they are and the gathered counts say how many of them are valid).  async_op: returns a
+    function that waits for the two collectives and hands out the result."""
     world = dist.get_world_size(group)
     dev = visible_bytes.device
     if isinstance(count, torch.Tensor):
@@ -158,6 +167,14 @@ def gather_visible(visible_bytes, count, group=None, capacity=4096):
         cnt = torch.tensor([n], dtype=torch.int64, device=dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    if async_op:
+        works = [dist.all_gather(bufs, buf, group=group, async_op=True), dist.all_gather(cnts, cnt, group=group, async_op=True)]
+
+        def finish():
+            for w in works:
+                w.wait()
+            return torch.stack(bufs), torch.cat(cnts)
+        return finish
     dist.all_gather(bufs, buf, group=group)
     dist.all_gather(cnts, cnt, group=group)
     return torch.stack(bufs), torch.cat(cnts)

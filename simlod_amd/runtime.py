@@ -333,6 +333,12 @@ class DeviceOctree:
         off = abi.stats_dtype.fields["numVisibleNodes"][1]
         return self.render_buffer, self.stats[off: off + 4].view(torch.int32)
 
+    def visible_records_early(self):
+        """As visible_records, but the count comes from the frame's own counter (valid once part 0 of the frame has run, clamped by the
+        consumer): the all-gather of the visible nodes can be issued right behind part 0 and overlap the rest of the frame."""
+        off = abi.MAX_VISIBLE_NODES * abi.node_dtype.itemsize
+        return self.render_buffer, self.render_buffer[off: off + 4].view(torch.int32)
+
     def lists_read_through_table(self):
         """How many chunk lists the last frame's r_visible read through the builder's chunk table instead of chasing `next`
         (render.hip: counter 5 of the frame counters behind the visible-node array)."""

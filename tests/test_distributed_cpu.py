@@ -57,6 +57,10 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(cnts, cnts2)
     for r in range(world):
         assert torch.equal(recs[r, : int(cnts[r])], recs2[r, : int(cnts2[r])])
+    # ... and issued asynchronously (render_frame: behind part 0, beside the rest of the frame), collected later
+    finish = distributed.gather_visible(padded, torch.tensor([len(o.visible)], dtype=torch.int32), async_op=True)
+    recs3, cnts3 = finish()
+    assert torch.equal(cnts, cnts3) and all(torch.equal(recs[r, : int(cnts[r])], recs3[r, : int(cnts3[r])]) for r in range(world))
     np.save(os.path.join(out_dir, f"fb_{rank}.npy"), t.numpy().view(np.uint64))
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([int(o.stats["numPoints"][0]), int(cnts.sum()), int(o.stats["numVisibleNodes"][0])]))
     # whole frames through render_frame: plain, HQS (depth MIN / colour SUM between the passes), HQS with bounding boxes
