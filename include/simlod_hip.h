@@ -56,7 +56,7 @@ extern "C" {
  * simlod_context_reload_env reads the environment again.  ctx == NULL means the default context everywhere. */
 typedef struct SimlodContext SimlodContext;
 int simlod_context_create(SimlodContext** out);
-int simlod_context_destroy(SimlodContext* ctx);                               /* waits for the context's second stream; detaches its node arrays */
+int simlod_context_destroy(SimlodContext* ctx);                               /* synchronises the device, detaches the context's node arrays; no launch with one of them may be in progress on another thread */
 int simlod_context_attach(SimlodContext* ctx, const SimlodNode* nodes);       /* launches given `nodes` run in ctx from now on (NULL: default again) */
 int simlod_context_set_node_capacity(SimlodContext* ctx, uint32_t numNodes);
 int simlod_context_set_ingest_mode(SimlodContext* ctx, uint32_t mode);

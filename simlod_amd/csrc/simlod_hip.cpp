@@ -32,7 +32,10 @@ void Context::reload_env() {
 
 Context::~Context() {
 	for (SideStream*& s : side) { if (s != nullptr) destroy_side_stream(s); s = nullptr; }
-	// (the page-locked feedback words of the launch history stay allocated: a copy of an earlier launch may still be on its way)
+	// the page-locked feedback words: a copy enqueued by the context's last launches (on the CALLER's streams) may still be on its way
+	(void)hipDeviceSynchronize();
+	for (LaunchHistory& h : history) (void)hipHostFree(const_cast<uint32_t*>(h.seen));
+	(void)hipGetLastError();
 }
 
 // node array -> context (simlod_context_attach); everything else runs in the default context

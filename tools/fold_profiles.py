@@ -31,7 +31,9 @@ for k, v in summ["hbm_traffic"].items():
         out[base] = total / (n_ingests * n_batches * per_batch.get(base, 1))
     elif k in names:
         out[names[k]] = total / frames
-    elif k in ("r_visible", "r_clear", "r_output", "r_resolve"):
-        out[k] = total / (frames * (1 if k == "r_resolve" else 2))
+    elif k in ("r_output<true>", "r_output<false>", "r_resolve"):      # one mode's frames only (<true>: HQS, resolve fused in)
+        out[k] = total / frames
+    elif k == "r_visible":                                              # both modes' frames (it clears 8 B/px for a plain frame, 36 B/px for an HQS one: the mean)
+        out[k] = total / (frames * 2)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"traffic_{tag}.json"), "w"), indent=1)
 print(json.dumps({k: round(v / 1e6, 2) for k, v in out.items() if not k.startswith("_")}), "MB")
