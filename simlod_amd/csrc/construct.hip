@@ -1291,8 +1291,8 @@ __device__ __forceinline__ void store_voxels_wave(const BuildArgs& a, Ctl* ctl, 
 // and nothing in the two passes over the samples leaves the CU.
 //   pass A  every sample: mark its cell in the deepest cube; if the cell was clear, mark `fresh` and climb to the next cube ...
 //   write-back  old = atomicOr(grid word, fresh bits); won = fresh & ~old; Node.numVoxels += popcount(won)   (voxels.cu:96-101)
-//   pass B  every sample: if its cell is still marked won, take the mark: this sample colours the voxel (which sample of a cell does
-//           is scheduling dependent in the reference too).
+//   pass B  the sample that set a cell in pass A looks whether the cell is still marked won: it colours the voxel (which sample of a cell
+//           does is scheduling dependent in the reference too)
 //   reserve  per ancestor with won cells: slot range from atomicAdd(Node.numVoxels); chunks the range starts are allocated here and now
 //   store    every sample that took a mark writes its voxel into slot base + rank (voxels.cu:674-698), through the hash directory of chunks
 static constexpr uint32_t VOX_CHUNKS = VOX_PIECE / SIMLOD_POINTS_PER_CHUNK + 2;   // chunks a piece's voxels of one ancestor can span
@@ -1563,13 +1563,14 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 #pragma unroll
 						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) old[j] = atomicOr(&sh.occ[word[j]], 1u << bit[j]); }   // voxels.cu:93-96
 #pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) atomicOr(&sh.fresh[word[j]], 1u << bit[j]); }   // lost: the winner climbs on
+						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) { atomicOr(&sh.fresh[word[j]], 1u << bit[j]); levels[j] |= 1u << d; } }   // lost: the winner climbs on (and remembers where it won: pass B)
 					} else {
 #pragma unroll
 						for (uint32_t j = 0; j < VOX_SPT; j++) {
 							if (!go[j]) continue;
 							if (sh.hiOcc[d - 1] != 0u || atomicOr(&sh.hiOcc[d - 1], 1u) != 0u) { go[j] = false; continue; }
 							sh.hiFresh[d - 1] = 1u;
+							levels[j] |= 1u << d;
 						}
 					}
 				}
@@ -1656,26 +1657,24 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 			}
 			ph.mark(28);
 
-			// pass B: every cell this piece won becomes a voxel, coloured by whichever of its samples gets there first
-			uint32_t levelsWithNew = 0;
-			for (uint32_t d = 1; d <= depth; d++) if (sh.cnt[d] != 0u) levelsWithNew |= 1u << d;
+			// pass B: every cell this piece won becomes a voxel, coloured by the sample that set it in pass A — one sample per cell (the one whose
+			// atomicOr found the cell clear), which kept the ancestors it won in `levels` (as a mask of d): it looks whether the write-back left
+			// the cell marked (nobody else had it) and turns the mask into the levels it colours.  No atomics, and three samples in four have
+			// nothing to look up.  (Which sample of a cell colours the voxel is scheduling dependent in the reference too)
 			if (it.leaf != 0u) {
-				for (uint32_t left = levelsWithNew; left != 0u; left &= left - 1u) {       // only the cubes that gained cells
-					const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
-					const uint32_t level = path_level(sh.anc[d - 1]);
-					if (d <= ldsDepth) {
-						uint32_t word[VOX_SPT], bit[VOX_SPT], cur[VOX_SPT];
 #pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell_of(d, level, pX[j], pY[j], pZ[j], word[j], bit[j]); cur[j] = live[j] ? sh.fresh[word[j]] : 0u; }
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) cur[j] = ((cur[j] >> bit[j]) & 1u) != 0u ? atomicAnd(&sh.fresh[word[j]], ~(1u << bit[j])) : 0u;   // take the mark
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) if (((cur[j] >> bit[j]) & 1u) != 0u) levels[j] |= 1u << level;                        // (unless somebody else just did)
-					} else {
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++)
-							if (live[j] && sh.hiFresh[d - 1] != 0u && atomicExch(&sh.hiFresh[d - 1], 0u) != 0u) levels[j] |= 1u << level;
+				for (uint32_t j = 0; j < VOX_SPT; j++) {
+					uint32_t colours = 0;
+					for (uint32_t left = levels[j]; left != 0u; left &= left - 1u) {
+						const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
+						const uint32_t level = path_level(sh.anc[d - 1]);
+						if (d <= ldsDepth) {
+							uint32_t word, bit;
+							cube_cell_of(d, level, pX[j], pY[j], pZ[j], word, bit);
+							if (((sh.fresh[word] >> bit) & 1u) != 0u) colours |= 1u << level;
+						} else if (sh.hiFresh[d - 1] != 0u) colours |= 1u << level;
 					}
+					levels[j] = colours;
 				}
 			}
 			// ... and stores the voxel: the cell's centre in its own colour (voxels.cu:103-114, 674-698), in the next free slot of the piece's range
