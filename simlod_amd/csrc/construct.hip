@@ -405,7 +405,7 @@ __device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCt
 	const uint32_t before = atomicExch(at<uint32_t>(a, a.offTouchTag) + leafIdx, bc->tag);
 	atomicMax(at<unsigned long long>(a, a.offStartOf) + leafIdx, ((unsigned long long)bc->tag << 32) | (0xffffffffu - old));
 	uint32_t flags = before != bc->tag ? FIRST : 0u;
-	// A node at MAX_DEPTH cannot be subdivided (descend() stops there): it keeps growing instead of spilling.
+	// A node at MAX_DEPTH cannot be subdivided (the descent stops there): it keeps growing instead of spilling.
 	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, bc->tag) != bc->tag) flags |= CROSSED;
 	return flags;
 }

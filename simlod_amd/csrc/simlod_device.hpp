@@ -45,19 +45,9 @@ __device__ __forceinline__ bool node_is_leaf(const SimlodNode* n) {
 	return (a.x | a.y | b.x | b.y | d.x | d.y | e.x | e.y) == 0ull;
 }
 
-// Descend from `cur` (at level `level`) to the leaf that owns (X,Y,Z); progressive_octree_voxels.cu:169-187.
-__device__ __forceinline__ SimlodNode* descend(SimlodNode* cur, int level, uint32_t X, uint32_t Y, uint32_t Z) {
-#pragma unroll 1
-	for (; level < SIMLOD_MAX_DEPTH; ++level) {
-		SimlodNode* ch = cur->children[child_index(X, Y, Z, level)];
-		if (ch == nullptr) break;
-		cur = ch;
-	}
-	return cur;
-}
-
-// P descents in lockstep, one level per step: the P child-pointer loads of a step are independent, so a thread keeps P L2 round trips
-// in flight instead of walking its samples one after the other (a descent is a chain of 5-8 dependent loads).
+// P descents to the leaves that own the samples (progressive_octree_voxels.cu:169-187) in lockstep, one level per step: the P child-pointer
+// loads of a step are independent, so a thread keeps P L2 round trips in flight instead of walking its samples one after the other (a
+// descent is a chain of 5-8 dependent loads).
 template <int P>
 __device__ __forceinline__ void descend_lockstep(SimlodNode* nodes, uint32_t (&cur)[P], uint32_t (&level)[P], const uint32_t (&X)[P], const uint32_t (&Y)[P],
                                                  const uint32_t (&Z)[P], bool (&walking)[P]) {
@@ -86,57 +76,6 @@ __device__ __forceinline__ uint8_t* persistent_alloc(uint8_t* pers, uint64_t siz
 	unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a->offset),
 	                                   (unsigned long long)(SIMLOD_ALLOC_ROUND(size) * count));
 	return pers + old;
-}
-
-// ---- workgroup-level key -> count aggregation in LDS ------------------------------------------------------------------
-// A device-scope atomic on ONE address retires at ~88 M/s on this chip (MI355X_MICROARCH.md, rows fanin / dequeue), and a
-// spatially compact 1 M-point batch funnels most of its points into a few dozen leaves: per-wave aggregation still
-// leaves ~16 k atomics per hot counter per batch.  So every counter update of the build (leaf arrival counters, slot
-// reservations, voxel counters, split histograms) is first combined per WORKGROUP in an open-addressing LDS table and flushed
-// with one global atomic per (workgroup, key).  tab_add returns the entry and the value the entry's counter had before
-// (= rank of this caller inside the workgroup), or -1 when 16 probes found no room; a key that failed once keeps
-// failing (entries are never removed), so callers can fall back consistently.
-static constexpr uint32_t TBL_EMPTY = 0xffffffffu;
-
-template <int BITS>
-struct Tab {
-	static constexpr int CAP = 1 << BITS;
-	uint32_t keys[CAP];
-	uint32_t vals[CAP];
-};
-
-template <int BITS>
-__device__ __forceinline__ void tab_init(Tab<BITS>& t) {
-	for (uint32_t i = threadIdx.x; i < (uint32_t)Tab<BITS>::CAP; i += blockDim.x) { t.keys[i] = TBL_EMPTY; t.vals[i] = 0u; }
-}
-
-template <int BITS>
-__device__ __forceinline__ uint32_t tab_hash(uint32_t key) { return (key * 2654435761u) >> (32 - BITS); }
-
-template <int BITS>
-__device__ __forceinline__ int tab_add(Tab<BITS>& t, uint32_t key, uint32_t inc, uint32_t* rank) {
-	uint32_t h = tab_hash<BITS>(key);
-#pragma unroll 1
-	for (int probe = 0; probe < 16; ++probe) {
-		uint32_t k = t.keys[h];
-		if (k == TBL_EMPTY) { k = atomicCAS(&t.keys[h], TBL_EMPTY, key); if (k == TBL_EMPTY) k = key; }
-		if (k == key) { *rank = atomicAdd(&t.vals[h], inc); return (int)h; }
-		h = (h + 1) & (Tab<BITS>::CAP - 1);
-	}
-	return -1;
-}
-
-template <int BITS>
-__device__ __forceinline__ int tab_find(const Tab<BITS>& t, uint32_t key) {
-	uint32_t h = tab_hash<BITS>(key);
-#pragma unroll 1
-	for (int probe = 0; probe < 16; ++probe) {
-		const uint32_t k = t.keys[h];
-		if (k == key) return (int)h;
-		if (k == TBL_EMPTY) return -1;
-		h = (h + 1) & (Tab<BITS>::CAP - 1);
-	}
-	return -1;
 }
 
 // ---- grid barrier (expand loop only) --------------------------------------------------------------------------
