@@ -77,3 +77,32 @@ def test_runtime_refuses_to_run_without_gpu(built_libs):
     from simlod_amd.runtime import DeviceOctree, SimlodError
     with pytest.raises(SimlodError):
         DeviceOctree("cuda:0")
+
+
+def test_context_surface_without_a_device(built_libs):
+    """simlod_context_*: contexts are host objects (nothing touches a device before the first launch); settings are validated like the
+    process-wide setters, knobs are known by their environment names, a context's scratch need follows ITS node capacity."""
+    from simlod_amd import runtime
+    L = runtime.lib()
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.simlod_context_create(ctypes.byref(a)) == 0 and L.simlod_context_create(ctypes.byref(b)) == 0 and a.value != b.value
+    assert L.simlod_context_create(None) != 0
+    assert L.simlod_context_set_ingest_mode(a, 1) == 0 and L.simlod_context_set_ingest_mode(a, 2) != 0
+    assert L.simlod_context_set_construct_batch_limit(a, 0) != 0 and L.simlod_context_set_construct_batch_limit(a, 1000) == 0      # (clamped to 20)
+    assert L.simlod_context_set_node_capacity(a, 8) != 0 and L.simlod_context_set_node_capacity(a, (1 << 19) + 1) != 0
+    assert L.simlod_context_set_node_capacity(a, 40_000) == 0 and L.simlod_context_set_node_capacity(b, 400_000) == 0
+    small, large, default = (int(L.simlod_context_construct_buffer_min_bytes(c)) for c in (a, b, None))
+    assert small < default < large and default == int(L.simlod_construct_buffer_min_bytes())
+    for name in (b"SIMLOD_OVERLAP_TAIL", b"SIMLOD_EXPAND_WGS", b"SIMLOD_RASTER_LDS_TILES", b"SIMLOD_GROUP_BATCHES", b"SIMLOD_DEBUG_BUDGET_US"):
+        assert L.simlod_context_set_knob(a, name, 1, 1) == 0 and L.simlod_context_set_knob(a, name, 0, 0) == 0
+    assert L.simlod_context_set_knob(a, b"SIMLOD_NO_SUCH_KNOB", 1, 1) != 0 and L.simlod_context_set_knob(a, None, 1, 1) != 0
+    os.environ["SIMLOD_EXPAND_WGS"] = "32"
+    try:
+        assert L.simlod_context_reload_env(a) == 0 and L.simlod_context_reload_env(None) == 0
+    finally:
+        del os.environ["SIMLOD_EXPAND_WGS"]
+        L.simlod_context_reload_env(None)
+    fake_nodes = ctypes.c_void_p(0x1000)
+    assert L.simlod_context_attach(a, fake_nodes) == 0 and L.simlod_context_attach(b, fake_nodes) == 0 and L.simlod_context_attach(None, fake_nodes) == 0
+    assert L.simlod_context_attach(a, None) != 0
+    assert L.simlod_context_destroy(a) == 0 and L.simlod_context_destroy(b) == 0 and L.simlod_context_destroy(None) != 0
