@@ -1977,6 +1977,11 @@ void destroy_side_stream(SideStream* s) {
 	delete s;
 }
 namespace build {
+// The events order kernels of ONE device: no timing, and no system-scope fence when one is recorded (its cache write-back and invalidation
+// are for the host and for other devices; a kernel's own end makes its stores visible to the kernels that follow on this device).
+#ifndef SYNC_EVENT_FLAGS
+#define SYNC_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
 static SideStream* side_stream(Context& ctx) {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
@@ -1986,8 +1991,8 @@ static SideStream* side_stream(Context& ctx) {
 		SideStream* s = new SideStream();
 		bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
 		for (uint32_t i = 0; ok && i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++)
-			ok = hipEventCreateWithFlags(&s->expanded[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->inserted[i], hipEventDisableTiming) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags(&s->tailDone, hipEventDisableTiming) == hipSuccess;
+			ok = hipEventCreateWithFlags(&s->expanded[i], SYNC_EVENT_FLAGS) == hipSuccess && hipEventCreateWithFlags(&s->inserted[i], SYNC_EVENT_FLAGS) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&s->tailDone, SYNC_EVENT_FLAGS) == hipSuccess;
 		if (!ok) { (void)hipGetLastError(); delete s; return nullptr; }     // no side stream: everything stays on the caller's
 		ctx.side[dev] = s;
 	}
