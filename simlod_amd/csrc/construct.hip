@@ -2063,11 +2063,18 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->inserted[b - 1], 0) != hipSuccess) return (int)hipGetLastError();
 			if (single) SIMLOD_LAUNCH(k_hist<true>, dim3(gridPoints), dim3(TPB), stream, a, b);
 			else SIMLOD_LAUNCH(k_hist<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
-			SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
-			if (side != nullptr && (hipEventRecord(side->expanded[b], stream) != hipSuccess || hipStreamWaitEvent(back, side->expanded[b], 0) != hipSuccess)) return (int)hipGetLastError();
-			if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
-			else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
-			if (side != nullptr && hipEventRecord(side->inserted[b], back) != hipSuccess) return (int)hipGetLastError();
+			// (with two streams the kernels the other stream waits for carry their event as the launch's stop event: it is signalled by the
+			// kernel's own completion, where hipEventRecord puts a marker of its own behind the kernel — 3.93 -> 3.85 ms per ingest)
+			if (side != nullptr) {
+				SIMLOD_LAUNCH_STOP(k_expand, dim3(expandWgs), dim3(ETPB), stream, side->expanded[b], a, b);
+				if (hipStreamWaitEvent(back, side->expanded[b], 0) != hipSuccess) return (int)hipGetLastError();
+				if (single) SIMLOD_LAUNCH_STOP(k_insert<true>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
+				else SIMLOD_LAUNCH_STOP(k_insert<false>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);
+			} else {
+				SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
+				if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);
+				else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
+			}
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
 		}
 		if (side != nullptr && (hipEventRecord(side->tailDone, back) != hipSuccess || hipStreamWaitEvent(stream, side->tailDone, 0) != hipSuccess)) return (int)hipGetLastError();

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -109,6 +110,12 @@ void profile_close(hipStream_t stream);                           // records the
 		if (::simlod::profile_enabled()) ::simlod::profile_mark(#kernel, stream); \
 		hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);          \
 		if (::simlod::debug_sync()) ::simlod::debug_synced(#kernel);              \
+	} while (0)
+// a launch whose completion signals `stopEvent` (hipExtLaunchKernelGGL): for kernels another stream waits for
+#define SIMLOD_LAUNCH_STOP(kernel, grid, block, stream, stopEvent, ...)                       \
+	do {                                                                                      \
+		hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, stopEvent, 0, __VA_ARGS__); \
+		if (::simlod::debug_sync()) ::simlod::debug_synced(#kernel);                          \
 	} while (0)
 bool debug_sync();                           // SIMLOD_DEBUG_SYNC=1: synchronise the device after every kernel and name it on stderr (fault hunting)
 void debug_synced(const char* kernelName);
