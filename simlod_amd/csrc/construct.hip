@@ -133,6 +133,39 @@ __device__ __forceinline__ int table_add(BlockTable& t, uint32_t key, uint32_t i
 	return -1;
 }
 
+// The same table with every counter REP times (k_count): a swath-ordered batch sends most lanes of a wave to a handful of leaves, and the LDS
+// serialises atomics of one instruction on one address lane by lane (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.88 in k_count).  Lane l
+// adds to copy l % REP — REP consecutive words, REP different banks — and the flush sums the copies.
+template <uint32_t REP>
+struct SpreadTable {
+	uint32_t keys[TBL_CAP];
+	uint32_t vals[TBL_CAP * REP];
+};
+template <uint32_t REP>
+__device__ __forceinline__ void spread_init(SpreadTable<REP>& t) {
+	for (uint32_t i = threadIdx.x; i < (uint32_t)TBL_CAP; i += blockDim.x) t.keys[i] = TBL_EMPTY;
+	for (uint32_t i = threadIdx.x; i < (uint32_t)TBL_CAP * REP; i += blockDim.x) t.vals[i] = 0u;
+}
+template <uint32_t REP>
+__device__ __forceinline__ bool spread_add(SpreadTable<REP>& t, uint32_t key, uint32_t copy) {
+	uint32_t h = table_hash(key);
+#pragma unroll 1
+	for (int probe = 0; probe < 16; ++probe) {
+		uint32_t k = t.keys[h];
+		if (k == TBL_EMPTY) { k = atomicCAS(&t.keys[h], TBL_EMPTY, key); if (k == TBL_EMPTY) k = key; }
+		if (k == key) { atomicAdd(&t.vals[h * REP + copy], 1u); return true; }
+		h = (h + 1) & (TBL_CAP - 1);
+	}
+	return false;
+}
+template <uint32_t REP>
+__device__ __forceinline__ uint32_t spread_sum(const SpreadTable<REP>& t, uint32_t e) {
+	uint32_t s = 0;
+#pragma unroll
+	for (uint32_t r = 0; r < REP; r++) s += t.vals[e * REP + r];
+	return s;
+}
+
 __device__ __forceinline__ int table_find(const BlockTable& t, uint32_t key) {
 	uint32_t h = table_hash(key);
 #pragma unroll 1
@@ -373,7 +406,9 @@ struct LeafWords {
 };
 static constexpr uint32_t SLOT_CAP = 2048;                  // slots per batch (12 bits of a relabelled word and of the reservation word)
 static constexpr uint32_t HIST_BINS = 512;
-static constexpr uint32_t LEAF_FLAG = 0x80000000u;          // cached-leaf word: FLAG | slot << 9 | bin   (else: a node index)
+static constexpr uint32_t LEAF_FLAG = 0x80000000u;          // cached-leaf word: FLAG | slot << 9 | bin   (else: node index | bin below that node << 19, as k_count left it)
+static constexpr uint32_t LEAF_BIN_SHIFT = 19;              // node indices travel in 19 bits (simlod_context_set_node_capacity: <= 2^19 nodes)
+static constexpr uint32_t LEAF_NODE_MASK = (1u << LEAF_BIN_SHIFT) - 1u;
 static constexpr uint32_t MAP_LISTED = 0x80000000u;         // map entry: LISTED | level << 16 | slot of the NEXT round   (else: a node index)
 static constexpr uint32_t NONE = 0xffffffffu;
 struct SlotRec { uint32_t node, level, childBase, spillBase, stored, pad0, pad1, pad2; };   // node == NONE: nothing could be reserved, the leaf stays as it is
@@ -548,7 +583,8 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr) return;
-	__shared__ BlockTable tbl;
+	constexpr uint32_t REP = 8;
+	__shared__ SpreadTable<REP> tbl;
 	__shared__ uint32_t sh_touch[TOUCH_CAP];
 	__shared__ uint32_t sh_numTouch, sh_touchBase;
 	const uint32_t n = bc->batchSize;
@@ -579,7 +615,7 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	};
 	// The LDS table lives for the whole workgroup: no barrier inside the chunk loop, so the waves never wait for each
 	// other's slowest descent; one flush at the end.
-	table_init(tbl);
+	spread_init(tbl);
 	if (threadIdx.x == 0) sh_numTouch = 0;
 	__syncthreads();
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
@@ -604,16 +640,15 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 			const uint32_t i = chunk * CPB + j * BT + threadIdx.x;
 			if (i >= n) continue;
 			const uint32_t leafIdx = cur[j];
-			leafOf.grp[i] = leafIdx;
-			uint32_t rank;
-			if (table_add(tbl, leafIdx, 1u, &rank) < 0) counted(leafIdx, count_into(a, bc, leafIdx, 1u));
+			leafOf.grp[i] = leafIdx | (bin_of(X[j], Y[j], Z[j], level[j]) << LEAF_BIN_SHIFT);      // the bin is what k_hist needs should this leaf split: it never reads the sample
+			if (!spread_add(tbl, leafIdx, threadIdx.x & (REP - 1u))) counted(leafIdx, count_into(a, bc, leafIdx, 1u));
 		}
 	}
 	__syncthreads();
 	ph.mark(0);
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += BT) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) counted(key, count_into(a, bc, key, tbl.vals[e]));
+		if (key != TBL_EMPTY) counted(key, count_into(a, bc, key, spread_sum(tbl, e)));
 	}
 	__syncthreads();
 	ph.mark(1);
@@ -795,7 +830,6 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 // (voxels.cu:253-289) — then the batch's samples.  Whatever lies in a queued leaf is added to the leaf's histogram (per workgroup in LDS
 // first, one global add per workgroup and bin) and its cached-leaf word is relabelled FLAG | slot | bin.  Exits at once when k_queue
 // queued nothing.
-template <bool SINGLE>
 __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
@@ -810,7 +844,6 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
-	const Samples<SINGLE> pts(a, bc);
 	const uint32_t n = bc->batchSize;
 	const uint32_t tag = bc->ordinal + 1u;
 	const uint32_t moved = min(bc->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
@@ -825,10 +858,11 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 		if (table_add(tbl, key, 1u, &rank) < 0) atomicAdd(hist + key, 1u);
 	};
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-		// stage by stage, eight elements per thread: cached-leaf words / work items; slot lookups; points; histogram
-		uint32_t ent[CPT], dst[CPT];                       // ent = level << 16 | slot, or NONE; dst = where the word / the moved point goes
+		// stage by stage, eight elements per thread.  A SAMPLE of the group is never read here: its word holds the leaf k_count found and the
+		// bin below that leaf (node | bin << 19) — if the leaf was queued, the word becomes FLAG | slot | bin and the bin is counted.  A STORED
+		// point of a queued leaf is read, binned and moved to the spill buffer.
+		uint32_t ent[CPT], dst[CPT], v[CPT];              // moved points: ent = level << 16 | slot (or NONE), dst = spill index; samples: v = the cached-leaf word (or NONE)
 		const float4* src[CPT];
-		uint32_t v[CPT];
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
 			const uint32_t e = chunk * CPB + j * TPB + threadIdx.x;
@@ -837,25 +871,27 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 				const SpillWork item = work[e / SIMLOD_POINTS_PER_CHUNK];
 				const uint32_t k = e % SIMLOD_POINTS_PER_CHUNK;
 				if (k < item.count) { ent[j] = (item.level << 16) | item.slot; src[j] = reinterpret_cast<const float4*>(item.chunk->points) + k; dst[j] = item.dstBase + k; }
-			} else if (e < total) v[j] = leafOf[e - moved];
+			} else if (e < total) v[j] = leafOf.grp[e - moved];
 		}
+		unsigned long long info[CPT];
 #pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) {
-			if (v[j] == NONE) continue;
-			const uint32_t e = chunk * CPB + j * TPB + threadIdx.x;
-			const unsigned long long info = slotOf[v[j]];
-			if ((uint32_t)(info >> 32) == tag) { ent[j] = (uint32_t)info; src[j] = pts.ptr(e - moved); dst[j] = e - moved; }
-		}
+		for (uint32_t j = 0; j < CPT; j++) info[j] = v[j] != NONE ? slotOf[v[j] & LEAF_NODE_MASK] : 0ull;
 		float4 p[CPT];
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) p[j] = ent[j] != NONE ? *src[j] : make_float4(0, 0, 0, 0);
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
+			if (v[j] == NONE || (uint32_t)(info[j] >> 32) != tag) continue;
+			const uint32_t key = (((uint32_t)info[j] & 0xffffu) << 9) | (v[j] >> LEAF_BIN_SHIFT);
+			leafOf.grp[chunk * CPB + j * TPB + threadIdx.x - moved] = LEAF_FLAG | key;
+			add(key);
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < CPT; j++) {
 			if (ent[j] == NONE) continue;
 			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
 			const uint32_t key = ((ent[j] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[j] >> 16);
-			if (v[j] == NONE) { spilled[dst[j]] = p[j]; leafOf[a.groupCap + dst[j]] = LEAF_FLAG | key; }      // a stored point moves
-			else leafOf[dst[j]] = LEAF_FLAG | key;
+			spilled[dst[j]] = p[j]; leafOf.mov[dst[j]] = LEAF_FLAG | key;                       // a stored point moves
 			add(key);
 		}
 	}
@@ -1151,17 +1187,9 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	}
 }
 
-// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction)
-__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
-	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
-	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
-	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
-	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
-	const uint32_t nsh = 28u - (uint32_t)level;
-	// masked to `level` bits: a coordinate exactly on the max face quantises to 2^20 (2^28 here) and the reference's descent, which
-	// looks at bits 19..0 only, files it under node coordinate 0 on that axis (voxels.cu:171-179) — the voxel sits at the LOW face
-	const uint32_t nmask = (1u << (uint32_t)level) - 1u;
-	const uint32_t nX = (pX >> nsh) & nmask, nY = (pY >> nsh) & nmask, nZ = (pZ >> nsh) & nmask;
+// cell-centre position of a voxel, voxels.cu:103-114, operation by operation (no contraction): cell (cx, cy, cz) of the 128^3 grid of the
+// level-`level` node with coordinates (nX, nY, nZ)
+__device__ __forceinline__ float4 voxel_at(const BuildArgs& a, int level, uint32_t nX, uint32_t nY, uint32_t nZ, uint32_t cx, uint32_t cy, uint32_t cz, float colorBits) {
 	const float nodeSize = a.size / exp2_int((uint32_t)level);
 	const float nminx = ((float)nX + 0.0f) * nodeSize + a.minx;
 	const float nminy = ((float)nY + 0.0f) * nodeSize + a.miny;
@@ -1172,6 +1200,18 @@ __device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32
 	v.z = nminz + (nodeSize * ((float)cz + 0.5f)) / 128.0f;
 	v.w = colorBits;                       // colour of the claiming point
 	return v;
+}
+// ... of the cell a sample with 28-bit coordinates (pX, pY, pZ) falls into
+__device__ __forceinline__ float4 voxel_of(const BuildArgs& a, int level, uint32_t pX, uint32_t pY, uint32_t pZ, float colorBits) {
+	const uint32_t sh = (uint32_t)(SIMLOD_MAX_DEPTH + 1 - level);
+	const uint32_t cx = (pX >> sh) & 127u, cy = (pY >> sh) & 127u, cz = (pZ >> sh) & 127u;
+	// Node.X/Y/Z of the level-`level` node that contains the sample: the top `level` bits of its 28-bit coordinate (the
+	// 2^20 grid the nodes are indexed in is the same fp32 quotient scaled by an exact power of two, simlod_device.hpp quantize)
+	const uint32_t nsh = 28u - (uint32_t)level;
+	// masked to `level` bits: a coordinate exactly on the max face quantises to 2^20 (2^28 here) and the reference's descent, which
+	// looks at bits 19..0 only, files it under node coordinate 0 on that axis (voxels.cu:171-179) — the voxel sits at the LOW face
+	const uint32_t nmask = (1u << (uint32_t)level) - 1u;
+	return voxel_at(a, level, (pX >> nsh) & nmask, (pY >> nsh) & nmask, (pZ >> nsh) & nmask, cx, cy, cz, colorBits);
 }
 
 // ---- voxel chunks, on demand (voxels.cu:641-698 allocateVoxelChunks + insertVoxels in one pass) ------------------------------------------
@@ -1289,22 +1329,32 @@ __device__ __forceinline__ void store_voxels_wave(const BuildArgs& a, Ctl* ctl, 
 // fewer workgroups, both made it SLOWER).  Here the global memory sees one atomicOr per touched WORD and piece — it returns which of
 // the new cells are really new (the pieces of one leaf share cubes; different leaves never share a cell below the 8th ancestor) —
 // and nothing in the two passes over the samples leaves the CU.
-//   pass A  every sample: mark its cell in the deepest cube; if the cell was clear, mark `fresh` and climb to the next cube ...
-//   write-back  old = atomicOr(grid word, fresh bits); won = fresh & ~old; Node.numVoxels += popcount(won)   (voxels.cu:96-101)
-//   pass B  the sample that set a cell in pass A looks whether the cell is still marked won: it colours the voxel (which sample of a cell
-//           does is scheduling dependent in the reference too)
-//   reserve  per ancestor with won cells: slot range from atomicAdd(Node.numVoxels); chunks the range starts are allocated here and now
-//   store    every sample that took a mark writes its voxel into slot base + rank (voxels.cu:674-698), through the hash directory of chunks
+//   level 1    every sample (eight per thread, in registers): test-and-set of its cell in the parent's cube; the samples that found their cell
+//              clear are the level's WINNERS: they go on a list (LDS) — cell and sample number in one word
+//   level d    the winners of level d - 1, DENSELY (a list entry per lane, not a sample per lane: three samples in four lose at level 1 and
+//              would idle through six more levels): test-and-set in cube d, winners on the list of level d.  The lists shrink with the cubes
+//              (<= 4096, 512, 64, 8, 1 winners from d = 3 on); from the 8th ancestor on the leaf is ONE cell: the last winner climbs alone
+//   write-back  old = atomicOr(grid word, bits set here); won = those & ~old; Node.numVoxels += popcount(won)   (voxels.cu:96-101).  What a
+//              thread set = its LDS words now minus the same words as it loaded them (kept in registers): no second bit plane
+//   reserve    per ancestor with won cells: slot range from atomicAdd(Node.numVoxels); chunks the range starts are allocated here and now
+//   store      a winner whose cell is still marked won colours the voxel — position from the CELL (list entry + the leaf's coordinates),
+//              colour from the sample (which sample of a cell does is scheduling dependent in the reference too) —
+//              into slot base + rank (voxels.cu:674-698), through the hash directory of chunks
 static constexpr uint32_t VOX_CHUNKS = VOX_PIECE / SIMLOD_POINTS_PER_CHUNK + 2;   // chunks a piece's voxels of one ancestor can span
+// winner lists: level d holds at most min(8192, (128 >> d)^3) entries
+static constexpr uint32_t VOX_LIST_WORDS = 2 * VOX_PIECE + 4096 + 512 + 64 + 8 + 8;
+__device__ __forceinline__ uint32_t list_offset(uint32_t d) { return d == 1u ? 0u : d == 2u ? VOX_PIECE : d == 3u ? 2u * VOX_PIECE : d == 4u ? 2u * VOX_PIECE + 4096u : d == 5u ? 2u * VOX_PIECE + 4608u : d == 6u ? 2u * VOX_PIECE + 4672u : 2u * VOX_PIECE + 4680u; }
 struct VoxShared {
-	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row
-	uint32_t fresh[CUBE_WORDS];                                 // pass A: cells this piece set; after the write-back: cells it won
+	uint32_t occ[CUBE_WORDS];                                   // cubes d = 1..7: rows of (128 >> d) x-bits; d = 1: two words per row.  After the write-back: the cells this piece WON
+	uint32_t list[VOX_LIST_WORDS];                              // winner = cell inside the leaf's level-1 cube (6 bits per axis) | sample << 18
+	uint32_t listCount[8];                                      // winners of level d
 	uint32_t hiOcc[PATH_WORDS], hiFresh[PATH_WORDS];            // ancestors d >= 8: the ONE cell the whole leaf falls into
+	uint32_t hiSample;                                          // the sample that climbs beyond the 7th ancestor
 	unsigned long long anc[PATH_WORDS];
 	uint32_t cnt[PATH_WORDS];
 	uint32_t first[PATH_WORDS], rank[PATH_WORDS];               // the slots this piece reserved in ancestor d's voxel list: [first, first + cnt); how many of them are taken
 	SimlodChunk* chunkOf[PATH_WORDS][VOX_CHUNKS];               // ... and the chunks they lie in, from chunk first / 1000 on
-	float color[VOX_PIECE];                                     // the samples' colours (coordinates stay in registers)
+	float color[VOX_PIECE];                                     // the samples' colours
 };
 __device__ __forceinline__ uint32_t cube_offset(uint32_t d) {          // word offset of cube d in VoxShared::occ / fresh
 	return d == 1u ? 0u : d == 2u ? 8192u : d == 3u ? 9216u : d == 4u ? 9472u : d == 5u ? 9536u : d == 6u ? 9552u : 9556u;
@@ -1313,21 +1363,21 @@ __device__ __forceinline__ uint32_t grid_cell(uint32_t level, uint32_t pX, uint3
 	const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level;
 	return ((pX >> shf) & 127u) + ((pY >> shf) & 127u) * SIMLOD_GRID_SIZE + ((pZ >> shf) & 127u) * SIMLOD_GRID_SIZE * SIMLOD_GRID_SIZE;
 }
-// word and bit of grid cell `cell` of ancestor d inside the leaf's cube (side = 128 >> d; the cube is aligned to its side)
-__device__ __forceinline__ void cube_cell(uint32_t d, uint32_t cell, uint32_t& word, uint32_t& bit) {
-	const uint32_t side = 128u >> d, lx = (cell & 127u) & (side - 1u), ly = ((cell >> 7) & 127u) & (side - 1u), lz = (cell >> 14) & (side - 1u);
-	const uint32_t row = ly + side * lz;
+// A winner names its cell by the cell's position inside the leaf's level-1 cube: code = lx | ly << 6 | lz << 12 (six bits per axis: the
+// leaf is 64^3 cells of its parent's grid).  The cell above it in ancestor d's cube (side 128 >> d, aligned to its side) is code >> (d - 1)
+// per axis: word and bit in the LDS cubes.
+__device__ __forceinline__ void cube_cell_from(uint32_t d, uint32_t code, uint32_t& word, uint32_t& bit) {
+	const uint32_t s = d - 1u;
+	const uint32_t lx = (code & 63u) >> s, row = (((code >> 6) & 63u) >> s) + ((((code >> 12) & 63u) >> s) << (7u - d));
 	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
 	else { word = cube_offset(d) + row; bit = lx; }
 }
-// the same for a sample, straight from its 28-bit coordinates: `level` = the ancestor's (its grid cell is coordinate >> (21 - level), voxels.cu:78-92);
-// the low bits of the cell index are the position inside the leaf's cube (the cube is aligned to its side).  A dozen integer operations —
-// the two passes over the samples are bound by instruction issue (16 waves share four SIMDs), not by LDS.
-__device__ __forceinline__ void cube_cell_of(uint32_t d, uint32_t level, uint32_t pX, uint32_t pY, uint32_t pZ, uint32_t& word, uint32_t& bit) {
-	const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 1) - level, m = (128u >> d) - 1u;
-	const uint32_t lx = (pX >> shf) & m, row = ((pY >> shf) & m) + (((pZ >> shf) & m) << (7u - d));
-	if (d == 1u) { word = row * 2u + (lx >> 5); bit = lx & 31u; }
-	else { word = cube_offset(d) + row; bit = lx; }
+// the voxel of that cell in ancestor d of the leaf (LX, LY, LZ) at level leafLevel: the cube starts at cell (L & (2^d - 1)) * side of the
+// ancestor's grid, the ancestor's own coordinates are L >> d   (the same cell, hence the same voxel, as voxel_of() finds for any sample in it)
+__device__ __forceinline__ float4 voxel_from(const BuildArgs& a, uint32_t d, uint32_t code, uint32_t leafLevel, uint32_t LX, uint32_t LY, uint32_t LZ, float colorBits) {
+	const uint32_t s = d - 1u, side = 128u >> d, m = (1u << d) - 1u;
+	const uint32_t cx = (LX & m) * side + ((code & 63u) >> s), cy = (LY & m) * side + (((code >> 6) & 63u) >> s), cz = (LZ & m) * side + (((code >> 12) & 63u) >> s);
+	return voxel_at(a, (int)(leafLevel - d), LX >> d, LY >> d, LZ >> d, cx, cy, cz, colorBits);
 }
 // LDS word w of the cubes -> which ancestor's grid word it mirrors: d (0: none), the word's index in that grid, the bit offset of the
 // cube's row inside the word, and the row's mask
@@ -1469,6 +1519,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
 	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
+	const uint32_t lane = (uint32_t)lane_id();
 	Phase ph(ctl, blockIdx.x == ((ctl->debugFlags >> 8) & 0xffffu));     // (SIMLOD_DEBUG_PHASE_WG: whose phase times tools/probe.py prints; default workgroup 0)
 	const bool clocked = (ctl->debugFlags & 2u) != 0u;       // SIMLOD_DEBUG_VOXELIZE_CLOCK (tools/probe.py): when the first workgroup came, the last piece was done, the last workgroup left
 	if (clocked && blockIdx.x == 0 && threadIdx.x == 0) ctl->voxT[ordinal][0] = wall_ns();
@@ -1488,6 +1539,66 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 			if (it.leaf == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; e = (threadIdx.x == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
 			else e = threadIdx.x < PATH_WORDS - 1 ? rec[threadIdx.x] : 0ull;
 			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0; sh.rank[threadIdx.x] = 0;
+			if (threadIdx.x < 8u) sh.listCount[threadIdx.x] = 0;
+		}
+		if (it.leaf == 0u) __syncthreads();
+		if (it.leaf == 0u) {
+			// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample, one after the other
+			// (this path runs for the first batch of an octree at most: nothing here is worth a register of the main path); the winners
+			// share ONE voxel list (the root's): one reservation for the whole piece
+			const unsigned long long ent = sh.anc[0];
+			auto sample = [&](uint32_t j, uint32_t& pX, uint32_t& pY, uint32_t& pZ) -> float {
+				const uint32_t i = it.s0 + j * VTPB + threadIdx.x;
+				const float4 q = reinterpret_cast<const float4*>(chunkDir[it.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - it.ptFirst)]->points)[i % SIMLOD_POINTS_PER_CHUNK];
+				pX = quantize(F_FULL, q.x, a.minx, a.size); pY = quantize(F_FULL, q.y, a.miny, a.size); pZ = quantize(F_FULL, q.z, a.minz, a.size);
+				return q.w;
+			};
+			uint32_t wonMask = 0;
+			if (ent != 0ull) {
+#pragma unroll 1
+				for (uint32_t j = 0; j < VOX_SPT; j++) {
+					if (it.s0 + j * VTPB + threadIdx.x >= it.s1) continue;
+					uint32_t pX, pY, pZ;
+					(void)sample(j, pX, pY, pZ);
+					const uint32_t cell = grid_cell(0u, pX, pY, pZ), bit = cell & 31u;
+					uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
+					if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
+					if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
+					wonMask |= 1u << j;
+					atomicAdd(&sh.cnt[1], 1u);
+				}
+			}
+			__syncthreads();
+			if (threadIdx.x == 0u && sh.cnt[1] != 0u) {
+				const uint32_t cnt = sh.cnt[1];
+				const uint32_t first = atomicAdd(&a.nodes[0].numVoxels, cnt);
+				const uint32_t existing = (a.nodes[0].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+				const uint32_t kFirst = first / SIMLOD_POINTS_PER_CHUNK, kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
+				const uint32_t ownFirst = first % SIMLOD_POINTS_PER_CHUNK == 0u ? kFirst : kFirst + 1u;
+				const uint32_t own = kLast + 1u > ownFirst ? kLast + 1u - ownFirst : 0u;
+				SimlodChunk* mem = own != 0u ? reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), own)) : nullptr;
+				for (uint32_t q = 0; q < own; q++) {
+					SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+					if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+					vox_chunk_publish(a, ctl, tag, 0u, ownFirst + q, c);
+					sh.chunkOf[1][ownFirst + q - kFirst] = c;
+				}
+				SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[0].voxelChunks) : nullptr;
+				if (own != 0u) vox_chunk_link(a, ctl, tag, 0u, ownFirst, existing, oldTail, mem);
+				if (ownFirst != kFirst) sh.chunkOf[1][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, 0u, kFirst);
+				sh.first[1] = first;
+			}
+			__syncthreads();
+#pragma unroll 1
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				if (((wonMask >> j) & 1u) == 0u) continue;
+				uint32_t pX, pY, pZ;
+				const float colour = sample(j, pX, pY, pZ);
+				const uint32_t slot = sh.first[1] + atomicAdd(&sh.rank[1], 1u);
+				SimlodChunk* c = sh.chunkOf[1][slot / SIMLOD_POINTS_PER_CHUNK - sh.first[1] / SIMLOD_POINTS_PER_CHUNK];
+				if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, 0, pX, pY, pZ, colour);
+			}
+			continue;
 		}
 		const SimlodChunk* chunk[VOX_SPT];
 		bool live[VOX_SPT];
@@ -1504,15 +1615,16 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 		// voxels.cu:449: the traverse loop samples levels 0..19 only — an ancestor is at level 19 at most (leaves are at most at 20)
 		const uint32_t ldsDepth = it.leaf == 0u ? 0u : min(depth, LDS_LEVELS);       // a root that is still a leaf: its "cube" is the whole grid
 
-		// the leaf's cubes, as the grids hold them now; the single cells of the ancestors above; the samples
+		// the leaf's cubes, as the grids hold them now (each thread keeps what it loaded: the write-back needs it); the single cells of the
+		// ancestors above; the samples
+		uint32_t snap[WPT];
 		{
-			uint32_t raw[WPT], sft[WPT], msk[WPT];
+			uint32_t raw[WPT];
 #pragma unroll
 			for (uint32_t k = 0; k < WPT; k++) {
-				uint32_t gw;
-				const uint32_t d = cube_word(k * VTPB + threadIdx.x, LX, LY, LZ, gw, sft[k], msk[k]);
-				if (d == 0u || d > ldsDepth) { msk[k] = 0u; raw[k] = 0u; }
-				else raw[k] = path_grid(a.pers, sh.anc[d - 1])->values[gw];
+				uint32_t gw, sft, msk;
+				const uint32_t d = cube_word(k * VTPB + threadIdx.x, LX, LY, LZ, gw, sft, msk);
+				raw[k] = (d == 0u || d > ldsDepth) ? 0u : path_grid(a.pers, sh.anc[d - 1])->values[gw];
 			}
 			uint32_t hi = 0;
 			const bool hiMine = it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth;   // d = threadIdx.x + 1 >= 8: every sample of the leaf has the same cell
@@ -1530,169 +1642,178 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 #pragma unroll
 			for (uint32_t k = 0; k < WPT; k++) {
 				const uint32_t w = k * VTPB + threadIdx.x;
-				if (w < CUBE_WORDS) { sh.occ[w] = (raw[k] >> sft[k]) & msk[k]; sh.fresh[w] = 0u; }
+				uint32_t gw, sft, msk;
+				const uint32_t d = cube_word(w, LX, LY, LZ, gw, sft, msk);                  // (recomputed rather than kept: registers)
+				snap[k] = (d == 0u || d > ldsDepth) ? 0u : (raw[k] >> sft) & msk;
+				if (w < CUBE_WORDS) sh.occ[w] = snap[k];
 			}
 			if (hiMine) sh.hiOcc[threadIdx.x] = hi;
 			__syncthreads();
 			ph.mark(25);
-			// (the samples stay in registers: coordinates and the levels they end up colouring)
-			uint32_t pX[VOX_SPT], pY[VOX_SPT], pZ[VOX_SPT], levels[VOX_SPT];
-#pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				pX[j] = quantize(F_FULL, p[j].x, a.minx, a.size); pY[j] = quantize(F_FULL, p[j].y, a.miny, a.size); pZ[j] = quantize(F_FULL, p[j].z, a.minz, a.size);
-				sh.color[j * VTPB + threadIdx.x] = p[j].w;
-				levels[j] = 0u;
-			}
 
-			// pass A: test-and-set, bottom-up, one level at a time for the thread's eight samples (their LDS atomics overlap); a sample
-			// climbs while its cell is new
-			if (it.leaf != 0u) {
-				bool go[VOX_SPT];
-#pragma unroll
-				for (uint32_t j = 0; j < VOX_SPT; j++) go[j] = live[j];
-				for (uint32_t d = 1; d <= depth; d++) {
-					bool any = false;
-#pragma unroll
-					for (uint32_t j = 0; j < VOX_SPT; j++) any = any || go[j];
-					if (!any) break;
-					const uint32_t level = path_level(sh.anc[d - 1]);
-					if (d <= ldsDepth) {
-						uint32_t word[VOX_SPT], bit[VOX_SPT], old[VOX_SPT];
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { cube_cell_of(d, level, pX[j], pY[j], pZ[j], word[j], bit[j]); old[j] = go[j] ? sh.occ[word[j]] : 0xffffffffu; }
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) old[j] = atomicOr(&sh.occ[word[j]], 1u << bit[j]); }   // voxels.cu:93-96
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) { go[j] = go[j] && ((old[j] >> bit[j]) & 1u) == 0u; if (go[j]) { atomicOr(&sh.fresh[word[j]], 1u << bit[j]); levels[j] |= 1u << d; } }   // lost: the winner climbs on (and remembers where it won: pass B)
-					} else {
-#pragma unroll
-						for (uint32_t j = 0; j < VOX_SPT; j++) {
-							if (!go[j]) continue;
-							if (sh.hiOcc[d - 1] != 0u || atomicOr(&sh.hiOcc[d - 1], 1u) != 0u) { go[j] = false; continue; }
-							sh.hiFresh[d - 1] = 1u;
-							levels[j] |= 1u << d;
-						}
-					}
-				}
-			} else {
-				// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample
-				const unsigned long long ent = sh.anc[0];
-				if (ent != 0ull) {
-#pragma unroll
-					for (uint32_t j = 0; j < VOX_SPT; j++) {
-						if (!live[j]) continue;
-						const uint32_t cell = grid_cell(0u, pX[j], pY[j], pZ[j]), bit = cell & 31u;
-						uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
-						if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
-						if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
-						levels[j] |= 1u;
-						atomicAdd(&sh.cnt[1], 1u);
-					}
-				}
-			}
-			__syncthreads();
-			ph.mark(26);
-
-			// write-back: the grids learn the new cells and tell which of them are new for everybody (pieces of one leaf share the cubes):
-			// every thread's atomics are in flight together
+			// level 1: every sample, from registers.  Its cell inside the leaf's cube of the parent's grid: six bits per axis below the leaf's
+			// own bits (the parent's grid cell is coordinate >> (21 - parentLevel), voxels.cu:78-92)
 			{
-				uint32_t f[WPT], old[WPT], gw[WPT];
-#pragma unroll
-				for (uint32_t k = 0; k < WPT; k++) {
-					const uint32_t w = k * VTPB + threadIdx.x;
-					const uint32_t d = cube_word(w, LX, LY, LZ, gw[k], sft[k], msk[k]);
-					f[k] = (d != 0u && d <= ldsDepth) ? sh.fresh[w] : 0u;
-					old[k] = f[k] != 0u ? atomicOr(&path_grid(a.pers, sh.anc[d - 1])->values[gw[k]], f[k] << sft[k]) : 0u;   // voxels.cu:96
-				}
-#pragma unroll
-				for (uint32_t k = 0; k < WPT; k++) {
-					if (f[k] == 0u) continue;
-					const uint32_t w = k * VTPB + threadIdx.x;
-					const uint32_t won = f[k] & ~(old[k] >> sft[k]);
-					sh.fresh[w] = won;
-					if (won != 0u) atomicAdd(&sh.cnt[w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : 7u], (uint32_t)__popc(won));
-				}
-				if (hiMine && sh.hiFresh[threadIdx.x] != 0u) {
-					const unsigned long long ent = sh.anc[threadIdx.x];
-					const uint32_t d = threadIdx.x + 1u, level = path_level(ent), s2 = 28u - (level + d), cell = grid_cell(level, LX << s2, LY << s2, LZ << s2);
-					const uint32_t o = atomicOr(&path_grid(a.pers, ent)->values[cell >> 5], 1u << (cell & 31u));
-					const uint32_t won = ((o >> (cell & 31u)) & 1u) ^ 1u;
-					sh.hiFresh[threadIdx.x] = won;
-					sh.cnt[d] = won;
-				}
-			}
-			__syncthreads();
-			ph.mark(27);
-			// The cells this piece won in ancestor d become voxels: the add to Node.numVoxels (voxels.cu:101) reserves their slots in d's voxel
-			// list, and the chunks those slots lie in are made or found here (see "voxel chunks, on demand") — one lane per ancestor, all in
-			// wave 0: first every lane allocates and publishes what it owns, then every lane links / looks up (which may wait for another piece).
-			{
-				const uint32_t d = threadIdx.x;
-				const bool mineD = d >= 1u && d <= depth && sh.cnt[d] != 0u;
-				uint32_t node = 0, first = 0, existing = 0, kFirst = 0, ownFirst = 0, own = 0;
-				SimlodChunk* mem = nullptr;
-				if (mineD) {
-					node = path_node(sh.anc[d - 1u]);
-					const uint32_t cnt = sh.cnt[d];
-					first = atomicAdd(&a.nodes[node].numVoxels, cnt);
-					existing = (a.nodes[node].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-					kFirst = first / SIMLOD_POINTS_PER_CHUNK;
-					const uint32_t kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
-					ownFirst = first % SIMLOD_POINTS_PER_CHUNK == 0u ? kFirst : kFirst + 1u;           // chunk k is this piece's to make when it holds slot k * 1000
-					own = kLast + 1u > ownFirst ? kLast + 1u - ownFirst : 0u;
-					if (own != 0u) mem = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), own));   // voxel chunks never come from the pool (voxels.cu:656-659)
-					for (uint32_t q = 0; q < own; q++) {
-						SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-						if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));   // (the last one's: vox_chunk_link)
-						vox_chunk_publish(a, ctl, tag, node, ownFirst + q, c);
-						sh.chunkOf[d][ownFirst + q - kFirst] = c;
-					}
-					sh.first[d] = first;
-				}
-				if (mineD) {
-					SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[node].voxelChunks) : nullptr;
-					if (own != 0u) vox_chunk_link(a, ctl, tag, node, ownFirst, existing, oldTail, mem);
-					if (ownFirst != kFirst) sh.chunkOf[d][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, node, kFirst);
-				}
-			}
-			ph.mark(28);
-
-			// pass B: every cell this piece won becomes a voxel, coloured by the sample that set it in pass A — one sample per cell (the one whose
-			// atomicOr found the cell clear), which kept the ancestors it won in `levels` (as a mask of d): it looks whether the write-back left
-			// the cell marked (nobody else had it) and turns the mask into the levels it colours.  No atomics, and three samples in four have
-			// nothing to look up.  (Which sample of a cell colours the voxel is scheduling dependent in the reference too)
-			if (it.leaf != 0u) {
+				const uint32_t shf = (uint32_t)(SIMLOD_MAX_DEPTH + 2) - leafLevel;
+				uint32_t code[VOX_SPT], word[VOX_SPT], bit[VOX_SPT], old[VOX_SPT];
 #pragma unroll
 				for (uint32_t j = 0; j < VOX_SPT; j++) {
-					uint32_t colours = 0;
-					for (uint32_t left = levels[j]; left != 0u; left &= left - 1u) {
-						const uint32_t d = (uint32_t)__ffs((int)left) - 1u;
-						const uint32_t level = path_level(sh.anc[d - 1]);
-						if (d <= ldsDepth) {
-							uint32_t word, bit;
-							cube_cell_of(d, level, pX[j], pY[j], pZ[j], word, bit);
-							if (((sh.fresh[word] >> bit) & 1u) != 0u) colours |= 1u << level;
-						} else if (sh.hiFresh[d - 1] != 0u) colours |= 1u << level;
-					}
-					levels[j] = colours;
+					const uint32_t pX = quantize(F_FULL, p[j].x, a.minx, a.size), pY = quantize(F_FULL, p[j].y, a.miny, a.size), pZ = quantize(F_FULL, p[j].z, a.minz, a.size);
+					code[j] = ((pX >> shf) & 63u) | (((pY >> shf) & 63u) << 6) | (((pZ >> shf) & 63u) << 12);
+					sh.color[j * VTPB + threadIdx.x] = p[j].w;
+					cube_cell_from(1u, code[j], word[j], bit[j]);
+					old[j] = live[j] ? sh.occ[word[j]] : 0xffffffffu;
 				}
-			}
-			// ... and stores the voxel: the cell's centre in its own colour (voxels.cu:103-114, 674-698), in the next free slot of the piece's range
-			__syncthreads();
-			ph.mark(29);
 #pragma unroll
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				for (uint32_t left = levels[j]; left != 0u; left &= left - 1u) {
-					const uint32_t level = (uint32_t)__ffs((int)left) - 1u;
-					const uint32_t d = it.leaf == 0u ? 1u : leafLevel - level;                      // ancestor d sits d levels above the leaf (a root that is still a leaf: itself)
-					const uint32_t slot = sh.first[d] + atomicAdd(&sh.rank[d], 1u);
-					SimlodChunk* c = sh.chunkOf[d][slot / SIMLOD_POINTS_PER_CHUNK - sh.first[d] / SIMLOD_POINTS_PER_CHUNK];
-					if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, (int)level, pX[j], pY[j], pZ[j], sh.color[j * VTPB + threadIdx.x]);
-				}
+				for (uint32_t j = 0; j < VOX_SPT; j++) if (((old[j] >> bit[j]) & 1u) == 0u) old[j] = atomicOr(&sh.occ[word[j]], 1u << bit[j]);   // voxels.cu:93-96
+				// the thread's winners go on the list (the losers' cells had been set: their climb ends here): one reservation per wave
+				uint32_t wins = 0;
+#pragma unroll
+				for (uint32_t j = 0; j < VOX_SPT; j++) if (((old[j] >> bit[j]) & 1u) == 0u) wins |= 1u << j;
+				uint32_t total;
+				const uint32_t before = wave_exclusive((uint32_t)__popc(wins), total);
+				uint32_t base = 0;
+				if (lane == 0u && total != 0u) base = atomicAdd(&sh.listCount[1], total);
+				base = (uint32_t)__shfl((int)base, 0, 64) + before;
+#pragma unroll
+				for (uint32_t j = 0; j < VOX_SPT; j++) if (((wins >> j) & 1u) != 0u) sh.list[base++] = code[j] | ((j * VTPB + threadIdx.x) << 18);
 			}
-			ph.mark(30);
-			if (ph.on) ctl->phaseNs[31] += 1;
 		}
+		__syncthreads();
+		ph.mark(26);
+		// levels 2 .. 7: the winners of the level below, a list entry per lane
+		for (uint32_t d = 2; d <= ldsDepth; d++) {
+			const uint32_t n = sh.listCount[d - 1u];
+			if (n == 0u) break;                                                    // (uniform: read after a barrier)
+			const uint32_t* src = sh.list + list_offset(d - 1u);
+			uint32_t* dst = sh.list + list_offset(d);
+			// four entries of a thread at a time (their LDS round trips overlap)
+			auto four = [&](const uint32_t e0, const uint32_t e1, const uint32_t e2, const uint32_t e3) {
+				const uint32_t e[4] = {e0, e1, e2, e3};
+				uint32_t word[4], bit[4], old[4];
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) { cube_cell_from(d, e[q] & 0x3ffffu, word[q], bit[q]); old[q] = e[q] != NONE ? sh.occ[word[q]] : 0xffffffffu; }
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) if (((old[q] >> bit[q]) & 1u) == 0u) old[q] = atomicOr(&sh.occ[word[q]], 1u << bit[q]);
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) {
+					const bool win = ((old[q] >> bit[q]) & 1u) == 0u;
+					const unsigned long long wm = __ballot(win);
+					if (wm != 0ull) {
+						uint32_t base = 0;
+						if (lane == 0u) base = atomicAdd(&sh.listCount[d], (uint32_t)__popcll(wm));
+						base = (uint32_t)__shfl((int)base, 0, 64);
+						if (win) dst[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = e[q];
+					}
+				}
+			};
+			for (uint32_t i0 = 0; i0 < n; i0 += 4u * VTPB) {
+				const uint32_t i = i0 + threadIdx.x;
+				four(i < n ? src[i] : NONE, i + VTPB < n ? src[i + VTPB] : NONE, i + 2u * VTPB < n ? src[i + 2u * VTPB] : NONE, i + 3u * VTPB < n ? src[i + 3u * VTPB] : NONE);
+			}
+			__syncthreads();
+		}
+		// from the 8th ancestor on the whole leaf is one cell: the winner of the 7th cube (there is at most one) climbs alone
+		if (threadIdx.x == 0u && depth > LDS_LEVELS && sh.listCount[LDS_LEVELS] != 0u) {
+			sh.hiSample = sh.list[list_offset(LDS_LEVELS)] >> 18;
+			for (uint32_t d = LDS_LEVELS + 1u; d <= depth; d++) {
+				if (sh.hiOcc[d - 1u] != 0u) break;
+				sh.hiOcc[d - 1u] = 1u; sh.hiFresh[d - 1u] = 1u;
+			}
+		}
+		__syncthreads();
+		ph.mark(27);
+
+		// write-back: the grids learn the new cells and tell which of them are new for everybody (pieces of one leaf share the cubes):
+		// every thread's atomics are in flight together.  What this piece set in a word = the word now minus the word as it was loaded.
+		{
+			uint32_t f[WPT], old[WPT], gw[WPT], sft[WPT], msk[WPT];
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				const uint32_t w = k * VTPB + threadIdx.x;
+				const uint32_t d = cube_word(w, LX, LY, LZ, gw[k], sft[k], msk[k]);
+				f[k] = (d != 0u && d <= ldsDepth) ? sh.occ[w] & ~snap[k] : 0u;
+				old[k] = f[k] != 0u ? atomicOr(&path_grid(a.pers, sh.anc[d - 1])->values[gw[k]], f[k] << sft[k]) : 0u;   // voxels.cu:96
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < WPT; k++) {
+				const uint32_t w = k * VTPB + threadIdx.x;
+				if (w >= CUBE_WORDS) continue;
+				const uint32_t won = f[k] & ~(old[k] >> sft[k]);
+				sh.occ[w] = won;                                                   // from here on: the cells this piece won
+				if (won != 0u) atomicAdd(&sh.cnt[w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : 7u], (uint32_t)__popc(won));
+			}
+			const bool hiMine = threadIdx.x >= LDS_LEVELS && threadIdx.x < depth;
+			if (hiMine && sh.hiFresh[threadIdx.x] != 0u) {
+				const unsigned long long ent = sh.anc[threadIdx.x];
+				const uint32_t d = threadIdx.x + 1u, level = path_level(ent), s2 = 28u - (level + d), cell = grid_cell(level, LX << s2, LY << s2, LZ << s2);
+				const uint32_t o = atomicOr(&path_grid(a.pers, ent)->values[cell >> 5], 1u << (cell & 31u));
+				const uint32_t won = ((o >> (cell & 31u)) & 1u) ^ 1u;
+				sh.hiFresh[threadIdx.x] = won;
+				sh.cnt[d] = won;
+			}
+		}
+		__syncthreads();
+		ph.mark(28);
+		// The cells this piece won in ancestor d become voxels: the add to Node.numVoxels (voxels.cu:101) reserves their slots in d's voxel
+		// list, and the chunks those slots lie in are made or found here (see "voxel chunks, on demand") — one lane per ancestor, all in
+		// wave 0: first every lane allocates and publishes what it owns, then every lane links / looks up (which may wait for another piece).
+		{
+			const uint32_t d = threadIdx.x;
+			const bool mineD = d >= 1u && d <= depth && sh.cnt[d] != 0u;
+			uint32_t node = 0, first = 0, existing = 0, kFirst = 0, ownFirst = 0, own = 0;
+			SimlodChunk* mem = nullptr;
+			if (mineD) {
+				node = path_node(sh.anc[d - 1u]);
+				const uint32_t cnt = sh.cnt[d];
+				first = atomicAdd(&a.nodes[node].numVoxels, cnt);
+				existing = (a.nodes[node].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+				kFirst = first / SIMLOD_POINTS_PER_CHUNK;
+				const uint32_t kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
+				ownFirst = first % SIMLOD_POINTS_PER_CHUNK == 0u ? kFirst : kFirst + 1u;           // chunk k is this piece's to make when it holds slot k * 1000
+				own = kLast + 1u > ownFirst ? kLast + 1u - ownFirst : 0u;
+				if (own != 0u) mem = reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), own));   // voxel chunks never come from the pool (voxels.cu:656-659)
+				for (uint32_t q = 0; q < own; q++) {
+					SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+					if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));   // (the last one's: vox_chunk_link)
+					vox_chunk_publish(a, ctl, tag, node, ownFirst + q, c);
+					sh.chunkOf[d][ownFirst + q - kFirst] = c;
+				}
+				sh.first[d] = first;
+			}
+			if (mineD) {
+				SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[node].voxelChunks) : nullptr;
+				if (own != 0u) vox_chunk_link(a, ctl, tag, node, ownFirst, existing, oldTail, mem);
+				if (ownFirst != kFirst) sh.chunkOf[d][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, node, kFirst);
+			}
+		}
+		__syncthreads();
+		ph.mark(29);
+
+		// store: every winner whose cell is still marked won (nobody else had it) becomes a voxel — the cell's centre in the winner's colour
+		// (voxels.cu:103-114, 674-698) — in the next free slot of the piece's range in that ancestor's list.  Level 1: the thread's own samples;
+		// levels 2..7: the lists, an entry per lane; beyond: the one sample that climbed alone.
+		auto store = [&](uint32_t d, const float4& vox) {
+			const uint32_t slot = sh.first[d] + atomicAdd(&sh.rank[d], 1u);
+			SimlodChunk* c = sh.chunkOf[d][slot / SIMLOD_POINTS_PER_CHUNK - sh.first[d] / SIMLOD_POINTS_PER_CHUNK];
+			if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = vox;
+		};
+		for (uint32_t d = 1; d <= ldsDepth; d++) {
+			const uint32_t n = sh.listCount[d];
+			const uint32_t* src = sh.list + list_offset(d);
+			for (uint32_t i = threadIdx.x; i < n; i += VTPB) {
+				const uint32_t e = src[i];
+				uint32_t word, bit;
+				cube_cell_from(d, e & 0x3ffffu, word, bit);
+				if (((sh.occ[word] >> bit) & 1u) != 0u) store(d, voxel_from(a, d, e & 0x3ffffu, leafLevel, LX, LY, LZ, sh.color[e >> 18]));
+			}
+		}
+		if (threadIdx.x >= LDS_LEVELS && threadIdx.x < depth && sh.hiFresh[threadIdx.x] != 0u) {
+			const uint32_t d = threadIdx.x + 1u, level = leafLevel - d, s2 = 28u - leafLevel;
+			store(d, voxel_of(a, (int)level, LX << s2, LY << s2, LZ << s2, sh.color[sh.hiSample]));
+		}
+		ph.mark(30);
+		if (ph.on) ctl->phaseNs[31] += 1;
 	}
 	if (clocked && threadIdx.x == 0 && blockIdx.x < numItems) atomicMax(reinterpret_cast<unsigned long long*>(&ctl->voxT[ordinal][1]), (unsigned long long)wall_ns());
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
@@ -1797,8 +1918,9 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
-				// a sample that k_hist / k_expand relabelled (slot, bin): its leaf is one word of the slot's map
-				if (v[j] == NONE || (v[j] & LEAF_FLAG) == 0u) continue;
+				// a sample that k_hist / k_expand relabelled (slot, bin): its leaf is one word of the slot's map; any other: the leaf k_count found
+				if (v[j] == NONE) continue;
+				if ((v[j] & LEAF_FLAG) == 0u) { v[j] &= LEAF_NODE_MASK; continue; }
 				uint32_t e = map[v[j] & 0x1fffffu];
 				if ((e & MAP_LISTED) != 0u) e = slot_recs(a, ordinal)[e & 0xffffu].node;      // (a node that got a slot but no round any more: it stays a leaf)
 				v[j] = e;
@@ -1837,7 +1959,7 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 			for (uint32_t j = 0; j < PPT; j++) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
 				if (t >= total) continue;
-				const uint32_t leafIdx = leafOf[t < n ? t : a.groupCap + (t - n)];
+				const uint32_t leafIdx = leafOf[t < n ? t : a.groupCap + (t - n)] & LEAF_NODE_MASK;
 				const int e = table_find(sh.tbl, leafIdx);
 				uint32_t slot, base, first;
 				if (e >= 0) { slot = sh.base[e] + atomicAdd(&sh.tbl.vals[e], 1u); base = sh.dirBase[e]; first = sh.dirFirst[e]; }
@@ -2061,8 +2183,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 			} else SIMLOD_LAUNCH((k_count<512, false>), dim3(gridPoints / 2), dim3(512), stream, a, b);
 			SIMLOD_LAUNCH(k_queue, dim3(single ? 16 : 128), dim3(TPB), stream, a, b);   // one wave per crossing leaf: a couple per batch, hundreds per coalesced group (36 M terrain, groups of 10: 42 us on 16 workgroups)
 			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->inserted[b - 1], 0) != hipSuccess) return (int)hipGetLastError();
-			if (single) SIMLOD_LAUNCH(k_hist<true>, dim3(gridPoints), dim3(TPB), stream, a, b);
-			else SIMLOD_LAUNCH(k_hist<false>, dim3(gridPoints), dim3(TPB), stream, a, b);
+			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a, b);
 			// (with two streams the kernels the other stream waits for carry their event as the launch's stop event: it is signalled by the
 			// kernel's own completion, where hipEventRecord puts a marker of its own behind the kernel — 3.93 -> 3.85 ms per ingest)
 			if (side != nullptr) {

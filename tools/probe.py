@@ -79,7 +79,7 @@ for var in args.variants:
     ph = dev.momentary[696:696 + 48 * 8].cpu().numpy().view(np.uint64).astype(np.float64)
     f = lambda lo, n, cnt: " ".join(f"{ph[lo + i] / 1e3 / max(ph[cnt], 1):5.1f}" for i in range(n))
     print(f"    us per call, one workgroup: k_count [main loop, flush, queue_split] {f(0, 3, 3)} | k_hist [loop, flush] {f(4, 2, 6)} | k_insert wg0 [alloc, clear, count, reserve, wait, store] {f(8, 6, 14)}"
-          f" | k_insert last wg {f(16, 6, 22)} | k_voxelize wg0 per piece [item+path+chunks, cubes+samples, pass A, write-back, reserve+chunks, pass B, store] {f(24, 7, 31)}", flush=True)
+          f" | k_insert last wg {f(16, 6, 22)} | k_voxelize wg0 per piece [item+path+chunks, cubes+samples, level 1, levels 2+, write-back, reserve+chunks, store] {f(24, 7, 31)}", flush=True)
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
