@@ -29,3 +29,19 @@ if len(counts) > skip + nb:
     for r in rows[i0:i1 + 1]:
         print("%-22s q%-3s start %7.1f us  end %7.1f us  (%5.1f us)" % (name(r), r.get("Queue_Id", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+
+# the last ingest: start-to-start of consecutive k_count launches (the per-batch cycle), with the kernel times of that batch
+resets = [i for i, r in enumerate(rows) if name(r) == "k_reset"]
+if resets:
+    seg = rows[resets[-1]:]
+    cs = [r for r in seg if name(r).startswith("k_count")]
+    starts = [int(r["Start_Timestamp"]) for r in cs]
+    cyc = [(starts[i + 1] - starts[i]) / 1e3 for i in range(len(starts) - 1)]
+    per = lambda k: [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in seg if name(r).startswith(k)]
+    print("last ingest: %.0f us from k_reset to the last kernel's end" % ((max(int(r["End_Timestamp"]) for r in seg) - int(seg[0]["Start_Timestamp"])) / 1e3))
+    print("cycle  ", [round(c) for c in cyc])
+    for k in ("k_count", "k_hist", "k_expand", "k_insert", "k_voxelize"):
+        print("%-7s" % k[2:], per(k))
+    act = sorted(c for c in cyc if c > 30)
+    if act:
+        print("median active cycle %.1f us, mean %.1f us over %d" % (act[len(act) // 2], sum(act) / len(act), len(act)))
