@@ -73,13 +73,15 @@ struct DrawItem {
 	uint32_t samples, visibleIdx;
 	int32_t  tileX, tileY;                          // origin of the LDS tile, or tileX < 0: no tile
 	uint32_t tileWH;                                // its extent, width | height << 16: the node's screen box, at most TILE x TILE
+	uint32_t took;                                  // measurement aid (tools/raster_items.py): how long the item's workgroup took over it in the frame's last draw pass, in 10 ns
 };
+static_assert(sizeof(DrawItem) == 32, "tools/raster_items.py reads draw items as 32-byte records");
 static constexpr int TILE = 128;
 static constexpr int TILE_EXACT_AREA = TILE * TILE / 2;   // HQS colour: tiles up to this area keep two 64-bit words per pixel (exact 32-bit sums)
 static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a frame: 2 G visible samples
 
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
-enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5 };   // [5]: lists r_visible read through the builder's chunk table
+enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5, C_OUTSIDE_TILES = 6 };   // [5]: lists r_visible read through the builder's chunk table; [6]: samples the first draw pass sent down the global-atomic path (outside their item's LDS tile, or no tile)
 
 // ---- clear (render.cu:1126-1131, 233-241) ---------------------------------------------------------------------
 // Part of r_visible's launch: the planes are cleared by ALL its workgroups (a thousand, of which the octree's nodes keep a few dozen busy
@@ -239,14 +241,46 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	// one reservation per wave and counter (returning device-scope atomics on one word retire at ~11 ns each, and a lane waits ~2.5 us
 	// for each one it depends on): visible-list slots, directory entries, draw items
 	const bool draws = emit && a.showPoints;
+	// the LDS tile of the node's draw items: its screen box when that fits a tile; else a tile in the MIDDLE of the box (the corners of a
+	// cube's screen box are empty, the terrain runs through its middle) — samples that fall outside take the global path.  A node that
+	// reaches behind the camera has no box and no tile.
+	int tileX = -1, tileY = -1;
+	uint32_t tileW = TILE, tileH = TILE;
+	bool noTile = draws;
+	if (draws && a.useTiles) {
+		const float nodeSize = a.cubeSize / exp2_int(level);
+		float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+		bool front = true;
+		for (int k = 0; k < 8; k++) {
+			const float x = a.minx + ((float)X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
+			const float z = a.minz + ((float)Z + ((k & 1) ? 1.0f : 0.0f)) * nodeSize;
+			const float cw = dot_row(a.transform.rows[3], x, y, z);
+			if (!(cw > 0.0f)) { front = false; break; }
+			const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
+			mnx = fminf(mnx, sx); mny = fminf(mny, sy); mxx = fmaxf(mxx, sx); mxy = fmaxf(mxy, sy);
+		}
+		if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) {
+			// the part of the box that is on the screen
+			const int x0 = max((int)mnx - 1, 0), y0 = max((int)mny - 1, 0);
+			const int x1 = min((int)fminf(mxx, 1.0e6f) + a.pointSize + 2, a.W + 1), y1 = min((int)fminf(mxy, 1.0e6f) + a.pointSize + 2, a.H + 1);
+			const int bw = max(x1 - x0, 1), bh = max(y1 - y0, 1);
+			tileW = (uint32_t)min(bw, TILE); tileH = (uint32_t)min(bh, TILE);
+			tileX = x0 + (bw - (int)tileW) / 2; tileY = y0 + (bh - (int)tileH) / 2;
+			noTile = false;
+		}
+	}
+	// ... and their size: up to ITEM_CHUNKS chunks; an eighth of that for a node without a tile: every sample of such an item is a scattered
+	// global atomic, 64 memory transactions per wave instruction — a 32 000-sample item of that kind took ~100 us, the frame's makespan in the
+	// close-up preset; short ones spread over the CUs (and have no tile to clear or flush)
+	const uint32_t perItem = noTile ? ITEM_CHUNKS / 8u : ITEM_CHUNKS;
 	uint32_t numChunks[2], pieces[2];
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
 		const bool have = draws && counts[l] != 0u && heads[l] != nullptr;
 		numChunks[l] = have ? (counts[l] + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
-		pieces[l] = (numChunks[l] + ITEM_CHUNKS - 1) / ITEM_CHUNKS;
+		pieces[l] = (numChunks[l] + perItem - 1) / perItem;
 	}
-	const uint32_t myChunks = numChunks[0] + numChunks[1], myPieces = pieces[0] + pieces[1];
+	const uint32_t myChunks = numChunks[0] + numChunks[1];
 	// A node has one list worth drawing (a leaf its points, an inner node its voxels): that one may come from the builder's chunk table
 	const int rowList = numChunks[0] != 0u ? 0 : 1;
 	const SimlodChunk* const* slots = tableValid && draws && a.leafTableSlots <= 64u ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
@@ -255,10 +289,9 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
 		if (pieces[l] == 0u) continue;
-		const uint32_t lastClass = item_class(numChunks[l] - (pieces[l] - 1u) * ITEM_CHUNKS);
-		myClass[0] += pieces[l] - 1u;
+		const uint32_t fullClass = item_class(perItem), lastClass = item_class(numChunks[l] - (pieces[l] - 1u) * perItem);
 #pragma unroll
-		for (int cl = 0; cl < ITEM_CLASSES; cl++) myClass[cl] += lastClass == (uint32_t)cl ? 1u : 0u;
+		for (int cl = 0; cl < ITEM_CLASSES; cl++) myClass[cl] += (fullClass == (uint32_t)cl ? pieces[l] - 1u : 0u) + (lastClass == (uint32_t)cl ? 1u : 0u);
 	}
 	const uint32_t slotsBefore = wave_prefix_u32(emit ? 1u : 0u), chunksBefore = wave_prefix_u32(myChunks);
 	const uint32_t waveSlots = (uint32_t)__popcll(__ballot(emit)), waveChunks = wave_sum_u32(myChunks);
@@ -301,28 +334,6 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 #pragma unroll
 			for (int w = 0; w < (int)(sizeof(SimlodNode) / 8); w++) dst[w] = src[w];
 		}
-		// the LDS tile sits at the low corner of the node's screen box (samples that fall outside it take the global path)
-		int tileX = -1, tileY = -1;
-		uint32_t tileW = TILE, tileH = TILE;
-		if (a.useTiles && myPieces != 0u) {
-			const float nodeSize = a.cubeSize / exp2_int(level);
-			float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
-			bool front = true;
-			for (int k = 0; k < 8; k++) {
-				const float x = a.minx + ((float)X + ((k & 4) ? 1.0f : 0.0f)) * nodeSize, y = a.miny + ((float)Y + ((k & 2) ? 1.0f : 0.0f)) * nodeSize;
-				const float z = a.minz + ((float)Z + ((k & 1) ? 1.0f : 0.0f)) * nodeSize;
-				const float cw = dot_row(a.transform.rows[3], x, y, z);
-				if (!(cw > 0.0f)) { front = false; break; }
-				const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
-				mnx = fminf(mnx, sx); mny = fminf(mny, sy); mxx = fmaxf(mxx, sx); mxy = fmaxf(mxy, sy);
-			}
-			if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) {
-				tileX = max((int)mnx - 1, 0); tileY = max((int)mny - 1, 0);
-				// the tile covers the node's screen box (a small node clears and flushes a small tile), capped at TILE x TILE
-				tileW = (uint32_t)min(max((int)fminf(mxx, 1.0e6f) - tileX + a.pointSize + 2, 1), TILE);
-				tileH = (uint32_t)min(max((int)fminf(mxy, 1.0e6f) - tileY + a.pointSize + 2, 1), TILE);
-			}
-		}
 		for (int l = 0; l < 2; l++, dirBase += numChunks[l - 1]) {
 			if (numChunks[l] == 0u) continue;
 			const bool fits = listed && dirBase + numChunks[l] <= MAX_DIR_CHUNKS;
@@ -335,16 +346,16 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 			}
 			const uint32_t have = min(counts[l], k * SIMLOD_POINTS_PER_CHUNK);      // a list shorter than its counter says: draw what is there
 			for (uint32_t p = 0; p < pieces[l]; p++) {
-				const uint32_t firstSample = p * ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK;
-				const uint32_t cl = p + 1u < pieces[l] ? 0u : item_class(numChunks[l] - p * ITEM_CHUNKS);
+				const uint32_t firstSample = p * perItem * SIMLOD_POINTS_PER_CHUNK;
+				const uint32_t cl = p + 1u < pieces[l] ? item_class(perItem) : item_class(numChunks[l] - p * perItem);
 				uint32_t at = 0;
 #pragma unroll
 				for (int q = 0; q < ITEM_CLASSES; q++) if (cl == (uint32_t)q) at = classBase[q]++;
 				if (at >= a.itemCap) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); continue; }
 				DrawItem it;
-				it.chunks = (l == rowList && rowDirect ? slots : dir + dirBase) + p * ITEM_CHUNKS;
-				it.samples = have > firstSample ? min(have - firstSample, ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK) : 0u;
-				it.visibleIdx = slot; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16);
+				it.chunks = (l == rowList && rowDirect ? slots : dir + dirBase) + p * perItem;
+				it.samples = have > firstSample ? min(have - firstSample, perItem * SIMLOD_POINTS_PER_CHUNK) : 0u;
+				it.visibleIdx = slot; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16); it.took = 0u;
 				items[(uint64_t)cl * a.itemCap + at] = it;
 			}
 		}
@@ -401,7 +412,7 @@ struct DrawCtx {
 };
 
 template <int MODE>
-__device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, const uint32_t overrideColor, const bool useOverride) {
+__device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, const uint32_t overrideColor, const bool useOverride, uint32_t& outside) {
 	// render.cu:62-70 — transform, perspective divide, pixel in fp64
 	const float cx = dot_row(c.r0, p.x, p.y, p.z);
 	const float cy = dot_row(c.r1, p.x, p.y, p.z);
@@ -447,6 +458,7 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 				continue;
 			}
 		}
+		outside += 1u;
 		if (MODE == MODE_MIN64) {
 			const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
 			if (enc < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), enc);   // render.cu:95-100
@@ -489,7 +501,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 
 template <int MODE>
-__device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, const bool have, const uint32_t overrideColor, const bool useOverride) {
+__device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, const bool have, const uint32_t overrideColor, const bool useOverride, uint32_t& outside) {
 	const float cx = dot_row(c.r0, p.x, p.y, p.z);
 	const float cy = dot_row(c.r1, p.x, p.y, p.z);
 	const float depth = dot_row(c.r3, p.x, p.y, p.z);
@@ -554,6 +566,7 @@ __device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, cons
 		}
 	}
 	if (valid && !inTile) {                          // outside the tile: the global path of draw_sample
+		outside += 1u;
 		if (MODE == MODE_MIN64) {
 			const unsigned long long enc = ((unsigned long long)dbits << 32) | color;
 			if (enc < c.fb[pixel]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), enc);
@@ -579,7 +592,7 @@ __device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, cons
 //   3. otherwise every lane issues its LDS atomics straight away — no read-compare first: an LDS atomic that does not change the word
 //      costs what the read would, and returns nothing to wait for.  min and add commute: the tile ends up identical.
 template <int MODE, uint32_t DU>
-__device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[DU], const bool (&have)[DU], const uint32_t overrideColor, const bool useOverride) {
+__device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[DU], const bool (&have)[DU], const uint32_t overrideColor, const bool useOverride, uint32_t& outside) {
 	uint32_t pixel[DU], t[DU], dbits[DU], color[DU];
 	float depth[DU];
 	bool valid[DU], inTile[DU], accept[DU];
@@ -604,10 +617,12 @@ __device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[
 		t[u] = tx + ty * (unsigned)c.tileW;
 		accept[u] = true;
 	}
+	uint32_t ref[DU];
 	if (MODE == MODE_COLOR) {
-		uint32_t ref[DU];
 #pragma unroll
 		for (uint32_t u = 0; u < DU; u++) ref[u] = c.depth[valid[u] ? pixel[u] : 0u];
+	}
+	if (MODE == MODE_COLOR) {
 #pragma unroll
 		for (uint32_t u = 0; u < DU; u++) accept[u] = valid[u] && depth[u] < __uint_as_float(ref[u]) * 1.01f;          // render.cu:485-493
 	}
@@ -630,13 +645,18 @@ __device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[
 				}
 			}
 		}
+	}
+#pragma unroll
+	for (uint32_t u = 0; u < DU; u++) {
 		if (valid[u] && !inTile[u]) {                  // outside the tile: the global path of draw_sample
-			if (MODE == MODE_MIN64) {
-				const unsigned long long enc = ((unsigned long long)dbits[u] << 32) | color[u];
-				if (enc < c.fb[pixel[u]]) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel[u]]), enc);
-			} else if (MODE == MODE_DEPTH) {
-				if (dbits[u] < c.depth[pixel[u]]) atomicMin(&c.depth[pixel[u]], dbits[u]);
-			} else if (accept[u]) {
+			outside += 1u;
+			// No read-compare first (render.cu:95-100, 304-308 test before they exchange): a node close to the camera is larger than any tile, a
+			// sixth of the close-up frame's samples come this way, and a wave that waits for a framebuffer read per sample draws at half the speed
+			// (measured: r_draw 157 us with the reads — in flight together or not —, against 69 us for a frame whose samples stay in their
+			// tiles).  The atomic returns nothing to wait for; min is idempotent: the framebuffer ends up identical.
+			if (MODE == MODE_MIN64) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel[u]]), ((unsigned long long)dbits[u] << 32) | color[u]);
+			else if (MODE == MODE_DEPTH) atomicMin(&c.depth[pixel[u]], dbits[u]);
+			else if (accept[u]) {
 				const unsigned long long r = color[u] & 0xffu, g = (color[u] >> 8) & 0xffu, b = (color[u] >> 16) & 0xffu;
 				const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
 				const unsigned long long old = atomicAdd(&c.color[pixel[u]], pk);
@@ -651,12 +671,14 @@ __device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[
 }
 
 template <int MODE>
-__device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* const* dir, uint32_t count, uint32_t overrideColor, bool useOverride) {
+__device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* const* dir, uint32_t count, uint32_t overrideColor, bool useOverride, uint32_t& outside) {
 	// render.cu:106-159: chunk i holds samples [1000 i, 1000 i + 1000); the chunk addresses come from the frame's directory (staged in LDS).
 	// Four samples per thread are loaded before the first is drawn: the loads overlap instead of queueing behind the atomics.
 	constexpr uint32_t DU = 4;
-	const bool wave = c.pointSize == 1 && c.tileX >= 0;
-	const bool merge = c.tileW * c.tileH <= 64;     // a node a few pixels across: most lanes of a wave hit the same pixel
+	// (an item without a tile — a node that reaches behind the camera — is staged like the others: all its samples take the global path,
+	// DU of a lane in flight together; sample by sample such an item took 60-150 us and was the frame's makespan in the close-up preset)
+	const bool wave = c.pointSize == 1;
+	const bool merge = c.tileX >= 0 && c.tileW * c.tileH <= 64;     // a node a few pixels across: most lanes of a wave hit the same pixel
 	for (uint32_t base = 0; base < count; base += DTPB * DU) {          // uniform trip count: the whole wave stays in step
 		float4 p[DU];
 		bool have[DU];
@@ -668,12 +690,12 @@ __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* c
 		}
 		if (wave && merge) {
 #pragma unroll
-			for (uint32_t u = 0; u < DU; u++) draw_wave<MODE>(c, p[u], have[u], overrideColor, useOverride);
+			for (uint32_t u = 0; u < DU; u++) draw_wave<MODE>(c, p[u], have[u], overrideColor, useOverride, outside);
 		} else if (wave) {
-			draw_staged<MODE, DU>(c, p, have, overrideColor, useOverride);
+			draw_staged<MODE, DU>(c, p, have, overrideColor, useOverride, outside);
 		} else {
 #pragma unroll
-			for (uint32_t u = 0; u < DU; u++) if (have[u]) draw_sample<MODE>(c, p[u], overrideColor, useOverride);
+			for (uint32_t u = 0; u < DU; u++) if (have[u]) draw_sample<MODE>(c, p[u], overrideColor, useOverride, outside);
 		}
 	}
 }
@@ -741,10 +763,13 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	// Workgroup-level queue of draw items.  The first item of a workgroup is its own index, the following ones come from a shared
 	// cursor that starts behind the statically assigned range.
 	uint32_t idx = blockIdx.x;
+	uint32_t outside = 0;                                                                   // samples of this thread that went down the global-atomic path
 	while (idx < numItems) {
 		uint32_t cl = 0;
 		while (idx >= classEnd[cl]) cl++;
-		const DrawItem it = items[(uint64_t)cl * a.itemCap + (idx - (cl > 0u ? classEnd[cl - 1u] : 0u))];
+		const uint64_t itemAt = (uint64_t)cl * a.itemCap + (idx - (cl > 0u ? classEnd[cl - 1u] : 0u));
+		const DrawItem it = items[itemAt];
+		const uint64_t itemStart = threadIdx.x == 0 ? wall_clock64() : 0ull;
 		uint32_t overrideColor = 0; bool useOverride = false;
 		if (MODE != MODE_DEPTH && (a.colorByNode || a.colorByLOD)) {
 			const SimlodNode* node = visible + it.visibleIdx;
@@ -752,6 +777,7 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 			useOverride = true;
 		}
 		c.tileX = it.tileX; c.tileY = it.tileY; c.tileW = (int)(it.tileWH & 0xffffu); c.tileH = (int)(it.tileWH >> 16);
+		if (it.tileX < 0) { c.tileW = 0; c.tileH = 0; }                                       // no tile: nothing is inside it
 		c.tileExact = c.tileW * c.tileH <= TILE_EXACT_AREA;
 		bool gap = false;
 		if (threadIdx.x < ITEM_CHUNKS && threadIdx.x * SIMLOD_POINTS_PER_CHUNK < it.samples) {
@@ -766,12 +792,17 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 			while (whole < ITEM_CHUNKS && whole * SIMLOD_POINTS_PER_CHUNK < it.samples && sh_dir[whole] != nullptr) whole++;
 			samples = min(samples, whole * SIMLOD_POINTS_PER_CHUNK);
 		}
-		draw_item<MODE>(c, sh_dir, samples, overrideColor, useOverride);
+		draw_item<MODE>(c, sh_dir, samples, overrideColor, useOverride, outside);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
+		if (threadIdx.x == 0) const_cast<DrawItem*>(items)[itemAt].took = (uint32_t)(wall_clock64() - itemStart);
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
 		__syncthreads();
 		idx = sh_idx;
+	}
+	if (MODE != MODE_COLOR) {                                                               // (the colour pass draws the same samples again)
+		outside = wave_sum_u32(outside);
+		if (lane_id() == 0 && outside != 0u) atomicAdd(counter_at(a, C_OUTSIDE_TILES), outside);
 	}
 }
 

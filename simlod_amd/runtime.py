@@ -345,6 +345,12 @@ class DeviceOctree:
         off = abi.MAX_VISIBLE_NODES * abi.node_dtype.itemsize + 5 * 16
         return int(self.render_buffer[off: off + 4].view(torch.int32).item())
 
+    def samples_outside_tiles(self):
+        """How many samples the last frame's first draw pass sent down the global-atomic path — outside their draw item's LDS tile, or drawn
+        without one (render.hip: counter 6 of the frame counters behind the visible-node array)."""
+        off = abi.MAX_VISIBLE_NODES * abi.node_dtype.itemsize + 6 * 16
+        return int(self.render_buffer[off: off + 4].view(torch.int32).item())
+
     # -- readback ------------------------------------------------------------------------------------------------
     def read_stats(self):
         return self.stats.cpu().numpy().view(abi.stats_dtype)[0].copy()
