@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--b0-points", type=int, default=36_000_000, help="how much of the same terrain B0 — the reference's own sources as host code — is given (it stops after 25 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("SIMLOD_BENCH_BACKEND", "nccl"), help="torch.distributed backend of the N>1 path: nccl (= RCCL over xGMI) or gloo (dry runs: "
+                                                                                          "tests/test_gpu_distributed.py drives the same code path with two processes on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (dry runs of the N>1 path on a one-GPU box)")
+    ap.add_argument("--profiles", default=None, help="directory under profiles/ whose kept measurements (PMC traffic, rocprofv3 kernel table, config 3) may be quoted; default: the newest "
+                                                       "profiles/r*/ — and only while its fingerprint.json names the kernel sources of THIS tree (simlod_amd/fingerprint.py)")
     ap.add_argument("--coalesce", action="store_true", help="opt-in coalesced ingest (simlod_set_ingest_mode(1)): all pending batches of a launch as one")
     ap.add_argument("--momentary-mb", type=int, default=None, help="size of kernel_construct's momentary buffer (the reference host gives 300 MB)")
     ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
@@ -92,6 +97,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     use_dist = "WORLD_SIZE" in os.environ            # launched through torch.distributed.run (also with one rank)
     if use_dist:
@@ -101,7 +108,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(args.backend)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -145,16 +155,16 @@ def main():
         torch.cuda.synchronize(); barrier()
         if use_dist:
             t0 = time.perf_counter()
-            chunk = 64_000_000                                                                    # (cell codes in slices: the int64 temporaries of 500 M points are not small)
-            codes = torch.cat([distributed.cell_codes(generated[i * 16: (i + chunk) * 16], box, 3) for i in range(0, n_points, chunk)])
-            owner, counts = distributed.balanced_owners(codes, world, 3)
-            mine, recv = distributed.route_points(generated, codes, owner)
+            # histogram, assignment and routing in slices of 32 M records: on top of the generated points and the routed result a rank holds two
+            # slices of records and one slice's index arrays (~2.8 GB), whatever --points is (distributed.partition_and_route)
+            mine, owner, counts, recv = distributed.partition_and_route(generated, box, world, level=3, slice_points=32_000_000)
             torch.cuda.synchronize(); barrier()
             t_part = time.perf_counter() - t0
             load = np.array([int(counts[owner.cpu().numpy() == r].sum()) for r in range(world)])
             partition = {"level": 3, "cells_occupied": int((counts > 0).sum()), "per_rank_points": load.tolist(), "max_over_mean": float(load.max() / load.mean()),
-                         "histogram_assign_route_ms": t_part * 1e3, "kept_local": int(recv[rank]), "what": "all-reduce of 512-cell histograms, greedy by count, one all_to_all_single of the records"}
-            del generated, codes
+                         "histogram_assign_route_ms": t_part * 1e3, "kept_local": int(recv[rank]), "slice_points": 32_000_000,
+                         "what": "all-reduce of 512-cell histograms, greedy by count, the records routed in slices (one all_to_all_single per slice of 32 M)"}
+            del generated
         else:
             mine = generated.reshape(-1, 16)
         my_points = int(mine.shape[0])
@@ -202,7 +212,24 @@ def main():
     from simlod_amd import distributed
 
     raster = {}
-    tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("traffic_r03.json", "traffic_r02.json")) if os.path.exists(f)), None)
+    # Kept measurements (profiles/): quoted ONLY when they were taken on the kernel sources of this tree — the fingerprint the profiling tools
+    # record must equal the one computed here; otherwise the fields stay null and `profiles_note` says why.
+    from simlod_amd.fingerprint import csrc_sha16
+    import glob as _glob
+    sha_now = csrc_sha16()
+    pdirs = [os.path.join(ROOT, "profiles", args.profiles)] if args.profiles else sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*")), reverse=True)
+    pdir, profiles_note = None, "no profiles/r*/ directory"
+    for d in pdirs:
+        fp = os.path.join(d, "fingerprint.json")
+        sha = json.load(open(fp)).get("_csrc_sha16") if os.path.exists(fp) else None
+        if sha == sha_now:
+            pdir, profiles_note = d, f"{os.path.relpath(d, ROOT)}: measured on these kernel sources (csrc sha {sha_now})"
+            break
+        profiles_note = f"{os.path.relpath(d, ROOT)} was measured on other kernel sources (csrc sha {sha} != {sha_now}): nothing quoted from it"
+        break
+    tfile = os.path.join(ROOT, "profiles", "traffic_" + os.path.basename(pdir) + ".json") if pdir else None
+    if tfile and not (os.path.exists(tfile) and json.load(open(tfile)).get("_csrc_sha16") == sha_now):
+        tfile = None
     rtraffic = json.load(open(tfile)) if tfile else {}
     presets = args.raster_presets.split(",")
     for name, hqs, Tcam in [m for m in (("hqs", 1, T), ("plain", 0, T), ("hqs_close", 1, T_close), ("plain_close", 0, T_close)) if ("close" if "close" in m[0] else "bird") in presets]:
@@ -221,8 +248,12 @@ def main():
             frame()
         torch.cuda.synchronize(); barrier()
         t0 = time.perf_counter()
-        for _ in range(args.frames):
-            frame()
+        if use_dist and world > 1:
+            # two frames in flight: the plane reductions of frame f travel while frame f + 1 is rasterised (distributed.render_frames_pipelined)
+            distributed.render_frames_pipelined(dev, [uc] * args.frames)
+        else:
+            for _ in range(args.frames):
+                frame()
         torch.cuda.synchronize(); barrier()
         dtf = time.perf_counter() - t0
         tm = torch.tensor([dtf], dtype=torch.float64, device=dev.device)
@@ -239,7 +270,8 @@ def main():
         # counters saw the whole frame move (profiles/traffic_r0x.json, bird preset; None for the other preset / without the file).
         rb = (32.0 + 4.0) * vs + 48.0 * W * H if hqs else 24.0 * vs + 20.0 * W * H
         fkeys = (["r_visible", "r_draw<MODE_DEPTH>", "r_draw<MODE_COLOR>", "r_output<true>"] if hqs else ["r_visible", "r_draw<MODE_MIN64>", "r_output<false>"])
-        ftraffic = sum(rtraffic.get(k, 0.0) for k in fkeys) if (rtraffic and name in ("hqs", "plain") and "r_draw<MODE_MIN64>" in rtraffic) else None
+        pre = "close/" if "close" in name else ""                      # (tools/fold_profiles.py: the close-up preset's passes are folded under "close/...")
+        ftraffic = sum(rtraffic.get(pre + k, 0.0) for k in fkeys) if (rtraffic and (pre + "r_draw<MODE_MIN64>") in rtraffic) else None
         raster[name] = {"value": vs / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,
                         "camera": "Morro Bay - close (main_progressive_octree.cpp:1323-1328)" if "close" in name else "Morro Bay - bird (:1314-1320)",
                         "visible_samples": int(vs), "visible_nodes": int(st["numVisibleNodes"]),
@@ -270,7 +302,7 @@ def main():
         kernels = {k: {"launches": n, "total_ms": ms, "avg_ms": ms / max(n, 1)} for k, (n, ms) in {**prof_c, **prof_r}.items()}
         kernels["_measured_with"] = "HIP events between launches, ONE stream: the side-stream overlap of the headline run is off in this pass"
         rocprof = {}
-        kpath = os.path.join(ROOT, "profiles", "r03", "kernel_stats.csv")
+        kpath = os.path.join(pdir, "kernel_stats.csv") if pdir else ""
         if os.path.exists(kpath):
             import csv
             for row in csv.DictReader(open(kpath)):
@@ -294,16 +326,14 @@ def main():
         active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, args.coalesce)))
         bytes_per_launch = per_ingest[dom] / active
         avg_ms = prof_c[dom_full][1] / active
-        traffic, traffic_src = None, None
-        for tname in ("traffic_r03.json", "traffic_r02.json"):               # rocprofv3 --pmc passes of THIS command, folded by tools/fold_profiles.py
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath) and dom in json.load(open(tpath)):
-                traffic, traffic_src = json.load(open(tpath)).get(dom), "profiles/" + tname
-                break
+        traffic, traffic_src = None, None                                     # rocprofv3 --pmc passes of THIS command on THESE sources, folded by tools/fold_profiles.py
+        if tfile and dom in rtraffic:
+            traffic, traffic_src = rtraffic.get(dom), os.path.relpath(tfile, ROOT) + f" (csrc sha {sha_now})"
         roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
                     "measured_with": "HIP events on one stream (overlap off); rocprof_overlap_on = the same kernel in the headline configuration",
+                    "profiles_note": profiles_note,
                     "rocprof_overlap_on": rocprof.get(dom_full) or rocprof.get(dom),
                     "moved_points": moved, "new_voxels": new_voxels, "per_kernel_algorithmic_bytes_per_ingest": per_ingest}
         if rocprof:
@@ -474,10 +504,10 @@ def main():
     # upload stream): a 9 GB file does not belong in a run that has to finish within minutes, so the object quotes the kept measurement of
     # tools/config3.py (profiles/r03/) and says so
     config3 = None
-    c3path = os.path.join(ROOT, "profiles", "r03", "config3_350m.json")
-    if rank == 0 and os.path.exists(c3path):
+    c3path = os.path.join(pdir, "config3_350m.json") if pdir else ""
+    if rank == 0 and os.path.exists(c3path) and json.load(open(c3path)).get("_csrc_sha16") == sha_now:
         c3 = json.load(open(c3path))
-        config3 = {"measured_by": "tools/config3.py on MI355X (not in this run); transcript profiles/r03/config3_350m_las_scan.txt",
+        config3 = {"measured_by": f"tools/config3.py on MI355X (not in this run) on these kernel sources (csrc sha {sha_now}); transcript {os.path.relpath(pdir, ROOT)}/config3_350m_las_scan.txt",
                    "input": f"{c3['points']} points, fractal terrain {c3['terrain_extent_m'][0]:.0f} m x {c3['terrain_extent_m'][1]:.0f} m, LAS 1.4 format 2 ({c3['las_file_bytes'] / 1e9:.1f} GB), flight lines of 250 m",
                    "host": "harness/_ref/ref_host_replay: the reference's resetCUDA / updateOctree / renderCUDA / initCudaProgram text, uploader on its own thread + stream, 50-slot ring",
                    "las_scan_page_locked": c3.get("las_scan_pinned"), "las_scan_pageable": c3.get("las_scan_pageable"), "adversarial_scatter_order": c3.get("adversarial_scatter")}
@@ -496,6 +526,7 @@ def main():
                                    f"(<= 20 batches and <= 10 ms each; " + ("Stats read back after every launch); " if source is not None else "the launches the pending batches need are enqueued back to back, Stats read back after them); ") +
                                    f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order if not use_dist else "device-generated tiles, swath order",
                        "parallelism": f"one global cube, level-3 cells dealt to {world} rank(s) by point count"},
+            "profiles_note": profiles_note, "csrc_sha16": sha_now,
             "coalesced_ingest": coalesced, "config3": config3, "partition": partition, "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu, "loader": loader,
             "octree": {k: int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels", "allocatedBytes_persistent")},
         }

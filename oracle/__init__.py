@@ -164,6 +164,15 @@ class HostOctree:
             if int(self.stats["batchletIndex"][0]) == before:
                 break
 
+    def select_frame(self, k):
+        """Switch between two sets of frame planes (the CPU stand-in for DeviceOctree.select_frame in distributed.render_frames_pipelined)."""
+        names = ("_fb", "_color", "_visible", "_depth", "_sums")
+        frames = self.__dict__.setdefault("_frames", {})
+        frames[self.__dict__.get("_frame", 0)] = {n: getattr(self, n, None) for n in names}
+        for n, v in frames.get(k, {}).items():
+            setattr(self, n, v)
+        self._frame = k
+
     # -- a frame in parts (oracle_render_part), the CPU stand-in for DeviceOctree in distributed.render_frame ------------------
     def render_part(self, uniforms, part, edl=False):
         import torch

@@ -112,6 +112,60 @@ def route_points(points, codes, owner_table, group=None):
     return out, rs
 
 
+def partition_and_route(points, box_size, world, level=3, slice_points=32_000_000, group=None):
+    """cell_codes -> balanced_owners -> route_points for inputs of any size with BOUNDED transient memory: the records are looked at in
+    slices of `slice_points` (codes, destinations and the sort permutation of one slice at a time: 56 B per slice point = 1.8 GB for the
+    default slice, whatever the input's size), the result is allocated ONCE from the exchanged totals, and every slice is one
+    all_to_all_single into a slice-sized staging buffer whose per-source parts are appended to the result (records from rank 0 first,
+    original order inside a source rank — the order route_points leaves).  Peak per rank on top of the input: the result (what the rank
+    owns) + 2 slices of records + the slice's index arrays; a rank may free its input afterwards.
+    Returns (records this rank owns [n, 16] uint8, owner table, global counts per cell, records received from each rank)."""
+    rec = points.reshape(-1, 16)
+    n = rec.shape[0]
+    ncell = 8 ** level
+    hist = torch.zeros(ncell, dtype=torch.int64, device=points.device)
+    for first in range(0, n, slice_points):
+        hist += torch.bincount(cell_codes(rec[first: first + slice_points], box_size, level), minlength=ncell)
+    local = hist.clone()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    counts = hist.cpu().numpy()
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.zeros(ncell, dtype=np.int64)
+    for c in sorted(range(ncell), key=lambda c: (-int(counts[c]), c)):             # (balanced_owners' rule)
+        r = int(np.argmin(load))
+        owner[c] = r
+        load[r] += counts[c]
+    owner_table = torch.from_numpy(owner).to(points.device)
+    # what this rank sends to / receives from everybody, in all: from its own histogram
+    send_total = torch.zeros(world, dtype=torch.int64, device=points.device).index_add_(0, owner_table, local)
+    recv_total = torch.zeros_like(send_total)
+    dist.all_to_all_single(recv_total, send_total, group=group)
+    rt = [int(v) for v in recv_total.cpu()]
+    out = torch.empty((sum(rt), 16), dtype=torch.uint8, device=points.device)
+    offset = np.concatenate([[0], np.cumsum(rt)])[:-1].astype(np.int64)             # where source rank r's records start in `out`
+    filled = np.zeros(world, dtype=np.int64)
+    nslices = torch.tensor([(n + slice_points - 1) // slice_points], dtype=torch.int64, device=points.device)
+    dist.all_reduce(nslices, op=dist.ReduceOp.MAX, group=group)                     # every rank takes part in every exchange, with an empty slice if it has run out
+    for k in range(int(nslices.item())):
+        sl = rec[k * slice_points: (k + 1) * slice_points]
+        dest = owner_table[cell_codes(sl, box_size, level)] if sl.shape[0] else torch.zeros(0, dtype=torch.int64, device=points.device)
+        send = sl[torch.argsort(dest, stable=True)].contiguous()
+        sc = torch.bincount(dest, minlength=world).to(torch.int64)
+        rc = torch.zeros_like(sc)
+        dist.all_to_all_single(rc, sc, group=group)
+        rs, ss = [int(v) for v in rc.cpu()], [int(v) for v in sc.cpu()]
+        stage = torch.empty((sum(rs), 16), dtype=torch.uint8, device=points.device)
+        dist.all_to_all_single(stage, send, rs, ss, group=group)
+        at = 0
+        for r in range(world):
+            out[offset[r] + filled[r]: offset[r] + filled[r] + rs[r]] = stage[at: at + rs[r]]
+            filled[r] += rs[r]; at += rs[r]
+        del dest, send, stage
+    assert [int(v) for v in filled] == rt
+    return out, owner_table, counts, rt
+
+
 def compose_min(framebuffer_u64_as_i64, group=None):
     """In-place all-reduce(MIN) over the 64-bit depth|colour words.  The sign bit of a stored word is never set (a sample
     with negative depth bits never beats the +inf clear value, render.cu:95-100), so signed MIN == unsigned MIN."""
@@ -150,31 +204,127 @@ def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
     return gather_visible(vis, n, group=group, capacity=gather_capacity)
 
 
+def render_frames_pipelined(renderer, frames, group=None, gather_capacity=4096, on_frame=None):
+    """A sequence of frames (`frames`: one Uniforms record each) composed across ranks exactly as render_frame composes one, with TWO frames
+    in flight: while the planes of frame f are on the wire, the ranks rasterise the next part of frame f + 1 — on an 8-GPU ring over xGMI the
+    reductions of an HQS frame (8.3 + 33.2 MB at 1080p) take about as long as its passes, and inside ONE frame each reduction feeds the very
+    next pass, so only a second frame gives the links something to overlap with.  Needs a second set of planes: `renderer.select_frame(k)`
+    (runtime.DeviceOctree, oracle.HostOctree) switches between two render buffers; the octree, and Stats, are shared — Stats holds the
+    counters of the frame whose part 3 ran last.  `on_frame(index, renderer, records, counts)` is called as each frame completes (frames of
+    one kind complete in order; a plain frame has fewer stages than an HQS one and can overtake it), with that frame's buffers selected."""
+    todo = list(enumerate(frames))
+    active = []                                              # frames in flight, oldest first: dicts with slot, uniforms, next stage, pending collectives
+
+    def issue(f, stage):
+        """run stage `stage` of frame f (its inputs are complete) and put what it produced on the wire; returns False when the frame is done"""
+        renderer.select_frame(f["slot"])
+        u = f["u"]
+        hqs, boxes = f["hqs"], f["boxes"]
+        f["works"] = []
+        if stage == 0:
+            renderer.render_part(u, 0)
+            if hasattr(renderer, "visible_records_early"):
+                vis, n = renderer.visible_records_early()
+                f["vis"] = gather_visible(vis, n, group=group, capacity=gather_capacity, async_op=True)
+            if hqs:
+                f["works"].append(dist.all_reduce(renderer.depth_plane(), op=dist.ReduceOp.MIN, group=group, async_op=True)); f["next"] = 1
+            else:
+                f["works"].append(dist.all_reduce(renderer.framebuffer_words(), op=dist.ReduceOp.MIN, group=group, async_op=True)); f["next"] = 3
+        elif stage == 1:
+            renderer.render_part(u, 1)
+            f["works"].append(dist.all_reduce(renderer.sum_planes(), op=dist.ReduceOp.SUM, group=group, async_op=True)); f["next"] = 2
+        elif stage == 2:
+            renderer.render_part(u, 2)
+            if boxes:
+                f["works"].append(dist.all_reduce(renderer.framebuffer_words(), op=dist.ReduceOp.MIN, group=group, async_op=True))
+            f["next"] = 3
+        else:
+            renderer.render_part(u, 3)
+            if f.get("vis") is not None:
+                recs, cnts = f["vis"]()
+            else:
+                vis, n = renderer.visible_records()
+                recs, cnts = gather_visible(vis, n, group=group, capacity=gather_capacity)
+            if on_frame is not None:
+                on_frame(f["index"], renderer, recs, cnts)
+            return False
+        return True
+
+    while todo or active:
+        if todo and len(active) < 2:                         # admit a frame: its part 0 runs beside the older frame's reduction
+            index, u = todo.pop(0)
+            uu = np.ascontiguousarray(u).reshape(1)
+            slot = 1 if any(g["slot"] == 0 for g in active) else 0
+            f = {"index": index, "u": u, "slot": slot, "hqs": bool(uu["useHighQualityShading"][0]), "boxes": bool(uu["showBoundingBox"][0]), "vis": None}
+            issue(f, 0)
+            active.append(f)
+            if todo and len(active) < 2:
+                continue
+        f = active[0]                                        # the older frame: its reduction has had a whole part of the other frame to complete
+        for w in f["works"]:
+            w.wait()
+        if issue(f, f["next"]):
+            active.append(active.pop(0))                     # it is on the wire again: the other frame's turn
+        else:
+            active.pop(0)
+
+
+class VisibleOverflow(RuntimeError):
+    """A rank has more visible nodes than the visible-node array holds (render.cu:1108: 100 000) — the multi-rank counterpart of
+    SIMLOD_ERR_VISIBLE_OVERFLOW in Stats.dbg."""
+
+
 def gather_visible(visible_bytes, count, group=None, capacity=4096, async_op=False):
-    """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, capacity, 152], counts).
-    `count` may be a host int or a one-element tensor on the records' device (then nothing synchronises with the host: the
-    first `capacity` records travel as they are and the gathered counts say how many of them are valid).  async_op: returns a
-    function that waits for the two collectives and hands out the result."""
+    """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, cap, 152], counts) with
+    cap >= every rank's count: NOTHING is dropped.  `capacity` records per rank travel at once (no host synchronisation: `count` may be a
+    one-element tensor on the records' device); the gathered counts are the TRUE counts, and should one of them exceed `capacity` — BASELINE
+    config 5 has 4 097 visible nodes on one GPU — the records are gathered once more with room for the largest (the power of two above it).
+    More than the visible-node array can hold (abi.MAX_VISIBLE_NODES) raises VisibleOverflow.  async_op: returns a function that waits for
+    the collectives and hands out the result."""
     world = dist.get_world_size(group)
     dev = visible_bytes.device
-    if isinstance(count, torch.Tensor):
-        buf = visible_bytes[: capacity * 152].view(capacity, 152).contiguous()
-        cnt = torch.clamp(count.to(torch.int64).reshape(1), max=capacity)
-    else:
-        n = min(int(count), capacity)
-        buf = torch.zeros((capacity, 152), dtype=torch.uint8, device=dev)
-        buf[:n] = visible_bytes[: n * 152].view(n, 152)
-        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+
+    def buffers(cap):
+        if isinstance(count, torch.Tensor):
+            have = visible_bytes.numel() // 152
+            if have >= cap:
+                buf = visible_bytes[: cap * 152].view(cap, 152).contiguous()
+            else:
+                buf = torch.zeros((cap, 152), dtype=torch.uint8, device=dev)
+                buf[:have] = visible_bytes[: have * 152].view(have, 152)
+            cnt = count.to(torch.int64).reshape(1).clone()
+        else:
+            n = min(int(count), cap)
+            buf = torch.zeros((cap, 152), dtype=torch.uint8, device=dev)
+            buf[:n] = visible_bytes[: n * 152].view(n, 152)
+            cnt = torch.tensor([int(count)], dtype=torch.int64, device=dev)
+        return buf, cnt
+
+    buf, cnt = buffers(capacity)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
+
+    def complete():
+        counts = torch.cat(cnts)
+        most = int(counts.max().item())                       # (the frame is over by now: this is the one look at the counts from the host)
+        if most > abi.MAX_VISIBLE_NODES:
+            raise VisibleOverflow(f"a rank reports {most} visible nodes; the visible-node array holds {abi.MAX_VISIBLE_NODES}")
+        if most <= capacity:
+            return torch.stack(bufs), counts
+        cap = 1 << (most - 1).bit_length()                    # every rank sees the same counts: every rank gathers again, with the same room
+        big, _ = buffers(cap)
+        bigs = [torch.empty_like(big) for _ in range(world)]
+        dist.all_gather(bigs, big, group=group)
+        return torch.stack(bigs), counts
+
     if async_op:
         works = [dist.all_gather(bufs, buf, group=group, async_op=True), dist.all_gather(cnts, cnt, group=group, async_op=True)]
 
         def finish():
             for w in works:
                 w.wait()
-            return torch.stack(bufs), torch.cat(cnts)
+            return complete()
         return finish
     dist.all_gather(bufs, buf, group=group)
     dist.all_gather(cnts, cnt, group=group)
-    return torch.stack(bufs), torch.cat(cnts)
+    return complete()

@@ -297,6 +297,17 @@ class DeviceOctree:
                                            self._p(self.stats), self._p(self.frame_start), None, self._stream()), "kernel_render")
         return W, H
 
+    def select_frame(self, k):
+        """Switch between render buffers (distributed.render_frames_pipelined keeps two frames in flight: while the planes of one are being
+        reduced across ranks, the next is rasterised into the other buffer).  Buffer 0 is the one the object was made with."""
+        frames = self.__dict__.setdefault("_frames", {0: None})
+        cur = self.__dict__.get("_frame", 0)
+        frames[cur] = (self.render_buffer, self.colorbuffer, getattr(self, "_frame_size", None))
+        if frames.get(k) is None:
+            frames[k] = (torch.empty_like(self.render_buffer), torch.zeros_like(self.colorbuffer), None)
+        self.render_buffer, self.colorbuffer, self._frame_size = frames[k]
+        self._frame = k
+
     # -- a frame in parts, for composition across GPUs (simlod_launch_render_part; driven by distributed.render_frame) ----------
     def render_part(self, uniforms, part):
         u, up = self._u(uniforms)

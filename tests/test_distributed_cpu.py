@@ -192,3 +192,70 @@ def test_four_ranks_one_global_cube_balanced_cells_all_to_all(built_libs, tmp_pa
         assert int((covered & want_covered).sum()) >= 0.97 * int(want_covered.sum()), name
         same_depth = (frames[0] >> np.uint64(32)) == (want >> np.uint64(32))
         assert int((same_depth & want_covered).sum()) >= 0.5 * int(want_covered.sum()), name
+
+
+def _worker_hardening(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from simlod_amd import abi, camera, distributed, synthetic
+    # 1. more visible nodes on one rank than gather_visible sends at once (BASELINE config 5: 4 097 on one GPU): nothing may be dropped
+    n_mine = 5000 if rank == 0 else 10
+    recs = np.zeros(abi.MAX_VISIBLE_NODES, dtype=abi.node_dtype)
+    recs["level"][:n_mine] = 7; recs["X"][:n_mine] = np.arange(n_mine) + 1000 * rank
+    vb = torch.from_numpy(recs.view(np.uint8).reshape(-1))
+    for count in (n_mine, torch.tensor([n_mine], dtype=torch.int32)):
+        for async_op in (False, True):
+            r = distributed.gather_visible(vb, count, capacity=4096, async_op=async_op)
+            got, cnts = r() if async_op else r
+            assert [int(c) for c in cnts] == [5000, 10] and got.shape[1] >= 5000
+            back = got[0, :5000].numpy().view(abi.node_dtype).reshape(-1)
+            assert np.array_equal(back["X"], np.arange(5000)) and int(got[1, :10].numpy().view(abi.node_dtype).reshape(-1)["X"][9]) == 1009
+    try:
+        distributed.gather_visible(vb, abi.MAX_VISIBLE_NODES + 1, capacity=64)
+        raise AssertionError("a count beyond the visible-node array must raise")
+    except distributed.VisibleOverflow:
+        pass
+    # 2. routing in slices == routing at once (same records, same order), whatever the slice size; ranks with different input sizes
+    pts, box = synthetic.terrain(300_000 + 50_000 * rank, seed=5 + rank)
+    t = torch.from_numpy(np.ascontiguousarray(pts).view(np.uint8).reshape(-1, 16).copy())
+    codes = distributed.cell_codes(t, box, 3)
+    owner, counts = distributed.balanced_owners(codes, world, 3)
+    want, want_rs = distributed.route_points(t, codes, owner)
+    for slice_points in (70_000, 1_000_000):
+        got, owner2, counts2, rs = distributed.partition_and_route(t, box, world, level=3, slice_points=slice_points)
+        assert torch.equal(owner, owner2) and np.array_equal(counts, counts2) and rs == want_rs and torch.equal(got, want), slice_points
+    # 3. frames with two in flight == the same frames one after the other
+    W = H = 192
+    upts, ubox = synthetic.uniform_cube(300_000, seed=33)
+    T = camera.lookat_transform((1.8, -1.2, 1.4), (0.5, 0.5, 0.3), W, H)
+    u = abi.make_uniforms(W, H, T, ubox, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
+    o = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=2)
+    o.reset(u)
+    mine = upts[distributed.owner_of(upts, ubox, world) == rank]
+    o.upload(mine); o.construct(u)
+    seq = []
+    for name, kw in FRAME_VARIANTS:
+        uv = u.copy()
+        for k, v in kw.items():
+            uv[k] = v
+        seq.append(uv)
+    frames = seq + seq[::-1] + [seq[1]] * 3
+    want = []
+    for uv in frames:
+        distributed.render_frame(o, uv)
+        want.append((o._fb.copy(), o._color.copy()))
+    got = {}
+    distributed.render_frames_pipelined(o, frames, on_frame=lambda i, r, recs, cnts: got.__setitem__(i, (r._fb.copy(), r._color.copy(), int(cnts.sum()))))
+    assert sorted(got) == list(range(len(frames)))
+    for i, (fb, col) in enumerate(want):
+        assert np.array_equal(got[i][0], fb) and np.array_equal(got[i][1], col), f"frame {i} differs when two frames are in flight"
+    dist.destroy_process_group()
+
+
+def test_gather_beyond_capacity_sliced_routing_and_pipelined_frames(built_libs, tmp_path):
+    """The multi-GPU path's hardening (world 2, gloo): the visible-node gather never truncates (5 000 records through a 4 096-record
+    exchange; VisibleOverflow beyond the array), routing in slices delivers exactly what routing at once delivers, and frames composed with
+    two in flight are the frames composed one after the other."""
+    mp.spawn(_worker_hardening, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

@@ -50,6 +50,10 @@ def _worker(rank, world, port, out_dir):
     owner, counts = distributed.balanced_owners(codes, world, 3)
     mine, recv = distributed.route_points(generated, codes, owner)
     assert int(sum(recv)) == mine.shape[0] and int(counts.sum()) == world * N_PER_RANK
+    # the same in slices (what bench.py --gpus N does with 500 M points per rank): the same records in the same order
+    mine2, owner2, counts2, recv2 = distributed.partition_and_route(generated, box, world, level=3, slice_points=700_000)
+    assert torch.equal(mine, mine2) and torch.equal(owner, owner2) and recv2 == recv
+    del mine2
     u = _uniforms(None, box, True, persistent)
     dev.reset(u)
     launches = dev.stream(u, mine.reshape(-1), int(mine.shape[0]))
@@ -63,6 +67,17 @@ def _worker(rank, world, port, out_dir):
         frames[name] = dev.framebuffer(W, H)
         frames[name + "_color"] = dev.color(W, H)
         frames[name + "_visible"] = cnt.cpu().numpy()
+    # ... and with two frames in flight (the plane reductions of one frame beside the rasterisation of the next): the same frames
+    seq = [_uniforms(None, box, h, persistent) for h in (True, False, True, True, False)]
+    got = {}
+    def keep(i, r, recs, cnts):
+        torch.cuda.synchronize()
+        got[i] = r.framebuffer(W, H)
+    distributed.render_frames_pipelined(dev, seq, on_frame=keep)
+    dev.select_frame(0)
+    assert sorted(got) == [0, 1, 2, 3, 4]
+    for i, h in enumerate((True, False, True, True, False)):
+        assert np.array_equal(got[i], frames["hqs" if h else "plain"]), f"frame {i} differs when two frames are in flight"
     nodes, pers, n, nodes_base, pers_base = dev.download_image()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), mine=mine.cpu().numpy(), owner=owner.cpu().numpy(), counts=counts, nodes=nodes.view(np.uint8), pers=pers, n=n,
              nodes_base=nodes_base, pers_base=pers_base, stats=np.frombuffer(dev.stats.cpu().numpy().tobytes(), dtype=np.uint8), **frames)
@@ -140,3 +155,24 @@ def test_two_ranks_on_one_gpu_partition_ingest_and_compose_frames_like_the_oracl
             # the all-gathered visible-node counts: what every rank's own visibility pass found
             assert [int(v) for v in d[name + "_visible"]] == [int(t["stats"]["numVisibleNodes"][0]) for t in state]
         assert np.array_equal(ranks[0][name], ranks[1][name]), f"{name}: the ranks hold different composed frames"
+
+
+def test_bench_n2_runs_its_multi_rank_path_with_two_processes_on_one_gpu_over_gloo(built_libs):
+    """`bench.py --gpus 2` — generation per rank, partition in slices, streamed ingest of what each rank owns, composed frames with two in
+    flight, max-over-ranks timing, ONE JSON line from rank 0 — launched the way the driver launches it (torch.distributed.run, one process
+    per rank), but with --backend gloo --one-device: RCCL refuses two ranks on one device, and this box has one.  Everything above the
+    process group is the code the 8-GPU run executes."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "3", "--points", "6000000", "--backend", "gloo", "--one-device",
+           "--no-cpu-baseline", "--no-profile"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["points_per_gpu"] == 6_000_000
+    assert sum(out["partition"]["per_rank_points"]) == 12_000_000 and out["partition"]["max_over_mean"] <= 1.5
+    assert set(out["raster"]) == {"hqs", "plain", "hqs_close", "plain_close"} and all(v["visible_samples"] > 0 for v in out["raster"].values())

@@ -85,7 +85,8 @@ def parse(out):
     return r
 
 
-text, result = [], {"points": n, "terrain_extent_m": extent, "points_per_m2": n / (extent[0] * extent[1]), "las_file_bytes": os.path.getsize(args.las), "las_write_s": t_file}
+from simlod_amd.fingerprint import csrc_sha16
+text, result = [], {"_csrc_sha16": csrc_sha16(), "points": n, "terrain_extent_m": extent, "points_per_m2": n / (extent[0] * extent[1]), "las_file_bytes": os.path.getsize(args.las), "las_write_s": t_file}
 text.append(f"# BASELINE config 3: {n} points, fractal terrain {extent[0]:.0f} m x {extent[1]:.0f} m ({n / (extent[0] * extent[1]):.1f} points/m2), LAS 1.4 format 2, scan order\n")
 host = os.path.join("harness", "_ref", "ref_host_replay")
 if not os.path.exists(os.path.join(ROOT, host)):

@@ -22,8 +22,10 @@ out = {"_comment": "HBM bytes per ACTIVE launch of the ingest kernels (a launch 
                    "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 2 --warmup 1 --frames 4`.  FETCH_SIZE doubled as MI355X_MICROARCH.md "
                    "prescribes for gfx950 (64 B tallied per 128-B request; calibrated for wide coalesced streams only, scattered 4-16 B accesses are "
                    "uncalibrated)." % (n_ingests, n_batches, frames),
-       "_source": f"profiles/{tag}/rocprofv3_summary.json (tools/profile.sh {tag}; tools/fold_profiles.py)"}
+       "_source": f"profiles/{tag}/rocprofv3_summary.json (tools/profile.sh {tag}; tools/fold_profiles.py)",
+       "_csrc_sha16": summ.get("_csrc_sha16")}
 names = {"r_draw<0>": "r_draw<MODE_MIN64>", "r_draw<1>": "r_draw<MODE_DEPTH>", "r_draw<2>": "r_draw<MODE_COLOR>"}
+json.dump({"_csrc_sha16": summ.get("_csrc_sha16"), "what": "simlod_amd.fingerprint.csrc_sha16() of the sources the files of this directory were measured on"}, open(os.path.join(dst, "fingerprint.json"), "w"))
 for k, v in summ["hbm_traffic"].items():
     total = v["fetch_bytes_x2"] + v["write_bytes"]
     base = k.split("<")[0]

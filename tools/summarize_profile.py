@@ -70,6 +70,9 @@ if "pmc_l2" in summary:
         t = v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)
         if t > 0:
             v["hit_rate"] = v.get("TCC_HIT_sum", 0.0) / t
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simlod_amd.fingerprint import csrc_sha16
+summary["_csrc_sha16"] = csrc_sha16()          # the kernel sources these counters were collected on (bench.py quotes them only while it matches)
 os.makedirs("gpurun_out", exist_ok=True)
 with open(os.path.join("gpurun_out", f"profile_summary_{tag}.json"), "w") as f:
     json.dump(summary, f, indent=1)
