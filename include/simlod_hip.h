@@ -51,7 +51,7 @@ extern "C" {
  *
  * Tuning knobs (SIMLOD_OVERLAP_TAIL, SIMLOD_EXPAND_WGS, SIMLOD_GRID_MULT, SIMLOD_COUNT_TPB, SIMLOD_VOXELIZE_WGS, SIMLOD_ADAPTIVE_GROUPS,
  * SIMLOD_RASTER_LEAF_TABLE, SIMLOD_RASTER_LDS_TILES, SIMLOD_DRAW_MULT, SIMLOD_RASTER_FUSED_RESOLVE, SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT,
- * SIMLOD_DEBUG_VOXELIZE_CLOCK, SIMLOD_DEBUG_BUDGET_US, SIMLOD_GROUP_BATCHES, SIMLOD_DEBUG_PHASE_WG) are read from the environment ONCE, when a context is made (the default
+ * SIMLOD_DEBUG_VOXELIZE_CLOCK, SIMLOD_DEBUG_BUDGET_US, SIMLOD_GROUP_BATCHES, SIMLOD_DEBUG_PHASE_WG, SIMLOD_EVENT_SYSTEM_FENCE) are read from the environment ONCE, when a context is made (the default
  * context: at its first use); simlod_context_set_knob overrides one by name (set = 0: back to the built-in default),
  * simlod_context_reload_env reads the environment again.  ctx == NULL means the default context everywhere. */
 typedef struct SimlodContext SimlodContext;
@@ -138,6 +138,30 @@ int simlod_launch_render_part(uint32_t part, uint32_t* buffer, const SimlodUnifo
                               void* stream);
 uint64_t simlod_render_depth_plane_offset(uint32_t width, uint32_t height);
 uint64_t simlod_render_sum_planes_offset(uint32_t width, uint32_t height);
+
+/* The four parts and the reductions between them in ONE call, for hosts that are not Python (simlod_amd/distributed.py render_frame is the
+ * same sequence over torch.distributed).  `reduce` is called on the launch stream's timeline, between the parts, with the plane to reduce
+ * IN PLACE over all ranks: `data` (device memory inside `buffer`), `count` elements of `elemBytes` bytes, `op`; it returns 0 or an error
+ * code, which ends the frame.  Plane and order, per frame:
+ *     HQS:   SIMLOD_PLANE_DEPTH (uint32, MIN) after part 0;  SIMLOD_PLANE_SUMS (uint32 x 4 per pixel, SUM) after part 1;
+ *            SIMLOD_PLANE_FRAMEBUFFER (uint64, MIN) after part 2 only when Uniforms.showBoundingBox is set
+ *     plain: SIMLOD_PLANE_FRAMEBUFFER (uint64, MIN) after part 0
+ * reduce == NULL: no reduction — the frame of simlod_launch_render.  The all-gather of the visible-node records (the first Stats.numVisibleNodes
+ * records of `buffer`, 152 bytes each) is the host's own business: nothing in the frame depends on it. */
+#define SIMLOD_PLANE_DEPTH       0u
+#define SIMLOD_PLANE_SUMS        1u
+#define SIMLOD_PLANE_FRAMEBUFFER 2u
+#define SIMLOD_REDUCE_MIN        0u
+#define SIMLOD_REDUCE_SUM        1u
+typedef int (*SimlodReduceFn)(void* user, uint32_t plane, void* data, uint64_t count, uint32_t elemBytes, uint32_t op, void* stream);
+int simlod_render_frame_composed(uint32_t* buffer, const SimlodUniforms* uniforms /*host*/, SimlodNode* nodes, uint32_t* colorbuffer,
+                                 SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream,
+                                 SimlodReduceFn reduce, void* user);
+/* ... with the reductions as ncclAllReduce calls on `ncclComm` (an ncclComm_t of RCCL: one rank per GPU over xGMI), enqueued on `stream`.
+ * librccl.so is looked up when this is first called (dlopen: the library itself does not link against it); hipErrorNotSupported if it is
+ * not there. */
+int simlod_render_frame_rccl(uint32_t* buffer, const SimlodUniforms* uniforms /*host*/, SimlodNode* nodes, uint32_t* colorbuffer,
+                             SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream, void* ncclComm);
 
 /* ---- CudaModularProgram-shaped surface ------------------------------------------------------------------- */
 typedef struct SimlodProgram SimlodProgram;

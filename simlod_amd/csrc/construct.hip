@@ -1489,8 +1489,8 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, Bat
 }
 
 // ---- end of batch: bookkeeping (voxels.cu:535-537, 925-949), then make the next batch current ------------------
-// One thread of k_insert part 0, the last kernel of a batch on the caller's stream, once the batch's chunk allocations are complete
-// (nothing the rest of that launch or the voxel half on the side stream reads is touched here: they know their batch by its parity copy).
+// One thread of k_voxelize, the kernel behind the group's k_insert: the group's points are stored and its ring slots no longer read
+// (nothing the rest of that launch reads is touched here: the kernels know their group by its parity copy).
 __device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
 	if (ctl->abortBatch) __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // scratch overflow: this batch is lost, report through Stats.dbg
 	else {
@@ -1513,6 +1513,8 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr || ctl->abortBatch) return;
+	// the group's points are stored (k_insert has ended: nobody reads its ring slots any more): voxels.cu:925-949
+	if (blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);
 	const uint32_t numItems = min(bc->numVoxItems, VOX_BIG_ITEMS);
 	__shared__ VoxShared sh;
 	const VoxItem* items = vox_items(a, bc);
@@ -1884,9 +1886,11 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 	{
 		Phase ph(ctl, blockIdx.x == 0 || blockIdx.x + 1u == numChunks);
 		const uint32_t pb = blockIdx.x == 0 ? 8u : 16u;
-		// The end-of-batch bookkeeping needs nothing this kernel produces (the batch's chunks were allocated by k_expand, the counters it folds
-		// into Stats are final): the LAST workgroup of the grid, which as a rule has no samples to store, does it right away.
-		if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) end_of_batch(a, ctl, bc);
+		// (The end-of-batch bookkeeping — voxels.cu:925-949: Stats.batchletIndex, numPointsProcessed, the time budget — is k_voxelize's first act:
+		// a host that watches Stats.batchletIndex outside stream order, as the reference's uploader does with its back-pressure rule
+		// (main_progressive_octree.cpp:1012), may refill the group's ring slots the moment the index moves, and until this kernel has ENDED
+		// its workgroups may still be reading them.  Counting the workgroups in with an atomic each was measured: 2 048 adds on one word,
+		// 4.7 ms per ingest instead of 3.7.)
 		// ... and the 32 before it close the voxel lists of the previous batch (voxdone_nodes: this kernel has waited for its k_voxelize)
 		{
 			constexpr uint32_t DONE_WGS = 32;
@@ -2112,9 +2116,13 @@ static SideStream* side_stream(Context& ctx) {
 	if (ctx.side[dev] == nullptr) {
 		SideStream* s = new SideStream();
 		bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+		// SIMLOD_EVENT_SYSTEM_FENCE=1 (read when the context's second stream is made): events WITH the system-scope release — the fallback should a
+		// ROCm release ever stop publishing a kernel's stores to the other stream's kernels without it (the parity tests and
+		// test_repeated_ingests_leave_identical_counters would show it)
+		const unsigned flags = ctx.tune(KNOB_EVENT_SYSTEM_FENCE, 0) != 0 ? (unsigned)hipEventDisableTiming : (unsigned)SYNC_EVENT_FLAGS;
 		for (uint32_t i = 0; ok && i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++)
-			ok = hipEventCreateWithFlags(&s->expanded[i], SYNC_EVENT_FLAGS) == hipSuccess && hipEventCreateWithFlags(&s->inserted[i], SYNC_EVENT_FLAGS) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags(&s->tailDone, SYNC_EVENT_FLAGS) == hipSuccess;
+			ok = hipEventCreateWithFlags(&s->expanded[i], flags) == hipSuccess && hipEventCreateWithFlags(&s->inserted[i], flags) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&s->tailDone, flags) == hipSuccess;
 		if (!ok) { (void)hipGetLastError(); delete s; return nullptr; }     // no side stream: everything stays on the caller's
 		ctx.side[dev] = s;
 	}
@@ -2176,29 +2184,40 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		const bool single = a.groupMax == 1u;
 		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
 		hipStream_t back = side != nullptr ? side->stream : stream;
+		// an enqueue that fails in the middle of the chain: the second stream may hold kernels that read and write the caller's buffers — the
+		// call does not return before they have ended (the caller may free or reset those buffers next)
+		auto fail = [&](hipError_t e) { if (side != nullptr) (void)hipStreamSynchronize(side->stream); (void)hipGetLastError(); return (int)(e != hipSuccess ? e : hipErrorUnknown); };
 		for (uint32_t b = 0; b < numGroups; b++) {
 			if (single) {
 				if (countTpb == 256) SIMLOD_LAUNCH((k_count<TPB, true>), dim3(gridPoints), dim3(TPB), stream, a, b);
 				else SIMLOD_LAUNCH((k_count<512, true>), dim3(gridPoints / 2), dim3(512), stream, a, b);
 			} else SIMLOD_LAUNCH((k_count<512, false>), dim3(gridPoints / 2), dim3(512), stream, a, b);
 			SIMLOD_LAUNCH(k_queue, dim3(single ? 16 : 128), dim3(TPB), stream, a, b);   // one wave per crossing leaf: a couple per batch, hundreds per coalesced group (36 M terrain, groups of 10: 42 us on 16 workgroups)
-			if (side != nullptr && b > 0 && hipStreamWaitEvent(stream, side->inserted[b - 1], 0) != hipSuccess) return (int)hipGetLastError();
+			if (side != nullptr && b > 0) { const hipError_t e = hipStreamWaitEvent(stream, side->inserted[b - 1], 0); if (e != hipSuccess) return fail(e); }
 			SIMLOD_LAUNCH(k_hist, dim3(gridPoints), dim3(TPB), stream, a, b);
 			// (with two streams the kernels the other stream waits for carry their event as the launch's stop event: it is signalled by the
 			// kernel's own completion, where hipEventRecord puts a marker of its own behind the kernel — 3.93 -> 3.85 ms per ingest)
 			if (side != nullptr) {
+				const bool gated = expand_gate_enter(ctx, stream);
 				SIMLOD_LAUNCH_STOP(k_expand, dim3(expandWgs), dim3(ETPB), stream, side->expanded[b], a, b);
-				if (hipStreamWaitEvent(back, side->expanded[b], 0) != hipSuccess) return (int)hipGetLastError();
+				expand_gate_leave(ctx, stream, side->expanded[b], gated);
+				{ const hipError_t e = hipStreamWaitEvent(back, side->expanded[b], 0); if (e != hipSuccess) return fail(e); }
 				if (single) SIMLOD_LAUNCH_STOP(k_insert<true>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
 				else SIMLOD_LAUNCH_STOP(k_insert<false>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);
 			} else {
+				const bool gated = expand_gate_enter(ctx, stream);
 				SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
+				expand_gate_leave(ctx, stream, nullptr, gated);
 				if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);
 				else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
 			}
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
 		}
-		if (side != nullptr && (hipEventRecord(side->tailDone, back) != hipSuccess || hipStreamWaitEvent(stream, side->tailDone, 0) != hipSuccess)) return (int)hipGetLastError();
+		if (side != nullptr) {
+			hipError_t e = hipEventRecord(side->tailDone, back);
+			if (e == hipSuccess) e = hipStreamWaitEvent(stream, side->tailDone, 0);
+			if (e != hipSuccess) return fail(e);
+		}
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}

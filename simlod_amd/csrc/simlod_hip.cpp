@@ -1,6 +1,8 @@
 // simlod_hip.cpp — the C ABI of libsimlod_hip.so (include/simlod_hip.h): typed launches plus the
 // CudaModularProgram / cuLaunchCooperativeKernel shaped surface of the reference host
 // (include/CudaModularProgram.h:140-264, modules/progressive_octree/main_progressive_octree.cpp:333-546).
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -18,10 +20,47 @@ namespace simlod {
 const char* const KNOB_NAMES[KNOB_COUNT_] = {
 	"SIMLOD_OVERLAP_TAIL", "SIMLOD_EXPAND_WGS", "SIMLOD_GRID_MULT", "SIMLOD_COUNT_TPB", "SIMLOD_VOXELIZE_WGS", "SIMLOD_ADAPTIVE_GROUPS",
 	"SIMLOD_RASTER_LEAF_TABLE", "SIMLOD_RASTER_LDS_TILES", "SIMLOD_DRAW_MULT", "SIMLOD_RASTER_FUSED_RESOLVE",
-	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US", "SIMLOD_GROUP_BATCHES", "SIMLOD_DEBUG_PHASE_WG",
+	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US", "SIMLOD_GROUP_BATCHES", "SIMLOD_DEBUG_PHASE_WG", "SIMLOD_EVENT_SYSTEM_FENCE",
 };
 
-Context::Context() { reload_env(); }
+static std::atomic<uint32_t> g_liveContexts{0};
+uint32_t live_contexts() { return g_liveContexts.load(); }
+
+Context::Context() { reload_env(); g_liveContexts.fetch_add(1); }
+
+// ---- one chain of k_expand launches per device while several contexts are alive (simlod_internal.hpp) ----------------------------
+namespace {
+struct ExpandGate { std::mutex lock; hipEvent_t last = nullptr; const Context* owner = nullptr; };
+ExpandGate g_gate[64];
+int gate_device() { int dev = 0; (void)hipGetDevice(&dev); return dev < 0 || dev >= 64 ? 0 : dev; }
+}  // namespace
+
+bool expand_gate_enter(Context& ctx, hipStream_t stream) {
+	ExpandGate& g = g_gate[gate_device()];
+	g.lock.lock();                                            // held until expand_gate_leave: the launch and the gate's new state change hands together
+	if (g.last != nullptr && g.owner != &ctx) (void)hipStreamWaitEvent(stream, g.last, 0);
+	return true;
+}
+
+void expand_gate_leave(Context& ctx, hipStream_t stream, hipEvent_t ended, bool held) {
+	if (!held) return;
+	const int dev = gate_device();
+	ExpandGate& g = g_gate[dev];
+	if (ended == nullptr && live_contexts() > 1u) {           // (one stream, one context: nobody will ever wait for it)
+		if (ctx.gateEvent[dev] == nullptr && hipEventCreateWithFlags(&ctx.gateEvent[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx.gateEvent[dev] = nullptr; }
+		ended = ctx.gateEvent[dev];
+		if (ended != nullptr) (void)hipEventRecord(ended, stream);
+	}
+	if (ended != nullptr) { g.last = ended; g.owner = &ctx; }
+	g.lock.unlock();
+}
+
+void expand_gate_forget(Context& ctx) {
+	for (ExpandGate& g : g_gate) {
+		std::lock_guard<std::mutex> hold(g.lock);
+		if (g.owner == &ctx) { g.last = nullptr; g.owner = nullptr; }
+	}
+}
 
 void Context::reload_env() {
 	for (int k = 0; k < KNOB_COUNT_; k++) {
@@ -31,10 +70,13 @@ void Context::reload_env() {
 }
 
 Context::~Context() {
+	expand_gate_forget(*this);
+	g_liveContexts.fetch_sub(1);
 	for (SideStream*& s : side) { if (s != nullptr) destroy_side_stream(s); s = nullptr; }
 	// the page-locked feedback words: a copy enqueued by the context's last launches (on the CALLER's streams) may still be on its way
 	(void)hipDeviceSynchronize();
 	for (LaunchHistory& h : history) (void)hipHostFree(const_cast<uint32_t*>(h.seen));
+	for (hipEvent_t& e : gateEvent) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
 	(void)hipGetLastError();
 }
 
@@ -328,6 +370,59 @@ int simlod_launch_render_part(uint32_t part, uint32_t* buffer, const SimlodUnifo
 	(void)cudaprint;
 	if (!uniforms || !buffer || !nodes || !stats || !frameStartTimestamp || part > 3) return (int)hipErrorInvalidValue;
 	return launch_render(context_of(nodes), buffer, uniforms, nodes, colorbuffer, stats, frameStartTimestamp, (hipStream_t)stream, 1u << part);
+}
+
+// ---- a frame composed across ranks in one call (include/simlod_hip.h) -------------------------------------------------------------------
+int simlod_render_frame_composed(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
+                                 uint64_t* frameStartTimestamp, void* cudaprint, void* stream, SimlodReduceFn reduce, void* user) {
+	(void)cudaprint;
+	if (!u || !buffer || !nodes || !stats || !frameStartTimestamp) return (int)hipErrorInvalidValue;
+	Context& ctx = context_of(nodes);
+	hipStream_t st = (hipStream_t)stream;
+	const uint32_t W = (uint32_t)u->width, H = (uint32_t)u->height;
+	const uint64_t px = (uint64_t)W * H;
+	uint8_t* base = reinterpret_cast<uint8_t*>(buffer);
+	auto part = [&](uint32_t k) { return launch_render(ctx, buffer, u, nodes, colorbuffer, stats, frameStartTimestamp, st, 1u << k); };
+	auto red = [&](uint32_t plane, uint64_t offset, uint64_t count, uint32_t elemBytes, uint32_t op) { return reduce ? reduce(user, plane, base + offset, count, elemBytes, op, stream) : 0; };
+	const bool hqs = u->useHighQualityShading != 0, boxes = u->showBoundingBox != 0;
+	int rc = part(0);
+	if (rc == 0 && hqs) rc = red(SIMLOD_PLANE_DEPTH, render_depth_plane_offset(W, H), px, 4, SIMLOD_REDUCE_MIN);
+	if (rc == 0 && hqs) rc = part(1);
+	if (rc == 0 && hqs) rc = red(SIMLOD_PLANE_SUMS, render_sum_planes_offset(W, H), px * 4, 4, SIMLOD_REDUCE_SUM);
+	if (rc == 0 && hqs) rc = part(2);
+	if (rc == 0 && (!hqs || boxes)) rc = red(SIMLOD_PLANE_FRAMEBUFFER, simlod_render_framebuffer_offset(), px, 8, SIMLOD_REDUCE_MIN);
+	if (rc == 0) rc = part(3);
+	return rc;
+}
+
+// RCCL, found at run time: ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream)
+namespace {
+using AllReduceFn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+AllReduceFn rccl_all_reduce() {
+	static AllReduceFn fn = [] {
+		for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+			if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+				if (void* f = dlsym(h, "ncclAllReduce")) return reinterpret_cast<AllReduceFn>(f);
+			}
+		}
+		return static_cast<AllReduceFn>(nullptr);
+	}();
+	return fn;
+}
+int reduce_over_rccl(void* comm, uint32_t plane, void* data, uint64_t count, uint32_t elemBytes, uint32_t op, void* stream) {
+	(void)plane;
+	AllReduceFn f = rccl_all_reduce();
+	if (f == nullptr) return (int)hipErrorNotSupported;
+	enum { ncclUint32 = 3, ncclUint64 = 5, ncclSum = 0, ncclMin = 3 };       // rccl.h: ncclDataType_t, ncclRedOp_t
+	return f(data, data, (size_t)count, elemBytes == 8 ? ncclUint64 : ncclUint32, op == SIMLOD_REDUCE_SUM ? ncclSum : ncclMin, comm, (hipStream_t)stream) == 0 ? 0 : (int)hipErrorUnknown;
+}
+}  // namespace
+
+int simlod_render_frame_rccl(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
+                             uint64_t* frameStartTimestamp, void* cudaprint, void* stream, void* ncclComm) {
+	if (!ncclComm) return (int)hipErrorInvalidValue;
+	if (rccl_all_reduce() == nullptr) return (int)hipErrorNotSupported;
+	return simlod_render_frame_composed(buffer, u, nodes, colorbuffer, stats, frameStartTimestamp, cudaprint, stream, reduce_over_rccl, ncclComm);
 }
 
 uint64_t simlod_render_depth_plane_offset(uint32_t width, uint32_t height) { return render_depth_plane_offset(width, height); }

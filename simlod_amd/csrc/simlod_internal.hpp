@@ -44,7 +44,7 @@ __host__ __device__ inline uint64_t table_signature(const SimlodStats* s) {
 enum Knob : int {
 	KNOB_OVERLAP_TAIL, KNOB_EXPAND_WGS, KNOB_GRID_MULT, KNOB_COUNT_TPB, KNOB_VOXELIZE_WGS, KNOB_ADAPTIVE_GROUPS,
 	KNOB_RASTER_LEAF_TABLE, KNOB_RASTER_LDS_TILES, KNOB_DRAW_MULT, KNOB_RASTER_FUSED_RESOLVE,
-	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_GROUP_BATCHES, KNOB_DEBUG_PHASE_WG, KNOB_COUNT_
+	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_GROUP_BATCHES, KNOB_DEBUG_PHASE_WG, KNOB_EVENT_SYSTEM_FENCE, KNOB_COUNT_
 };
 static constexpr int KNOB_UNSET = INT_MIN;
 extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...
@@ -64,12 +64,22 @@ struct Context {
 	std::vector<LeafTableRef> tables;
 	std::mutex historyLock;
 	std::vector<LaunchHistory> history;
+	hipEvent_t gateEvent[64] = {};                            // per device ordinal: the end of this context's latest k_expand, when it runs without a second stream (expand_gate)
 	Context();
 	~Context();
 	void reload_env();
 	int tune(Knob k, int dflt) const { return knob[k] == KNOB_UNSET ? dflt : knob[k]; }
 };
 Context& context_of(const void* nodes);                      // the context `nodes` is attached to, else the default one
+uint32_t live_contexts();                                    // contexts that exist right now (the default one included once it has been used)
+
+// k_expand's workgroups meet at a hand-rolled grid barrier and must all be resident.  Two such kernels of two contexts, running at once on
+// one device, can each hold part of the CUs and wait for workgroups of their own that the other keeps from becoming resident.  So, while more
+// than one context is alive, the k_expand launches of a device form ONE chain: a launch waits for the end of the latest k_expand of any OTHER
+// context (its own are ordered by its stream).  One context — the reference host's case — pays nothing.
+bool expand_gate_enter(Context& ctx, hipStream_t stream);                      // before the launch: wait for the other contexts' latest k_expand; true: the gate is held until expand_gate_leave
+void expand_gate_leave(Context& ctx, hipStream_t stream, hipEvent_t ended, bool held);   // after it: `ended` is signalled by its end (nullptr: an event of the context is recorded behind it)
+void expand_gate_forget(Context& ctx);                                         // the context goes away
 
 namespace build {  // construct.hip: kernel_construct — one ring batch at a time (exact mode) or groups of pending batches (coalesced mode)
 

@@ -59,6 +59,8 @@ def lib():
         L.simlod_launch_construct.argtypes = [vp] * 11
         L.simlod_launch_render.argtypes = [vp] * 8
         L.simlod_launch_render_part.argtypes = [ctypes.c_uint32] + [vp] * 8
+        L.simlod_render_frame_composed.argtypes = [vp] * 10
+        L.simlod_render_frame_rccl.argtypes = [vp] * 9
         L.simlod_render_depth_plane_offset.restype = u64
         L.simlod_render_depth_plane_offset.argtypes = [u32, u32]
         L.simlod_render_sum_planes_offset.restype = u64
@@ -89,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
     "simlod_context_create", "simlod_context_destroy", "simlod_context_attach", "simlod_context_set_node_capacity", "simlod_context_set_ingest_mode",
     "simlod_context_set_construct_batch_limit", "simlod_context_set_knob", "simlod_context_reload_env", "simlod_context_construct_buffer_min_bytes",
-    "simlod_octree_image_replaced",
+    "simlod_octree_image_replaced", "simlod_render_frame_composed", "simlod_render_frame_rccl",
     "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_generate_terrain_scan", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 
@@ -252,11 +254,10 @@ class DeviceOctree:
         t = tuple(-float(v) for v in h.min) if translation is None else translation
         for first, count in lasio.batches(h, batch):
             if self.uploaded_host - self.processed_host >= self.ring_slots:
-                self.drain(uniforms)
-                self.processed_host = self.uploaded_host
+                self.drain(uniforms)                   # (sets processed_host to what it read back)
+                assert self.uploaded_host - self.processed_host < self.ring_slots, "kernel_construct left the ring full"
             self.upload_las(lasio.read_records(path, h, first, count), h, t)
         self.drain(uniforms)
-        self.processed_host = self.uploaded_host
         return h
 
     def colorfilter(self, uniforms):
@@ -319,6 +320,27 @@ class DeviceOctree:
             self.colorbuffer = torch.zeros(W * H, dtype=torch.int32, device=self.device)
         _check(self.L.simlod_launch_render_part(ctypes.c_uint32(part), self._p(self.render_buffer), up, self._p(self.nodes), self._p(self.colorbuffer),
                                                 self._p(self.stats), self._p(self.frame_start), None, self._stream()), "kernel_render part")
+        self._frame_size = (W, H)
+
+    REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p)
+
+    def render_composed(self, uniforms, reduce=None, rccl_comm=None):
+        """One frame through simlod_render_frame_composed / simlod_render_frame_rccl (include/simlod_hip.h): the four parts of kernel_render with
+        a reduction of the named plane over all ranks in between — `reduce(plane, data_ptr, count, elem_bytes, op, stream) -> int`, or an
+        ncclComm_t as an integer address."""
+        u, up = self._u(uniforms)
+        W, H = int(u["width"][0]), int(u["height"][0])
+        need = int(self.L.simlod_render_buffer_bytes(W, H))
+        if self.render_buffer.numel() < need:
+            self.render_buffer = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self.colorbuffer.numel() < W * H:
+            self.colorbuffer = torch.zeros(W * H, dtype=torch.int32, device=self.device)
+        args = [self._p(self.render_buffer), up, self._p(self.nodes), self._p(self.colorbuffer), self._p(self.stats), self._p(self.frame_start), None, self._stream()]
+        if rccl_comm is not None:
+            _check(self.L.simlod_render_frame_rccl(*args, ctypes.c_void_p(rccl_comm)), "simlod_render_frame_rccl")
+        else:
+            cb = self.REDUCE_FN(lambda user, plane, data, count, eb, op, stream: int(reduce(plane, data, count, eb, op, stream))) if reduce is not None else None
+            _check(self.L.simlod_render_frame_composed(*args, ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None), "simlod_render_frame_composed")
         self._frame_size = (W, H)
 
     def depth_plane(self):
@@ -407,6 +429,9 @@ class DeviceOctree:
         processed (back-pressure, :1012); every frame launches kernel_construct once (<= 20 batches, <= 10 ms) and reads Stats back.
         Returns the number of launches.  Arbitrarily long inputs go through 50 slots."""
         nb = (num_points + batch - 1) // batch
+        if self.processed() < self.uploaded_host:      # batches uploaded earlier and not yet ingested: the back-pressure below counts from an empty ring
+            self.drain(uniforms)
+            assert self.processed_host == self.uploaded_host, "kernel_construct left batches pending"
         base = self.uploaded_host
         src = source.reshape(-1)
         uploaded, processed, launches, stalls = 0, 0, 0, 0
@@ -456,10 +481,9 @@ class DeviceOctree:
         for i in range(0, len(points), batch):
             if self.uploaded_host - self.processed_host >= self.ring_slots:
                 self.drain(uniforms)
-                self.processed_host = self.uploaded_host
+                assert self.uploaded_host - self.processed_host < self.ring_slots, "kernel_construct left the ring full"
             self.upload(points[i:i + batch])
         self.drain(uniforms)
-        self.processed_host = self.uploaded_host
 
     def upload_image(self, nodes, persistent, num_nodes, stats=None):
         """Load an octree image whose pointers were already rewritten for THIS object's device buffers (self.nodes.data_ptr(),

@@ -96,7 +96,6 @@ def test_config3_350m_scan_ordered_las_records_streamed_in_1m_batches_equal_the_
         rec = rec.reshape(-1)
         if dev.uploaded_host - dev.processed_host >= dev.ring_slots:
             dev.drain(u)
-            dev.processed_host = dev.uploaded_host
         dev.upload_las(rec, h, tr)
         if int(ref.num_uploaded[0]) - int(ref.stats["batchletIndex"][0]) >= abi.BATCH_STREAM_SIZE:
             drain_ref()

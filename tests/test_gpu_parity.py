@@ -56,17 +56,8 @@ def _oracle_render(nodes, nn, u):
     return fb, col, stats[0]
 
 
-@pytest.fixture(params=["exact"])
-def chain(request):
-    """kernel_construct in exact mode (one ring batch at a time, the reference's granularity: every Stats counter after every batch is the
-    reference's).  The opt-in coalesced mode runs the same kernels on groups of batches; its contract is tested separately
-    (test_coalesced_ingest_builds_the_same_octree_content)."""
-    yield request.param
-
-
-# ---- construct ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", CASES)
-def test_construct_matches_golden_and_oracle(built_libs, name, chain):
+def test_construct_matches_golden_and_oracle(built_libs, name):
     g = load_golden(name)
     pts, box, batch, T = case(name)
     dev = _device(ring_slots=8)
@@ -83,7 +74,7 @@ def test_construct_matches_golden_and_oracle(built_libs, name, chain):
 
 @pytest.mark.parametrize("kind,n,batch", [("uniform", 1_000_000, 1_000_000), ("uniform", 3_000_000, 1_000_000),
                                           ("terrain", 4_000_000, 1_000_000), ("hotspot", 3_000_000, 1_000_000)])
-def test_construct_full_batches_match_oracle(built_libs, kind, n, batch, chain):
+def test_construct_full_batches_match_oracle(built_libs, kind, n, batch):
     pts, box = {"uniform": lambda: synthetic.uniform_cube(n, seed=1234), "terrain": lambda: synthetic.terrain(n, seed=7),
                 "hotspot": lambda: synthetic.hotspot(n, seed=11)}[kind]()
     T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
@@ -133,7 +124,7 @@ def test_too_small_momentary_buffer_is_reported_not_silently_overrun(built_libs)
     assert int(s["dbg"]) & 0x1 and int(s["batchletIndex"]) == 0
 
 
-def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs, chain):
+def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs):
     """voxels.cu:896-912: a batch is taken only while allocator offset + 200 MB < persistentBufferCapacity; otherwise
     Stats.memCapacityReached is raised and the launch does nothing — and neither do later launches.  Same stopping batch,
     same octree as the restatement; nothing is written beyond the capacity the kernels were told."""
@@ -169,7 +160,7 @@ def test_persistent_memory_guard_stops_ingest_like_the_reference(built_libs, cha
     assert int(ds["allocatedBytes_persistent"]) <= cap and bool((dev.persistent[cap:] == 0x3C).all())
 
 
-def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs, chain):
+def test_full_node_array_stops_splitting_but_keeps_every_point(built_libs):
     """The reference's node array holds 263 157 nodes (main_progressive_octree.cpp:552) and its kernel writes past the end when
     more are needed.  Here a split that finds no eight free slots is refused: the leaf keeps growing, Stats.dbg says so."""
     from simlod_amd.runtime import lib
@@ -251,7 +242,7 @@ def test_memory_guard_trips_while_launches_take_several_batches_each(built_libs,
         dev.drain(u)
 
 
-def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs, chain):
+def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
     """70 000 identical points force twenty split rounds inside one batch, down to level 20 where a node cannot split any more;
     8 000 points sit exactly on the faces / corners of the bounding box (coordinate == boxMax quantises to 2^20 and, as in the
     reference, wraps into the low child).  Tree shape, voxels, grids and counts must be the reference restatement's.  One
@@ -295,7 +286,7 @@ def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs, chain):
     assert voxel_colors_are_member(nodes, nn, pts, box, max_level=12) == int(nodes["numVoxelsStored"][:nn].sum()) - deep
 
 
-def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs, chain):
+def test_scarce_scratch_defers_splits_without_losing_a_point(built_libs):
     """Scattered input makes hundreds of leaves cross the limit in the same batch.  With a momentary buffer that can hold only
     a fraction of their stored points (the reference drops points here) the splits that do not fit are deferred:
     the leaves stay intact, grow past 50 000, and split in a later batch.  Every point must be in the octree, the image must
@@ -912,7 +903,7 @@ def test_render_parts_equal_the_whole_frame_and_two_emulated_ranks_compose_exact
 
 # ---- BASELINE configs 3 and 5 at a size the oracle still finishes in seconds; the ring; ingest granularity ---------------------------
 @pytest.mark.parametrize("overlap", ["1", "0"])
-def test_ring_wraps_around_more_than_twice(built_libs, chain, overlap, monkeypatch):
+def test_ring_wraps_around_more_than_twice(built_libs, overlap, monkeypatch):
     """Config 3's mechanism: batches stream through the 50-slot ring (slot = batchletIndex % 50, voxels.cu:883-925) with the host's
     back-pressure rule.  130 batches of 50 000 points wrap the ring 2.6 times; the octree must be the oracle's after the same 130 batches.
     With the voxel tail of a batch on the library's side stream (the default of the exact chain) and on the caller's stream."""
@@ -1045,7 +1036,7 @@ def test_reference_host_functions_drive_the_library(built_libs, tmp_path, kind, 
     assert drawn > (5000 if kind == "simlod" else 1500), f"only {drawn} pixels drawn; harness said: {out.stdout[-600:]}"
 
 
-def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs, chain):
+def test_points_exactly_on_the_max_faces_give_the_reference_voxels(built_libs):
     """A coordinate equal to boxMax quantises to 2^20; the reference's descent looks at bits 19..0 and files the point (and the voxels
     it creates) under node coordinate 0 of that axis.  Only such points here, so they are the ones that win the cells."""
     rs = np.random.RandomState(8)
@@ -1079,7 +1070,7 @@ def test_node_capacity_beyond_the_packed_index_width_is_rejected(built_libs):
         L.simlod_set_node_capacity(263_157)
 
 
-def test_forced_barrier_timeout_aborts_the_batch_and_stays_fatal_until_reset(built_libs, chain):
+def test_forced_barrier_timeout_aborts_the_batch_and_stays_fatal_until_reset(built_libs):
     """The split cascade's grid barrier giving up (here: forced) must not let the rest of the chain run on a half-built state: the batch
     is not counted, Stats.dbg carries the fatal bit, later launches refuse to touch the octree, and a reset brings everything back."""
     from simlod_amd.runtime import SimlodError
@@ -1373,7 +1364,7 @@ def test_bench_runs_under_torch_distributed_run_and_prints_one_json_line(built_l
 
 
 @pytest.mark.parametrize("kind", ["uniform", "terrain"])
-def test_many_tiny_batches_match_oracle(built_libs, chain, kind):
+def test_many_tiny_batches_match_oracle(built_libs, kind):
     """300 batches of 3 000 points, 20 per launch: the root stays a leaf for the first 16 batches (its samples are voxelized on the
     caller's stream), then splits while the previous batch's voxel half may still be running on the side stream; every later batch
     leaves a few samples in many leaves (the wave-per-leaf path of k_voxelize).  Octree and Stats == oracle after the same batches."""
@@ -1393,3 +1384,132 @@ def test_many_tiny_batches_match_oracle(built_libs, chain, kind):
     nodes, pers, nn = host_image_of(dev)
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), kind)
     oracle.check_invariants(nodes, nn)
+
+
+@pytest.mark.parametrize("variant", ["plain", "hqs", "hqs_boxes"])
+def test_composed_frame_entry_points_call_the_reductions_in_order_and_draw_the_same_frame(built_libs, variant):
+    """simlod_render_frame_composed (the C entry a non-Python host drives N GPUs with): the reductions are requested in the order and with
+    the shapes include/simlod_hip.h states, and with reductions that change nothing (one rank) the frame is simlod_launch_render's.
+    simlod_render_frame_rccl: the same through ncclAllReduce on a ONE-rank RCCL communicator made here (what one GPU can exercise of the
+    RCCL path: library lookup, data types, in-place all-reduce on the launch stream)."""
+    import torch
+    pts, box = synthetic.terrain(2_000_000, seed=3)
+    Wd, Hd = 640, 360
+    T = camera.lookat_transform((1.1 * box[0], -0.9 * box[1], 1.2 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), Wd, Hd)
+    dev = _device(max_pixels=Wd * Hd)
+    u = dev.uniforms(Wd, Hd, T, box, hqs=variant.startswith("hqs"), show_bounding_box=variant.endswith("boxes"))
+    _ingest(dev, u, [pts[i:i + abi.MAX_BATCH_SIZE] for i in range(0, len(pts), abi.MAX_BATCH_SIZE)])
+    dev.render(u)
+    want_fb, want_color = dev.framebuffer(Wd, Hd), dev.color(Wd, Hd)
+    calls = []
+    dev.render_buffer.fill_(0xA5)
+    dev.render_composed(u, reduce=lambda plane, data, count, eb, op, stream: calls.append((plane, data - dev.render_buffer.data_ptr(), count, eb, op)) or 0)
+    px = Wd * Hd
+    fb_off, d_off, s_off = int(dev.L.simlod_render_framebuffer_offset()), int(dev.L.simlod_render_depth_plane_offset(Wd, Hd)), int(dev.L.simlod_render_sum_planes_offset(Wd, Hd))
+    expect = {"plain": [(2, fb_off, px, 8, 0)], "hqs": [(0, d_off, px, 4, 0), (1, s_off, 4 * px, 4, 1)], "hqs_boxes": [(0, d_off, px, 4, 0), (1, s_off, 4 * px, 4, 1), (2, fb_off, px, 8, 0)]}[variant]
+    assert calls == expect
+    assert np.array_equal(dev.framebuffer(Wd, Hd), want_fb) and np.array_equal(dev.color(Wd, Hd), want_color)
+    # a failing reduction ends the frame with its code
+    from simlod_amd.runtime import SimlodError
+    with pytest.raises(SimlodError):
+        dev.render_composed(u, reduce=lambda *a: 7)
+    # RCCL, one rank
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = ctypes.CDLL(name); break
+        except OSError:
+            pass
+    if rccl is None:
+        pytest.skip("no librccl.so on this box")
+    uid = (ctypes.c_char * 128)()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    uid_s = UniqueId(); ctypes.memmove(ctypes.byref(uid_s), uid, 128)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid_s, 0) == 0
+    try:
+        dev.render_buffer.fill_(0xA5)
+        dev.render_composed(u, rccl_comm=comm.value)
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.framebuffer(Wd, Hd), want_fb) and np.array_equal(dev.color(Wd, Hd), want_color)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+def test_repeated_ingests_leave_identical_counters(built_libs):
+    """The race hunt of tools/stress.py in the test tier: the 36 M ingest over and over through the two-stream pipeline (kernels of one group
+    on two streams, ordered by events without a system-scope fence) — in exact mode every build counter of Stats is the reference's, hence
+    the same in every pass; a lost update between the streams shows up as a few thousand missing voxels once in a while."""
+    n = 36_000_000
+    pts, box = synthetic.terrain(n, seed=7)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(persistent_bytes=4 << 30)
+    u = dev.uniforms(W, H, T, box)
+    fields = ["numNodes", "numInner", "numLeaves", "numNonemptyLeaves", "numPoints", "numVoxels", "numChunksPoints", "numChunksVoxels", "batchletIndex",
+              "numPointsProcessed", "numAllocatedChunks", "chunkPoolSize", "allocatedBytes_persistent", "dbg", "memCapacityReached"]
+    batches = [pts[i:i + abi.MAX_BATCH_SIZE] for i in range(0, n, abi.MAX_BATCH_SIZE)]
+    import torch
+    rv = dev.ring.view(torch.uint8)
+    for i, b in enumerate(batches):
+        rv[i * abi.MAX_BATCH_SIZE * 16: i * abi.MAX_BATCH_SIZE * 16 + len(b) * 16].copy_(torch.from_numpy(b.view(np.uint8).reshape(-1)))
+    sizes = torch.tensor([len(b) for b in batches], dtype=torch.int32, device=dev.device)
+    first = None
+    for p in range(40):
+        dev.reset(u)
+        dev.batch_sizes[: len(batches)] = sizes
+        dev.num_uploaded.fill_(len(batches))
+        dev.uploaded_host = len(batches)
+        dev.drain(u)
+        st = dev.read_stats()
+        got = {f: int(st[f]) for f in fields}
+        if first is None:
+            first = got
+            assert got["numPoints"] == n and got["dbg"] == 0
+        assert got == first, f"pass {p}: " + str({f: (first[f], got[f]) for f in fields if got[f] != first[f]})
+
+
+def test_two_coalesced_contexts_ingest_from_two_threads(built_libs):
+    """Two octrees, each with its own context in coalesced mode (k_expand on every CU, meeting at a grid barrier), fed from two host threads
+    at once: the k_expand launches of the device form one chain across contexts (simlod_internal.hpp expand_gate_*), so two barrier kernels
+    never hold the CUs against each other; both octrees end as their oracle octrees (content fields; the coalesced mode's contract)."""
+    import threading
+    import torch
+    sets = [synthetic.terrain(9_000_000, seed=21), synthetic.terrain(9_000_000, seed=22)]
+    T = [camera.lookat_transform((1.8 * b[0], -1.2 * b[1], 1.4 * max(b)), (0.5 * b[0], 0.5 * b[1], 0.3 * b[2]), W, H) for _, b in sets]
+    from simlod_amd.runtime import DeviceOctree
+    devs = [DeviceOctree("cuda:0", persistent_bytes=2 << 30, momentary_bytes=700_000_000, max_pixels=W * H, coalesce=True) for _ in sets]
+    us = [d.uniforms(W, H, t, b) for d, t, (_, b) in zip(devs, T, sets)]
+    errors = []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for rep in range(3):
+                    devs[k].reset(us[k])
+                    devs[k].add_points(us[k], sets[k][0])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                                  # noqa: BLE001
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=300)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    torch.cuda.synchronize()
+    for k, (pts, box) in enumerate(sets):
+        ds = devs[k].read_stats()
+        assert int(ds["dbg"]) == 0 and int(ds["numPoints"]) == len(pts)
+        ref = oracle.HostOctree("port", persistent_bytes=2 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+        ref.reset(us[k]); ref.add_points(us[k], pts)
+        assert_stats_equal(ds, ref.stats[0], GRANULARITY_FREE_STATS, f"context {k}")
+        nodes, pers, nn = host_image_of(devs[k])
+        da, db = oracle.dump_image(nodes, nn), ref.dump()
+        for f in GRANULARITY_FREE_FIELDS:
+            assert np.array_equal(da[f], db[f]), f"context {k}: {f}"
+    for d in devs:
+        d.close()
