@@ -93,7 +93,7 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, leafOfStride;
+	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, offTop, leafOfStride;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax, crossCap;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
 };
 
@@ -211,6 +211,25 @@ __device__ __forceinline__ uint32_t path_node(unsigned long long e) { return (ui
 __device__ __forceinline__ uint32_t path_level(unsigned long long e) { return (uint32_t)(e >> 36) & 31u; }
 __device__ __forceinline__ SimlodOccupancyGrid* path_grid(uint8_t* pers, unsigned long long e) {
 	return reinterpret_cast<SimlodOccupancyGrid*>(pers + ((e & 0xfffffffffull) << 4));
+}
+
+// Top table: for every cell of the 32^3 grid of level 5, the deepest node at level <= 5 that contains it, as node | level << 19 — where k_count's
+// descent STARTS (one load instead of up to five dependent ones; nodes are never removed, so an entry is always a valid starting point).
+// Rebuilt at the start of every launch (k_paths), kept current by k_expand: only a split of a leaf at level <= 4 makes nodes that belong in
+// it, which a stream does in its first batches over a region and hardly ever again (the 36 M terrain: leaves live at levels 6 to 8).
+// (Round 3 measured the same idea one level deeper — 64^3, level 6 — and dropped it: every other split had to update it, +3.4 us in k_expand.)
+static constexpr uint32_t TOP_LEVEL = 5, TOP_SIDE = 1u << TOP_LEVEL, TOP_CELLS = TOP_SIDE * TOP_SIDE * TOP_SIDE;
+__device__ __forceinline__ uint32_t top_cell(uint32_t X, uint32_t Y, uint32_t Z) {      // X, Y, Z: 20-bit grid coordinates (bits 19..0 count, as in the descent)
+	const uint32_t s = (uint32_t)SIMLOD_MAX_DEPTH - TOP_LEVEL;
+	return (((X >> s) & (TOP_SIDE - 1u)) << (2u * TOP_LEVEL)) | (((Y >> s) & (TOP_SIDE - 1u)) << TOP_LEVEL) | ((Z >> s) & (TOP_SIDE - 1u));
+}
+// node `idx` at `level` <= TOP_LEVEL with coordinates (X, Y, Z) becomes the entry of every cell it covers
+__device__ __forceinline__ void top_fill(uint32_t* top, uint32_t idx, uint32_t level, uint32_t X, uint32_t Y, uint32_t Z) {
+	const uint32_t k = TOP_LEVEL - level, side = 1u << k, x0 = X << k, y0 = Y << k, z0 = Z << k, e = idx | (level << 19);      // (sides are powers of two: shifts, no division)
+	for (uint32_t i = 0; i < (1u << (3u * k)); i++) {
+		const uint32_t dx = i >> (2u * k), dy = (i >> k) & (side - 1u), dz = i & (side - 1u);
+		top[((x0 + dx) << (2u * TOP_LEVEL)) | ((y0 + dy) << TOP_LEVEL) | (z0 + dz)] = e;
+	}
 }
 
 __device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
@@ -376,6 +395,17 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i < TOP_CELLS) {                               // the top table: cell i's deepest node at level <= TOP_LEVEL, by descent from the root
+		const uint32_t s = (uint32_t)SIMLOD_MAX_DEPTH - TOP_LEVEL;
+		const uint32_t X = (i >> (2u * TOP_LEVEL)) << s, Y = ((i >> TOP_LEVEL) & (TOP_SIDE - 1u)) << s, Z = (i & (TOP_SIDE - 1u)) << s;
+		uint32_t cur = 0, level = 0;
+		while (level < TOP_LEVEL) {
+			const SimlodNode* c = a.nodes[cur].children[child_index(X, Y, Z, (int)level)];
+			if (c == nullptr) break;
+			cur = (uint32_t)(c - a.nodes); level++;
+		}
+		at<uint32_t>(a, a.offTop)[i] = cur | (level << 19);
+	}
 	if (i >= numNodes) return;
 	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
 	unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
@@ -632,7 +662,15 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
 			X[j] = quantize(F_GRID, p[j].x, a.minx, a.size); Y[j] = quantize(F_GRID, p[j].y, a.miny, a.size); Z[j] = quantize(F_GRID, p[j].z, a.minz, a.size);
-			cur[j] = 0u; level[j] = 0u; walking[j] = chunk * CPB + j * BT + threadIdx.x < n;
+			walking[j] = chunk * CPB + j * BT + threadIdx.x < n;
+		}
+		{   // the descent starts at the deepest node of level <= 5 above the sample (the top table: the eight loads go out together)
+			const uint32_t* top = at<const uint32_t>(a, a.offTop);
+			uint32_t e[CPT];
+#pragma unroll
+			for (uint32_t j = 0; j < CPT; j++) e[j] = walking[j] ? top[top_cell(X[j], Y[j], Z[j])] : 0u;
+#pragma unroll
+			for (uint32_t j = 0; j < CPT; j++) { cur[j] = e[j] & LEAF_NODE_MASK; level[j] = e[j] >> 19; }
 		}
 		descend_lockstep<(int)CPT>(a.nodes, cur, level, X, Y, Z, walking);
 #pragma unroll
@@ -928,7 +966,8 @@ struct ExpandShared {
 	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
 	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
 	uint2 fresh[LOCAL_NODES];                      // the cascade's nodes that hold samples: {node, samples} — they get their chunks before the kernel ends
-	uint32_t numFresh;
+	uint32_t numFresh, numFill;
+	uint4 fill[8 + 64];                            // new leaves at level <= 3 whose cells of the top table the whole workgroup fills: {node | level << 19, X, Y, Z}
 	AllocShared alloc;
 	SimlodOccupancyGrid* grid[8 + 64];             // grids of the children / grandchildren that split here
 	unsigned long long pathL[PATH_WORDS];          // the slot node's own ancestor path
@@ -1072,7 +1111,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			if (t < PATH_WORDS) sh.pathL[t] = t + 1 < PATH_WORDS ? paths[(uint64_t)L * PATH_WORDS + t] : 0ull;
 			for (uint32_t i = t; i < LOCAL_NODES; i += ETPB) sh.listed[i] = NONE;
 			if (t < 72u) sh.grid[t] = nullptr;
-			if (t == 0u) sh.numFresh = 0;
+			if (t == 0u) { sh.numFresh = 0; sh.numFill = 0; }
 			__syncthreads();
 			if (t < 64u) { uint32_t c = 0; for (uint32_t k = 0; k < 8; k++) c += sh.bins[t * 8 + k]; sh.c2[t] = c; }
 			__syncthreads();
@@ -1160,6 +1199,12 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 					if (e == 0ull) break;
 				}
 				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
+				// the top table (where k_count's descent starts): a new node at level <= 5 that has no children in the table's range takes over the cells it covers
+				// (a node two or more levels above the table's — 64 to 4096 cells, the first batches over a region — is filled by the whole workgroup, below)
+				if (level <= TOP_LEVEL && (!split || level == TOP_LEVEL)) {
+					if (TOP_LEVEL - level <= 1u) top_fill(at<uint32_t>(a, a.offTop), idx, level, X, Y, Z);
+					else sh.fill[atomicAdd(&sh.numFill, 1u)] = make_uint4(idx | (level << 19), X, Y, Z);
+				}
 			}
 			if (t == 0u) { a.nodes[L].numPoints = 0; a.nodes[L].points = nullptr; }          // voxels.cu:359-360 (its points are in the spill buffer, its chunks on the recycle stack: k_queue, k_hist)
 			// the nodes of the cascade that hold samples and stay leaves (one that was queued again is none by the time its chunks would be used)
@@ -1173,6 +1218,15 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			}
 			// ... and their chunks, 64 leaves at a time (voxels.cu:485-538; the nodes written above are this workgroup's own stores: visible after the barrier)
 			__syncthreads();
+			for (uint32_t j = 0; j < sh.numFill; j++) {                          // the top table's cells under the big new leaves, all threads
+				const uint4 f = sh.fill[j];
+				const uint32_t flevel = f.x >> 19, k = TOP_LEVEL - flevel, side = 1u << k;
+				uint32_t* top = at<uint32_t>(a, a.offTop);
+				for (uint32_t i = t; i < (1u << (3u * k)); i += ETPB) {
+					const uint32_t dx = i >> (2u * k), dy = (i >> k) & (side - 1u), dz = i & (side - 1u);
+					top[(((f.y << k) + dx) << (2u * TOP_LEVEL)) | (((f.z << k) + dy) << TOP_LEVEL) | ((f.w << k) + dz)] = f.x;
+				}
+			}
 			for (uint32_t first = 0; first < sh.numFresh; first += ALLOC_LEAVES) {
 				alloc_points(a, ctl, bc, sh.alloc, nullptr, sh.fresh, first, sh.numFresh);
 				__syncthreads();
@@ -1683,35 +1737,38 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 		}
 		__syncthreads();
 		ph.mark(26);
-		// levels 2 .. 7: the winners of the level below, a list entry per lane
-		for (uint32_t d = 2; d <= ldsDepth; d++) {
-			const uint32_t n = sh.listCount[d - 1u];
-			if (n == 0u) break;                                                    // (uniform: read after a barrier)
-			const uint32_t* src = sh.list + list_offset(d - 1u);
-			uint32_t* dst = sh.list + list_offset(d);
-			// four entries of a thread at a time (their LDS round trips overlap)
-			auto four = [&](const uint32_t e0, const uint32_t e1, const uint32_t e2, const uint32_t e3) {
-				const uint32_t e[4] = {e0, e1, e2, e3};
-				uint32_t word[4], bit[4], old[4];
+		// levels 2 .. 7: the winners of level 1, a list entry per lane, climb on INSIDE their wave — no workgroup barrier per level (six of them
+		// cost more than the climbing): a wave takes four entries per lane, tests and sets their cells level by level while any of them still
+		// finds its cell clear, and appends each level's winners to that level's list (one reservation per wave and level).  Waves never need
+		// each other: the cubes of different levels are different words, and a cell has ONE winner whoever gets there first.
+		{
+			const uint32_t n1 = sh.listCount[1];
+			const uint32_t* src = sh.list + list_offset(1u);
+			for (uint32_t i0 = 0; i0 < n1 && ldsDepth >= 2u; i0 += 4u * VTPB) {
+				uint32_t e[4];
+				bool go[4];
 #pragma unroll
-				for (uint32_t q = 0; q < 4; q++) { cube_cell_from(d, e[q] & 0x3ffffu, word[q], bit[q]); old[q] = e[q] != NONE ? sh.occ[word[q]] : 0xffffffffu; }
+				for (uint32_t q = 0; q < 4; q++) { const uint32_t i = i0 + q * VTPB + threadIdx.x; go[q] = i < n1; e[q] = go[q] ? src[i] : 0u; }
+				for (uint32_t d = 2; d <= ldsDepth; d++) {
+					if (__ballot(go[0] || go[1] || go[2] || go[3]) == 0ull) break;      // (wave-uniform)
+					uint32_t* dst = sh.list + list_offset(d);
+					uint32_t word[4], bit[4], old[4];
 #pragma unroll
-				for (uint32_t q = 0; q < 4; q++) if (((old[q] >> bit[q]) & 1u) == 0u) old[q] = atomicOr(&sh.occ[word[q]], 1u << bit[q]);
+					for (uint32_t q = 0; q < 4; q++) { cube_cell_from(d, e[q] & 0x3ffffu, word[q], bit[q]); old[q] = go[q] ? sh.occ[word[q]] : 0xffffffffu; }
 #pragma unroll
-				for (uint32_t q = 0; q < 4; q++) {
-					const bool win = ((old[q] >> bit[q]) & 1u) == 0u;
-					const unsigned long long wm = __ballot(win);
-					if (wm != 0ull) {
-						uint32_t base = 0;
-						if (lane == 0u) base = atomicAdd(&sh.listCount[d], (uint32_t)__popcll(wm));
-						base = (uint32_t)__shfl((int)base, 0, 64);
-						if (win) dst[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = e[q];
+					for (uint32_t q = 0; q < 4; q++) if (((old[q] >> bit[q]) & 1u) == 0u) old[q] = atomicOr(&sh.occ[word[q]], 1u << bit[q]);
+#pragma unroll
+					for (uint32_t q = 0; q < 4; q++) {
+						go[q] = ((old[q] >> bit[q]) & 1u) == 0u;                    // lost: the winner climbs on
+						const unsigned long long wm = __ballot(go[q]);
+						if (wm != 0ull) {
+							uint32_t base = 0;
+							if (lane == 0u) base = atomicAdd(&sh.listCount[d], (uint32_t)__popcll(wm));
+							base = (uint32_t)__shfl((int)base, 0, 64);
+							if (go[q]) dst[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = e[q];
+						}
 					}
 				}
-			};
-			for (uint32_t i0 = 0; i0 < n; i0 += 4u * VTPB) {
-				const uint32_t i = i0 + threadIdx.x;
-				four(i < n ? src[i] : NONE, i + VTPB < n ? src[i + VTPB] : NONE, i + 2u * VTPB < n ? src[i + 2u * VTPB] : NONE, i + 3u * VTPB < n ? src[i + 3u * VTPB] : NONE);
 			}
 			__syncthreads();
 		}
@@ -2063,6 +2120,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t g
 	a.offChunkDir = off; off += align_up(2ull * a.dirCap * 8, 256);            // (two copies, by batch parity)
 	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
+	a.offTop = off;   off += align_up((uint64_t)TOP_CELLS * 4, 256);
 	a.voxItemCap = min(a.nodeCapacity + 2u * VOX_BIG_ITEMS, 1u << 20);         // VOX_BIG_ITEMS pieces + small items: a leaf has one more than its new samples / 128, and 65 536 x 128 = 8 M samples
 	a.offVoxItems = off; off += align_up(2ull * a.voxItemCap * sizeof(VoxItem), 256);   // (two copies, by batch parity)
 	// what is left is shared by the per-sample arrays: the 4-byte cached-leaf word of the group's and of the moved samples, 16 B per moved point.
@@ -2156,7 +2214,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
 		if (e != hipSuccess) return (int)e;
 		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(k_paths, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(k_paths, dim3(std::max<uint32_t>((a.nodeCapacity + TPB - 1) / TPB, TOP_CELLS / TPB)), dim3(TPB), stream, a);   // (also one thread per cell of the top table)
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):

@@ -259,3 +259,76 @@ def test_gather_beyond_capacity_sliced_routing_and_pipelined_frames(built_libs, 
     exchange; VisibleOverflow beyond the array), routing in slices delivers exactly what routing at once delivers, and frames composed with
     two in flight are the frames composed one after the other."""
     mp.spawn(_worker_hardening, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _rank_octrees(pts, box, world, u):
+    """The per-rank octrees of the multi-GPU layer (level-3 cells dealt by point count), built by the oracle in one process."""
+    import oracle
+    from simlod_amd import abi, distributed
+    t = torch.from_numpy(np.ascontiguousarray(pts).view(np.uint8).reshape(-1, 16).copy())
+    codes = distributed.cell_codes(t, box, 3)
+    owner, _ = distributed.balanced_owners(codes, world, 3)
+    dest = owner[codes].numpy()
+    trees = []
+    for r in range(world):
+        o = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+        o.reset(u)
+        o.add_points(u, pts[dest == r])
+        trees.append(o)
+    return trees
+
+
+def test_composed_frame_equals_the_single_gpu_frame_unless_a_rank_keeps_an_upper_node_as_a_leaf(built_libs):
+    """Pins DESIGN.md §9's "known limit": ranks own level-3 cells of ONE global cube, so below level 3 a rank's octree IS the single-GPU
+    octree's subtree; the nodes above (levels 0-2) are shared, and each rank grows them from its own points only.  Their voxels are the
+    same cells (a cell of an upper node's grid lies inside one level-3 cell: exactly one rank can set it), so the composed frame has the
+    single-GPU frame's DEPTH at every pixel — unless an upper node that is INNER in the single-GPU octree stays a LEAF on some rank (the
+    rank holds fewer than 50 000 points under it): that rank draws the node's points where a single GPU draws the node's voxels.  Then, and
+    only then, the frames differ, and only inside the screen boxes of those nodes."""
+    import oracle
+    from simlod_amd import abi, camera, synthetic
+    W = H = 256
+    world = 2
+    # uniform 1.6 M: the single octree's inner nodes above level 3 are the root and the eight level-1 nodes (200 000 points each, ~100 000 of them
+    #                on either rank: inner there too); the level-2 nodes are leaves on one GPU and on the ranks.
+    # terrain 3 M:   one level-2 node at the edge of the terrain is inner in the single octree and a leaf on the rank that owns few of its cells.
+    for name, (pts, box), expect_equal in (("uniform 1.6 M", synthetic.uniform_cube(1_600_000, seed=8), True),
+                                           ("terrain 3 M", synthetic.terrain(3_000_000, seed=4, box=(600.0, 400.0, 40.0)), False)):
+        T = camera.lookat_transform((2.4 * box[0], -2.0 * box[1], 2.2 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)     # far: upper nodes are drawn by their voxels
+        u = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
+        single = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+        single.reset(u)
+        single.add_points(u, pts)
+        fb_single, _ = single.render(u)
+        trees = _rank_octrees(pts, box, world, u)
+        fb = np.minimum.reduce([t.render(u)[0] for t in trees])                 # the composition of distributed.render_frame for a plain frame
+        ds = single.dump()
+        inner_single = {(int(d["level"]), int(d["X"]), int(d["Y"]), int(d["Z"])) for d in ds if d["level"] < 3 and not d["isLeaf"]}
+        culprits = []                                                             # upper nodes that are inner in the single octree but a (non-empty) leaf on a rank
+        for t in trees:
+            for d in t.dump():
+                key = (int(d["level"]), int(d["X"]), int(d["Y"]), int(d["Z"]))
+                if d["level"] < 3 and d["isLeaf"] and d["numPoints"] > 0 and key in inner_single:
+                    culprits.append(key)
+        depth_equal = np.array_equal(fb >> np.uint64(32), fb_single >> np.uint64(32))
+        if expect_equal:
+            assert not culprits, (name, culprits)
+            assert depth_equal, f"{name}: every rank refines the shared upper nodes: the composed frame must have the single-GPU frame's depth everywhere"
+        else:
+            assert culprits, f"{name}: expected a rank with fewer than 50 000 points under a shared node"
+            # the frames may differ only inside the screen boxes of those nodes
+            bad = np.nonzero((fb >> np.uint64(32)) != (fb_single >> np.uint64(32)))[0]
+            size = float(max(box))
+            M = np.asarray(T, dtype=np.float32).reshape(4, 4)
+            allowed = np.zeros(W * H, dtype=bool)
+            for (lv, X, Y, Z) in set(culprits):
+                s = size / 2 ** lv
+                cs = np.array([[(X + a) * s, (Y + b) * s, (Z + c) * s, 1.0] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=np.float32)
+                clip = cs @ M.T
+                px = (clip[:, 0] / clip[:, 3] * 0.5 + 0.5) * W
+                py = (clip[:, 1] / clip[:, 3] * 0.5 + 0.5) * H
+                x0, x1 = max(int(px.min()) - 2, 0), min(int(px.max()) + 3, W)
+                y0, y1 = max(int(py.min()) - 2, 0), min(int(py.max()) + 3, H)
+                m = np.zeros((H, W), dtype=bool); m[y0:y1, x0:x1] = True
+                allowed |= m.reshape(-1)
+            assert allowed[bad].all(), f"{name}: {int((~allowed[bad]).sum())} differing pixels lie outside the screen boxes of the nodes a rank kept as leaves"

@@ -37,5 +37,13 @@ for k, v in summ["hbm_traffic"].items():
         out[k] = total / frames
     elif k == "r_visible":                                              # both modes' frames (it clears 8 B/px for a plain frame, 36 B/px for an HQS one: the mean)
         out[k] = total / (frames * 2)
+for k, v in summ.get("hbm_traffic_close", {}).items():                  # the close-up preset's frames (bench.py --raster-presets close --frames 4: 2 + 4 frames per mode)
+    total = v["fetch_bytes_x2"] + v["write_bytes"]
+    if k in names:
+        out["close/" + names[k]] = total / frames
+    elif k in ("r_output<true>", "r_output<false>", "r_resolve"):
+        out["close/" + k] = total / frames
+    elif k == "r_visible":
+        out["close/" + k] = total / (frames * 2)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"traffic_{tag}.json"), "w"), indent=1)
 print(json.dumps({k: round(v / 1e6, 2) for k, v in out.items() if not k.startswith("_")}), "MB")

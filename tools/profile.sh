@@ -24,6 +24,12 @@ pass pmc_sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 pass pmc_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
 pass pmc_atomic TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum
 pass pmc_atomic2 TCC_EA0_ATOMIC_LEVEL_sum TCC_EA0_RDREQ_sum
+# the close-up camera preset (most samples of the near leaves leave their tiles): the byte passes of the raster kernels alone
+CMDC="python $REPO/bench.py --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-profile --raster-presets close"
+passc() { local name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- $CMDC > /dev/null 2> $OUT/$name.err || echo "pass $name failed" >> $OUT/failed.txt; }
+passc pmc_fetch_close FETCH_SIZE
+passc pmc_write_close WRITE_SIZE
+passc pmc_atomic_close TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum
 cd $REPO
 python tools/summarize_profile.py $OUT $TAG
 find $OUT -name "*.csv" -size +3M -delete

@@ -32,7 +32,8 @@ if trace:
 for name, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]),
                        ("pmc_sq", ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]),
                        ("pmc_lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS"]),
-                       ("pmc_atomic", ["TCC_EA0_ATOMIC_sum", "TCC_ATOMIC_sum"]), ("pmc_atomic2", ["TCC_EA0_ATOMIC_LEVEL_sum", "TCC_EA0_RDREQ_sum"])):
+                       ("pmc_atomic", ["TCC_EA0_ATOMIC_sum", "TCC_ATOMIC_sum"]), ("pmc_atomic2", ["TCC_EA0_ATOMIC_LEVEL_sum", "TCC_EA0_RDREQ_sum"]),
+                       ("pmc_fetch_close", ["FETCH_SIZE"]), ("pmc_write_close", ["WRITE_SIZE"]), ("pmc_atomic_close", ["TCC_EA0_ATOMIC_sum", "TCC_ATOMIC_sum"])):
     path = find(f"{name}/**/*counter_collection.csv")
     if not path:
         continue
@@ -57,6 +58,13 @@ if "pmc_fetch" in summary and "pmc_write" in summary:
         traffic[k] = {"dispatches": v["dispatches"], "fetch_bytes_raw": v["FETCH_SIZE"] * 1024, "fetch_bytes_x2": v["FETCH_SIZE"] * 2048,
                       "write_bytes": w["WRITE_SIZE"] * 1024}
 summary["hbm_traffic"] = traffic
+traffic_close = {}
+if "pmc_fetch_close" in summary and "pmc_write_close" in summary:          # the raster kernels of the close-up preset
+    for k, v in summary["pmc_fetch_close"].items():
+        if k.startswith("r_"):
+            w = summary["pmc_write_close"].get(k, {"WRITE_SIZE": 0.0})
+            traffic_close[k] = {"dispatches": v["dispatches"], "fetch_bytes_raw": v["FETCH_SIZE"] * 1024, "fetch_bytes_x2": v["FETCH_SIZE"] * 2048, "write_bytes": w["WRITE_SIZE"] * 1024}
+summary["hbm_traffic_close"] = traffic_close
 # wave-level picture per kernel: share of wave cycles spent waiting (s_waitcnt / barriers), issuing, stalled at issue
 if "pmc_sq" in summary:
     for k, v in summary["pmc_sq"].items():
