@@ -40,8 +40,10 @@ struct RenderArgs {
 	int32_t      W, H, pointSize;
 	uint32_t     numPixels, nodeCapacity, frameCounter;
 	uint8_t      showPoints, colorByNode, colorByLOD, hqs;
-	uint64_t     offWork, offItems, offDepth, offColor, offOverflow, offDir;
+	uint64_t     offWork, offItems, offDepth, offColor, offOverflow, offDir, offBinPool, offBinSegs, offBinSegCount;
 	uint32_t     itemCap, useTiles, launchSeq;
+	uint32_t     useBins, binTilesX, binTiles, binPoolCap, binMinArea, binsPossible;
+	uint32_t*    binFeedback;                       // page-locked: the frame's first draw pass stores here how many nodes sort, or would (launch_render)      // screen bins of the samples that leave their item's tile (r_overflow): tiles per row, tiles in all, entries in the pool
 	// the builder's leaf chunk table (simlod_internal.hpp LeafTableRef), or table == nullptr: r_visible walks every list
 	const SimlodChunk* const* leafTable;
 	const uint32_t* leafTableMagic;
@@ -52,7 +54,7 @@ struct RenderArgs {
 };
 
 // work area: [0..2] draw cursors of the three draw modes, [3] unused, [4] chunk directory entries in use, [8..11] draw items per size class
-static constexpr int WORK_WORDS = 12;
+static constexpr int WORK_WORDS = 15;                // ... [12] entries taken from the bin pool, [13] samples that were binned (first draw pass), [14] nodes that sort or would
 // Draw items are queued by size, biggest first (longest-processing-time order): the draw workgroups take items from one shared
 // cursor, and a 64 000-sample item taken last would keep one CU busy long after the others ran dry (measured on the bench frame:
 // average workgroup 55 us, slowest 92 us with the items in emission order).  Class of an item = its chunk count: > 16, > 8, > 4, rest;
@@ -77,6 +79,20 @@ struct DrawItem {
 };
 static_assert(sizeof(DrawItem) == 32, "tools/raster_items.py reads draw items as 32-byte records");
 static constexpr int TILE = 128;
+// Screen bins.  A node close to the camera is larger on screen than any LDS tile and its samples are thinly spread (fewer than one per
+// pixel): each of them used to be one device-scope atomic on the framebuffer, and ~25 G scattered 64-bit atomics per second is all the
+// memory system does (measured: 2 M such samples = 80 us whatever the number of CUs that issue them — the whole close-up frame took twice
+// the time of the bird's-eye frame with fewer samples).  The draw items of such a node do not rasterise: they SORT — every sample becomes a
+// 16-byte entry in the queue of the 64 x 64-pixel screen bin it falls into (two passes over the item's samples: count per tile in LDS,
+// ONE reservation per item and tile, then store) — and r_overflow gives every screen tile one workgroup that rasterises the tile's queue in
+// LDS and merges it into the plane with plain loads and stores (the tile's pixels are nobody else's in that kernel).
+static constexpr int TILE_BINNED = -2;                     // DrawItem::tileX of such an item
+static constexpr uint32_t BIN_SHIFT = 5, BIN = 1u << BIN_SHIFT;   // a bin = 32 x 32 pixels: 2074 of them at 1920 x 1080 — the terrain towards the horizon of a close-up is a strip of three hundred
+static constexpr uint32_t BIN_ITEM_CHUNKS = 8;            // a sorting item: 16 000 samples, 16 per thread — kept in registers between the count and the store
+static constexpr uint32_t BIN_POOL_ENTRIES = 3000000;      // 48 MB of entries per frame and pass: the buffer stays inside the host's 200 MB at 1920 x 1080 (main_progressive_octree.cpp:555) (what does not fit: device-scope atomics, as before)
+static constexpr uint32_t BIN_SEG_CAP = 256;               // segments (item x bin) a bin can list
+static constexpr uint32_t BIN_MAX_TILES = 8704;            // (3840 x 2160 pixels: 8228) the per-bin counters of a sorting workgroup live in its LDS; larger frames do not sort
+struct BinSeg { uint32_t base, count; };
 static constexpr int TILE_EXACT_AREA = TILE * TILE / 2;   // HQS colour: tiles up to this area keep two 64-bit words per pixel (exact 32-bit sums)
 static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a frame: 2 G visible samples
 
@@ -105,6 +121,7 @@ __device__ __forceinline__ void clear_frame(const RenderArgs& a) {
 	};
 	const uint32_t lo = (uint32_t)SIMLOD_CLEAR_PIXEL, hi = (uint32_t)(SIMLOD_CLEAR_PIXEL >> 32);
 	fill(R_OFF_FB, (uint64_t)a.numPixels * 8, make_uint4(lo, hi, lo, hi), SIMLOD_CLEAR_PIXEL, 8);
+	if (a.useBins) { uint32_t* segCount = reinterpret_cast<uint32_t*>(a.mom + a.offBinSegCount); for (uint32_t i = first; i < a.binTiles; i += stride) segCount[i] = 0u; }
 	if (a.hqs) {
 		fill(a.offDepth, (uint64_t)a.numPixels * 4, make_uint4(0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u), 0x7f800000u, 4);
 		fill(a.offColor, (uint64_t)a.numPixels * 8, make_uint4(0, 0, 0, 0), 0ull, 8);
@@ -246,7 +263,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	// reaches behind the camera has no box and no tile.
 	int tileX = -1, tileY = -1;
 	uint32_t tileW = TILE, tileH = TILE;
-	bool noTile = draws;
+	bool noTile = draws, sorts = false;
 	if (draws && a.useTiles) {
 		const float nodeSize = a.cubeSize / exp2_int(level);
 		float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
@@ -264,15 +281,23 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 			const int x0 = max((int)mnx - 1, 0), y0 = max((int)mny - 1, 0);
 			const int x1 = min((int)fminf(mxx, 1.0e6f) + a.pointSize + 2, a.W + 1), y1 = min((int)fminf(mxy, 1.0e6f) + a.pointSize + 2, a.H + 1);
 			const int bw = max(x1 - x0, 1), bh = max(y1 - y0, 1);
-			tileW = (uint32_t)min(bw, TILE); tileH = (uint32_t)min(bh, TILE);
+			// the tile takes the box's shape: TILE x TILE words, as wide or as high as the box asks for (a node seen at a grazing angle — the
+			// terrain towards the horizon of a close-up — is a strip of 1000 x 40 pixels: under a square tile most of its samples went outside)
+			if (bh <= bw) { tileH = (uint32_t)min(bh, TILE); tileW = (uint32_t)min(bw, TILE * TILE / (int)tileH); }
+			else { tileW = (uint32_t)min(bw, TILE); tileH = (uint32_t)min(bh, TILE * TILE / (int)tileW); }
 			tileX = x0 + (bw - (int)tileW) / 2; tileY = y0 + (bh - (int)tileH) / 2;
 			noTile = false;
-		}
+			sorts = a.binsPossible && (uint32_t)bw * (uint32_t)bh > a.binMinArea;                 // much larger than a tile: its samples are sorted into the screen bins
+		} else sorts = a.binsPossible != 0u;                                                      // reaches behind the camera: no box, no tile — sorted
+		if (sorts && a.useBins) { tileX = TILE_BINNED; noTile = false; }
 	}
+	// (launch_render leaves the bins out of a frame — two kernels — when the buffer's previous frame had nothing to sort: this frame tells the next)
+	const uint32_t waveSorts = (uint32_t)__popcll(__ballot(sorts));
 	// ... and their size: up to ITEM_CHUNKS chunks; an eighth of that for a node without a tile: every sample of such an item is a scattered
 	// global atomic, 64 memory transactions per wave instruction — a 32 000-sample item of that kind took ~100 us, the frame's makespan in the
 	// close-up preset; short ones spread over the CUs (and have no tile to clear or flush)
-	const uint32_t perItem = noTile ? ITEM_CHUNKS / 8u : ITEM_CHUNKS;
+	const uint32_t perItem = noTile ? ITEM_CHUNKS / 8u : tileX == TILE_BINNED ? BIN_ITEM_CHUNKS : ITEM_CHUNKS;
+	const uint32_t weight = tileX == TILE_BINNED ? 2u : 1u;                                 // a sorting item takes what a tile item of twice its samples takes: it queues with those
 	uint32_t numChunks[2], pieces[2];
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
@@ -289,7 +314,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
 		if (pieces[l] == 0u) continue;
-		const uint32_t fullClass = item_class(perItem), lastClass = item_class(numChunks[l] - (pieces[l] - 1u) * perItem);
+		const uint32_t fullClass = item_class(perItem * weight), lastClass = item_class((numChunks[l] - (pieces[l] - 1u) * perItem) * weight);
 #pragma unroll
 		for (int cl = 0; cl < ITEM_CLASSES; cl++) myClass[cl] += (fullClass == (uint32_t)cl ? pieces[l] - 1u : 0u) + (lastClass == (uint32_t)cl ? 1u : 0u);
 	}
@@ -306,6 +331,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	if (lane_id() == 0) {
 		wait_frame_ready(a);
 		slot = atomicAdd(counter_at(a, C_VISIBLE), waveSlots);
+		if (waveSorts != 0u) atomicAdd(work + 14, waveSorts);
 		if (waveChunks != 0u) {
 			dirBase = atomicAdd(work + 4, waveChunks);
 #pragma unroll
@@ -347,7 +373,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 			const uint32_t have = min(counts[l], k * SIMLOD_POINTS_PER_CHUNK);      // a list shorter than its counter says: draw what is there
 			for (uint32_t p = 0; p < pieces[l]; p++) {
 				const uint32_t firstSample = p * perItem * SIMLOD_POINTS_PER_CHUNK;
-				const uint32_t cl = p + 1u < pieces[l] ? item_class(perItem) : item_class(numChunks[l] - p * perItem);
+				const uint32_t cl = p + 1u < pieces[l] ? item_class(perItem * weight) : item_class((numChunks[l] - p * perItem) * weight);
 				uint32_t at = 0;
 #pragma unroll
 				for (int q = 0; q < ITEM_CLASSES; q++) if (cl == (uint32_t)q) at = classBase[q]++;
@@ -700,6 +726,149 @@ __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* c
 	}
 }
 
+// One item of a node that is much larger than a tile (DrawItem::tileX == TILE_BINNED): its samples are sorted into the screen bins.  Every
+// thread projects its <= 16 samples ONCE and keeps {bin, pixel inside it, value} in registers, counting per bin in LDS; then the workgroup
+// scans the counters, takes ALL its entries from the pool with ONE atomic (every item of the frame reserves on that word: one atomic per
+// item and bin on it took 11 ns each, 200 us a frame) and lists one segment per bin with samples; then every sample writes its entry.
+// Value: depth | colour (plain frames), depth (HQS depth pass), colour of an ACCEPTED sample (HQS colour pass, render.cu:485-493).  Pool
+// exhausted: the item's samples take the device-scope atomics, as before; a bin's list full: that bin's.
+template <int MODE>
+__device__ __forceinline__ void bin_item(const DrawCtx& c, const RenderArgs& a, uint32_t* lds, const SimlodChunk* const* dir, uint32_t count, uint32_t overrideColor, bool useOverride,
+                                         uint32_t& outside) {
+	// (opaque to the optimiser: what depends on the thread only — chunk and offset of each of its 16 samples, the addresses of its bins' words —
+	// was hoisted out of r_draw's item loop and occupied 40 registers for the whole kernel: every draw path spilled)
+	uint32_t tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
+	uint32_t* cnt = lds;                           // [binTiles]: samples of this item per bin, then the cursor inside the segment
+	uint32_t* base = lds + BIN_MAX_TILES;          // [binTiles]: first pool entry of the item's segment in that bin, or NONE
+	uint32_t* scratch = lds + 2 * BIN_MAX_TILES;   // [16] sums of the waves, [16] the item's first pool entry
+	constexpr uint32_t NONE = 0xffffffffu, DU = 4, SLOTS = (BIN_ITEM_CHUNKS * SIMLOD_POINTS_PER_CHUNK + DTPB - 1) / DTPB;
+	static_assert(SLOTS % DU == 0, "a thread's samples come in batches of DU loads");
+	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
+	uint32_t* segCount = reinterpret_cast<uint32_t*>(a.mom + a.offBinSegCount);
+	BinSeg* segs = reinterpret_cast<BinSeg*>(a.mom + a.offBinSegs);
+	uint4* pool = reinterpret_cast<uint4*>(a.mom + a.offBinPool);
+	for (uint32_t t = tid; t < a.binTiles; t += DTPB) cnt[t] = 0u;
+	__syncthreads();
+	uint32_t key[SLOTS], lo[SLOTS], hi[SLOTS];     // bin << 10 | pixel inside the bin, or NONE; the value's halves
+#pragma unroll
+	for (uint32_t r = 0; r < SLOTS / DU; r++) {
+		float4 p[DU];
+		bool have[DU];
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) {
+			const uint32_t sIdx = (r * DU + u) * DTPB + tid;
+			have[u] = sIdx < count;
+			p[u] = have[u] ? reinterpret_cast<const float4*>(dir[sIdx / SIMLOD_POINTS_PER_CHUNK]->points)[sIdx % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
+		}
+		uint32_t pixel[DU];
+		float depth[DU];
+		bool valid[DU];
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) {
+			const uint32_t k = r * DU + u;
+			const float cx = dot_row(c.r0, p[u].x, p[u].y, p[u].z);
+			const float cy = dot_row(c.r1, p[u].x, p[u].y, p[u].z);
+			depth[u] = dot_row(c.r3, p[u].x, p[u].y, p[u].z);
+			const float nx = cx / depth[u], ny = cy / depth[u];
+			const double fx = ((double)nx * 0.5 + 0.5) * (double)c.width;
+			const double fy = ((double)ny * 0.5 + 0.5) * (double)c.height;
+			const int x = (int)fx, y = (int)fy;
+			valid[u] = have[u] && (x > 1 && (double)x < c.wlim) && (y > 1 && (double)y < c.hlim);
+			if (MODE != MODE_MIN64) valid[u] = valid[u] && depth[u] > 0.0f;
+			const int px = min(max(x, 0), c.W), py = min(max(y, 0), c.H);
+			pixel[u] = (uint32_t)px + (uint32_t)c.W * (uint32_t)py;
+			valid[u] = valid[u] && pixel[u] < c.numPixels;
+			const uint32_t bin = ((uint32_t)py >> BIN_SHIFT) * a.binTilesX + ((uint32_t)px >> BIN_SHIFT);
+			key[k] = (bin << (2 * BIN_SHIFT)) | (((uint32_t)py & (BIN - 1u)) << BIN_SHIFT) | ((uint32_t)px & (BIN - 1u));
+			const uint32_t color = useOverride ? overrideColor : __float_as_uint(p[u].w);
+			lo[k] = MODE == MODE_DEPTH ? __float_as_uint(depth[u]) : color;
+			hi[k] = MODE == MODE_MIN64 ? __float_as_uint(depth[u]) : 0u;
+		}
+		if (MODE == MODE_COLOR) {                                           // render.cu:485-493
+			uint32_t ref[DU];
+#pragma unroll
+			for (uint32_t u = 0; u < DU; u++) ref[u] = c.depth[valid[u] ? pixel[u] : 0u];
+#pragma unroll
+			for (uint32_t u = 0; u < DU; u++) valid[u] = valid[u] && depth[u] < __uint_as_float(ref[u]) * 1.01f;
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) {
+			const uint32_t k = r * DU + u;
+			if (valid[u]) atomicAdd(&cnt[key[k] >> (2 * BIN_SHIFT)], 1u); else key[k] = NONE;
+		}
+
+	}
+	__syncthreads();
+	// exclusive scan of the counters over the workgroup -> every bin's offset inside the item's reservation
+	uint32_t carry = 0;
+	for (uint32_t t0 = 0; t0 < a.binTiles; t0 += DTPB) {               // uniform
+		const uint32_t t = t0 + tid;
+		const uint32_t n = t < a.binTiles ? cnt[t] : 0u;
+		const uint32_t before = wave_prefix_u32(n), waveTotal = wave_sum_u32(n);
+		if (lane_id() == 0) scratch[tid / 64u] = waveTotal;
+		__syncthreads();
+		uint32_t waveBase = 0, roundTotal = 0;
+		for (uint32_t w = 0; w < DTPB / 64u; w++) { const uint32_t v = scratch[w]; waveBase += w < tid / 64u ? v : 0u; roundTotal += v; }
+		if (t < a.binTiles) base[t] = carry + waveBase + before;
+		carry += roundTotal;
+		__syncthreads();
+	}
+	// the item's entries and, per bin, a place in the bin's list: all reservations in flight together (a list place taken in vain — pool
+	// exhausted — holds an empty segment)
+	constexpr uint32_t ROUNDS = (BIN_MAX_TILES + DTPB - 1) / DTPB;
+	uint32_t seg[ROUNDS];
+#pragma unroll
+	for (uint32_t q = 0; q < ROUNDS; q++) {
+		const uint32_t t = q * DTPB + tid;
+		seg[q] = t < a.binTiles && cnt[t] != 0u ? atomicAdd(&segCount[t], 1u) : NONE;
+	}
+	if (tid == 0) {
+		uint32_t at = NONE;
+		if (carry != 0u) { at = atomicAdd(work + 12, carry); if ((unsigned long long)at + carry > a.binPoolCap) at = NONE; }
+		scratch[16] = at;
+	}
+	__syncthreads();
+	const uint32_t itemBase = scratch[16];
+	uint32_t binned = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < ROUNDS; q++) {
+		const uint32_t t = q * DTPB + tid;
+		if (t >= a.binTiles) continue;
+		const uint32_t n = cnt[t];
+		uint32_t b = NONE;
+		if (seg[q] < BIN_SEG_CAP) {
+			if (itemBase != NONE) { b = itemBase + base[t]; binned += n; }
+			segs[(uint64_t)t * BIN_SEG_CAP + seg[q]] = BinSeg{b != NONE ? b : 0u, b != NONE ? n : 0u};
+		}
+		base[t] = b; cnt[t] = 0u;
+	}
+	if (MODE != MODE_COLOR) { binned = wave_sum_u32(binned); if (lane_id() == 0 && binned != 0u) atomicAdd(work + 13, binned); }
+	__syncthreads();
+#pragma unroll
+	for (uint32_t k = 0; k < SLOTS; k++) {
+		if (key[k] == NONE) continue;
+		const uint32_t bin = key[k] >> (2 * BIN_SHIFT), local = key[k] & (BIN * BIN - 1u);
+		const uint32_t b = base[bin];
+		if (b != NONE) { pool[b + atomicAdd(&cnt[bin], 1u)] = make_uint4(lo[k], hi[k], local, 0u); continue; }
+		outside += 1u;                                                     // no room in the bins: the global path of draw_sample
+		const uint32_t px = ((bin % a.binTilesX) << BIN_SHIFT) | (local & (BIN - 1u)), py = ((bin / a.binTilesX) << BIN_SHIFT) | (local >> BIN_SHIFT);
+		const uint32_t pixel = px + (uint32_t)c.W * py;
+		if (MODE == MODE_MIN64) atomicMin(reinterpret_cast<unsigned long long*>(&c.fb[pixel]), ((unsigned long long)hi[k] << 32) | lo[k]);
+		else if (MODE == MODE_DEPTH) atomicMin(&c.depth[pixel], lo[k]);
+		else {
+			const unsigned long long r = lo[k] & 0xffu, g = (lo[k] >> 8) & 0xffu, bl = (lo[k] >> 16) & 0xffu;
+			const unsigned long long pk = bl | (g << 14) | (r << 28) | (1ull << 42);
+			const unsigned long long old = atomicAdd(&c.color[pixel], pk);
+			if ((old >> 42) >= 64ull) {
+				atomicAdd(&c.color[pixel], 0ull - pk);
+				atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
+				atomicAdd(&c.overflow[2 * pixel + 1], bl | (1ull << 32));
+			}
+		}
+	}
+}
+
 template <int MODE>
 __device__ __forceinline__ void tile_clear(const DrawCtx& c) {
 	const int words = c.tileW * c.tileH * (MODE == MODE_COLOR && c.tileExact ? 2 : 1);
@@ -742,7 +911,8 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	if (!a.showPoints) return;
 	__shared__ uint32_t sh_idx;
 	__shared__ const SimlodChunk* sh_dir[ITEM_CHUNKS];
-	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? TILE * TILE / 2 : TILE * TILE];
+	constexpr uint32_t BIN_WORDS = 2 * BIN_MAX_TILES + 32;                                  // bin_item's counters, in the tile's place
+	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? (TILE * TILE > BIN_WORDS ? TILE * TILE : BIN_WORDS) / 2 : TILE * TILE];
 	DrawCtx c;
 	c.tile = sh_tile; c.tile32 = reinterpret_cast<uint32_t*>(sh_tile); c.tileX = -1; c.tileY = -1; c.tileW = TILE; c.tileH = TILE; c.tileExact = false;
 	c.r0 = a.transform.rows[0]; c.r1 = a.transform.rows[1]; c.r3 = a.transform.rows[3];
@@ -755,6 +925,7 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	c.overflow = reinterpret_cast<unsigned long long*>(a.mom + a.offOverflow);
 	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
 	uint32_t* cursor = work + MODE;
+	if (MODE != MODE_COLOR && blockIdx.x == 0 && threadIdx.x == 0 && a.binFeedback != nullptr) *a.binFeedback = work[14];
 	uint32_t classEnd[ITEM_CLASSES];                                                       // position q of the cursor: class c while q < classEnd[c]
 	for (int cl = 0; cl < ITEM_CLASSES; cl++) classEnd[cl] = (cl > 0 ? classEnd[cl - 1] : 0u) + min(work[8 + cl], a.itemCap);
 	const uint32_t numItems = classEnd[ITEM_CLASSES - 1];
@@ -776,7 +947,8 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 			overrideColor = a.colorByNode ? node_color(node) : lod_color((int)node->level);
 			useOverride = true;
 		}
-		c.tileX = it.tileX; c.tileY = it.tileY; c.tileW = (int)(it.tileWH & 0xffffu); c.tileH = (int)(it.tileWH >> 16);
+		const bool binned = it.tileX == TILE_BINNED;
+		c.tileX = binned ? -1 : it.tileX; c.tileY = it.tileY; c.tileW = (int)(it.tileWH & 0xffffu); c.tileH = (int)(it.tileWH >> 16);
 		if (it.tileX < 0) { c.tileW = 0; c.tileH = 0; }                                       // no tile: nothing is inside it
 		c.tileExact = c.tileW * c.tileH <= TILE_EXACT_AREA;
 		bool gap = false;
@@ -792,7 +964,8 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 			while (whole < ITEM_CHUNKS && whole * SIMLOD_POINTS_PER_CHUNK < it.samples && sh_dir[whole] != nullptr) whole++;
 			samples = min(samples, whole * SIMLOD_POINTS_PER_CHUNK);
 		}
-		draw_item<MODE>(c, sh_dir, samples, overrideColor, useOverride, outside);
+		if (binned) bin_item<MODE>(c, a, reinterpret_cast<uint32_t*>(sh_tile), sh_dir, samples, overrideColor, useOverride, outside);
+		else draw_item<MODE>(c, sh_dir, samples, overrideColor, useOverride, outside);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
 		if (threadIdx.x == 0) const_cast<DrawItem*>(items)[itemAt].took = (uint32_t)(wall_clock64() - itemStart);
@@ -803,6 +976,102 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	if (MODE != MODE_COLOR) {                                                               // (the colour pass draws the same samples again)
 		outside = wave_sum_u32(outside);
 		if (lane_id() == 0 && outside != 0u) atomicAdd(counter_at(a, C_OUTSIDE_TILES), outside);
+	}
+}
+
+// ---- overflow: the screen bins (what the sorting items of r_draw queued) into the planes -----------------------------------------------
+// One workgroup per 32 x 32-pixel bin: the bin's pixels in LDS, every wave takes segments of the bin's list — consecutive 16-byte entries, four
+// of a lane in flight —, LDS atomics; then the touched pixels are merged into the plane with PLAIN loads and stores: r_draw has ended, and
+// in this kernel a pixel belongs to one workgroup.  The colour pass keeps exact 32-bit sums (two 64-bit words per pixel).  Leaves the bins
+// empty for the next pass.
+template <int MODE>
+__global__ __launch_bounds__(DTPB) void r_overflow(RenderArgs a) {
+	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
+	uint32_t* segCount = reinterpret_cast<uint32_t*>(a.mom + a.offBinSegCount);
+	const uint32_t T = blockIdx.x;
+	const uint32_t numSegs = min(segCount[T], BIN_SEG_CAP);
+	const uint64_t started = threadIdx.x == 0u ? wall_clock64() : 0ull;
+	if (T == 0u && threadIdx.x == 0u) work[12] = 0u;                 // (nobody appends in this kernel; this pass's entries stay where they are until the next pass overwrites them)
+	if (numSegs == 0u) return;
+	// (one workgroup per bin, not a few hundred that loop: a workgroup's bins would go one after the other, each three dependent round trips
+	// — 30 us against 24 for the close-up; what the 2000 workgroups of a frame without sorting items cost, 4 us, launch_render avoids)
+	constexpr uint32_t PIXELS = BIN * BIN, DU = 8;
+	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? PIXELS / 2 : MODE == MODE_COLOR ? 2 * PIXELS : PIXELS];
+	__shared__ BinSeg sh_segs[BIN_SEG_CAP];
+	uint32_t* tile32 = reinterpret_cast<uint32_t*>(sh_tile);
+	const uint4* pool = reinterpret_cast<const uint4*>(a.mom + a.offBinPool);
+	__shared__ uint32_t sh_first[BIN_SEG_CAP + 1], sh_waves[DTPB / 64];      // first chunk of every segment; [numSegs] = chunks in all
+	static_assert(BIN_SEG_CAP <= DTPB, "one thread per segment");
+	uint64_t* fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
+	uint32_t* depth = reinterpret_cast<uint32_t*>(a.mom + a.offDepth);
+	unsigned long long* overflow = reinterpret_cast<unsigned long long*>(a.mom + a.offOverflow);
+	const BinSeg* segs = reinterpret_cast<const BinSeg*>(a.mom + a.offBinSegs) + (uint64_t)T * BIN_SEG_CAP;
+	{
+		BinSeg seg = BinSeg{0u, 0u};
+		if (threadIdx.x < numSegs) { seg = segs[threadIdx.x]; sh_segs[threadIdx.x] = seg; }
+		const uint32_t n = (seg.count + 64u * DU - 1u) / (64u * DU);
+		const uint32_t before = wave_prefix_u32(n), waveTotal = wave_sum_u32(n);
+		if (lane_id() == 0) sh_waves[threadIdx.x / 64u] = waveTotal;
+		__syncthreads();
+		uint32_t waveBase = 0;
+		for (uint32_t w = 0; w < threadIdx.x / 64u; w++) waveBase += sh_waves[w];
+		if (threadIdx.x <= numSegs) sh_first[threadIdx.x] = waveBase + before;      // (thread numSegs has n = 0: its prefix is the total)
+	}
+	for (uint32_t t = threadIdx.x; t < PIXELS * (MODE == MODE_COLOR ? 2u : 1u); t += DTPB) {
+		if (MODE == MODE_DEPTH) tile32[t] = 0xffffffffu; else sh_tile[t] = MODE == MODE_COLOR ? 0ull : ~0ull;
+	}
+	__syncthreads();
+	const uint32_t numChunks = sh_first[numSegs];
+	// the list as chunks of 64 x DU entries: chunk c belongs to the segment whose first chunk is the last one <= c; waves take chunks in turn
+	// (a segment per wave left most waves idle: a bin lists 10-20 segments of 50 to 5000 entries)
+	for (uint32_t c = threadIdx.x / 64u; c < numChunks; c += DTPB / 64u) {
+		uint32_t sgLo = 0, sgHi = numSegs;                       // sh_first[sgLo] <= c < sh_first[sgHi]
+		while (sgHi - sgLo > 1u) { const uint32_t mid = (sgLo + sgHi) / 2u; if (sh_first[mid] <= c) sgLo = mid; else sgHi = mid; }
+		const BinSeg seg = sh_segs[sgLo];
+		const uint32_t first = (c - sh_first[sgLo]) * 64u * DU;
+		uint4 e[DU];
+		bool have[DU];
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) {
+			const uint32_t i = first + u * 64u + lane_id();
+			have[u] = i < seg.count;
+			e[u] = have[u] ? pool[seg.base + i] : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < DU; u++) {
+			if (!have[u]) continue;
+			const uint32_t local = e[u].z & (PIXELS - 1u);
+			if (MODE == MODE_MIN64) atomicMin(&sh_tile[local], ((unsigned long long)e[u].y << 32) | e[u].x);
+			else if (MODE == MODE_DEPTH) atomicMin(&tile32[local], e[u].x);
+			else {
+				atomicAdd(&sh_tile[2 * local + 0], (unsigned long long)(e[u].x & 0xffu) | ((unsigned long long)((e[u].x >> 8) & 0xffu) << 32));
+				atomicAdd(&sh_tile[2 * local + 1], (unsigned long long)((e[u].x >> 16) & 0xffu) | (1ull << 32));
+			}
+		}
+	}
+	__syncthreads();
+	const int x0 = (int)(T % a.binTilesX) * (int)BIN, y0 = (int)(T / a.binTilesX) * (int)BIN;
+	for (uint32_t t = threadIdx.x; t < PIXELS; t += DTPB) {
+		const int px = x0 + (int)(t & (BIN - 1u)), py = y0 + (int)(t >> BIN_SHIFT);
+		if (px >= a.W || py >= a.H) continue;                 // (a valid sample's pixel is inside (1, W - 2) x (1, H - 2): never a pixel of another bin's row)
+		const uint32_t pixel = (uint32_t)px + (uint32_t)a.W * (uint32_t)py;
+		if (MODE == MODE_MIN64) {
+			const unsigned long long v = sh_tile[t];
+			if (v != ~0ull && v < fb[pixel]) fb[pixel] = v;
+		} else if (MODE == MODE_DEPTH) {
+			const uint32_t v = tile32[t];
+			if (v != 0xffffffffu && v < depth[pixel]) depth[pixel] = v;
+		} else {
+			const unsigned long long rg = sh_tile[2 * t], bc = sh_tile[2 * t + 1];
+			if ((bc >> 32) != 0ull) { overflow[2 * pixel + 0] += rg; overflow[2 * pixel + 1] += bc; }      // exact: resolve adds the packed plane and the {R, G, B, count} plane
+		}
+	}
+	if (threadIdx.x == 0u) {
+		segCount[T] = 0u;
+		uint32_t entries = 0;
+		for (uint32_t k = 0; k < numSegs; k++) entries += sh_segs[k].count;
+		BinSeg* stat = reinterpret_cast<BinSeg*>(segCount + (a.binTiles + 3u) / 4u * 4u);          // measurement aid (tools/raster_bins.py): {entries, segments << 20 | 10 ns}
+		stat[T] = BinSeg{entries, (numSegs << 20) | min((uint32_t)(wall_clock64() - started), 0xfffffu)};
 	}
 }
 
@@ -1088,12 +1357,22 @@ __global__ __launch_bounds__(TPB) void k_reset(uint8_t* pers, SimlodNode* nodes,
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-static constexpr uint32_t MAX_DRAW_ITEMS = 400000;   // 100 000 visible nodes x 2 lists + slices of long voxel lists
+static constexpr uint32_t MAX_DRAW_ITEMS = 150000;   // per size class: 100 000 visible nodes, one list each, + slices of long lists
 static inline uint64_t align16(uint64_t v) { return (v + 15) / 16 * 16; }
+static inline uint32_t bin_tiles_x(uint32_t width) { return (width >> BIN_SHIFT) + 1u; }      // pixel columns 0..W (render.cu:91-92 clamps to W, not W - 1)
+static inline uint32_t bin_tiles(uint32_t width, uint32_t height) {
+	const uint64_t n = (uint64_t)bin_tiles_x(width) * ((height >> BIN_SHIFT) + 1u);
+	return n <= BIN_MAX_TILES ? (uint32_t)n : 0u;
+}
+static inline uint64_t bin_bytes(uint32_t width, uint32_t height) {                   // pool, segment lists, segment counters
+	const uint64_t tiles = bin_tiles(width, height);
+	return tiles == 0 ? 0 : (uint64_t)BIN_POOL_ENTRIES * 16 + tiles * BIN_SEG_CAP * sizeof(BinSeg) + align16(tiles * 4) + tiles * sizeof(BinSeg);
+}
 
 uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 	const uint64_t px = (uint64_t)width * height;
-	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * ITEM_CLASSES * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + (uint64_t)MAX_DIR_CHUNKS * 8 + 256;
+	return R_OFF_FB + align16(px * 8) + 256 + (uint64_t)MAX_DRAW_ITEMS * ITEM_CLASSES * sizeof(DrawItem) + align16(px * 4) + align16(px * 8) + px * 16 + (uint64_t)MAX_DIR_CHUNKS * 8 +
+	       bin_bytes(width, height) + 256;
 }
 
 int launch_reset(Context& ctx, const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
@@ -1147,6 +1426,19 @@ int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, Simlo
 	}
 	a.itemCap = MAX_DRAW_ITEMS;
 	a.useTiles = (uint32_t)ctx.tune(KNOB_RASTER_LDS_TILES, 1);
+	a.binTiles = bin_tiles(u->width, u->height); a.binTilesX = bin_tiles_x(u->width); a.binPoolCap = (uint32_t)min(max(ctx.tune(KNOB_DEBUG_BIN_POOL, (int)BIN_POOL_ENTRIES), 0), (int)BIN_POOL_ENTRIES);   // (tests: a pool that runs out)
+	// SIMLOD_RASTER_SCREEN_BINS: 0 = off, else the screen-box area from which a node sorts, in units of 1024 pixels (default: two tiles)
+	const int binKnob = ctx.tune(KNOB_RASTER_SCREEN_BINS, 32);
+	a.binsPossible = a.useTiles != 0u && a.binTiles != 0u && binKnob > 0 && a.pointSize == 1 ? 1u : 0u;
+	a.binMinArea = (uint32_t)max(binKnob, 0) * 1024u;
+	// ... and a frame sorts when the buffer's previous frame had nodes to sort (a frame that has none pays 4-5 us for two idle kernels; one that
+	// has some and does not sort them draws them the slow way, with the same result)
+	bool bins = a.binsPossible != 0u;
+	a.binFeedback = bins ? frame_feedback(ctx, buffer, (parts & RENDER_FIRST) != 0u, bins) : nullptr;
+	a.useBins = bins ? 1u : 0u;
+	a.offBinPool = a.offDir + (uint64_t)MAX_DIR_CHUNKS * 8;
+	a.offBinSegs = a.offBinPool + (uint64_t)BIN_POOL_ENTRIES * 16;
+	a.offBinSegCount = a.offBinSegs + (uint64_t)a.binTiles * BIN_SEG_CAP * sizeof(BinSeg);
 	// (what thread 0 of r_visible publishes once the frame's counters are zero: never the value a stale or poisoned buffer holds)
 	static std::atomic<uint32_t> launchSeq{(uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1u};
 	a.launchSeq = launchSeq.fetch_add(2u);
@@ -1166,11 +1458,18 @@ int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, Simlo
 	};
 	if (parts & RENDER_FIRST) {
 		SIMLOD_LAUNCH(r_visible, dim3(gridNodes), dim3(TPB), stream, a);
-		if (a.hqs) SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(DTPB), stream, a);
-		else { SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(DTPB), stream, a); lines(); }
+		if (a.hqs) {
+			SIMLOD_LAUNCH(r_draw<MODE_DEPTH>, dim3(gridDraw), dim3(DTPB), stream, a);
+			if (a.useBins) SIMLOD_LAUNCH(r_overflow<MODE_DEPTH>, dim3(a.binTiles), dim3(DTPB), stream, a);
+		} else {
+			SIMLOD_LAUNCH(r_draw<MODE_MIN64>, dim3(gridDraw), dim3(DTPB), stream, a);
+			if (a.useBins) SIMLOD_LAUNCH(r_overflow<MODE_MIN64>, dim3(a.binTiles), dim3(DTPB), stream, a);
+			lines();
+		}
 	}
 	if (a.hqs && (parts & RENDER_COLOR)) {
 		SIMLOD_LAUNCH(r_draw<MODE_COLOR>, dim3(gridDraw), dim3(DTPB), stream, a);
+		if (a.useBins) SIMLOD_LAUNCH(r_overflow<MODE_COLOR>, dim3(a.binTiles), dim3(DTPB), stream, a);
 		if (!whole) SIMLOD_LAUNCH(r_unpack, dim3(gridPixels), dim3(TPB), stream, a);     // ranks all-reduce(SUM) the {R,G,B,count} plane
 	}
 	// whole HQS frames without debug lines resolve inside r_output

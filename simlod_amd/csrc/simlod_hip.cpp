@@ -20,7 +20,7 @@ namespace simlod {
 const char* const KNOB_NAMES[KNOB_COUNT_] = {
 	"SIMLOD_OVERLAP_TAIL", "SIMLOD_EXPAND_WGS", "SIMLOD_GRID_MULT", "SIMLOD_COUNT_TPB", "SIMLOD_VOXELIZE_WGS", "SIMLOD_ADAPTIVE_GROUPS",
 	"SIMLOD_RASTER_LEAF_TABLE", "SIMLOD_RASTER_LDS_TILES", "SIMLOD_DRAW_MULT", "SIMLOD_RASTER_FUSED_RESOLVE",
-	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US", "SIMLOD_GROUP_BATCHES", "SIMLOD_DEBUG_PHASE_WG", "SIMLOD_EVENT_SYSTEM_FENCE",
+	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US", "SIMLOD_GROUP_BATCHES", "SIMLOD_DEBUG_PHASE_WG", "SIMLOD_EVENT_SYSTEM_FENCE", "SIMLOD_RASTER_SCREEN_BINS", "SIMLOD_DEBUG_BIN_POOL",
 };
 
 static std::atomic<uint32_t> g_liveContexts{0};
@@ -76,6 +76,7 @@ Context::~Context() {
 	// the page-locked feedback words: a copy enqueued by the context's last launches (on the CALLER's streams) may still be on its way
 	(void)hipDeviceSynchronize();
 	for (LaunchHistory& h : history) (void)hipHostFree(const_cast<uint32_t*>(h.seen));
+	for (FrameFeedback& f : frames) (void)hipHostFree(const_cast<uint32_t*>(f.seen));
 	for (hipEvent_t& e : gateEvent) if (e != nullptr) { (void)hipEventDestroy(e); e = nullptr; }
 	(void)hipGetLastError();
 }
@@ -207,6 +208,30 @@ void forget_launch_history(Context& ctx, const SimlodStats* stats) {
 	std::lock_guard<std::mutex> hold(ctx.historyLock);
 	LaunchHistory* h = history_of(ctx, stats, false);
 	if (h != nullptr) { h->seen[0] = NOTHING_SEEN; h->seen[1] = NOTHING_SEEN; h->havePrev = false; }
+}
+
+// ---- frame feedback: did the render buffer's previous frame have nodes that sort into the screen bins (render.hip r_overflow) ----------
+uint32_t* frame_feedback(Context& ctx, const void* buffer, bool firstPart, bool& bins) {
+	std::lock_guard<std::mutex> hold(ctx.framesLock);
+	FrameFeedback* f = nullptr;
+	for (FrameFeedback& g : ctx.frames) if (g.buffer == buffer) f = &g;
+	if (f == nullptr) {
+		volatile uint32_t* seen = nullptr;
+		if (ctx.frames.size() >= 64) {                       // the oldest entry makes room; its word is handed on (a late store into it: a stale hint)
+			seen = ctx.frames.front().seen;
+			ctx.frames.erase(ctx.frames.begin());
+		} else {
+			void* pinned = nullptr;
+			if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); bins = true; return nullptr; }
+			seen = static_cast<volatile uint32_t*>(pinned);
+		}
+		seen[0] = 1u;                                        // a buffer's first frame sorts
+		ctx.frames.push_back(FrameFeedback{buffer, seen, true});
+		f = &ctx.frames.back();
+	}
+	if (firstPart) f->bins = f->seen[0] != 0u;
+	bins = f->bins;
+	return const_cast<uint32_t*>(f->seen);
 }
 
 // ---- optional per-kernel profiling ------------------------------------------------------------------------------

@@ -44,12 +44,13 @@ __host__ __device__ inline uint64_t table_signature(const SimlodStats* s) {
 enum Knob : int {
 	KNOB_OVERLAP_TAIL, KNOB_EXPAND_WGS, KNOB_GRID_MULT, KNOB_COUNT_TPB, KNOB_VOXELIZE_WGS, KNOB_ADAPTIVE_GROUPS,
 	KNOB_RASTER_LEAF_TABLE, KNOB_RASTER_LDS_TILES, KNOB_DRAW_MULT, KNOB_RASTER_FUSED_RESOLVE,
-	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_GROUP_BATCHES, KNOB_DEBUG_PHASE_WG, KNOB_EVENT_SYSTEM_FENCE, KNOB_COUNT_
+	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_GROUP_BATCHES, KNOB_DEBUG_PHASE_WG, KNOB_EVENT_SYSTEM_FENCE, KNOB_RASTER_SCREEN_BINS, KNOB_DEBUG_BIN_POOL, KNOB_COUNT_
 };
 static constexpr int KNOB_UNSET = INT_MIN;
 extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...
 
 struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter
+struct FrameFeedback { const void* buffer; volatile uint32_t* seen; bool bins; };                       // render.hip launch_render: seen[0] = nodes of the buffer's latest frame that sort (or would)
 struct SideStream;                                           // construct.hip: the second stream of kernel_construct and its events
 void destroy_side_stream(SideStream* s);
 
@@ -64,12 +65,18 @@ struct Context {
 	std::vector<LeafTableRef> tables;
 	std::mutex historyLock;
 	std::vector<LaunchHistory> history;
+	std::mutex framesLock;
+	std::vector<FrameFeedback> frames;
 	hipEvent_t gateEvent[64] = {};                            // per device ordinal: the end of this context's latest k_expand, when it runs without a second stream (expand_gate)
 	Context();
 	~Context();
 	void reload_env();
 	int tune(Knob k, int dflt) const { return knob[k] == KNOB_UNSET ? dflt : knob[k]; }
 };
+// The frame's feedback word (page-locked, written by the frame's first draw pass) of the render buffer, and whether this frame sorts the
+// samples of its large nodes into the screen bins: decided by the frame's first part from what the buffer's previous frame found, kept for
+// the frame's other parts.  nullptr (no page-locked memory): every frame sorts.
+uint32_t* frame_feedback(Context& ctx, const void* buffer, bool firstPart, bool& bins);
 Context& context_of(const void* nodes);                      // the context `nodes` is attached to, else the default one
 uint32_t live_contexts();                                    // contexts that exist right now (the default one included once it has been used)
 

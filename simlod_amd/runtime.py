@@ -384,6 +384,12 @@ class DeviceOctree:
         off = abi.MAX_VISIBLE_NODES * abi.node_dtype.itemsize + 6 * 16
         return int(self.render_buffer[off: off + 4].view(torch.int32).item())
 
+    def samples_binned(self, width, height):
+        """How many samples the last frame's first draw pass sorted into the screen bins (render.hip r_overflow: word 13 of the frame's work
+        area, behind the framebuffer plane)."""
+        off = int(self.L.simlod_render_framebuffer_offset()) + (width * height * 8 + 15) // 16 * 16 + 13 * 4
+        return int(self.render_buffer[off: off + 4].view(torch.int32).item())
+
     # -- readback ------------------------------------------------------------------------------------------------
     def read_stats(self):
         return self.stats.cpu().numpy().view(abi.stats_dtype)[0].copy()

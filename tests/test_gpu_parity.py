@@ -525,14 +525,17 @@ def test_render_bit_exact_on_device_built_octree(built_libs, variant):
 
 
 @pytest.mark.parametrize("variant", ["odd_size_hqs", "odd_size_plain_boxes", "tiny_frame", "inside_the_cloud_hqs", "inside_the_cloud_plain",
-                                     "point_size_5", "fine_lod_hqs", "boxes_only", "terrain_close_hqs", "hotspot_tiles_hqs", "hotspot_tiles_plain"])
+                                     "point_size_5", "fine_lod_hqs", "boxes_only", "terrain_close_hqs", "hotspot_tiles_hqs", "hotspot_tiles_plain",
+                                     "grazing_plain", "grazing_hqs", "grazing_hqs_by_node", "grazing_plain_small_pool", "grazing_hqs_small_pool", "grazing_plain_no_bins"])
 def test_render_edge_cases_bit_exact(built_libs, variant):
     """Frame sizes that are not multiples of the 16-pixel EDL tile (nor of the 32-pixel LDS tile), a camera inside the point cloud
     (samples behind the eye, w <= 0), point sizes that reach over the frame border, a LOD threshold that makes thousands of nodes
-    visible, lines without points, nodes small enough on screen for the LDS-tile path: pre-EDL framebuffer bit-identical to the
-    oracle on the same octree image, RGBA8 within 1 per channel."""
-    Wd, Hd = (250, 131) if "odd_size" in variant else (40, 23) if variant == "tiny_frame" else (640, 360) if "hotspot" in variant else (384, 256)
-    if "terrain" in variant:
+    visible, lines without points, nodes small enough on screen for the LDS-tile path, a camera that skims the terrain (leaves much larger
+    on screen than an LDS tile: their samples are sorted into the screen bins — render.hip r_overflow —, also with a bin pool that runs
+    out after a few thousand entries, and with the bins switched off): pre-EDL framebuffer bit-identical to the oracle on the same
+    octree image, RGBA8 within 1 per channel."""
+    Wd, Hd = (250, 131) if "odd_size" in variant else (40, 23) if variant == "tiny_frame" else (640, 360) if "hotspot" in variant else (1000, 562) if "grazing" in variant else (384, 256)
+    if "terrain" in variant or "grazing" in variant:
         pts, box = synthetic.terrain(1_500_000, seed=3, box=(600.0, 400.0, 40.0), tile=50.0)
     elif "hotspot" in variant:
         pts, box = synthetic.hotspot(1_200_000, seed=11, level=4, cell=(5, 9, 6))
@@ -540,6 +543,10 @@ def test_render_edge_cases_bit_exact(built_libs, variant):
         pts, box = synthetic.uniform_cube(1_000_000, seed=77)
     if "inside" in variant:
         eye, target = (0.52 * box[0], 0.48 * box[1], 0.5 * box[2]), (0.9 * box[0], 0.6 * box[1], 0.45 * box[2])
+    elif "grazing" in variant:
+        ex, ey = 0.5 * float(box[0]), 0.3 * float(box[1])
+        ground = synthetic.terrain_height(ex, ey, seed=3, box=(600.0, 400.0, 40.0))
+        eye, target = (ex, ey, ground + 6.0), (ex + 20.0, ey + 200.0, ground - 4.0)
     elif "terrain" in variant:
         eye, target = (0.5 * box[0], 0.45 * box[1], 0.9 * box[2]), (0.52 * box[0], 0.6 * box[1], 0.4 * box[2])
     elif "hotspot" in variant:
@@ -549,9 +556,14 @@ def test_render_edge_cases_bit_exact(built_libs, variant):
         eye, target = (1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2])
     T = camera.lookat_transform(eye, target, Wd, Hd)
     dev = _device(ring_slots=2)
+    if "small_pool" in variant:
+        dev.tune("SIMLOD_DEBUG_BIN_POOL", 20_000)
+    if "no_bins" in variant:
+        dev.tune("SIMLOD_RASTER_SCREEN_BINS", 0)
     u = dev.uniforms(Wd, Hd, T, box)
     _ingest(dev, u, [pts[i:i + 1_000_000] for i in range(0, len(pts), 1_000_000)])
     u["useHighQualityShading"] = 1 if "hqs" in variant else 0
+    u["colorByNode"] = 1 if "by_node" in variant else 0
     u["showBoundingBox"] = 1 if "boxes" in variant else 0
     u["showPoints"] = 0 if variant == "boxes_only" else 1
     u["pointSize"] = 5 if variant == "point_size_5" else 1
@@ -562,6 +574,18 @@ def test_render_edge_cases_bit_exact(built_libs, variant):
     dev.render(u)
     fb_dev, col_dev, ds = dev.framebuffer(Wd, Hd), dev.color(Wd, Hd), dev.read_stats()
     assert int(ds["dbg"]) == 0
+    if "grazing" in variant:
+        binned, outside = dev.samples_binned(Wd, Hd), dev.samples_outside_tiles()
+        if "no_bins" in variant:
+            assert binned == 0 and outside > 10_000, (binned, outside)
+        elif "small_pool" in variant:
+            assert 0 < binned <= 20_000 and outside > 10_000, (binned, outside)      # what the pool could not take went the global way
+        else:
+            assert binned > 50_000, (binned, outside)
+        # the buffer's next frames (the second one still sorts or not as the first did; from the third on the first frame's finding decides)
+        for _ in range(3):
+            dev.render(u)
+            assert np.array_equal(dev.framebuffer(Wd, Hd), fb_dev) and np.array_equal(dev.color(Wd, Hd), col_dev)
     nodes, pers, nn = host_image_of(dev)
     fb, col, st = _oracle_render(nodes, nn, u)
     assert_stats_equal(ds, st, STATS_RENDER_FIELDS, variant)

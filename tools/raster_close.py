@@ -38,6 +38,6 @@ for var in (sys.argv[2:] or [""]):
             vs = int(st["numVisiblePoints"]) + int(st["numVisibleVoxels"])
             ms = t0.elapsed_time(t1) / frames
             print(f"{var or 'default':32s} {name:5s} {'hqs  ' if hqs else 'plain'} {ms:7.4f} ms/frame  {vs / ms / 1e6:7.1f} G samples/s  visible {vs:9d} samples, {int(st['numVisibleNodes']):5d} nodes; "
-                  f"outside tiles {dev.samples_outside_tiles():9d} ({100.0 * dev.samples_outside_tiles() / max(vs, 1):5.1f} %)", flush=True)
+                  f"outside tiles {dev.samples_outside_tiles():9d} ({100.0 * dev.samples_outside_tiles() / max(vs, 1):5.1f} %), binned {dev.samples_binned(W, H):9d}", flush=True)
     for kv in var.split():
         os.environ.pop(kv.split("=", 1)[0], None)

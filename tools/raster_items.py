@@ -26,7 +26,7 @@ for name, Tc in [q for q in (("bird", T), ("close", T_close)) if q[0] in os.envi
     torch.cuda.synchronize()
     off_work = int(dev.L.simlod_render_framebuffer_offset()) + (W * H * 8 + 15) // 16 * 16
     work = dev.render_buffer[off_work: off_work + 64].cpu().numpy().view(np.uint32)
-    cap = 400000
+    cap = 150000
     items = []
     for cl in range(4):
         n = int(work[8 + cl])
@@ -35,7 +35,7 @@ for name, Tc in [q for q in (("bird", T), ("close", T_close)) if q[0] in os.envi
     it = np.concatenate(items)
     us = it["took"] / 100.0
     print(f"== {name}: {len(it)} items, {int(it['samples'].sum())} samples; sum of item times {us.sum():.0f} us = {us.sum() / 256:.1f} us per workgroup of 256; longest item {us.max():.1f} us")
-    kinds = {"no tile": it["tileX"] < 0, "tile 128x128": (it["tileX"] >= 0) & (it["tileW"].astype(int) * it["tileH"] >= 128 * 128), "smaller tile": (it["tileX"] >= 0) & (it["tileW"].astype(int) * it["tileH"] < 128 * 128)}
+    kinds = {"sorting": it["tileX"] == -2, "no tile": it["tileX"] == -1, "tile 128x128": (it["tileX"] >= 0) & (it["tileW"].astype(int) * it["tileH"] >= 128 * 128), "smaller tile": (it["tileX"] >= 0) & (it["tileW"].astype(int) * it["tileH"] < 128 * 128)}
     for k, m in kinds.items():
         if m.any():
             print(f"   {k:14s} {int(m.sum()):5d} items, {int(it['samples'][m].sum()):9d} samples, {us[m].sum():8.0f} us in all, {1e3 * us[m].sum() / max(int(it['samples'][m].sum()), 1):6.2f} ns per sample, longest {us[m].max():6.1f} us, mean tile {it['tileW'][m].mean():.0f} x {it['tileH'][m].mean():.0f}")
