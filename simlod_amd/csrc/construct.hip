@@ -2203,7 +2203,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
 		note_leaf_table(ctx, LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
-		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS});
+		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS, a.nodeCapacity});
 	} else forget_leaf_table(ctx, nodes);
 	const DeviceInfo& dev = device_info();
 

@@ -50,7 +50,7 @@ struct RenderArgs {
 	const uint32_t* leafTableBatch;
 	const uint64_t* leafTableNodes;
 	const uint64_t* leafTableSig;
-	uint32_t     leafTableMagicValue, leafTableSlots;
+	uint32_t     leafTableMagicValue, leafTableSlots, leafTableRows;
 };
 
 // work area: [0..2] draw cursors of the three draw modes, [3] unused, [4] chunk directory entries in use, [8..11] draw items per size class
@@ -99,6 +99,13 @@ static constexpr uint32_t MAX_DIR_CHUNKS = 2000000; // chunk directory of a fram
 __device__ __forceinline__ uint32_t* counter_at(const RenderArgs& a, int k) { return reinterpret_cast<uint32_t*>(a.mom + R_OFF_COUNTERS + 16 * k); }
 enum { C_VISIBLE = 0, C_POINTS = 1, C_VOXELS = 2, C_INNER = 3, C_LEAVES = 4, C_TABLE_LISTS = 5, C_OUTSIDE_TILES = 6 };   // [5]: lists r_visible read through the builder's chunk table; [6]: samples the first draw pass sent down the global-atomic path (outside their item's LDS tile, or no tile)
 
+#ifdef VAR_PROBE
+#define R_PROBE_MAX(k) do { if (lane_id() == 0) reinterpret_cast<unsigned long long*>(a.mom + R_OFF_VERTICES + 8000000ull)[(k) * 8192u + blockIdx.x * (TPB / 64u) + threadIdx.x / 64u] = (unsigned long long)wall_clock64(); } while (0)
+#define R_PROBE_MIN(k) R_PROBE_MAX(k)
+#else
+#define R_PROBE_MAX(k) do {} while (0)
+#define R_PROBE_MIN(k) do {} while (0)
+#endif
 // ---- clear (render.cu:1126-1131, 233-241) ---------------------------------------------------------------------
 // Part of r_visible's launch: the planes are cleared by ALL its workgroups (a thousand, of which the octree's nodes keep a few dozen busy
 // for three dependent memory round trips), the frame's counters by thread 0 of workgroup 0, which then publishes the launch's
@@ -213,13 +220,22 @@ __device__ __forceinline__ void node_geometry(const RenderArgs& a, const float (
 	large = (double)dx > lim || (double)dy > lim;                                           // render.cu:860-861
 }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide sums by DPP (row shifts inside the 16-lane rows, then the rows' totals broadcast from lanes 15 and 31): six VALU operations.
+// Through ds_bpermute (__shfl_up / __shfl_xor) every step is an LDS round trip; r_visible's dozen scans in a row were 2.5 us of its 19.
+__device__ __forceinline__ uint32_t wave_inclusive_u32(uint32_t v) {
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
 	return v;
 }
-__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v) {      // exclusive prefix sum over the wave
-	uint32_t incl = v;
-	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane_id() >= o) incl += t; }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_u32(v), 63); }
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v) { return wave_inclusive_u32(v) - v; }      // exclusive prefix sum over the wave
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v, uint32_t& total) {                          // ... and the wave's total
+	const uint32_t incl = wave_inclusive_u32(v);
+	total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 	return incl - v;
 }
 
@@ -232,15 +248,25 @@ __device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t v) {      // exclus
 // (node fields; one reservation per wave; the chunk-table row; stores) instead of three kernels with twelve.
 // Draw items: a lane writes its node's chunk addresses into the frame's directory — copied from the builder's chunk table when that is
 // valid, else by walking the list (the only serial pointer chase left in a frame) — and cuts the list into items of <= 64 chunks.
-__device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (&planes)[6][4], const uint32_t numNodes) {
+__device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (&planes)[6][4], const uint32_t numNodes, SimlodNode* staged, const uint32_t readyEarly) {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	const bool active = i < numNodes;
-	SimlodNode* n = a.nodes + (active ? i : 0u);
+	// the workgroup's 256 nodes were staged in LDS with coalesced loads (r_visible): a lane reading ITS 152-byte node from memory touched a
+	// cache line per lane and field — a thousand line requests per wave, 5 us of the kernel's 19
+	SimlodNode* n = staged + (active ? threadIdx.x : 0u);
+	SimlodNode* nGlobal = a.nodes + (active ? i : 0u);
 	// The builder keeps, per node, the addresses of the first chunks of its list (construct_*.hip, leaf chunk table: a leaf's row lists
 	// its point chunks, an inner node's its voxel chunks) and stamps the table with the octree it describes (k_finish).  When that stamp
 	// matches THIS octree as it is now, and the node's row starts at the list's head, the row IS the list.
-	const bool tableValid = a.leafTable != nullptr && *a.leafTableMagic == a.leafTableMagicValue && *a.leafTableBatch == a.stats->batchletIndex &&
-	                        *a.leafTableNodes == (uint64_t)a.nodes && *a.leafTableSig == table_signature(a.stats);
+	// (all words of the stamp in flight together: tested one after the other, each waited for the one before — five round trips)
+	bool tableValid = false;
+	const SimlodChunk* rowHead = nullptr;                    // first entry of this node's row of the table: in flight with the node's fields
+	if (a.leafTable != nullptr) {
+		const uint32_t magic = *a.leafTableMagic, batch = *a.leafTableBatch, batchNow = a.stats->batchletIndex;
+		const uint64_t tableNodes = *a.leafTableNodes, sig = *a.leafTableSig, sigNow = table_signature(a.stats);
+		if (a.leafTableSlots <= 64u && a.leafTableRows != 0u) rowHead = a.leafTable[(uint64_t)(active && i < a.leafTableRows ? i : 0u) * a.leafTableSlots];
+		tableValid = (magic == a.leafTableMagicValue) & (batch == batchNow) & (tableNodes == (uint64_t)a.nodes) & (sig == sigNow);
+	}
 	const uint32_t level = n->level, X = n->X, Y = n->Y, Z = n->Z;
 	const uint32_t counts[2] = {n->numPoints, n->numVoxels};
 	const SimlodChunk* heads[2] = {n->points, n->voxelChunks};
@@ -250,9 +276,10 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	bool inside, large, unused, parentLarge = false;
 	node_geometry<true>(a, planes, level, X, Y, Z, inside, large);
 	const bool visible = inside && (counts[0] > 0u || counts[1] > 0u);
-	if (active) { n->visible = visible ? 1 : 0; n->isLarge = large ? 1 : 0; }
+	if (active) { n->visible = visible ? 1 : 0; n->isLarge = large ? 1 : 0; nGlobal->visible = visible ? 1 : 0; nGlobal->isLarge = large ? 1 : 0; }      // (the staged copy goes to the visible list)
 	if (active && visible && !large && level > 0u) node_geometry<false>(a, planes, level - 1u, X >> 1, Y >> 1, Z >> 1, unused, parentLarge);   // only who needs it
 	const bool emit = active && visible && (large ? leaf : parentLarge);
+	R_PROBE_MAX(2);
 	if (__ballot(emit) == 0ull) return;
 
 	// one reservation per wave and counter (returning device-scope atomics on one word retire at ~11 ns each, and a lane waits ~2.5 us
@@ -273,7 +300,10 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 			const float z = a.minz + ((float)Z + ((k & 1) ? 1.0f : 0.0f)) * nodeSize;
 			const float cw = dot_row(a.transform.rows[3], x, y, z);
 			if (!(cw > 0.0f)) { front = false; break; }
-			const float sx = ((dot_row(a.transform.rows[0], x, y, z) / cw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) / cw) * 0.5f + 0.5f) * a.height;
+			// (the hardware's approximate reciprocal: where the tile lies decides how fast a frame is drawn, not what it shows; the correctly
+			// rounded divisions of eight corners were a microsecond of this kernel)
+			const float rw = __builtin_amdgcn_rcpf(cw);
+			const float sx = ((dot_row(a.transform.rows[0], x, y, z) * rw) * 0.5f + 0.5f) * a.width, sy = ((dot_row(a.transform.rows[1], x, y, z) * rw) * 0.5f + 0.5f) * a.height;
 			mnx = fminf(mnx, sx); mny = fminf(mny, sy); mxx = fmaxf(mxx, sx); mxy = fmaxf(mxy, sy);
 		}
 		if (front && mnx > -1.0e6f && mny > -1.0e6f && mnx < 1.0e6f && mny < 1.0e6f) {
@@ -293,6 +323,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	}
 	// (launch_render leaves the bins out of a frame — two kernels — when the buffer's previous frame had nothing to sort: this frame tells the next)
 	const uint32_t waveSorts = (uint32_t)__popcll(__ballot(sorts));
+	R_PROBE_MAX(9);
 	// ... and their size: up to ITEM_CHUNKS chunks; an eighth of that for a node without a tile: every sample of such an item is a scattered
 	// global atomic, 64 memory transactions per wave instruction — a 32 000-sample item of that kind took ~100 us, the frame's makespan in the
 	// close-up preset; short ones spread over the CUs (and have no tile to clear or flush)
@@ -308,7 +339,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	const uint32_t myChunks = numChunks[0] + numChunks[1];
 	// A node has one list worth drawing (a leaf its points, an inner node its voxels): that one may come from the builder's chunk table
 	const int rowList = numChunks[0] != 0u ? 0 : 1;
-	const SimlodChunk* const* slots = tableValid && draws && a.leafTableSlots <= 64u ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
+	const SimlodChunk* const* slots = tableValid && draws && a.leafTableSlots <= 64u && i < a.leafTableRows ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
 	const uint32_t fromTable = slots != nullptr ? min(numChunks[rowList], a.leafTableSlots) : 0u;
 	uint32_t myClass[ITEM_CLASSES] = {0u, 0u, 0u, 0u};                                   // a list's pieces: full ones (class 0), then the rest
 #pragma unroll
@@ -318,18 +349,22 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 #pragma unroll
 		for (int cl = 0; cl < ITEM_CLASSES; cl++) myClass[cl] += (fullClass == (uint32_t)cl ? pieces[l] - 1u : 0u) + (lastClass == (uint32_t)cl ? 1u : 0u);
 	}
-	const uint32_t slotsBefore = wave_prefix_u32(emit ? 1u : 0u), chunksBefore = wave_prefix_u32(myChunks);
-	const uint32_t waveSlots = (uint32_t)__popcll(__ballot(emit)), waveChunks = wave_sum_u32(myChunks);
+	const unsigned long long emitters = __ballot(emit);
+	const uint32_t slotsBefore = __builtin_amdgcn_mbcnt_hi((uint32_t)(emitters >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emitters, 0u)), waveSlots = (uint32_t)__popcll(emitters);
+	uint32_t waveChunks;
+	const uint32_t chunksBefore = wave_prefix_u32(myChunks, waveChunks);
 	uint32_t classBase[ITEM_CLASSES], waveClass[ITEM_CLASSES];
 #pragma unroll
-	for (int cl = 0; cl < ITEM_CLASSES; cl++) { classBase[cl] = wave_prefix_u32(myClass[cl]); waveClass[cl] = wave_sum_u32(myClass[cl]); }
+	for (int cl = 0; cl < ITEM_CLASSES; cl++) classBase[cl] = wave_prefix_u32(myClass[cl], waveClass[cl]);
 	const bool isLeafDraw = emit && counts[0] > 0u, isInnerDraw = emit && counts[0] == 0u && counts[1] > 0u;   // render.cu:748-754
 	const uint32_t wLeaves = (uint32_t)__popcll(__ballot(isLeafDraw)), wInner = (uint32_t)__popcll(__ballot(isInnerDraw));
 	const uint32_t wPts = wave_sum_u32(isLeafDraw ? counts[0] : 0u), wVox = wave_sum_u32(isInnerDraw ? counts[1] : 0u);
 	uint32_t* work = reinterpret_cast<uint32_t*>(a.mom + a.offWork);
 	uint32_t slot = 0, dirBase = 0, waveBase[ITEM_CLASSES] = {0u, 0u, 0u, 0u};
+	R_PROBE_MAX(10);
 	if (lane_id() == 0) {
-		wait_frame_ready(a);
+		if (readyEarly != a.launchSeq) { wait_frame_ready(a); R_PROBE_MAX(11); }            // (read while the nodes were on their way: by then thread 0 had long published)
+		R_PROBE_MAX(8);
 		slot = atomicAdd(counter_at(a, C_VISIBLE), waveSlots);
 		if (waveSorts != 0u) atomicAdd(work + 14, waveSorts);
 		if (waveChunks != 0u) {
@@ -341,6 +376,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 		if (wInner) { atomicAdd(counter_at(a, C_INNER), wInner); atomicAdd(counter_at(a, C_VOXELS), wVox); }
 	}
 	slot = __shfl(slot, 0) + slotsBefore; dirBase = __shfl(dirBase, 0) + chunksBefore;
+	if (slot != 0xffffffffu) R_PROBE_MAX(3);
 #pragma unroll
 	for (int cl = 0; cl < ITEM_CLASSES; cl++) classBase[cl] += __shfl(waveBase[cl], 0);      // this lane's next free slot in class cl
 	DrawItem* items = reinterpret_cast<DrawItem*>(a.mom + a.offItems);
@@ -349,7 +385,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	// all: its draw item points INTO the row, once the row is seen to start with the list's head (r_draw ends the item at a gap, should
 	// a row ever have one).  Measured: copying the rows into the frame's directory — per lane, or by whole waves — was 10 us of this
 	// kernel's 28 (the visible nodes are neighbours in the node array: a few waves had all the copying to do).
-	const bool rowDirect = fromTable != 0u && numChunks[rowList] <= a.leafTableSlots && slots[0] == heads[rowList];
+	const bool rowDirect = fromTable != 0u && numChunks[rowList] <= a.leafTableSlots && rowHead == heads[rowList];
 	uint32_t throughTable = 0;
 	if (emit) {
 		const bool listed = slot < SIMLOD_MAX_VISIBLE_NODES;
@@ -386,20 +422,36 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 			}
 		}
 	}
+	R_PROBE_MAX(4);
 	const uint32_t waveTable = wave_sum_u32(throughTable);
 	if (lane_id() == 0 && waveTable != 0u) atomicAdd(counter_at(a, C_TABLE_LISTS), waveTable);
 }
 
 __global__ __launch_bounds__(TPB) void r_visible(RenderArgs a) {
+	R_PROBE_MIN(0);
 	if (blockIdx.x == 0 && threadIdx.x == 0) clear_counters(a);
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	if (numNodes != 0xffffffffu) R_PROBE_MAX(1);
 	if (blockIdx.x * TPB < numNodes) {                                                 // whole workgroups: the lanes of a wave reserve together
 		__shared__ float planes[6][4];
+		__shared__ unsigned long long staged[TPB * sizeof(SimlodNode) / 8];
+		static_assert(sizeof(SimlodNode) % 8 == 0, "nodes are staged as 8-byte words");
+		const uint32_t words = min((uint32_t)TPB, numNodes - blockIdx.x * TPB) * (uint32_t)(sizeof(SimlodNode) / 8);
+		const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.nodes + (uint64_t)blockIdx.x * TPB);
+		constexpr uint32_t PER_THREAD = sizeof(SimlodNode) / 8;                     // all of a thread's loads in flight, then the stores
+		unsigned long long held[PER_THREAD];
+#pragma unroll
+		for (uint32_t q = 0; q < PER_THREAD; q++) { const uint32_t w = q * TPB + threadIdx.x; held[q] = w < words ? src[w] : 0ull; }
+#pragma unroll
+		for (uint32_t q = 0; q < PER_THREAD; q++) staged[q * TPB + threadIdx.x] = held[q];
+		const uint32_t readyEarly = __hip_atomic_load(frame_ready_word(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (threadIdx.x < 6) frustum_plane(a.transformUpdate, (int)threadIdx.x, planes[threadIdx.x]);
 		__syncthreads();
-		visible_nodes(a, planes, numNodes);
+		visible_nodes(a, planes, numNodes, reinterpret_cast<SimlodNode*>(staged), readyEarly);
+		R_PROBE_MAX(5);
 	}
 	clear_frame(a);
+	R_PROBE_MAX(6); R_PROBE_MIN(7);
 }
 
 // ---- draw ---------------------------------------------------------------------------------------------------------------
@@ -805,7 +857,8 @@ __device__ __forceinline__ void bin_item(const DrawCtx& c, const RenderArgs& a, 
 	for (uint32_t t0 = 0; t0 < a.binTiles; t0 += DTPB) {               // uniform
 		const uint32_t t = t0 + tid;
 		const uint32_t n = t < a.binTiles ? cnt[t] : 0u;
-		const uint32_t before = wave_prefix_u32(n), waveTotal = wave_sum_u32(n);
+		uint32_t waveTotal;
+		const uint32_t before = wave_prefix_u32(n, waveTotal);
 		if (lane_id() == 0) scratch[tid / 64u] = waveTotal;
 		__syncthreads();
 		uint32_t waveBase = 0, roundTotal = 0;
@@ -1010,7 +1063,8 @@ __global__ __launch_bounds__(DTPB) void r_overflow(RenderArgs a) {
 		BinSeg seg = BinSeg{0u, 0u};
 		if (threadIdx.x < numSegs) { seg = segs[threadIdx.x]; sh_segs[threadIdx.x] = seg; }
 		const uint32_t n = (seg.count + 64u * DU - 1u) / (64u * DU);
-		const uint32_t before = wave_prefix_u32(n), waveTotal = wave_sum_u32(n);
+		uint32_t waveTotal;
+		const uint32_t before = wave_prefix_u32(n, waveTotal);
 		if (lane_id() == 0) sh_waves[threadIdx.x / 64u] = waveTotal;
 		__syncthreads();
 		uint32_t waveBase = 0;
@@ -1422,7 +1476,7 @@ int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, Simlo
 	LeafTableRef lt;
 	if (ctx.tune(KNOB_RASTER_LEAF_TABLE, 1) && find_leaf_table(ctx, nodes, lt)) {
 		a.leafTable = lt.table; a.leafTableMagic = lt.magic; a.leafTableBatch = lt.batch; a.leafTableNodes = lt.tableNodes; a.leafTableSig = lt.sig;
-		a.leafTableMagicValue = lt.magicValue; a.leafTableSlots = lt.slots;
+		a.leafTableMagicValue = lt.magicValue; a.leafTableSlots = lt.slots; a.leafTableRows = lt.rows;
 	}
 	a.itemCap = MAX_DRAW_ITEMS;
 	a.useTiles = (uint32_t)ctx.tune(KNOB_RASTER_LDS_TILES, 1);

@@ -31,6 +31,7 @@ struct LeafTableRef {
 	const uint64_t*           tableNodes;
 	const uint64_t*           sig;         // table_signature() of the Stats the table was stamped for
 	uint32_t                  magicValue, slots;
+	uint32_t                  rows;        // rows the table has (the node capacity of the launch that registered it)
 };
 // what the stamp remembers of the Stats block: an octree image that reached the buffers some other way (a host upload) differs here
 __host__ __device__ inline uint64_t table_signature(const SimlodStats* s) {
