@@ -129,11 +129,16 @@ __device__ __forceinline__ void clear_frame(const RenderArgs& a) {
 	const uint32_t lo = (uint32_t)SIMLOD_CLEAR_PIXEL, hi = (uint32_t)(SIMLOD_CLEAR_PIXEL >> 32);
 	fill(R_OFF_FB, (uint64_t)a.numPixels * 8, make_uint4(lo, hi, lo, hi), SIMLOD_CLEAR_PIXEL, 8);
 	if (a.useBins) { uint32_t* segCount = reinterpret_cast<uint32_t*>(a.mom + a.offBinSegCount); for (uint32_t i = first; i < a.binTiles; i += stride) segCount[i] = 0u; }
-	if (a.hqs) {
-		fill(a.offDepth, (uint64_t)a.numPixels * 4, make_uint4(0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u), 0x7f800000u, 4);
-		fill(a.offColor, (uint64_t)a.numPixels * 8, make_uint4(0, 0, 0, 0), 0ull, 8);
-		fill(a.offOverflow, (uint64_t)a.numPixels * 16, make_uint4(0, 0, 0, 0), 0ull, 8);
-	}
+	if (a.hqs) fill(a.offDepth, (uint64_t)a.numPixels * 4, make_uint4(0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u), 0x7f800000u, 4);
+}
+// The planes of the HQS colour pass — 24 bytes per pixel, two thirds of what a frame clears — are cleared by the DEPTH pass's draw workgroups
+// before they take their first item: stores nobody waits for, in a kernel that is bound by LDS atomics.  In r_visible they queued in
+// front of the node loads on its critical path: 6 us of that kernel.
+__device__ __forceinline__ void clear_colour_planes(const RenderArgs& a) {
+	const uint32_t stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+	uint4* q = reinterpret_cast<uint4*>(a.mom + a.offColor);                     // the packed plane and the {R, G, B, count} plane are neighbours
+	const uint64_t bytes = (a.offOverflow - a.offColor) + (uint64_t)a.numPixels * 16;
+	for (uint64_t i = first; i < bytes / 16; i += stride) q[i] = make_uint4(0, 0, 0, 0);
 }
 __device__ __forceinline__ void clear_counters(const RenderArgs& a) {     // one thread
 	*a.frameStart = wall_ns();                                        // render.cu:1100-1102
@@ -961,6 +966,7 @@ __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
 
 template <int MODE>
 __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
+	if (MODE == MODE_DEPTH) clear_colour_planes(a);
 	if (!a.showPoints) return;
 	__shared__ uint32_t sh_idx;
 	__shared__ const SimlodChunk* sh_dir[ITEM_CHUNKS];
