@@ -88,7 +88,7 @@ static constexpr int TILE = 128;
 // LDS and merges it into the plane with plain loads and stores (the tile's pixels are nobody else's in that kernel).
 static constexpr int TILE_BINNED = -2;                     // DrawItem::tileX of such an item
 static constexpr uint32_t BIN_SHIFT = 5, BIN = 1u << BIN_SHIFT;   // a bin = 32 x 32 pixels: 2074 of them at 1920 x 1080 — the terrain towards the horizon of a close-up is a strip of three hundred
-static constexpr uint32_t BIN_ITEM_CHUNKS = 8;            // a sorting item: 16 000 samples, 16 per thread — kept in registers between the count and the store
+static constexpr uint32_t BIN_ITEM_CHUNKS = 8;            // a sorting item: 8000 samples, 8 per thread — kept in registers between the count and the store (16: r_draw<MODE_MIN64> spills)
 static constexpr uint32_t BIN_POOL_ENTRIES = 3000000;      // 48 MB of entries per frame and pass: the buffer stays inside the host's 200 MB at 1920 x 1080 (main_progressive_octree.cpp:555) (what does not fit: device-scope atomics, as before)
 static constexpr uint32_t BIN_SEG_CAP = 256;               // segments (item x bin) a bin can list
 static constexpr uint32_t BIN_MAX_TILES = 8704;            // (3840 x 2160 pixels: 8228) the per-bin counters of a sorting workgroup live in its LDS; larger frames do not sort
@@ -784,7 +784,7 @@ __device__ __forceinline__ void draw_item(const DrawCtx& c, const SimlodChunk* c
 }
 
 // One item of a node that is much larger than a tile (DrawItem::tileX == TILE_BINNED): its samples are sorted into the screen bins.  Every
-// thread projects its <= 16 samples ONCE and keeps {bin, pixel inside it, value} in registers, counting per bin in LDS; then the workgroup
+// thread projects its <= 8 samples ONCE and keeps {bin, pixel inside it, value} in registers, counting per bin in LDS; then the workgroup
 // scans the counters, takes ALL its entries from the pool with ONE atomic (every item of the frame reserves on that word: one atomic per
 // item and bin on it took 11 ns each, 200 us a frame) and lists one segment per bin with samples; then every sample writes its entry.
 // Value: depth | colour (plain frames), depth (HQS depth pass), colour of an ACCEPTED sample (HQS colour pass, render.cu:485-493).  Pool
