@@ -51,7 +51,10 @@ extern "C" {
  *
  * Tuning knobs (SIMLOD_OVERLAP_TAIL, SIMLOD_EXPAND_WGS, SIMLOD_GRID_MULT, SIMLOD_COUNT_TPB, SIMLOD_VOXELIZE_WGS, SIMLOD_ADAPTIVE_GROUPS,
  * SIMLOD_RASTER_LEAF_TABLE, SIMLOD_RASTER_LDS_TILES, SIMLOD_DRAW_MULT, SIMLOD_RASTER_FUSED_RESOLVE, SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT,
- * SIMLOD_DEBUG_VOXELIZE_CLOCK, SIMLOD_DEBUG_BUDGET_US, SIMLOD_GROUP_BATCHES, SIMLOD_DEBUG_PHASE_WG, SIMLOD_EVENT_SYSTEM_FENCE) are read from the environment ONCE, when a context is made (the default
+ * SIMLOD_DEBUG_VOXELIZE_CLOCK, SIMLOD_DEBUG_BUDGET_US, SIMLOD_GROUP_BATCHES, SIMLOD_DEBUG_PHASE_WG, SIMLOD_EVENT_SYSTEM_FENCE — 1: the
+ * events between the builder's two streams keep the system-scope fence HIP gives an event by default —, SIMLOD_RASTER_SCREEN_BINS — 0:
+ * no screen bins; n: nodes whose screen box exceeds n x 1024 pixels sort their samples into the bins (default 32) —,
+ * SIMLOD_DEBUG_BIN_POOL — entries of the bin pool, for tests) are read from the environment ONCE, when a context is made (the default
  * context: at its first use); simlod_context_set_knob overrides one by name (set = 0: back to the built-in default),
  * simlod_context_reload_env reads the environment again.  ctx == NULL means the default context everywhere. */
 typedef struct SimlodContext SimlodContext;
