@@ -269,7 +269,8 @@ def main():
         # per-item LDS tiles the framebuffer RMW never reaches HBM, so `frac_by_traffic` prices the same frame by the bytes the PMC
         # counters saw the whole frame move (profiles/traffic_r0x.json, bird preset; None for the other preset / without the file).
         rb = (32.0 + 4.0) * vs + 48.0 * W * H if hqs else 24.0 * vs + 20.0 * W * H
-        fkeys = (["r_visible", "r_draw<MODE_DEPTH>", "r_draw<MODE_COLOR>", "r_output<true>"] if hqs else ["r_visible", "r_draw<MODE_MIN64>", "r_output<false>"])
+        fkeys = (["r_visible", "r_draw<MODE_DEPTH>", "r_overflow<MODE_DEPTH>", "r_draw<MODE_COLOR>", "r_overflow<MODE_COLOR>", "r_output<true>"] if hqs
+                 else ["r_visible", "r_draw<MODE_MIN64>", "r_overflow<MODE_MIN64>", "r_output<false>"])      # (r_overflow: frames that sort samples into the screen bins only)
         pre = "close/" if "close" in name else ""                      # (tools/fold_profiles.py: the close-up preset's passes are folded under "close/...")
         ftraffic = sum(rtraffic.get(pre + k, 0.0) for k in fkeys) if (rtraffic and (pre + "r_draw<MODE_MIN64>") in rtraffic) else None
         raster[name] = {"value": vs / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,

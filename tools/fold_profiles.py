@@ -24,7 +24,8 @@ out = {"_comment": "HBM bytes per ACTIVE launch of the ingest kernels (a launch 
                    "uncalibrated)." % (n_ingests, n_batches, frames),
        "_source": f"profiles/{tag}/rocprofv3_summary.json (tools/profile.sh {tag}; tools/fold_profiles.py)",
        "_csrc_sha16": summ.get("_csrc_sha16")}
-names = {"r_draw<0>": "r_draw<MODE_MIN64>", "r_draw<1>": "r_draw<MODE_DEPTH>", "r_draw<2>": "r_draw<MODE_COLOR>"}
+names = {"r_draw<0>": "r_draw<MODE_MIN64>", "r_draw<1>": "r_draw<MODE_DEPTH>", "r_draw<2>": "r_draw<MODE_COLOR>",
+         "r_overflow<0>": "r_overflow<MODE_MIN64>", "r_overflow<1>": "r_overflow<MODE_DEPTH>", "r_overflow<2>": "r_overflow<MODE_COLOR>"}
 json.dump({"_csrc_sha16": summ.get("_csrc_sha16"), "what": "simlod_amd.fingerprint.csrc_sha16() of the sources the files of this directory were measured on"}, open(os.path.join(dst, "fingerprint.json"), "w"))
 for k, v in summ["hbm_traffic"].items():
     total = v["fetch_bytes_x2"] + v["write_bytes"]

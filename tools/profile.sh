@@ -17,6 +17,7 @@ pass() {   # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- $CMD > /dev/null 2> $OUT/$name.err || echo "pass $name failed" >> $OUT/failed.txt
 }
+if [ "${PMC:-1}" = 1 ]; then      # PMC=0: the kernel trace alone
 pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_l2 TCC_HIT_sum TCC_MISS_sum
@@ -30,6 +31,7 @@ passc() { local name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" 
 passc pmc_fetch_close FETCH_SIZE
 passc pmc_write_close WRITE_SIZE
 passc pmc_atomic_close TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum
+fi
 cd $REPO
 python tools/summarize_profile.py $OUT $TAG
 find $OUT -name "*.csv" -size +3M -delete
