@@ -277,6 +277,18 @@ def test_collisions_at_max_depth_and_points_on_the_box_faces(built_libs):
     shallow = got["level"] < abi.MAX_DEPTH                          # what the reference stores it stores identically
     for f in ("counter", "pointChunks", "pointsSum", "pointsXor"):
         assert np.array_equal(got[f][shallow], want[f][shallow]), f
+    # the deviation, exactly: ONE node differs — the level-20 leaf of the collision chain.  Both count the k identical points that reach it
+    # (numPoints equal, above); the reference allocates it no chunk and stores none of them, here it holds ceil(k / 1000) chunks with
+    # exactly those k points and nothing else
+    deep = ~shallow
+    assert int(deep.sum()) == 8 and int((got["numPoints"][deep] > 0).sum()) == 1       # the eight children of the 20th split, one of them hit
+    k = int(got["numPoints"][deep].sum())
+    assert 0 < k <= 70_000 and k == int(want["numPoints"][deep].sum())
+    assert int(want["pointChunks"][deep].sum()) == 0 and int(want["pointsSum"][deep].sum()) == 0 and int(np.bitwise_xor.reduce(want["pointsXor"][deep])) == 0
+    assert int(got["pointChunks"][deep].sum()) == -(-k // abi.POINTS_PER_CHUNK)
+    ks, kx = points_multiset_hash(same[:k])
+    with np.errstate(over="ignore"):
+        assert ks == np.uint64(got["pointsSum"][deep].sum()) and kx == np.bitwise_xor.reduce(got["pointsXor"][deep])
     tot = oracle.check_invariants(nodes, nn)
     assert tot["points"] == len(pts)
     hs, hx = points_multiset_hash(pts)
