@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(OTPB) void r_overflow(RenderArgs a) {
 	if (numSegs == 0u) return;
 	// (one workgroup per bin, not a few hundred that loop: a workgroup's bins would go one after the other, each three dependent round trips
 	// — 30 us against 24 for the close-up; what the 2000 workgroups of a frame without sorting items cost, 4 us, launch_render avoids)
-	constexpr uint32_t PIXELS = BIN * BIN, DU = 8;
+	constexpr uint32_t PIXELS = BIN * BIN, DU = 4;
 	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? PIXELS / 2 : MODE == MODE_COLOR ? 2 * PIXELS : PIXELS];
 	__shared__ BinSeg sh_segs[BIN_SEG_CAP];
 	uint32_t* tile32 = reinterpret_cast<uint32_t*>(sh_tile);
@@ -1089,32 +1089,51 @@ __global__ __launch_bounds__(OTPB) void r_overflow(RenderArgs a) {
 	const uint32_t numChunks = sh_first[numSegs];
 	// the list as chunks of 64 x DU entries: chunk c belongs to the segment whose first chunk is the last one <= c; waves take chunks in turn
 	// (a segment per wave left most waves idle: a bin lists 10-20 segments of 50 to 5000 entries)
-	for (uint32_t c = threadIdx.x / 64u; c < numChunks; c += OTPB / 64u) {
+	// Two chunks of a wave in flight: the entries of the next one are requested before the current one's go into the tile.  Measured on the
+	// close-up's full bins (28 000 entries): the loads alone 7.5 us, the LDS work alone 7 us, one after the other 18 — a wave does not
+	// overlap them by itself; with two chunks in flight 14 (with 8 entries per lane and chunk the second set of registers halved the
+	// workgroups per CU and gained nothing: 4 entries).
+	auto fetch = [&](const uint32_t c, uint4 (&e)[DU], bool (&have)[DU]) {
 		uint32_t sgLo = 0, sgHi = numSegs;                       // sh_first[sgLo] <= c < sh_first[sgHi]
 		while (sgHi - sgLo > 1u) { const uint32_t mid = (sgLo + sgHi) / 2u; if (sh_first[mid] <= c) sgLo = mid; else sgHi = mid; }
 		const BinSeg seg = sh_segs[sgLo];
 		const uint32_t first = (c - sh_first[sgLo]) * 64u * DU;
-		uint4 e[DU];
-		bool have[DU];
 #pragma unroll
 		for (uint32_t u = 0; u < DU; u++) {
 			const uint32_t i = first + u * 64u + lane_id();
-			have[u] = i < seg.count;
+			have[u] = c < numChunks && i < seg.count;
 			e[u] = have[u] ? pool[seg.base + i] : make_uint4(0, 0, 0, 0);
 		}
+	};
+	auto apply = [&](const uint4 (&e)[DU], const bool (&have)[DU]) {
 #pragma unroll
 		for (uint32_t u = 0; u < DU; u++) {
 			if (!have[u]) continue;
 			const uint32_t local = e[u].z & (PIXELS - 1u);
-			// (a full bin has 20-30 entries per pixel and the LDS retires about one atomic per clock for the whole CU: most entries are not
-			// their pixel's minimum, and a read that says so is cheaper than the atomic it saves: 16.5 -> 13.5 us for 28 000 entries.
-			// Requesting a wave's next chunk before this one goes into the tile: no change — the bin's time is the LDS's, not the loads')
+			// (a full bin has 20-30 entries per pixel: most entries are not their pixel's minimum, and a read that says so is cheaper than
+			// the atomic it saves: 16.5 -> 13.5 us for 28 000 entries)
 			if (MODE == MODE_MIN64) { const unsigned long long v = ((unsigned long long)e[u].y << 32) | e[u].x; if (v < sh_tile[local]) atomicMin(&sh_tile[local], v); }
 			else if (MODE == MODE_DEPTH) { if (e[u].x < tile32[local]) atomicMin(&tile32[local], e[u].x); }
 			else {
 				atomicAdd(&sh_tile[2 * local + 0], (unsigned long long)(e[u].x & 0xffu) | ((unsigned long long)((e[u].x >> 8) & 0xffu) << 32));
 				atomicAdd(&sh_tile[2 * local + 1], (unsigned long long)((e[u].x >> 16) & 0xffu) | (1ull << 32));
 			}
+		}
+	};
+	{
+		constexpr uint32_t WAVES = OTPB / 64u;
+		uint4 eA[DU], eB[DU];
+		bool haveA[DU], haveB[DU];
+		uint32_t c = threadIdx.x / 64u;
+		if (c < numChunks) fetch(c, eA, haveA);
+		while (c < numChunks) {                                  // wave-uniform
+			fetch(c + WAVES, eB, haveB);                        // (past the end: nothing is loaded)
+			apply(eA, haveA);
+			c += WAVES;
+			if (c >= numChunks) break;
+			fetch(c + WAVES, eA, haveA);
+			apply(eB, haveB);
+			c += WAVES;
 		}
 	}
 	__syncthreads();
