@@ -1357,10 +1357,18 @@ __device__ __forceinline__ uint32_t resolved_depth_bits(const RenderArgs& a, con
 	return count != 0u ? d : (uint32_t)(fb[idx] >> 32);
 }
 
+// One workgroup per 64 x 16-pixel tile, four pixels per thread (rows ty, ty + 4, ty + 8, ty + 12: everything they read is requested
+// before the first value is used).  EDL wants log2 of the depth of a pixel and of its four neighbours: every pixel's logarithm is taken
+// ONCE, by its own thread, and passed on through LDS (plus a rim of 160 pixels around the tile).  The reference's neighbours are INDEX
+// neighbours (i +- 1, i +- W, clamped to the frame: render.cu:1296-1300): the left neighbour of a row's first pixel is the last pixel of
+// the row before; the rim is addressed the same way, and a pixel in the frame's last column or row that is not in its tile's last
+// column or row reads that one neighbour directly.
+static constexpr int OUT_TW = 64, OUT_TH = 16, OUT_PX = 4;
+static_assert(OUT_TW * OUT_TH == (int)TPB * OUT_PX && 2 * OUT_TW + 2 * OUT_TH <= (int)TPB, "four pixels per thread; one rim pixel per thread");
 template <bool RESOLVE>
 __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
 	uint64_t* fb = reinterpret_cast<uint64_t*>(a.mom + R_OFF_FB);
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
 		SimlodStats* s = a.stats;
 		s->numVisibleNodes = min(*counter_at(a, C_VISIBLE), SIMLOD_MAX_VISIBLE_NODES);
 		s->numVisibleInner = *counter_at(a, C_INNER);
@@ -1370,35 +1378,74 @@ __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
 		s->frameID = a.frameCounter;
 	}
 	if (a.colorbuffer == nullptr) return;
+	constexpr int PITCH = OUT_TW + 2, ROWS_PER_STEP = OUT_TH / OUT_PX;
+	__shared__ float sh_log[(OUT_TH + 2) * PITCH];
 	const int edlW = (a.W / 16) * 16, edlH = (a.H / 16) * 16;
 	const int last = (int)a.numPixels - 1;
-	const uint32_t stride = gridDim.x * TPB;
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < a.numPixels; i += stride) {
-		uint64_t enc;
-		if (RESOLVE) {
-			const unsigned long long pk = reinterpret_cast<const unsigned long long*>(a.mom + a.offColor)[i];
-			uint4 s = reinterpret_cast<const uint4*>(a.mom + a.offOverflow)[i];                 // as r_resolve
-			s.x += (uint32_t)((pk >> 28) & 0x3fffu); s.y += (uint32_t)((pk >> 14) & 0x3fffu); s.z += (uint32_t)(pk & 0x3fffu); s.w += (uint32_t)(pk >> 42);
-			if (s.w == 0u) enc = fb[i];
-			else {
+	const int tx = (int)threadIdx.x % OUT_TW, ty0 = (int)threadIdx.x / OUT_TW;
+	const int x0 = (int)blockIdx.x * OUT_TW, y0 = (int)blockIdx.y * OUT_TH;
+	const int x = x0 + tx;
+	auto log_at = [&](int idx) -> float {                    // log2 of the depth EDL sees at pixel idx (clamped like the reference's index)
+		idx = idx < 0 ? 0 : (idx > last ? last : idx);
+		return __log2f(__uint_as_float(resolved_depth_bits<RESOLVE>(a, fb, idx)));
+	};
+	bool inside[OUT_PX];
+	uint64_t enc[OUT_PX];
+	unsigned long long pk[OUT_PX];
+	uint4 sums[OUT_PX];
+	uint32_t own[OUT_PX];
+#pragma unroll
+	for (int q = 0; q < OUT_PX; q++) {
+		const int y = y0 + ty0 + q * ROWS_PER_STEP;
+		inside[q] = x < a.W && y < a.H;
+		const int i = inside[q] ? y * a.W + x : 0;
+		enc[q] = fb[i];
+		if (RESOLVE) { pk[q] = reinterpret_cast<const unsigned long long*>(a.mom + a.offColor)[i]; sums[q] = reinterpret_cast<const uint4*>(a.mom + a.offOverflow)[i]; own[q] = reinterpret_cast<const uint32_t*>(a.mom + a.offDepth)[i]; }
+	}
+	float rim = 0.0f;
+	int rimSlot = -1;
+	if ((int)threadIdx.x < 2 * OUT_TW + 2 * OUT_TH) {       // the rim: the index neighbours of the tile's border pixels
+		const int h = (int)threadIdx.x;
+		int cx, cy, off, slot;                                // the border pixel (tile coordinates), its neighbour's index offset, the rim's LDS slot
+		if (h < OUT_TW) { cx = h; cy = 0; off = -a.W; slot = cx + 1; }
+		else if (h < 2 * OUT_TW) { cx = h - OUT_TW; cy = OUT_TH - 1; off = a.W; slot = (OUT_TH + 1) * PITCH + cx + 1; }
+		else if (h < 2 * OUT_TW + OUT_TH) { cx = 0; cy = h - 2 * OUT_TW; off = -1; slot = (cy + 1) * PITCH; }
+		else { cx = OUT_TW - 1; cy = h - 2 * OUT_TW - OUT_TH; off = 1; slot = (cy + 1) * PITCH + OUT_TW + 1; }
+		if (x0 + cx < edlW && y0 + cy < edlH) { rim = log_at((y0 + cy) * a.W + x0 + cx + off); rimSlot = slot; }      // (only pixels EDL shades ask)
+	}
+#pragma unroll
+	for (int q = 0; q < OUT_PX; q++) {
+		if (!inside[q]) continue;
+		if (RESOLVE) {                                                                          // as r_resolve
+			uint4 s = sums[q];
+			s.x += (uint32_t)((pk[q] >> 28) & 0x3fffu); s.y += (uint32_t)((pk[q] >> 14) & 0x3fffu); s.z += (uint32_t)(pk[q] & 0x3fffu); s.w += (uint32_t)(pk[q] >> 42);
+			if (s.w != 0u) {
 				const uint32_t rgba = ((s.x / s.w) & 0xffu) | (((s.y / s.w) & 0xffu) << 8) | (((s.z / s.w) & 0xffu) << 16) | (255u << 24);
-				enc = ((uint64_t)reinterpret_cast<const uint32_t*>(a.mom + a.offDepth)[i] << 32) | rgba;
-				fb[i] = enc;
+				enc[q] = ((uint64_t)own[q] << 32) | rgba;
+				fb[(y0 + ty0 + q * ROWS_PER_STEP) * a.W + x] = enc[q];
 			}
-		} else enc = fb[i];
-		uint32_t color = (uint32_t)enc;
-		const int x = (int)(i % (uint32_t)a.W), y = (int)(i / (uint32_t)a.W);
+		}
+		sh_log[(ty0 + q * ROWS_PER_STEP + 1) * PITCH + tx + 1] = __log2f(__uint_as_float((uint32_t)(enc[q] >> 32)));
+	}
+	if (rimSlot >= 0) sh_log[rimSlot] = rim;
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < OUT_PX; q++) {
+		if (!inside[q]) continue;
+		const int ty = ty0 + q * ROWS_PER_STEP, y = y0 + ty, i = y * a.W + x;
+		uint32_t color = (uint32_t)enc[q];
 		if (x < edlW && y < edlH) {
-			const float lp = __log2f(__uint_as_float((uint32_t)(enc >> 32)));
+			const float lp = sh_log[(ty + 1) * PITCH + tx + 1];
 			// the four neighbours int(1.5 * sin/cos(k * 3.1415 / 2)) of render.cu:1296-1300: (0,+1), (+1,0), (0,-1), (-1,0)
-			const int offs[4] = {a.W, 1, -a.W, -1};
+			float ln[4];
+			ln[0] = (y == a.H - 1 && ty != OUT_TH - 1) ? log_at(i + a.W) : sh_log[(ty + 2) * PITCH + tx + 1];
+			ln[1] = (x == a.W - 1 && tx != OUT_TW - 1) ? log_at(i + 1) : sh_log[(ty + 1) * PITCH + tx + 2];
+			ln[2] = sh_log[ty * PITCH + tx + 1];
+			ln[3] = sh_log[(ty + 1) * PITCH + tx];
 			float sum = 0.0f;
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				int idx = (int)i + offs[k];
-				idx = idx < 0 ? 0 : (idx > last ? last : idx);
-				const float ln = __log2f(__uint_as_float(resolved_depth_bits<RESOLVE>(a, fb, idx)));
-				const float d = lp - ln;
+				const float d = lp - ln[k];
 				sum = sum + (d > 0.0f ? d : 0.0f);                 // max(NaN, 0) = 0
 			}
 			const float response = sum / 50.0f;
@@ -1566,8 +1613,9 @@ int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, Simlo
 		lines();
 	}
 	if (parts & RENDER_OUTPUT) {
-		if (fused) SIMLOD_LAUNCH(r_output<true>, dim3(gridPixels), dim3(TPB), stream, a);
-		else SIMLOD_LAUNCH(r_output<false>, dim3(gridPixels), dim3(TPB), stream, a);
+		const dim3 gridOutput((uint32_t)(a.W + OUT_TW - 1) / OUT_TW, (uint32_t)(a.H + OUT_TH - 1) / OUT_TH);
+		if (fused) SIMLOD_LAUNCH(r_output<true>, gridOutput, dim3(TPB), stream, a);
+		else SIMLOD_LAUNCH(r_output<false>, gridOutput, dim3(TPB), stream, a);
 	}
 	if (profile_enabled()) profile_close(stream);
 	return (int)hipGetLastError();
