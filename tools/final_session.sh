@@ -8,7 +8,7 @@ PMC=0 tools/profile.sh ${TAG}_coalesced --coalesce > $F/profile_sh_coalesced.txt
 timeout 600 python tools/config3.py --out gpurun_out/final_$TAG/config3_350m > $F/config3_stdout.txt 2>&1
 timeout 300 python tools/hotspot_ab.py 200000000 > $F/config5_200m.json 2> $F/config5_200m.err
 timeout 300 python tools/hotspot_ab.py 20000000 > $F/config5_20m.json 2>> $F/config5_200m.err
-timeout 300 python bench.py --stream --steps 1 --warmup 0 --no-cpu-baseline --no-profile --profiles $TAG > $F/bench_stream_500m_1gpu.json 2> $F/bench_stream.err
+timeout 300 python bench.py --stream --steps 2 --warmup 1 --no-cpu-baseline --no-profile --profiles $TAG > $F/bench_stream_500m_1gpu.json 2> $F/bench_stream.err
 timeout 200 python tools/raster_close.py 30 "" "X=1" "SIMLOD_RASTER_SCREEN_BINS=0" 2>&1 | grep -v amdgpu > $F/raster_presets.txt
 PRESETS=close timeout 100 python tools/raster_items.py 2>&1 | grep -v amdgpu > $F/raster_items_close.txt
 PRESETS=bird timeout 100 python tools/raster_items.py 2>&1 | grep -v amdgpu > $F/raster_items_bird.txt
