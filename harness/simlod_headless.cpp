@@ -5,7 +5,8 @@
 //
 //   initCuda()          main.cpp:272-281     context, upload stream, CU count
 //   initCudaProgram()   main.cpp:549-642     device buffers with the reference's sizes, three CudaModularPrograms
-//   getUniforms()       main.cpp:283-331     Uniforms from a camera (orbit controls, include/OrbitControls.h:140-159)
+//   getUniforms()       main.cpp:283-331     Uniforms from a camera (orbit controls, include/OrbitControls.h:140-159); in the _ref builds the
+//                                            reference's own text over its vendored glm (see SIMLOD_REF_UNIFORMS_EXTRACT below)
 //   resetCUDA()         main.cpp:333-361     `kernel`
 //   uploader            main.cpp:963-1063    pinned batch -> ring slot, batchSizes[slot], numBatchesUploaded on stream_upload,
 //                                            back-pressure: at most 50 M points ahead of Stats.numPointsProcessed (:1012)
@@ -38,6 +39,9 @@
 #include "CudaModularProgram.h"
 #include "cuda.h"
 #include "simlod_abi.h"
+#ifdef SIMLOD_REF_UNIFORMS_EXTRACT
+#include <glm/glm.hpp>                 // the reference's vendored copy (libs/glm, header-only), -DGLM_FORCE_CTOR_INIT: see getUniforms below
+#endif
 
 using namespace std;
 using Point = SimlodPoint;
@@ -48,7 +52,12 @@ using Stats = SimlodStats;
 struct GLTexture { GLuint handle = 1; };
 struct GLFramebuffer { vector<shared_ptr<GLTexture>> colorAttachments; };
 struct GLView { shared_ptr<GLFramebuffer> framebuffer; };
+#ifdef SIMLOD_REF_UNIFORMS_EXTRACT
+struct Camera { glm::dmat4 view, proj; double fovy = 60.0; };      // include/GLRenderer.h:130-163, what getUniforms reads of it
+struct GLRenderer { GLView view; int width = 0, height = 0, frameCount = 0; shared_ptr<Camera> camera = make_shared<Camera>(); };
+#else
 struct GLRenderer { GLView view; int width = 0, height = 0, frameCount = 0; };
+#endif
 template <class... A> static void printfmt(const char*, A&&...) {}      // the reference's fmt-style log lines are dropped
 
 constexpr uint64_t BATCH_STREAM_SIZE = SIMLOD_BATCH_STREAM_SIZE;
@@ -71,14 +80,22 @@ static Stats* h_stats_pinned;
 static simlod_float3 boxSize;
 static int width = 1920, height = 1080;
 static float viewProj[16];   // row-major world-view-projection (what glm::transpose leaves in Uniforms.transform)
+static double cameraView[16], cameraProj[16];   // row-major view and projection (fp64, as the reference's Camera keeps them)
 
 struct {
 	bool useHighQualityShading = true;
 	bool showBoundingBox = false;
+	bool doUpdateVisibility = true;
 	bool showPoints = true;
+	bool colorByNode = false;
+	bool colorByLOD = false;
+	bool colorWhite = false;
+	bool benchmarkRendering = false;
+	float LOD = 0.2f;
 	float minNodeSize = 64.0f;
 	int pointSize = 1;
-	bool benchmarkRendering = false;
+	bool enableEDL = true;
+	float edlStrength = 0.8f;
 } settings;   // main.cpp:123-139
 static bool requestBenchmark = true;                           // "benchmark mode": kernel durations are accumulated (main.cpp:411-422)
 static std::atomic_bool requestStep = false;
@@ -98,7 +115,11 @@ static void initCuda() {   // main.cpp:272-281
 	cuDeviceGetAttribute(&numSMs, CU_DEVICE_ATTRIBUTE_MULTIPROCESSOR_COUNT, device);
 }
 
+#ifdef SIMLOD_REF_UNIFORMS_EXTRACT
+Uniforms getUniforms(shared_ptr<GLRenderer> renderer);      // (defined by the reference's text)
+#else
 static Uniforms getUniforms(shared_ptr<GLRenderer> renderer);
+#endif
 
 #ifdef SIMLOD_REF_UPLOADER_EXTRACT
 // ---- SIMLOD_REF_UPLOADER_EXTRACT: the reference's own PinnedMemorySlot / PinnedMemPool (main.cpp:48-55, 141-222), reset() (:775-809) and
@@ -171,6 +192,17 @@ static void initCudaProgram(shared_ptr<GLRenderer> renderer) {   // main.cpp:549
 }
 #endif
 
+#ifdef SIMLOD_REF_UNIFORMS_EXTRACT
+// getUniforms as the reference wrote it (main.cpp:283-331, cut at build time like the other host functions).  One thing has to be decided
+// for it: it multiplies by a default-constructed `glm::mat4 world`, which the vendored glm 0.9.9 leaves UNINITIALISED unless
+// GLM_FORCE_CTOR_INIT is defined; the reference's tree does not define it and multiplies by whatever its stack holds.  The _ref builds
+// define it: `world` is the identity — the one value with which the author's proj * view * world is the camera's transform.  (The octree
+// does not depend on the camera; the frames do.)
+static glm::mat4 transform_updatebound;                     // main.cpp:116
+#define float3 simlod_float3                                // (Uniforms.boxMin / boxMax are this layout struct here, HIP's float3 is another type)
+#include SIMLOD_REF_UNIFORMS_EXTRACT
+#undef float3
+#else
 static Uniforms getUniforms(shared_ptr<GLRenderer>) {   // main.cpp:283-331
 	Uniforms u;
 	std::memset(&u, 0, sizeof(u));
@@ -197,6 +229,7 @@ static Uniforms getUniforms(shared_ptr<GLRenderer>) {   // main.cpp:283-331
 	u.edlStrength = 0.8f;
 	return u;
 }
+#endif
 
 #ifndef SIMLOD_REF_HOST_EXTRACT
 static void resetCUDA(shared_ptr<GLRenderer> renderer) {   // main.cpp:333-361
@@ -287,7 +320,7 @@ static void setCamera(double yaw, double pitch, double radius, const double targ
 	double proj[16] = {0};
 	proj[0] = 1 / (aspect * t); proj[5] = 1 / t; proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2 * zf * zn) / (zf - zn); proj[14] = -1;
 	float v32[16], p32[16];
-	for (int i = 0; i < 16; i++) { v32[i] = (float)view[i]; p32[i] = (float)proj[i]; }
+	for (int i = 0; i < 16; i++) { v32[i] = (float)view[i]; p32[i] = (float)proj[i]; cameraView[i] = view[i]; cameraProj[i] = proj[i]; }
 	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0; for (int k = 0; k < 4; k++) s += p32[4 * i + k] * v32[4 * k + j]; viewProj[4 * i + j] = s; }
 }
 
@@ -357,6 +390,9 @@ int main(int argc, char** argv) {
 	initCudaProgram(renderer);
 	const double target[3] = {boxSize.x * 0.5, boxSize.y * 0.5, boxSize.z * 0.3};
 	setCamera(-0.207, -0.797, 1.1 * std::max(boxSize.x, std::max(boxSize.y, boxSize.z)), target);
+#ifdef SIMLOD_REF_UNIFORMS_EXTRACT
+	for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { renderer->camera->view[c][r] = cameraView[4 * r + c]; renderer->camera->proj[c][r] = cameraProj[4 * r + c]; }   // glm: column-major
+#endif
 	resetCUDA(renderer);
 
 #ifdef SIMLOD_REF_UPLOADER_EXTRACT
