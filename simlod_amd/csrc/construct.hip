@@ -2067,10 +2067,11 @@ __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 	}
 }
 
-__global__ void k_finish(BuildArgs a, uint32_t fits) {
+__global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const uint32_t* numBatchesUploaded) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
 	SimlodStats* s = a.stats;
+	if (feedback != nullptr) { feedback[0] = s->batchletIndex; feedback[1] = *numBatchesUploaded; }      // what the next launch sizes itself by (groups_for_launch): page-locked host memory
 	s->numInner = ctl->statCounters[0];
 	s->numLeaves = ctl->statCounters[1];
 	s->numNonemptyLeaves = ctl->statCounters[2];
@@ -2279,9 +2280,8 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
 	}
-	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u);
+	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u, launch_feedback_words(ctx, stats), (const uint32_t*)numBatchesUploaded);
 	if (profile_enabled()) profile_close(stream);
-	if (note_launch_end(ctx, stats, numBatchesUploaded, stream) != 0) return (int)hipGetLastError();
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return (int)e;
 	return fits ? 0 : (int)hipErrorInvalidValue;

@@ -193,15 +193,11 @@ uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
 	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want;
 }
 
-int note_launch_end(Context& ctx, const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream) {
-	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return 0;
-	std::lock_guard<std::mutex> hold(ctx.historyLock);         // (held across the enqueue: the slot cannot change hands in between)
+uint32_t* launch_feedback_words(Context& ctx, const SimlodStats* stats) {
+	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return nullptr;
+	std::lock_guard<std::mutex> hold(ctx.historyLock);
 	LaunchHistory* h = history_of(ctx, stats, true);
-	if (h == nullptr) return 0;
-	volatile uint32_t* seen = h->seen;
-	hipError_t e = hipMemcpyAsync(const_cast<uint32_t*>(seen), &stats->batchletIndex, 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint32_t*>(seen) + 1, numBatchesUploaded, 4, hipMemcpyDeviceToHost, stream);
-	return (int)e;
+	return h != nullptr ? const_cast<uint32_t*>(h->seen) : nullptr;      // (a slot that changes hands before the launch's last kernel stores into it: a stale hint for the new owner)
 }
 
 void forget_launch_history(Context& ctx, const SimlodStats* stats) {

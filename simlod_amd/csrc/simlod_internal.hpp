@@ -107,7 +107,7 @@ bool find_leaf_table(Context& ctx, const void* nodes, LeafTableRef& ref);    // 
 // the recent launches processed + 2, at least 2, at most 20.  Unknown octree, or just reset: 20.  An idle frame loop pays for 2
 // groups instead of 20 (0.84 ms -> 0.1 ms per launch on MI355X, tools/idle_launch.py); a burst is picked up one launch late.
 uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats);
-int note_launch_end(Context& ctx, const SimlodStats* stats, const uint32_t* numBatchesUploaded, hipStream_t stream);
+uint32_t* launch_feedback_words(Context& ctx, const SimlodStats* stats);      // page-locked {batchletIndex, upload counter} the launch's last kernel stores into (two 4-byte copies behind it were 10 us of every launch); nullptr: no feedback
 void forget_launch_history(Context& ctx, const SimlodStats* stats);
 
 struct DeviceInfo {
