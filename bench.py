@@ -214,22 +214,8 @@ def main():
     raster = {}
     # Kept measurements (profiles/): quoted ONLY when they were taken on the kernel sources of this tree — the fingerprint the profiling tools
     # record must equal the one computed here; otherwise the fields stay null and `profiles_note` says why.
-    from simlod_amd.fingerprint import csrc_sha16
-    import glob as _glob
-    sha_now = csrc_sha16()
-    pdirs = [os.path.join(ROOT, "profiles", args.profiles)] if args.profiles else sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*")), reverse=True)
-    pdir, profiles_note = None, "no profiles/r*/ directory"
-    for d in pdirs:
-        fp = os.path.join(d, "fingerprint.json")
-        sha = json.load(open(fp)).get("_csrc_sha16") if os.path.exists(fp) else None
-        if sha == sha_now:
-            pdir, profiles_note = d, f"{os.path.relpath(d, ROOT)}: measured on these kernel sources (csrc sha {sha_now})"
-            break
-        profiles_note = f"{os.path.relpath(d, ROOT)} was measured on other kernel sources (csrc sha {sha} != {sha_now}): nothing quoted from it"
-        break
-    tfile = os.path.join(ROOT, "profiles", "traffic_" + os.path.basename(pdir) + ".json") if pdir else None
-    if tfile and not (os.path.exists(tfile) and json.load(open(tfile)).get("_csrc_sha16") == sha_now):
-        tfile = None
+    from simlod_amd.fingerprint import kept_profiles
+    pdir, tfile, profiles_note, sha_now = kept_profiles(args.profiles)
     rtraffic = json.load(open(tfile)) if tfile else {}
     presets = args.raster_presets.split(",")
     for name, hqs, Tcam in [m for m in (("hqs", 1, T), ("plain", 0, T), ("hqs_close", 1, T_close), ("plain_close", 0, T_close)) if ("close" if "close" in m[0] else "bird") in presets]:

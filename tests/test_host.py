@@ -70,3 +70,39 @@ def test_reference_host_functions_compile_unmodified_against_the_shim():
     out = subprocess.run(["make", "-C", os.path.join(root, "harness"), "ref_host"], capture_output=True, text=True)
     assert out.returncode == 0 and os.path.exists(exe), out.stdout + out.stderr
     assert not os.path.exists(os.path.join(root, "harness", "_ref", "ref_host_extract.inc")), "the extract must not be left behind"
+
+
+def test_kept_profiles_are_quoted_only_for_the_sources_they_were_measured_on(tmp_path):
+    """bench.py's honesty rule: a kept measurement carries the fingerprint of the kernel sources it was taken on; a tree
+    whose sources differ — one changed byte in csrc/ or include/ — gets nothing quoted from it, and the note says so."""
+    import json
+    import os
+    from simlod_amd import fingerprint
+    root = tmp_path
+    (root / "simlod_amd" / "csrc").mkdir(parents=True); (root / "include").mkdir(); (root / "profiles" / "r07").mkdir(parents=True)
+    (root / "simlod_amd" / "csrc" / "a.hip").write_text("kernel one"); (root / "include" / "x.h").write_text("header")
+    sha = fingerprint.csrc_sha16(str(root))
+    assert sha == fingerprint.csrc_sha16(str(root)) and len(sha) == 16
+    # no fingerprint in the directory: nothing may be quoted
+    pdir, tfile, note, now = fingerprint.kept_profiles(root=str(root))
+    assert pdir is None and tfile is None and now == sha and "other kernel sources" in note
+    (root / "profiles" / "r07" / "fingerprint.json").write_text(json.dumps({"_csrc_sha16": sha}))
+    pdir, tfile, note, _ = fingerprint.kept_profiles(root=str(root))
+    assert pdir is not None and pdir.endswith("r07") and tfile is None and "measured on these kernel sources" in note      # (no traffic file yet)
+    (root / "profiles" / "traffic_r07.json").write_text(json.dumps({"_csrc_sha16": sha, "k_count": 1.0}))
+    assert fingerprint.kept_profiles(root=str(root))[1].endswith("traffic_r07.json")
+    (root / "profiles" / "traffic_r07.json").write_text(json.dumps({"_csrc_sha16": "0" * 16, "k_count": 1.0}))
+    assert fingerprint.kept_profiles(root=str(root))[1] is None                               # a traffic file folded from another tree's passes
+    # a newer directory measured on other sources hides the older matching one: the newest decides
+    (root / "profiles" / "r08").mkdir(); (root / "profiles" / "r08" / "fingerprint.json").write_text(json.dumps({"_csrc_sha16": "f" * 16}))
+    pdir, tfile, note, _ = fingerprint.kept_profiles(root=str(root))
+    assert pdir is None and "r08" in note and "nothing quoted" in note
+    assert fingerprint.kept_profiles("r07", root=str(root))[0].endswith("r07")                # ... unless asked for by name
+    # one changed byte in a header
+    (root / "include" / "x.h").write_text("header!")
+    assert fingerprint.csrc_sha16(str(root)) != sha
+    assert fingerprint.kept_profiles("r07", root=str(root))[0] is None
+    # and the tree's own newest profiles carry a fingerprint at all
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    newest = sorted(d for d in os.listdir(os.path.join(here, "profiles")) if d.startswith("r") and d[1:].isdigit())[-1]
+    assert os.path.exists(os.path.join(here, "profiles", newest, "fingerprint.json"))
