@@ -46,7 +46,7 @@ extern "C" {
  * :374-382, :499-507).  What this library keeps between launches — ingest mode, node capacity, batch limit, tuning knobs, its second
  * stream and events, the table registry that links kernel_construct to kernel_render, the launch feedback — lives in a context; a
  * launch finds its context through the NODE ARRAY it is given.  Node arrays that were never attached share the default context, which
- * is what the simlod_set_* calls below configure: a host with one octree never needs these six functions.  A host with several octrees
+ * is what the simlod_set_* calls below configure: a host with one octree never needs these functions.  A host with several octrees
  * (one per tile, per data set, per thread) makes a context per octree and attaches the octree's node array to it.
  *
  * Tuning knobs (SIMLOD_OVERLAP_TAIL, SIMLOD_EXPAND_WGS, SIMLOD_GRID_MULT, SIMLOD_COUNT_TPB, SIMLOD_VOXELIZE_WGS, SIMLOD_ADAPTIVE_GROUPS,
@@ -64,6 +64,18 @@ int simlod_context_attach(SimlodContext* ctx, const SimlodNode* nodes);       /*
 int simlod_context_set_node_capacity(SimlodContext* ctx, uint32_t numNodes);
 int simlod_context_set_ingest_mode(SimlodContext* ctx, uint32_t mode);
 int simlod_context_set_construct_batch_limit(SimlodContext* ctx, uint32_t maxBatches);
+/* Multi-GPU jobs (no counterpart in the reference, which is single-GPU: main_progressive_octree.cpp:274, CudaModularProgram.h:215).  Ranks own
+ * level-3 cells of ONE global cube; the nodes of levels 0-2 exist on every rank.  The single-GPU octree of the whole data set splits such a
+ * node when the GLOBAL count under it crosses 50 000 (progressive_octree_voxels.cu:209-217); a rank that looked at its own count would keep it
+ * as a leaf and kernel_render would draw its points where one GPU draws the node's voxels (render.cu:918-932).  So the host names the upper
+ * nodes whose global count exceeds the limit — 73 bits: bit 0 the root; bit 1 + c the level-1 node with cell code c = x << 2 | y << 1 | z;
+ * bit 9 + c the level-2 node, c = its level-1 octant << 3 | the octant below (lo: bits 0..63, hi: bits 64..72) — and kernel_construct splits
+ * such a node as soon as it exists, whatever it holds: in the first batch ingested after the call, or, when no batch is pending, by a batch
+ * of ZERO points (publish batchSizes[slot] = 0 and bump numBatchesUploaded).  A named node's parent must be named too (hipErrorInvalidValue).
+ * Mask 0 (the default): the reference's rule alone — every Node and Stats field is the reference's.  simlod_amd/distributed.py trunk_mask
+ * derives the mask from the all-reduced histogram over the 512 level-3 cells; with it the composed frame of N ranks
+ * (simlod_render_frame_composed) has the single-GPU frame's depth at every pixel. */
+int simlod_context_set_trunk_mask(SimlodContext* ctx, uint64_t lo, uint64_t hi);
 int simlod_context_set_knob(SimlodContext* ctx, const char* name, int value, int set);
 int simlod_context_reload_env(SimlodContext* ctx);
 uint64_t simlod_context_construct_buffer_min_bytes(SimlodContext* ctx);

@@ -59,6 +59,7 @@ def port_lib():
         lib.oracle_create.restype = ctypes.c_void_p
         lib.oracle_create.argtypes = [ctypes.c_uint32]
         lib.oracle_destroy.argtypes = [ctypes.c_void_p]
+        lib.oracle_set_trunk_mask.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         lib.oracle_last_error.argtypes = [ctypes.c_void_p]
         lib.oracle_last_error.restype = ctypes.c_int
         lib.oracle_reset.argtypes = [ctypes.c_void_p] * 7
@@ -118,6 +119,12 @@ class HostOctree:
 
     def _fn(self, lib, name):
         return ctypes.cast(getattr(self.ref[lib], name), ctypes.c_void_p)
+
+    def set_trunk_mask(self, lo, hi):
+        """EXTENSION of the restatement (the reference is single-GPU): nodes of levels 0-2 that split whatever they hold — the multi-GPU
+        layer's shared upper levels (simlod_amd/distributed.trunk_mask; the CPU stand-in for DeviceOctree.set_trunk_mask)."""
+        assert self.kind == "port", "the reference's own sources know nothing of ranks"
+        self.lib.oracle_set_trunk_mask(self.ctx, ctypes.c_uint64(int(lo)), ctypes.c_uint64(int(hi)))
 
     # -- launch sequence ------------------------------------------------------------------------------
     def reset(self, uniforms):

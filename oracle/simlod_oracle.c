@@ -23,7 +23,12 @@
  *   - the EDL pass (render.cu:1255-1325) covers every full 16x16 tile instead of a launch-geometry
  *     dependent subset and clamps its neighbour index to W*H-1;
  *   - capacity cliffs of the reference are reported through oracle_last_error() instead
- *     of silently corrupting memory.
+ *     of silently corrupting memory;
+ *   - ONE EXTENSION the reference has no counterpart for (it is single-GPU): oracle_set_trunk_mask() names
+ *     nodes of levels 0-2 that split whatever their count — the multi-GPU layer's rule "a shared upper
+ *     node is inner on every rank iff the GLOBAL count under it exceeds 50 000" (simlod_amd/distributed.py
+ *     trunk_mask, include/simlod_hip.h simlod_context_set_trunk_mask).  With the mask at zero — its state
+ *     after oracle_create, and the only state the pin tests and golden fixtures use — nothing differs.
  * Everything else — operation order of every fp32/fp64 expression, traversal order, allocation order —
  * follows the cited lines, so a serial run reproduces the reference's serial run exactly.
  */
@@ -64,6 +69,7 @@ typedef struct OracleCtx {
 	uint32_t      numSpilling, numSpilled, numBacklog;
 	uint32_t      maxNodes;
 	int           lastError;
+	uint64_t      trunkMask[2]; /* EXTENSION: nodes of levels 0-2 that must be inner (bit: trunk_index) */
 } OracleCtx;
 
 OracleCtx* oracle_create(uint32_t maxNodes) {
@@ -88,6 +94,21 @@ void oracle_destroy(OracleCtx* c) {
 }
 
 int oracle_last_error(const OracleCtx* c) { return c->lastError; }
+
+/* EXTENSION (multi-GPU layer): bit trunk_index(level, X, Y, Z) set = that node of level 0, 1 or 2 splits as soon as
+ * it exists, whatever it holds.  Bit 0: the root; 1 + c: level 1, c = x << 2 | y << 1 | z; 9 + c: level 2, c = the
+ * level-1 octant << 3 | the octant below it (the cell codes of simlod_amd/distributed.py cell_codes). */
+void oracle_set_trunk_mask(OracleCtx* c, uint64_t lo, uint64_t hi) { c->trunkMask[0] = lo; c->trunkMask[1] = hi; }
+static uint32_t trunk_index(uint32_t level, uint32_t X, uint32_t Y, uint32_t Z) {
+	if (level == 0) return 0;
+	if (level == 1) return 1u + ((X & 1u) << 2 | (Y & 1u) << 1 | (Z & 1u));
+	return 9u + ((((X >> 1) & 1u) << 2 | ((Y >> 1) & 1u) << 1 | ((Z >> 1) & 1u)) << 3 | ((X & 1u) << 2 | (Y & 1u) << 1 | (Z & 1u)));
+}
+static int trunk_forced(const OracleCtx* c, const SimlodNode* n) {
+	if (n->level >= 3) return 0;
+	uint32_t i = trunk_index(n->level, n->X, n->Y, n->Z);
+	return (int)((c->trunkMask[i >> 6] >> (i & 63u)) & 1u);
+}
 
 /* ---- AllocatorGlobal::alloc, utils.h.cu:185-197 -------------------------------------------------- */
 static uint8_t* persistent_alloc(SimlodAllocatorGlobal* a, uint64_t size) {
@@ -201,6 +222,17 @@ static int do_counting(BuildEnv* e, const SimlodPoint* pts, uint32_t n, uint32_t
 	for (uint32_t i = 0; i < n; i++) count_point(e, &pts[i], countIteration);
 	uint32_t numSpilledBefore = c->numSpilled; /* processRange(*numSpilledPoints) captures the size first */
 	for (uint32_t i = 0; i < numSpilledBefore; i++) count_point(e, &c->spilled[i], countIteration);
+	/* EXTENSION (trunk mask, see oracle_set_trunk_mask): an upper node named by the mask that is still a leaf splits in this
+	 * round too (one above the limit has been listed by count_point already) */
+	if (c->trunkMask[0] | c->trunkMask[1]) {
+		for (uint32_t i = 0; i < e->stats->numNodes; i++) {
+			SimlodNode* nd = &e->nodes[i];
+			if (nd->level < 3 && nd->counter <= SIMLOD_MAX_POINTS_PER_NODE && node_is_leaf(nd) && trunk_forced(c, nd)) {
+				if (c->numSpilling >= SPILLING_CAPACITY) { c->lastError = ORACLE_ERR_SPILLING; break; }
+				c->spilling[c->numSpilling++] = nd;
+			}
+		}
+	}
 	/* move the stored points of every spilling node to the spill buffer, voxels.cu:253-289 */
 	for (uint32_t s = 0; s < c->numSpilling; s++) {
 		SimlodNode* node = c->spilling[s];

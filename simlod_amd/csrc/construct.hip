@@ -95,7 +95,26 @@ struct BuildArgs {
 	uint64_t     persCapacity, frameCounter, scratchBytes;
 	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, offTop, leafOfStride;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax, crossCap;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
+	uint64_t     trunkLo, trunkHi;   // simlod_context_set_trunk_mask: nodes of levels 0-2 that split whatever they hold (multi-GPU: the shared upper levels); zero on one GPU
 };
+
+// ---- the shared upper levels of a multi-GPU job (include/simlod_hip.h simlod_context_set_trunk_mask; no counterpart in the reference, which is
+// single-GPU) ----  Ranks own level-3 cells of one global cube; the nodes of levels 0-2 exist on every rank.  A rank that split them by ITS counts
+// would keep one as a leaf where the single-GPU octree of the whole data set has an inner node (voxels.cu:209-217: a leaf splits when the count
+// under it crosses 50 000 — the GLOBAL count there), and kernel_render would draw that rank's points where the single GPU draws voxels
+// (render.cu:918-932).  So the host names the upper nodes whose global count exceeds the limit: such a node splits as soon as it exists.
+// Bit 0: the root; 1 + c: the level-1 node with cell code c = x << 2 | y << 1 | z; 9 + c: the level-2 node, c = the level-1 octant << 3 | the octant below.
+static constexpr uint32_t TRUNK_LEVELS = 3, TRUNK_NODES = 1 + 8 + 64;
+__device__ __forceinline__ bool trunk_any(const BuildArgs& a) { return (a.trunkLo | a.trunkHi) != 0ull; }
+__device__ __forceinline__ uint32_t trunk_index(uint32_t level, uint32_t X, uint32_t Y, uint32_t Z) {
+	return level == 0u ? 0u : level == 1u ? 1u + ((X & 1u) << 2 | (Y & 1u) << 1 | (Z & 1u))
+	                        : 9u + ((((X >> 1) & 1u) << 2 | ((Y >> 1) & 1u) << 1 | ((Z >> 1) & 1u)) << 3 | ((X & 1u) << 2 | (Y & 1u) << 1 | (Z & 1u)));
+}
+__device__ __forceinline__ bool trunk_forced(const BuildArgs& a, uint32_t level, uint32_t X, uint32_t Y, uint32_t Z) {
+	if (level >= TRUNK_LEVELS) return false;
+	const uint32_t i = trunk_index(level, X, Y, Z);
+	return (((i < 64u ? a.trunkLo : a.trunkHi) >> (i & 63u)) & 1ull) != 0ull;
+}
 
 
 // ---- workgroup-level key -> count aggregation in LDS ------------------------------------------------------------------
@@ -470,8 +489,10 @@ __device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCt
 	const uint32_t before = atomicExch(at<uint32_t>(a, a.offTouchTag) + leafIdx, bc->tag);
 	atomicMax(at<unsigned long long>(a, a.offStartOf) + leafIdx, ((unsigned long long)bc->tag << 32) | (0xffffffffu - old));
 	uint32_t flags = before != bc->tag ? FIRST : 0u;
+	bool over = old + cnt > SIMLOD_MAX_POINTS_PER_NODE;
+	if (!over && trunk_any(a)) over = trunk_forced(a, leaf->level, leaf->X, leaf->Y, leaf->Z);      // (a multi-GPU job's shared upper node: splits by the global count)
 	// A node at MAX_DEPTH cannot be subdivided (the descent stops there): it keeps growing instead of spilling.
-	if (old + cnt > SIMLOD_MAX_POINTS_PER_NODE && leaf->level < SIMLOD_MAX_DEPTH && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, bc->tag) != bc->tag) flags |= CROSSED;
+	if (over && leaf->level < SIMLOD_MAX_DEPTH && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, bc->tag) != bc->tag) flags |= CROSSED;
 	return flags;
 }
 // what a leaf held when batch `tag` began (valid once the batch's k_count is complete)
@@ -629,7 +650,8 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
 		bc->reserve = (unsigned long long)a.stats->numNodes << 32;
 	}
-	if (blockIdx.x >= numChunks) return;
+	const bool trunkPass = blockIdx.x == 0 && trunk_any(a);     // (also for a group without samples: how a host flushes a mask it has just widened)
+	if (blockIdx.x >= numChunks && !trunkPass) return;
 	Phase ph(ctl, blockIdx.x == 0);
 	auto counted = [&](uint32_t leafIdx, uint32_t flags) {
 		if ((flags & FIRST) != 0u) {
@@ -648,6 +670,19 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	spread_init(tbl);
 	if (threadIdx.x == 0) sh_numTouch = 0;
 	__syncthreads();
+	if (trunkPass && threadIdx.x < TRUNK_NODES) {
+		// the upper nodes the host's mask names (simlod_context_set_trunk_mask): one that exists and is still a leaf is queued for splitting
+		// whether this group has a sample for it or not — "counted" with zero samples, so the exchange on its tag makes ONE caller queue it
+		const uint32_t t = threadIdx.x, level = t == 0u ? 0u : t < 9u ? 1u : 2u, code = t == 0u ? 0u : t < 9u ? t - 1u : t - 9u;
+		if ((((t < 64u ? a.trunkLo : a.trunkHi) >> (t & 63u)) & 1ull) != 0ull) {
+			uint32_t cur = 0;
+			for (uint32_t lv = 0; lv < level && cur != NONE; lv++) {
+				const SimlodNode* c = a.nodes[cur].children[(code >> (3u * (level - 1u - lv))) & 7u];
+				cur = c != nullptr ? (uint32_t)(c - a.nodes) : NONE;
+			}
+			if (cur != NONE && node_is_leaf(a.nodes + cur)) counted(cur, count_into(a, bc, cur, 0u));
+		}
+	}
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		float4 p[CPT];
 #pragma unroll
@@ -1119,9 +1154,18 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			__syncthreads();
 			if (t < 64u) {
 				// a child splits when it holds more than 50 000 and is above MAX_DEPTH (K >= 2 <=> level l + 1 <= 19); a grandchild likewise
-				const bool s1 = t < 8u && K >= 2u && sh.c1[t & 7u] > SIMLOD_MAX_POINTS_PER_NODE;
+				// (or when it is an upper node of a multi-GPU job that the host's mask names: trunk_forced)
+				bool f1 = false, f2 = false;
+				if (trunk_any(a) && l + 1u < TRUNK_LEVELS) {
+					const SimlodNode* nodeL = a.nodes + L;
+					// lane t < 8 as child t; every lane as grandchild t = child (t >> 3), octant (t & 7) below it
+					const uint32_t LX = nodeL->X, LY = nodeL->Y, LZ = nodeL->Z, j = t >> 3, k = t & 7u;
+					f1 = t < 8u && trunk_forced(a, l + 1u, 2u * LX + ((t >> 2) & 1u), 2u * LY + ((t >> 1) & 1u), 2u * LZ + (t & 1u));
+					f2 = trunk_forced(a, l + 2u, 4u * LX + 2u * ((j >> 2) & 1u) + ((k >> 2) & 1u), 4u * LY + 2u * ((j >> 1) & 1u) + ((k >> 1) & 1u), 4u * LZ + 2u * (j & 1u) + (k & 1u));
+				}
+				const bool s1 = t < 8u && K >= 2u && (sh.c1[t & 7u] > SIMLOD_MAX_POINTS_PER_NODE || f1);
 				uint32_t mask1 = (uint32_t)__ballot(s1) & 0xffu;
-				const bool s2 = K >= 3u && ((mask1 >> (t >> 3)) & 1u) != 0u && sh.c2[t] > SIMLOD_MAX_POINTS_PER_NODE;
+				const bool s2 = K >= 3u && ((mask1 >> (t >> 3)) & 1u) != 0u && (sh.c2[t] > SIMLOD_MAX_POINTS_PER_NODE || f2);
 				unsigned long long mask2 = __ballot(s2);
 				uint32_t n1 = (uint32_t)__popc(mask1), n2 = (uint32_t)__popcll(mask2);
 				uint32_t extraBase = 0;
@@ -2199,6 +2243,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	a.persCapacity = u->persistentBufferCapacity;
 	a.frameCounter = u->frameCounter;
 	a.nodeCapacity = ctx.nodeCapacity.load();
+	a.trunkLo = ctx.trunkLo.load(); a.trunkHi = ctx.trunkHi.load();
 	const bool coalesce = ctx.ingestMode.load() != 0u;
 	const bool fits = layout_construct(a, u->momentaryBufferCapacity, coalesce, (uint32_t)std::max(1, ctx.tune(KNOB_GROUP_BATCHES, 10)));   // coalesced mode: groups of 10 (36 M terrain: 20: 3.17 ms, 10: 2.95, 5: 3.10, 2: 3.66 — two groups per launch overlap front and back halves)
 	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)

@@ -313,6 +313,18 @@ int simlod_context_set_construct_batch_limit(SimlodContext* c, uint32_t maxBatch
 	ctx_or_default(c).batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
 	return 0;
 }
+int simlod_context_set_trunk_mask(SimlodContext* c, uint64_t lo, uint64_t hi) {
+	if ((hi >> 9) != 0ull) return (int)hipErrorInvalidValue;                  // 73 upper nodes: 1 + 8 + 64
+	// a node can only split once it exists: every node the mask names below the root must have its parent named too
+	for (uint32_t i = 1; i < 73u; i++) {
+		const bool set = (((i < 64u ? lo : hi) >> (i & 63u)) & 1ull) != 0ull;
+		const uint32_t parent = i < 9u ? 0u : 1u + ((i - 9u) >> 3);
+		if (set && ((lo >> parent) & 1ull) == 0ull) return (int)hipErrorInvalidValue;
+	}
+	Context& ctx = ctx_or_default(c);
+	ctx.trunkLo.store(lo); ctx.trunkHi.store(hi);
+	return 0;
+}
 int simlod_context_set_knob(SimlodContext* c, const char* name, int value, int set) {
 	if (!name) return (int)hipErrorInvalidValue;
 	for (int k = 0; k < KNOB_COUNT_; k++)

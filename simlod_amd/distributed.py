@@ -166,6 +166,48 @@ def partition_and_route(points, box_size, world, level=3, slice_points=32_000_00
     return out, owner_table, counts, rt
 
 
+MAX_POINTS_PER_NODE = 50_000          # structures.cuh:21: a leaf that holds more splits (progressive_octree_voxels.cu:209-217)
+TRUNK_LEVELS = 3                      # ranks own level-3 cells: the nodes of levels 0..2 are shared by all of them
+
+
+def trunk_mask(counts):
+    """Which nodes of the shared upper levels (0, 1, 2) are INNER nodes of the single-GPU octree of the whole data set: those whose GLOBAL
+    point count exceeds 50 000 (a leaf splits iff its count crosses the limit, progressive_octree_voxels.cu:209-217; the final topology does
+    not depend on the order of arrival).  `counts`: the all-reduced histogram over the 512 level-3 cells, indexed by cell code (cell_codes;
+    partition_and_route and balanced_owners return it).  Returns (lo, hi), the 73-bit mask of simlod_context_set_trunk_mask: bit 0 the
+    root, bit 1 + c the level-1 node with cell code c, bit 9 + c the level-2 node with code c.
+
+    A rank that refined these nodes from ITS points alone would keep one as a leaf (and draw its points) where the single GPU has an inner
+    node (and draws its voxels) — the composed frame would show a different LOD cut there.  With the mask every rank's upper levels have
+    the single-GPU octree's topology; a voxel cell of an upper node lies inside ONE level-3 cell (a level-l node's grid has 128 cells per
+    axis, a level-3 cell spans 128 / 2^(3 - l) >= 16 of them), so the ranks' voxel sets are disjoint, their union is the single GPU's, and
+    the MIN / SUM composition of render_frame yields the single-GPU frame."""
+    c = np.asarray(counts, dtype=np.int64).reshape(-1)
+    assert c.size == 8 ** TRUNK_LEVELS, "trunk_mask wants the histogram over the 512 level-3 cells"
+    mask = 0
+    if int(c.sum()) > MAX_POINTS_PER_NODE:
+        mask |= 1
+    for code, n in enumerate(c.reshape(8, 64).sum(axis=1)):
+        if int(n) > MAX_POINTS_PER_NODE:
+            mask |= 1 << (1 + code)
+    for code, n in enumerate(c.reshape(64, 8).sum(axis=1)):
+        if int(n) > MAX_POINTS_PER_NODE:
+            mask |= 1 << (9 + code)
+    return mask & ((1 << 64) - 1), mask >> 64
+
+
+def global_trunk_mask(points, box_size, group=None, slice_points=32_000_000):
+    """trunk_mask of the records the ranks hold between them (any partition, any order): level-3 histogram of this rank's records, one
+    all-reduce(SUM) of 512 counters.  For jobs that did not come through partition_and_route (pre-partitioned inputs, BASELINE config 4)."""
+    rec = points.reshape(-1, 16)
+    hist = torch.zeros(8 ** TRUNK_LEVELS, dtype=torch.int64, device=points.device)
+    for first in range(0, rec.shape[0], slice_points):
+        hist += torch.bincount(cell_codes(rec[first: first + slice_points], box_size, TRUNK_LEVELS), minlength=8 ** TRUNK_LEVELS)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    return trunk_mask(hist.cpu().numpy())
+
+
 def compose_min(framebuffer_u64_as_i64, group=None):
     """In-place all-reduce(MIN) over the 64-bit depth|colour words.  The sign bit of a stored word is never set (a sample
     with negative depth bits never beats the +inf clear value, render.cu:95-100), so signed MIN == unsigned MIN."""

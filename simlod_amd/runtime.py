@@ -49,6 +49,7 @@ def lib():
         L.simlod_context_set_construct_batch_limit.argtypes = [vp, u32]
         L.simlod_context_set_knob.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         L.simlod_context_reload_env.argtypes = [vp]
+        L.simlod_context_set_trunk_mask.argtypes = [vp, u64, u64]
         L.simlod_context_construct_buffer_min_bytes.restype = u64
         L.simlod_context_construct_buffer_min_bytes.argtypes = [vp]
         L.simlod_render_framebuffer_offset.restype = u64
@@ -91,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
     "simlod_context_create", "simlod_context_destroy", "simlod_context_attach", "simlod_context_set_node_capacity", "simlod_context_set_ingest_mode",
     "simlod_context_set_construct_batch_limit", "simlod_context_set_knob", "simlod_context_reload_env", "simlod_context_construct_buffer_min_bytes",
-    "simlod_octree_image_replaced", "simlod_render_frame_composed", "simlod_render_frame_rccl",
+    "simlod_octree_image_replaced", "simlod_render_frame_composed", "simlod_render_frame_rccl", "simlod_context_set_trunk_mask",
     "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_generate_terrain_scan", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 
@@ -181,6 +182,16 @@ class DeviceOctree:
     def reload_env(self):
         """Read the tuning knobs from the environment again (they are read once, when the context is made)."""
         _check(self.L.simlod_context_reload_env(self.ctx), "simlod_context_reload_env")
+
+    def set_trunk_mask(self, lo, hi):
+        """Multi-GPU jobs: the nodes of levels 0-2 that split whatever this rank holds under them (simlod_context_set_trunk_mask; the mask
+        comes from distributed.trunk_mask).  Takes effect with the next batch ingested — flush_trunk() ingests an empty one."""
+        _check(self.L.simlod_context_set_trunk_mask(self.ctx, ctypes.c_uint64(int(lo)), ctypes.c_uint64(int(hi))), "simlod_context_set_trunk_mask")
+
+    def flush_trunk(self, uniforms):
+        """Apply a trunk mask set (or widened) after the last batch: a batch of zero points goes through the ring."""
+        self.upload(np.zeros(0, dtype=abi.point_dtype))
+        self.drain(uniforms)
 
     def set_batch_limit(self, max_batches):
         _check(self.L.simlod_context_set_construct_batch_limit(self.ctx, max_batches), "simlod_context_set_construct_batch_limit")

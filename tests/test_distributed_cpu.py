@@ -149,6 +149,8 @@ def _worker4(rank, world, port, out_dir):
     u = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
     o = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=4)
     o.reset(u)
+    o.set_trunk_mask(*distributed.trunk_mask(counts))          # the shared upper levels split by the GLOBAL counts: the single-GPU octree's topology
+    assert distributed.global_trunk_mask(rec, box) == distributed.trunk_mask(counts)
     o.add_points(u, mine_np, 300_000)
     assert int(o.stats["numPoints"][0]) == len(mine_np)
     for name, kw in (("plain", dict(useHighQualityShading=0)), ("hqs", dict(useHighQualityShading=1))):
@@ -164,7 +166,7 @@ def _worker4(rank, world, port, out_dir):
 def test_four_ranks_one_global_cube_balanced_cells_all_to_all(built_libs, tmp_path):
     """Four ranks, a terrain (thin, uneven: half of the cube's cells are empty) in ONE global cube: level-3 cells dealt by point count —
     no rank carries more than 1.5 x the mean — records routed with one all-to-all, frames composed exactly: every rank ends with the
-    same frame, and it covers what the single-process frame covers."""
+    same frame, and it has the single-process frame's depth at every pixel."""
     world = 4
     port = _free_port()
     mp.spawn(_worker4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
@@ -185,13 +187,11 @@ def test_four_ranks_one_global_cube_balanced_cells_all_to_all(built_libs, tmp_pa
         frames = [np.load(tmp_path / f"frame4_{name}_{r}.npy") for r in range(world)]
         for r in range(1, world):
             assert np.array_equal(frames[0], frames[r]), f"{name}: rank {r} holds another frame than rank 0"
-        covered, want_covered = frames[0] != abi.CLEAR_PIXEL, want != abi.CLEAR_PIXEL
-        assert int(want_covered.sum()) > 3000
-        # the ranks' octrees refine their shared upper levels on their own points only, so the LOD cut may differ in places from the
-        # single-process octree's: same coverage up to a sliver, same depth wherever both drew the same level
-        assert int((covered & want_covered).sum()) >= 0.97 * int(want_covered.sum()), name
-        same_depth = (frames[0] >> np.uint64(32)) == (want >> np.uint64(32))
-        assert int((same_depth & want_covered).sum()) >= 0.5 * int(want_covered.sum()), name
+        assert int((want != abi.CLEAR_PIXEL).sum()) > 3000
+        # the shared upper levels split by the global counts (trunk_mask): the composed frame has the single-process frame's depth at every
+        # pixel (which point colours a voxel depends on batch boundaries, SURVEY.md H6 — on one GPU as well)
+        bad = int(((frames[0] >> np.uint64(32)) != (want >> np.uint64(32))).sum())
+        assert bad == 0, f"{name}: {bad} pixels of the composed frame have another depth than the single-process frame"
 
 
 def _worker_hardening(rank, world, port, out_dir):
@@ -261,74 +261,122 @@ def test_gather_beyond_capacity_sliced_routing_and_pipelined_frames(built_libs, 
     mp.spawn(_worker_hardening, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
 
 
-def _rank_octrees(pts, box, world, u):
-    """The per-rank octrees of the multi-GPU layer (level-3 cells dealt by point count), built by the oracle in one process."""
+def _rank_octrees(pts, box, world, u, trunk=True):
+    """The per-rank octrees of the multi-GPU layer (level-3 cells dealt by point count; the shared upper levels split by the GLOBAL counts:
+    distributed.trunk_mask), built by the oracle in one process."""
     import oracle
     from simlod_amd import abi, distributed
     t = torch.from_numpy(np.ascontiguousarray(pts).view(np.uint8).reshape(-1, 16).copy())
     codes = distributed.cell_codes(t, box, 3)
-    owner, _ = distributed.balanced_owners(codes, world, 3)
+    owner, counts = distributed.balanced_owners(codes, world, 3)
     dest = owner[codes].numpy()
+    lo, hi = distributed.trunk_mask(counts)
     trees = []
     for r in range(world):
         o = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
         o.reset(u)
+        if trunk:
+            o.set_trunk_mask(lo, hi)
         o.add_points(u, pts[dest == r])
         trees.append(o)
-    return trees
+    return trees, (lo, hi)
 
 
-def test_composed_frame_equals_the_single_gpu_frame_unless_a_rank_keeps_an_upper_node_as_a_leaf(built_libs):
-    """Pins DESIGN.md §9's "known limit": ranks own level-3 cells of ONE global cube, so below level 3 a rank's octree IS the single-GPU
-    octree's subtree; the nodes above (levels 0-2) are shared, and each rank grows them from its own points only.  Their voxels are the
-    same cells (a cell of an upper node's grid lies inside one level-3 cell: exactly one rank can set it), so the composed frame has the
-    single-GPU frame's DEPTH at every pixel — unless an upper node that is INNER in the single-GPU octree stays a LEAF on some rank (the
-    rank holds fewer than 50 000 points under it): that rank draws the node's points where a single GPU draws the node's voxels.  Then, and
-    only then, the frames differ, and only inside the screen boxes of those nodes."""
+def _compose_in_process(trees, uv):
+    """distributed.render_frame's sequence — the four parts of kernel_render with the reductions between them — over octrees that live in
+    ONE process: the reductions are numpy's (MIN of the depth planes, SUM of the colour sums, MIN of the framebuffers)."""
+    u = np.ascontiguousarray(uv).reshape(1)
+    hqs, boxes = bool(u["useHighQualityShading"][0]), bool(u["showBoundingBox"][0])
+    for t in trees:
+        t.render_part(uv, 0)
+    if hqs:
+        d = np.minimum.reduce([t._depth for t in trees])
+        for t in trees:
+            t._depth[:] = d
+            t.render_part(uv, 1)
+        sm = np.add.reduce([t._sums for t in trees], dtype=np.uint32)
+        for t in trees:
+            t._sums[:] = sm
+            t.render_part(uv, 2)
+    if not hqs or boxes:
+        fb = np.minimum.reduce([t._fb for t in trees])
+        for t in trees:
+            t._fb[:] = fb
+    for t in trees:
+        t.render_part(uv, 3)
+    for t in trees[1:]:
+        assert np.array_equal(t._fb, trees[0]._fb) and np.array_equal(t._color, trees[0]._color), "the ranks hold different frames"
+    return trees[0]._fb.copy(), trees[0]._color.copy()
+
+
+# (eye in units of the box, Uniforms.minNodeSize): between them the views draw nodes of levels 1, 2 and 3, inner ones by their voxels
+VIEWS = [((2.4, -2.0, 2.2), 24.0), ((1.8, -1.2, 1.4), 64.0), ((1.0, -0.6, 0.8), 64.0), ((1.8, -1.2, 1.4), 24.0)]
+
+
+def _trunk_topology(dump):
+    return {(int(d["level"]), int(d["X"]), int(d["Y"]), int(d["Z"])): bool(d["isLeaf"]) for d in dump if d["level"] < 3}
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_composed_frame_equals_the_single_gpu_frame(built_libs, world):
+    """VERDICT r4 item 1 / BASELINE north star ("rasterized framebuffers are bit-exact vs the reference for a fixed camera"), for N > 1 ranks.
+    Ranks own level-3 cells of ONE global cube, so below level 3 a rank's octree IS the single-GPU octree's subtree.  The nodes above
+    (levels 0-2) are shared; each rank splits them by the GLOBAL counts (distributed.trunk_mask -> set_trunk_mask), so on every rank they
+    have the single-GPU octree's topology, hold the voxels of the rank's own cells (a voxel cell of an upper node lies inside one level-3
+    cell), and the composition of distributed.render_frame is the single-GPU frame: the same DEPTH at every pixel for plain and HQS frames —
+    and, when no colour is scheduling dependent (which point colours a voxel depends on batch boundaries and split times,
+    on one GPU as well; a data set of ONE colour takes that out), the same 64-bit words and the same RGBA8 image.
+    The single-GPU frame comes from the UNMODIFIED path: the reference's own sources where oracle/_ref is built, else the restatement with
+    its mask at zero.  Without the mask the terrain's frames differ (a rank keeps an upper node as a leaf): asserted too, so that the test
+    would notice a mask that does nothing."""
     import oracle
     from simlod_amd import abi, camera, synthetic
     W = H = 256
-    world = 2
-    # uniform 1.6 M: the single octree's inner nodes above level 3 are the root and the eight level-1 nodes (200 000 points each, ~100 000 of them
-    #                on either rank: inner there too); the level-2 nodes are leaves on one GPU and on the ranks.
-    # terrain 3 M:   one level-2 node at the edge of the terrain is inner in the single octree and a leaf on the rank that owns few of its cells.
-    for name, (pts, box), expect_equal in (("uniform 1.6 M", synthetic.uniform_cube(1_600_000, seed=8), True),
-                                           ("terrain 3 M", synthetic.terrain(3_000_000, seed=4, box=(600.0, 400.0, 40.0)), False)):
-        T = camera.lookat_transform((2.4 * box[0], -2.0 * box[1], 2.2 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)     # far: upper nodes are drawn by their voxels
-        u = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
-        single = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
-        single.reset(u)
-        single.add_points(u, pts)
-        fb_single, _ = single.render(u)
-        trees = _rank_octrees(pts, box, world, u)
-        fb = np.minimum.reduce([t.render(u)[0] for t in trees])                 # the composition of distributed.render_frame for a plain frame
-        ds = single.dump()
-        inner_single = {(int(d["level"]), int(d["X"]), int(d["Y"]), int(d["Z"])) for d in ds if d["level"] < 3 and not d["isLeaf"]}
-        culprits = []                                                             # upper nodes that are inner in the single octree but a (non-empty) leaf on a rank
-        for t in trees:
-            for d in t.dump():
-                key = (int(d["level"]), int(d["X"]), int(d["Y"]), int(d["Z"]))
-                if d["level"] < 3 and d["isLeaf"] and d["numPoints"] > 0 and key in inner_single:
-                    culprits.append(key)
-        depth_equal = np.array_equal(fb >> np.uint64(32), fb_single >> np.uint64(32))
-        if expect_equal:
-            assert not culprits, (name, culprits)
-            assert depth_equal, f"{name}: every rank refines the shared upper nodes: the composed frame must have the single-GPU frame's depth everywhere"
-        else:
-            assert culprits, f"{name}: expected a rank with fewer than 50 000 points under a shared node"
-            # the frames may differ only inside the screen boxes of those nodes
-            bad = np.nonzero((fb >> np.uint64(32)) != (fb_single >> np.uint64(32)))[0]
-            size = float(max(box))
-            M = np.asarray(T, dtype=np.float32).reshape(4, 4)
-            allowed = np.zeros(W * H, dtype=bool)
-            for (lv, X, Y, Z) in set(culprits):
-                s = size / 2 ** lv
-                cs = np.array([[(X + a) * s, (Y + b) * s, (Z + c) * s, 1.0] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=np.float32)
-                clip = cs @ M.T
-                px = (clip[:, 0] / clip[:, 3] * 0.5 + 0.5) * W
-                py = (clip[:, 1] / clip[:, 3] * 0.5 + 0.5) * H
-                x0, x1 = max(int(px.min()) - 2, 0), min(int(px.max()) + 3, W)
-                y0, y1 = max(int(py.min()) - 2, 0), min(int(py.max()) + 3, H)
-                m = np.zeros((H, W), dtype=bool); m[y0:y1, x0:x1] = True
-                allowed |= m.reshape(-1)
-            assert allowed[bad].all(), f"{name}: {int((~allowed[bad]).sum())} differing pixels lie outside the screen boxes of the nodes a rank kept as leaves"
+    # uniform 1.6 M: root and the eight level-1 nodes are inner everywhere, the level-2 nodes leaves (25 000 points each)
+    # terrain 3 M:   level-2 nodes at the terrain's edge are inner in the single octree and hold fewer than 50 000 points on some rank
+    for name, (pts, box) in (("uniform 1.6 M", synthetic.uniform_cube(1_600_000, seed=8)),
+                             ("terrain 3 M", synthetic.terrain(3_000_000, seed=4, box=(600.0, 400.0, 40.0)))):
+        for recolour in (False, True):
+            if recolour:
+                pts = pts.copy(); pts["color"] = 0xff4080c0
+            u = abi.make_uniforms(W, H, np.eye(4), box, persistent_capacity=1 << 30, momentary_capacity=300_000_000)
+            single = oracle.HostOctree("ref" if oracle.have_ref() else "port", persistent_bytes=1 << 30, ring_slots=abi.BATCH_STREAM_SIZE)
+            single.reset(u)
+            single.add_points(u, pts)
+            trees, mask = _rank_octrees(pts, box, world, u)
+            want_top = _trunk_topology(single.dump())
+            inner = {k for k, leaf in want_top.items() if not leaf}
+            assert mask[0] | (mask[1] << 64) == sum(1 << (0 if k[0] == 0 else 1 + (k[1] << 2 | k[2] << 1 | k[3]) if k[0] == 1 else
+                                                       9 + (((k[1] >> 1) << 2 | (k[2] >> 1) << 1 | (k[3] >> 1)) << 3 | ((k[1] & 1) << 2 | (k[2] & 1) << 1 | (k[3] & 1)))) for k in inner), \
+                f"{name}: trunk_mask does not name the single octree's inner upper nodes"
+            for r, t in enumerate(trees):
+                assert t.last_error() == 0
+                assert _trunk_topology(t.dump()) == want_top, f"{name}: rank {r}'s upper levels differ from the single-GPU octree's"
+            assert sum(int(t.stats["numPoints"][0]) for t in trees) == len(pts)
+            drawn_levels = set()
+            for eye, min_node_size in VIEWS:
+                T = camera.lookat_transform((eye[0] * box[0], eye[1] * box[1], eye[2] * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+                u = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000, min_node_size=min_node_size)
+                for variant, kw in FRAME_VARIANTS:
+                    uv = u.copy()
+                    for k, v in kw.items():
+                        uv[k] = v
+                    want_fb, want_color = single.render(uv)
+                    drawn_levels |= {int(l) for l in single.visible["level"][single.visible["numVoxels"] > 0]}
+                    fb, color = _compose_in_process(trees, uv)
+                    assert int((want_fb != abi.CLEAR_PIXEL).sum()) > 1500, (name, eye, min_node_size)
+                    bad = int(((fb >> np.uint64(32)) != (want_fb >> np.uint64(32))).sum())
+                    assert bad == 0, f"{name}, {variant}, {world} ranks, view {eye}/{min_node_size}: {bad} pixels of the composed frame have another depth than the single-GPU frame"
+                    if recolour:
+                        assert np.array_equal(fb, want_fb) and np.array_equal(color, want_color), f"{name}, {variant}, {world} ranks: composed frame != single-GPU frame"
+            assert ({1} if name.startswith("uniform") else {1, 2}) <= drawn_levels, f"{name}: the views must draw shared upper nodes by their voxels (levels drawn as voxels: {sorted(drawn_levels)})"
+        # the control: ranks that refine the upper levels from their own points only show another LOD cut on the terrain
+        if name.startswith("terrain") and world == 2:
+            loose, _ = _rank_octrees(pts, box, world, u, trunk=False)
+            assert any(_trunk_topology(t.dump()) != want_top for t in loose)
+            differs = False
+            for eye, min_node_size in VIEWS:
+                T = camera.lookat_transform((eye[0] * box[0], eye[1] * box[1], eye[2] * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+                uv = abi.make_uniforms(W, H, T, box, persistent_capacity=1 << 30, momentary_capacity=300_000_000, min_node_size=min_node_size)
+                differs |= not np.array_equal(_compose_in_process(loose, uv)[0] >> np.uint64(32), single.render(uv)[0] >> np.uint64(32))
+            assert differs, "without the mask a rank keeps an upper node as a leaf: some view must show it"

@@ -56,6 +56,7 @@ def _worker(rank, world, port, out_dir):
     del mine2
     u = _uniforms(None, box, True, persistent)
     dev.reset(u)
+    dev.set_trunk_mask(*distributed.trunk_mask(counts))          # the shared upper levels split by the GLOBAL counts: the single-GPU octree's topology
     launches = dev.stream(u, mine.reshape(-1), int(mine.shape[0]))
     st = dev.read_stats()
     assert int(st["dbg"]) == 0 and int(st["numPoints"]) == mine.shape[0] and launches >= 1
@@ -114,6 +115,7 @@ def test_two_ranks_on_one_gpu_partition_ingest_and_compose_frames_like_the_oracl
         u = _uniforms(None, box, True, 1 << 30)
         ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
         ref.reset(u)
+        ref.set_trunk_mask(*distributed.trunk_mask(d["counts"]))
         ref.add_points(u, pts)
         nodes = np.ascontiguousarray(d["nodes"]).view(abi.node_dtype).copy()
         pers, n = d["pers"].copy(), int(d["n"])
@@ -155,6 +157,21 @@ def test_two_ranks_on_one_gpu_partition_ingest_and_compose_frames_like_the_oracl
             # the all-gathered visible-node counts: what every rank's own visibility pass found
             assert [int(v) for v in d[name + "_visible"]] == [int(t["stats"]["numVisibleNodes"][0]) for t in state]
         assert np.array_equal(ranks[0][name], ranks[1][name]), f"{name}: the ranks hold different composed frames"
+    # ... and the composed frames show what ONE GPU holding every record shows: one octree of all 6 M records, in this
+    # process, on the same device — the same depth at every pixel (which point colours a voxel is scheduling dependent)
+    from simlod_amd.runtime import DeviceOctree
+    single = DeviceOctree("cuda:0", persistent_bytes=1 << 30, max_pixels=W * H)
+    u = _uniforms(None, box, True, 1 << 30)
+    single.reset(u)
+    for d in ranks:
+        single.add_points(u, np.ascontiguousarray(d["mine"]).reshape(-1).view(abi.point_dtype))
+    assert int(single.read_stats()["numPoints"]) == world * N_PER_RANK
+    for name, hqs in (("hqs", True), ("plain", False)):
+        single.render(_uniforms(None, box, hqs, 1 << 30))
+        want = single.framebuffer(W, H)
+        bad = int(((ranks[0][name] >> np.uint64(32)) != (want >> np.uint64(32))).sum())
+        assert bad == 0, f"{name}: {bad} pixels of the two ranks' composed frame have another depth than the single-GPU frame"
+    single.close()
 
 
 def test_bench_n2_runs_its_multi_rank_path_with_two_processes_on_one_gpu_over_gloo(built_libs):
