@@ -165,6 +165,10 @@ def main():
                          "histogram_assign_route_ms": t_part * 1e3, "kept_local": int(recv[rank]), "slice_points": 32_000_000,
                          "what": "all-reduce of 512-cell histograms, greedy by count, the records routed in slices (one all_to_all_single per slice of 32 M)"}
             del generated
+            # the shared upper levels (0-2) split by the GLOBAL counts on every rank: composed frames equal the single-GPU frame (distributed.trunk_mask)
+            trunk = distributed.trunk_mask(counts)
+            dev.set_trunk_mask(*trunk)
+            partition["trunk_mask"] = f"{trunk[0] | (trunk[1] << 64):#x}"
         else:
             mine = generated.reshape(-1, 16)
         my_points = int(mine.shape[0])

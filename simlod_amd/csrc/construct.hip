@@ -64,14 +64,15 @@ struct BatchCtl {
 // (the recycle stack behind it, like the reference's chunkQueue, must survive between launches).
 struct Ctl {
 	uint32_t uploaded, firstBatch, numBatches, stop;
-	uint32_t errors, abortBatch, rebuildLeafChunks, debugFlags;   // rebuildLeafChunks: this launch found the leaf chunk table stale (first launch, reset, wiped momentary buffer): k_parents refills it
+	uint32_t errors, abortBatch, rebuildLeafChunks, debugFlags;   // rebuildLeafChunks: this launch found its side tables stale (first launch, reset, wiped or re-laid-out momentary buffer): k_rebuild / k_paths clear the tag words and refill parents, chunk table, paths and the top table — otherwise they are what the launch before left
 	uint32_t processed, budgetUs, consumed, groupMax;   // groups completed in this launch | its time budget in us (voxels.cu:22: 10 ms; SIMLOD_DEBUG_BUDGET_US overrides) | ring batches taken so far | batches per group (1: exact mode)
 	uint64_t startNs;
 	uint32_t statCounters[8];
 	uint32_t tableMagic, tableBatch;   // leaf chunk table is valid for the octree as it was after batch #tableBatch (k_finish) ...
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
-	uint64_t unused1[4];
+	uint64_t tableLayout;              // layout_signature() of the momentary buffer the side tables were built in
+	uint64_t unused1[3];
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
 	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 216: k_voxelize of group #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
 	uint64_t phaseNs[48];              // byte 696: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
@@ -80,6 +81,7 @@ struct Ctl {
 };
 static_assert(offsetof(Ctl, voxT) == 216 && offsetof(Ctl, phaseNs) == 696, "tools/probe.py reads Ctl.voxT at byte 216, Ctl.phaseNs at byte 696");
 static_assert(offsetof(Ctl, expandNs) == 152, "bench.py / tools read Ctl.expandNs at byte 152");
+static_assert(offsetof(Ctl, batch) == 1080 && sizeof(BatchCtl) == 264, "tools/batch_shape.py reads Ctl.batch at byte 1080");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
 struct BuildArgs {
@@ -210,7 +212,7 @@ struct NodeDir {          // per node, valid for the batch whose tag it carries:
 // Leaf chunk table: slot k of leaf i's point list -> chunk, LEAF_SLOTS entries per node.  A leaf that can still split stores
 // at most MAX_POINTS_PER_NODE points between batches (= 50 chunks), so the split reads its whole list from here with all
 // lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by alloc_points (k_expand); survives between
-// launches like the recycle stack does, and is refilled by k_parents whenever k_begin finds its stamp stale.
+// launches like the recycle stack does, and is refilled by k_rebuild whenever k_begin finds its stamp stale.
 static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
 static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
 
@@ -356,6 +358,11 @@ struct Samples {
 	__device__ __forceinline__ float4 operator[](uint32_t i) const { return *ptr(i); }
 };
 
+// what the stamp remembers of the momentary buffer's layout: side tables of another node capacity / buffer size / group size are not these
+__host__ __device__ inline uint64_t layout_signature(const BuildArgs& a) {
+	return a.scratchBytes ^ ((uint64_t)a.nodeCapacity << 40) ^ ((uint64_t)a.groupMax << 59) ^ (a.offSpilled * 0x9E3779B97F4A7C15ull);
+}
+
 // ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
 __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs, uint32_t groupMax) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -382,28 +389,43 @@ __global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchL
 	ctl->firstBatch = first;
 	ctl->numBatches = n;
 	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
-	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers) ? 1u : 0u;
+	// The side tables — parents, ancestor paths, the top table, the chunk table, the recycle stack — and the per-node tag words survive between
+	// launches: k_expand keeps them current split by split, and every tag is a batch index + 1, which only grows while an octree lives.  They
+	// are rebuilt (k_rebuild, k_paths) only when the stamp k_finish left does not name THIS octree in THIS state in THIS layout: the first launch,
+	// after a reset, an uploaded image, an aborted batch, a wiped or resized momentary buffer.  (Tags travel in 20 bits through the hash directory
+	// of voxel chunks: a full clear every 2^19 batches keeps them unambiguous.)
+	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers ||
+	                          ctl->tableLayout != layout_signature(a) || ctl->tableSig != table_signature(a.stats) ||
+	                          (first >= 0x80000u && (first & 0x7ffffu) < SIMLOD_MAX_BATCHES_PER_LAUNCH)) ? 1u : 0u;
 	ctl->tableMagic = 0;                        // valid again once k_finish has run
 	for (uint32_t i = 0; i < BATCH_COPIES; i++) ctl->batch[i].active = 0;
 	for (uint32_t i = 0; i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++) { ctl->voxT[i][0] = ~0ull; ctl->voxT[i][1] = 0; ctl->voxT[i][2] = 0; }
 	prepare_batch(a, ctl, 0);
 }
 
-// ---- parents: node index -> parent index, rebuilt at the start of every launch from the children pointers -----------
-// (a momentary table: nothing but the octree image itself and the recycle stack has to survive between launches)
-__global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= numNodes) return;
-	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
-	if (i == 0) parentOf[0] = 0xffffffffu;
-	const SimlodNode* n = a.nodes + i;
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		const SimlodNode* c = n->children[k];
-		if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
+// ---- rebuild: the side tables of an octree this buffer does not describe (see k_begin) --------------------------------------------------
+// k_rebuild: the per-node tag words and the hash directory are zeroed (offSplitTag .. offParent: a stale word could pass for a tag of this
+// octree's batches), parents come from the children pointers, the rows of the chunk table from the lists.  k_paths (needs the parents):
+// every node's ancestor list and the top table.  Both exit at once when the stamp is good — every launch but the first, as a rule: a launch
+// used to pay an 8 MB memset and two passes over the node CAPACITY (1 028 workgroups each) for tables that were valid.
+__global__ __launch_bounds__(TPB) void k_rebuild(BuildArgs a) {
+	if (ctl_of(a)->rebuildLeafChunks == 0u) return;
+	{
+		uint4* w = reinterpret_cast<uint4*>(a.mom + a.offSplitTag);
+		const uint64_t n = (a.offParent - a.offSplitTag) / 16;                 // (the offsets are 256-byte aligned)
+		for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) w[i] = make_uint4(0, 0, 0, 0);
 	}
-	if (ctl_of(a)->rebuildLeafChunks) {      // a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser)
+	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
+	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
+		if (i == 0) parentOf[0] = 0xffffffffu;
+		const SimlodNode* n = a.nodes + i;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const SimlodNode* c = n->children[k];
+			if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
+		}
+		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser)
 		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
 		const SimlodChunk* c = node_is_leaf(n) ? n->points : n->voxelChunks;
 		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
@@ -412,9 +434,9 @@ __global__ __launch_bounds__(TPB) void k_parents(BuildArgs a) {
 
 // ---- paths: every node's ancestor list, from the parent table (one thread per node, depth <= 20 steps) ---------------------
 __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
+	if (ctl_of(a)->rebuildLeafChunks == 0u) return;
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i < TOP_CELLS) {                               // the top table: cell i's deepest node at level <= TOP_LEVEL, by descent from the root
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < TOP_CELLS; i += gridDim.x * TPB) {      // the top table: cell i's deepest node at level <= TOP_LEVEL, by descent from the root
 		const uint32_t s = (uint32_t)SIMLOD_MAX_DEPTH - TOP_LEVEL;
 		const uint32_t X = (i >> (2u * TOP_LEVEL)) << s, Y = ((i >> TOP_LEVEL) & (TOP_SIDE - 1u)) << s, Z = (i & (TOP_SIDE - 1u)) << s;
 		uint32_t cur = 0, level = 0;
@@ -425,15 +447,16 @@ __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
 		}
 		at<uint32_t>(a, a.offTop)[i] = cur | (level << 19);
 	}
-	if (i >= numNodes) return;
 	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
-	unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
-	uint32_t k = 0;
-	for (uint32_t cur = parentOf[i]; cur != 0xffffffffu && k < PATH_WORDS - 1; cur = parentOf[cur]) {
-		const SimlodNode* n = a.nodes + cur;
-		rec[k++] = path_pack(a.pers, cur, n->level, n->grid);
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
+		unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
+		uint32_t k = 0;
+		for (uint32_t cur = parentOf[i]; cur != 0xffffffffu && k < PATH_WORDS - 1; cur = parentOf[cur]) {
+			const SimlodNode* n = a.nodes + cur;
+			rec[k++] = path_pack(a.pers, cur, n->level, n->grid);
+		}
+		rec[k] = 0;
 	}
-	rec[k] = 0;
 }
 
 // ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
@@ -579,7 +602,7 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 			if (grid == nullptr) { grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + gridAt); node->grid = grid; }
 			note_clear(a, bc, c, grid);
 			slot_recs(a, bc->ordinal)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, 0u, 0u, 0u};
-			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)(bc->ordinal + 1u) << 32) | (level << 16) | slot;
+			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)bc->tag << 32) | (level << 16) | slot;      // (the group's tag: unique while the octree lives, like every tag word)
 		}
 	}
 	ok = __shfl(ok, 0);
@@ -752,7 +775,10 @@ __global__ __launch_bounds__(TPB) void k_queue(BuildArgs a, uint32_t ordinal) {
 
 // ---- k_voxelize's work items (filled by the chunk allocation below) -----------------------------------------------------
 static constexpr uint32_t VTPB = 1024;
-static constexpr uint32_t VOX_SPT = 8;                          // samples per thread, kept in registers across both passes
+#ifndef VOX_SPT_N
+#define VOX_SPT_N 8
+#endif
+static constexpr uint32_t VOX_SPT = VOX_SPT_N;                  // samples per thread, kept in registers across both passes
 static constexpr uint32_t VOX_PIECE = VTPB * VOX_SPT;           // 8192 samples per workgroup
 static constexpr uint32_t VOX_BIG_ITEMS = 65536;                // entries of the item array for k_voxelize's pieces; the rest: one small item per leaf
 static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with fewer new samples than this takes the wave-per-leaf path ...
@@ -817,7 +843,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		if (i != NONE && fresh_leaves) { counter = entry.y; need = counter != 0u; }
 		else if (i != NONE) {
 			// (a leaf that k_count's tail has queued for splitting still looks like a leaf until k_expand gives it children: not this one's business)
-			const bool queued = (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[i] >> 32) == bc->ordinal + 1u;
+			const bool queued = (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[i] >> 32) == bc->tag;
 			counter = node->counter; head = node->points; need = !queued && stored < counter && node_is_leaf(node);
 		}
 		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
@@ -918,7 +944,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
 	const uint32_t n = bc->batchSize;
-	const uint32_t tag = bc->ordinal + 1u;
+	const uint32_t tag = bc->tag;
 	const uint32_t moved = min(bc->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
 	const uint32_t total = moved + n;
 	const uint32_t numChunks = (total + CPB - 1) / CPB;
@@ -2092,17 +2118,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	uint32_t v[7] = {0, 0, 0, 0, 0, 0, 0};   // inner, leaves, nonempty, points, voxels, chunksP, chunksV
-	if (i < numNodes) {
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {      // (a grid for the nodes that exist, not for the node capacity)
 		SimlodNode* n = a.nodes + i;
 		// voxels.cu:298-300: every counting pass stamps every node with (index of the batch + 1); what the host can see is the last stamp
 		if (ctl->processed != 0u) n->countIteration = a.stats->batchletIndex;
 		if (node_is_leaf(n)) {
-			v[1] = 1; v[3] = n->numPoints; v[5] = (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-			v[2] = n->numPoints > 0 ? 1u : 0u;
+			v[1] += 1; v[3] += n->numPoints; v[5] += (n->numPoints + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			v[2] += n->numPoints > 0 ? 1u : 0u;
 		} else {
-			v[0] = 1; v[4] = n->numVoxels; v[6] = (n->numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			v[0] += 1; v[4] += n->numVoxels; v[6] += (n->numVoxels + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		}
 	}
 	for (int k = 0; k < 7; k++) {
@@ -2133,6 +2158,7 @@ __global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const u
 		ctl->tableNodes = (uint64_t)a.nodes;
 		ctl->tablePers = (uint64_t)a.pers;
 		ctl->tableSig = table_signature(s);
+		ctl->tableLayout = layout_signature(a);
 		ctl->tableMagic = TABLE_MAGIC;
 	}
 }
@@ -2257,10 +2283,9 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
 	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), a.groupMax);
 	if (fits) {
-		hipError_t e = hipMemsetAsync(a.mom + a.offSplitTag, 0, (size_t)(a.offParent - a.offSplitTag), stream);   // split records and retry tags
-		if (e != hipSuccess) return (int)e;
-		SIMLOD_LAUNCH(k_parents, dim3((a.nodeCapacity + TPB - 1) / TPB), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(k_paths, dim3(std::max<uint32_t>((a.nodeCapacity + TPB - 1) / TPB, TOP_CELLS / TPB)), dim3(TPB), stream, a);   // (also one thread per cell of the top table)
+		// (both exit at once unless k_begin found the side tables stale: the first launch of an octree, as a rule)
+		SIMLOD_LAUNCH(k_rebuild, dim3(dev.numCUs * 2), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(k_paths, dim3(dev.numCUs), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
@@ -2323,7 +2348,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 			if (e != hipSuccess) return fail(e);
 		}
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
-		SIMLOD_LAUNCH(k_stats, dim3(gridNodes), dim3(TPB), stream, a);
+		SIMLOD_LAUNCH(k_stats, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
 	}
 	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u, launch_feedback_words(ctx, stats), (const uint32_t*)numBatchesUploaded);
 	if (profile_enabled()) profile_close(stream);

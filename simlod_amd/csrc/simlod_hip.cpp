@@ -207,27 +207,53 @@ void forget_launch_history(Context& ctx, const SimlodStats* stats) {
 }
 
 // ---- frame feedback: did the render buffer's previous frame have nodes that sort into the screen bins (render.hip r_overflow) ----------
-uint32_t* frame_feedback(Context& ctx, const void* buffer, bool firstPart, bool& bins) {
+static uint64_t bytes_behind(const void* buffer) {
+	hipDeviceptr_t base = nullptr;
+	size_t size = 0;
+	if (hipMemGetAddressRange(&base, &size, const_cast<void*>(buffer)) != hipSuccess || base == nullptr) { (void)hipGetLastError(); return 200000000ull; }   // main_progressive_octree.cpp:555
+	const uint64_t off = (uint64_t)((const uint8_t*)buffer - (const uint8_t*)base);
+	return off < size ? size - off : 0;
+}
+
+// The buffer's entry, made when the buffer is first seen.  The FIRST part of a frame decides (possible: the knobs and the buffer's size allow bins;
+// bins: and the buffer's previous frame had nodes to sort) and the decision is kept for the frame's other parts, whatever the knobs say by then:
+// r_visible has built the frame's draw items for it, and a colour pass that ran without the bins would drop the samples of the items that sort.
+// An entry whose frame is between its first and its last part is not evicted.
+uint32_t* frame_feedback(Context& ctx, const void* buffer, uint32_t parts, bool& possible, bool& bins, uint64_t& bufferBytes) {
 	std::lock_guard<std::mutex> hold(ctx.framesLock);
 	FrameFeedback* f = nullptr;
 	for (FrameFeedback& g : ctx.frames) if (g.buffer == buffer) f = &g;
 	if (f == nullptr) {
 		volatile uint32_t* seen = nullptr;
-		if (ctx.frames.size() >= 64) {                       // the oldest entry makes room; its word is handed on (a late store into it: a stale hint)
-			seen = ctx.frames.front().seen;
-			ctx.frames.erase(ctx.frames.begin());
+		if (ctx.frames.size() >= 64) {                       // the oldest entry without a frame in progress makes room; its word is handed on (a late store into it: a stale hint)
+			size_t victim = 0;
+			for (size_t i = 0; i < ctx.frames.size(); i++) if (!ctx.frames[i].open) { victim = i; break; }
+			seen = ctx.frames[victim].seen;
+			ctx.frames.erase(ctx.frames.begin() + (long)victim);
 		} else {
 			void* pinned = nullptr;
-			if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); bins = true; return nullptr; }
+			if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); bufferBytes = bytes_behind(buffer); bins = possible; return nullptr; }
 			seen = static_cast<volatile uint32_t*>(pinned);
 		}
 		seen[0] = 1u;                                        // a buffer's first frame sorts
-		ctx.frames.push_back(FrameFeedback{buffer, seen, true});
+		ctx.frames.push_back(FrameFeedback{buffer, seen, false, 0, false, false});
 		f = &ctx.frames.back();
 	}
-	if (firstPart) f->bins = f->seen[0] != 0u;
-	bins = f->bins;
+	if ((parts & RENDER_FIRST) != 0u) {
+		f->bytes = bytes_behind(buffer);                     // (a host may free a buffer and get the address back with another size)
+		f->possible = possible;
+		f->bins = possible && f->seen[0] != 0u;
+		f->open = true;
+	}
+	possible = f->possible; bins = f->bins; bufferBytes = f->bytes;
+	if ((parts & RENDER_OUTPUT) != 0u) f->open = false;
 	return const_cast<uint32_t*>(f->seen);
+}
+
+// the first part found that the buffer has no room for the bins after all (launch_render: the pool is what the allocation has left)
+void frame_feedback_no_bins(Context& ctx, const void* buffer) {
+	std::lock_guard<std::mutex> hold(ctx.framesLock);
+	for (FrameFeedback& g : ctx.frames) if (g.buffer == buffer) { g.possible = false; g.bins = false; }
 }
 
 // ---- optional per-kernel profiling ------------------------------------------------------------------------------

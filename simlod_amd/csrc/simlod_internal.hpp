@@ -51,7 +51,7 @@ static constexpr int KNOB_UNSET = INT_MIN;
 extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...
 
 struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter
-struct FrameFeedback { const void* buffer; volatile uint32_t* seen; bool bins; };                       // render.hip launch_render: seen[0] = nodes of the buffer's latest frame that sort (or would)
+struct FrameFeedback { const void* buffer; volatile uint32_t* seen; bool bins; uint64_t bytes; bool possible, open; };                       // render.hip launch_render: seen[0] = nodes of the buffer's latest frame that sort (or would)
 struct SideStream;                                           // construct.hip: the second stream of kernel_construct and its events
 void destroy_side_stream(SideStream* s);
 
@@ -78,7 +78,8 @@ struct Context {
 // The frame's feedback word (page-locked, written by the frame's first draw pass) of the render buffer, and whether this frame sorts the
 // samples of its large nodes into the screen bins: decided by the frame's first part from what the buffer's previous frame found, kept for
 // the frame's other parts.  nullptr (no page-locked memory): every frame sorts.
-uint32_t* frame_feedback(Context& ctx, const void* buffer, bool firstPart, bool& bins);
+uint32_t* frame_feedback(Context& ctx, const void* buffer, uint32_t parts, bool& possible, bool& bins, uint64_t& bufferBytes);   // parts: RENDER_* of this launch; bufferBytes: what the allocation behind `buffer` holds from `buffer` on
+void frame_feedback_no_bins(Context& ctx, const void* buffer);
 Context& context_of(const void* nodes);                      // the context `nodes` is attached to, else the default one
 uint32_t live_contexts();                                    // contexts that exist right now (the default one included once it has been used)
 

@@ -607,6 +607,56 @@ def test_render_edge_cases_bit_exact(built_libs, variant):
     assert int(np.abs(col_dev.view(np.uint8).astype(np.int16) - col.view(np.uint8).astype(np.int16)).max()) <= 1
 
 
+@pytest.mark.parametrize("size", [(1920, 1200), (2560, 1440)])
+def test_reference_hosts_200_mb_render_buffer_above_1080p(built_libs, size):
+    """the reference host allocates 200 000 000 bytes for kernel_render's buffer whatever the window's size
+    (main_progressive_octree.cpp:555-556) and renders at the window's size.  The planes grow with the frame and the screen bins lie behind them:
+    at 1920 x 1200 the buffer has room for part of the bin pool, at 2560 x 1440 for none of it.  The frame goes into a buffer of exactly that
+    size — hipMalloc, as the host's cuMemAlloc: the library asks the runtime what the allocation holds —, must not touch a byte beyond it (the
+    device faults on an unmapped page: the test would die here) and must equal the oracle's; a camera that skims the terrain, so that the bins
+    are wanted."""
+    import ctypes
+    import torch
+    Wd, Hd = size
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    pts, box = synthetic.terrain(1_500_000, seed=3, box=(600.0, 400.0, 40.0), tile=50.0)
+    ex, ey = 0.5 * float(box[0]), 0.3 * float(box[1])
+    ground = synthetic.terrain_height(ex, ey, seed=3, box=(600.0, 400.0, 40.0))
+    T = camera.lookat_transform((ex, ey, ground + 6.0), (ex + 20.0, ey + 200.0, ground - 4.0), Wd, Hd)
+    dev = _device(ring_slots=2, max_pixels=Wd * Hd)
+    u = dev.uniforms(Wd, Hd, T, box)
+    _ingest(dev, u, [pts[i:i + 1_000_000] for i in range(0, len(pts), 1_000_000)])
+    HOST_BYTES = 200_000_000
+    assert int(dev.L.simlod_render_buffer_bytes(Wd, Hd)) > HOST_BYTES, "the case: a frame whose full layout does not fit the host's buffer"
+    raw = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(raw), HOST_BYTES) == 0
+    try:
+        assert hip.hipMemset(raw, 0xA5, HOST_BYTES) == 0
+        uu, up = dev._u(u)
+        nodes, pers, nn = host_image_of(dev)
+        for hqs in (0, 1):
+            uu["useHighQualityShading"] = hqs
+            for _ in range(2):             # (a buffer's first frame decides about the bins; its second one runs with what the first found)
+                rc = dev.L.simlod_launch_render(raw, up, dev._p(dev.nodes), dev._p(dev.colorbuffer), dev._p(dev.stats), dev._p(dev.frame_start), None, dev._stream())
+                assert rc == 0
+                torch.cuda.synchronize()
+            fb_dev = np.zeros(Wd * Hd, dtype=np.uint64)
+            assert hip.hipMemcpy(fb_dev.ctypes.data, ctypes.c_void_p(raw.value + int(dev.L.simlod_render_framebuffer_offset())), Wd * Hd * 8, 2) == 0
+            ds = dev.read_stats()
+            assert int(ds["dbg"]) == 0
+            fb, col, st = _oracle_render(nodes, nn, uu[0])
+            assert_stats_equal(ds, st, STATS_RENDER_FIELDS, str(size))
+            bad = int((fb_dev != fb).sum())
+            assert bad == 0, f"{size}, hqs={hqs}: {bad} pixels differ from the oracle's frame"
+            assert int((fb != abi.CLEAR_PIXEL).sum()) > 20_000
+    finally:
+        hip.hipFree(raw)
+
+
 # ---- the reference's launch surface ------------------------------------------------------------------------------------------
 def test_cuda_modular_program_shaped_surface(built_libs):
     """Drive reset / construct / render exactly as main_progressive_octree.cpp does: program->kernels[name] and a

@@ -15,7 +15,7 @@ PRESETS=bird timeout 100 python tools/raster_items.py 2>&1 | grep -v amdgpu > $F
 timeout 100 python tools/raster_bins.py 2>&1 | grep -v amdgpu > $F/raster_bins_close.txt
 tools/raster_trace.sh ${TAG}_close close > $F/raster_kernels_close.txt 2>&1
 tools/raster_trace.sh ${TAG}_bird bird > $F/raster_kernels_bird.txt 2>&1
-tools/r4.sh final > $F/ingest_timeline.txt 2>&1
+tools/trace.sh final > $F/ingest_timeline.txt 2>&1
 python tools/fold_profiles.py $TAG > $F/fold.txt 2>&1
 mkdir -p profiles/$TAG; cp gpurun_out/final_$TAG/config3_350m* profiles/$TAG/ 2>/dev/null
 timeout 900 python bench.py --profiles $TAG > $F/bench_final.json 2> $F/bench_final.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/raster_trace.sh <tag> <preset>      rocprofv3 kernel trace of the rasteriser alone, one camera preset; per-kernel averages
 TAG=$1; PRESET=${2:-close}
-REPO=$(pwd); OUT=$REPO/gpurun_out/r4_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+REPO=$(pwd); OUT=$REPO/gpurun_out/rtrace_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
 PRESETS=$PRESET rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/tools/raster_close.py 20 > $OUT/out.txt 2> $OUT/trace.err
 cd $REPO
