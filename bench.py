@@ -211,6 +211,23 @@ def main():
     assert int(stats["numPointsProcessed"]) == my_points and int(stats["numPoints"]) == my_points, "ingest lost points"
     assert int(stats["dbg"]) == 0, f"device error bits {int(stats['dbg']):#x}"
     value = world * n_points / (ms_per_step * 1e-3) / 1e6
+    collective = None
+    if use_dist:
+        # what the process group really was: every rank adds 1 (ranks_seen must be the world size) and its point count (the octrees of all
+        # ranks together hold every generated point)
+        seen = torch.tensor([1, int(stats["numPoints"])], dtype=torch.int64, device=dev.device)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks_seen, total_points = int(seen[0].item()), int(seen[1].item())
+        assert ranks_seen == world, f"the all-reduce saw {ranks_seen} ranks, WORLD_SIZE is {world}"
+        assert total_points == world * n_points, f"the ranks' octrees hold {total_points} points, {world} x {n_points} were generated"
+        ver = None
+        if args.backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+        collective = {"backend": dist.get_backend(), "is_rccl": args.backend == "nccl" and torch.version.hip is not None, "world_size": dist.get_world_size(),
+                      "nccl_version": ver, "ranks_seen": ranks_seen, "points_in_all_octrees": total_points}
 
     # ---- raster ------------------------------------------------------------------------------------------------
     from simlod_amd import distributed
@@ -253,6 +270,15 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX); dist.all_reduce(samples, op=dist.ReduceOp.SUM)
         ms = float(tm.item()) * 1e3 / args.frames
         vs = float(samples.item())
+        if use_dist and world > 1:
+            # one more composed frame, its framebuffer folded into one word per rank: every rank must hold the same frame
+            distributed.render_frame(dev, uc)
+            fbw = dev.framebuffer_words()
+            h = (fbw ^ (fbw >> 29)).sum().reshape(1) if not hqs else (dev.colorbuffer[: W * H].to(torch.int64) * 2654435761 % 1000003).sum().reshape(1)
+            hs = [torch.zeros_like(h) for _ in range(world)]
+            dist.all_gather(hs, h)
+            assert all(int(x.item()) == int(hs[0].item()) for x in hs), f"{name}: the ranks hold different composed frames"
+            collective.setdefault("frames_identical_on_all_ranks", []).append(name)
         # plain 24 B/sample (16 B read + 8 B framebuffer RMW) + 20 B/px (8 clear + 12 output); HQS 32 B/sample (two
         # reads) + 4 B depth RMW per sample + 48 B/px (20 clear + 28 resolve) — the 16 B colour RMW per ACCEPTED sample is left out
         # (the kernels do not count acceptances), so the HQS figure is a lower bound.  `frac` prices the frame by THAT definition; with
@@ -264,21 +290,24 @@ def main():
         pre = "close/" if "close" in name else ""                      # (tools/fold_profiles.py: the close-up preset's passes are folded under "close/...")
         ftraffic = sum(rtraffic.get(pre + k, 0.0) for k in fkeys) if (rtraffic and (pre + "r_draw<MODE_MIN64>") in rtraffic) else None
         raster[name] = {"value": vs / (ms * 1e-3) / 1e6, "unit": "M samples/s @1920x1080", "ms_per_frame": ms,
-                        "camera": "Morro Bay - close (main_progressive_octree.cpp:1323-1328)" if "close" in name else "Morro Bay - bird (:1314-1320)",
+                        "camera": "close" if "close" in name else "bird",          # "Morro Bay - close" / "- bird", main_progressive_octree.cpp:1314-1328
                         "visible_samples": int(vs), "visible_nodes": int(st["numVisibleNodes"]),
                         "roofline": {"bound": "hbm", "achieved": rb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "algorithmic_bytes_per_frame": rb,
-                                     "traffic": ftraffic, "frac_by_traffic": (ftraffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ftraffic else None,
-                                     "traffic_source": (os.path.relpath(tfile, ROOT) + ": all kernels of one frame (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)") if ftraffic else None}}
+                                     "traffic": ftraffic, "frac_by_traffic": (ftraffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ftraffic else None}}
 
-    # ---- per-kernel attribution (separate, untimed pass) ------------------------------------------------------------------
-    # Two sources, both in the JSON: (1) HIP events recorded between the launches of one more ingest — that needs everything on ONE
-    # stream, so the voxel half does not overlap the next batch as it does in the headline run ("measured_with"); (2) the rocprofv3
-    # kernel trace of the headline configuration (overlap on) that profiles/r03/ holds, when it is there ("rocprof_overlap_on").
+    # ---- per-kernel attribution (separate, untimed passes) ----------------------------------------------------------------
+    # (1) the ROOFLINE kernel in the HEADLINE configuration: simlod_profile_enable(2) puts HIP events around k_voxelize — the builder's dominant
+    #     kernel — on the stream it is launched on (the library's second stream), the two-stream pipeline stays as it is in the timed region;
+    #     the average is over the launches that had a batch (a launch enqueues kernels for 20 batches; those without one exit in a few us).
+    # (2) every kernel's time on ONE stream (simlod_profile_enable(1): HIP events between the launches need one timeline) — the `kernels` table.
     roofline, chain, kernels = None, None, {}
     # measurement aid in the control block at byte 0 of the momentary buffer: construct.hip Ctl.expandNs[7] (stored points moved by splits) at byte 208
     CTL_COUNTERS = slice(208, 216)
     if rank == 0 and not args.no_profile:
+        L.simlod_profile_enable(2)
+        ingest_step()
+        torch.cuda.synchronize()
+        prof_dom = collect_profile(L)
         L.simlod_profile_enable(1)
         dev.momentary[CTL_COUNTERS].zero_()
         ingest_step()
@@ -290,47 +319,36 @@ def main():
         L.simlod_profile_enable(0)
         st = dev.read_stats()
         new_voxels = int(st["numVoxels"])
-        kernels = {k: {"launches": n, "total_ms": ms, "avg_ms": ms / max(n, 1)} for k, (n, ms) in {**prof_c, **prof_r}.items()}
-        kernels["_measured_with"] = "HIP events between launches, ONE stream: the side-stream overlap of the headline run is off in this pass"
-        rocprof = {}
-        kpath = os.path.join(pdir, "kernel_stats.csv") if pdir else ""
-        if os.path.exists(kpath):
-            import csv
-            for row in csv.DictReader(open(kpath)):
-                nm = row["Name"].split("(")[0].replace("void ", "").replace("simlod::build::", "").replace("simlod::", "")
-                rocprof[nm] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
-        chain_ms = sum(ms for k, (n, ms) in prof_c.items())
+        kernels = {k: round(ms / max(n, 1) * 1e3, 1) for k, (n, ms) in {**prof_c, **prof_r}.items()}
+        kernels["_what"] = "avg us per launch, HIP events between launches on ONE stream (the side-stream overlap of the headline run is off in this pass; idle launches included)"
         chain_bytes = 32.0 * my_points + 16.0 * new_voxels                 # 32 B/point + 16 B/new voxel
+        # PMC traffic of the kept profile (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command), only when it was taken on THESE sources
+        chain_keys = ("k_count", "k_queue", "k_hist", "k_expand", "k_insert", "k_voxelize")
+        chain_traffic = sum(rtraffic.get(k, 0.0) for k in chain_keys) * n_batches if (rtraffic and "k_voxelize" in rtraffic) else None
         chain = {"bound": "hbm", "achieved": chain_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": chain_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": ms_per_step, "algorithmic_bytes": chain_bytes,
-                 "what": "whole kernel_construct chain over the headline's own ms_per_step (reset + launches + Stats readbacks included)",
-                 "one_stream_event_pass_ms": chain_ms}
-        # Algorithmic bytes per kernel for one whole ingest: k_count reads every point (16 B); k_hist reads a moved point and writes
-        # it to the spill buffer (32 B; the samples of the splitting leaves it also reads are not counted: lower bound); k_insert reads and stores
-        # every point, moved ones too (32 B); k_voxelize reads every stored sample back (16 B; the cube words it loads and writes, ~40 KB per 8192
-        # samples, are not counted) and stores a voxel per new cell (16 B); k_expand moves no bulk data (decisions from histograms, node records,
-        # chunk links).  The coalesced mode runs the same kernels on groups of batches.
+                 "frac": chain_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": chain_bytes,
+                 "traffic": chain_traffic, "wasted_traffic_ratio": (chain_traffic / chain_bytes) if chain_traffic else None,
+                 "what": "32 B/point + 16 B/new voxel of the whole ingest over the headline ms_per_step"}
+        # Algorithmic bytes per kernel for one whole ingest: k_voxelize reads every stored sample back (16 B; moved points too) and
+        # stores a voxel per new cell (16 B); the cube words it loads and writes back are overhead, not algorithm.
         per_ingest = {"k_count": 16.0 * my_points, "k_hist": 32.0 * moved, "k_insert": 32.0 * (my_points + moved), "k_voxelize": 16.0 * (my_points + moved) + 16.0 * new_voxels}
-        base = lambda k: k.split("<")[0]                                     # k_ingest<4> -> k_ingest
-        dom_full = max((k for k in prof_c if base(k) in per_ingest), key=lambda k: prof_c[k][1])
-        dom = base(dom_full)
-        active = max(1, prof_c[dom_full][0] - (launches_idle(prof_c[dom_full][0], n_batches, args.coalesce)))
+        dom = "k_voxelize"
+        n_dom, ms_dom = prof_dom.get(dom, (0, 0.0))
+        # launches with a batch: the timed pass ingested n_batches groups; what the events saw beyond that are early exits (a few us each)
+        active = max(1, min(n_dom, n_batches if not args.coalesce else n_dom))
+        idle = max(0, n_dom - active)
+        avg_ms = max(ms_dom - idle * 0.004, 1e-6) / active                  # (a launch without a batch: ~4 us)
         bytes_per_launch = per_ingest[dom] / active
-        avg_ms = prof_c[dom_full][1] / active
-        traffic, traffic_src = None, None                                     # rocprofv3 --pmc passes of THIS command on THESE sources, folded by tools/fold_profiles.py
-        if tfile and dom in rtraffic:
-            traffic, traffic_src = rtraffic.get(dom), os.path.relpath(tfile, ROOT) + f" (csrc sha {sha_now})"
+        traffic = rtraffic.get(dom) if (tfile and dom in rtraffic) else None     # HBM bytes per launch from the PMC passes (kept profile, same sources)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_ms": avg_ms, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
-                    "measured_with": "HIP events on one stream (overlap off); rocprof_overlap_on = the same kernel in the headline configuration",
-                    "profiles_note": profiles_note,
-                    "rocprof_overlap_on": rocprof.get(dom_full) or rocprof.get(dom),
-                    "moved_points": moved, "new_voxels": new_voxels, "per_kernel_algorithmic_bytes_per_ingest": per_ingest}
-        if rocprof:
-            kernels["_rocprof_overlap_on"] = {k: v for k, v in rocprof.items() if k.startswith(("k_", "r_"))}
+                    "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
+                    "avg_launch_us": avg_ms * 1e3, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
+                    "measured_with": "HIP events in the launch's own start/stop slots (hipExtLaunchKernelGGL) on the stream the kernel runs on; two-stream pipeline as in the timed region",
+                    "per_kernel_wasted_traffic_ratio": {k: round(rtraffic[k] * n_batches / per_ingest[k], 2) for k in per_ingest if rtraffic.get(k) and per_ingest[k] > 0} or None,
+                    "moved_points": moved, "new_voxels": new_voxels}
 
-    # ---- loader row: LAS format-2 records (26 B) -> Points (16 B) on the device, one 1 M-point batch ----
+    # ---- loader row: LAS format-2 records (26 B) -> Points (16 B) on the device, one 1 M-point batch per launch ----
     loader = None
     if rank == 0 and not args.no_profile:
         from simlod_amd import lasio
@@ -347,16 +365,16 @@ def main():
         for k in range(NSET):
             call(k)
         torch.cuda.synchronize()
-        L.simlod_profile_enable(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)       # (the launches go to torch's current stream)
+        e0.record()
         for rep in range(3):
             for k in range(NSET):
                 call(k)
-        pl = collect_profile(L)
-        L.simlod_profile_enable(0)
-        nl, msl = pl["k_decode_las"]
-        gbs = (26.0 + 16.0) * batch / (msl / nl * 1e-3) / 1e9
-        loader = {"kernel": "k_decode_las", "value": batch / (msl / nl * 1e-3) / 1e6, "unit": "M points/s decoded (LAS format 2, 26 B records)",
-                  "avg_launch_ms": msl / nl, "working_set_bytes": int(NSET * batch * 42), "launches": nl,
+        e1.record(); torch.cuda.synchronize()
+        msl = e0.elapsed_time(e1) / (3 * NSET)
+        gbs = (26.0 + 16.0) * batch / (msl * 1e-3) / 1e9
+        loader = {"kernel": "k_decode_las", "value": batch / (msl * 1e-3) / 1e6, "unit": "M points/s decoded (LAS format 2, 26 B records)",
+                  "us_per_launch": msl * 1e3, "what": "126 back-to-back 1 M-point launches over 1.76 GB of rotating buffers, one event pair around all of them",
                   "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_point": 42.0}}
         del d_raw, d_out
 
@@ -372,10 +390,12 @@ def main():
             dst.copy_(src)
         e1.record(); torch.cuda.synchronize()
         copy_ms = e0.elapsed_time(e1) / 10
-        measured = {"what": "1 GiB device-to-device copy, read + write bytes per second", "GB/s": 2.0 * src.numel() / (copy_ms * 1e-3) / 1e9}
+        copy_gbs = 2.0 * src.numel() / (copy_ms * 1e-3) / 1e9          # 1 GiB device-to-device copy on this box, read + write bytes per second
         for r in (roofline, chain):
-            r["measured_copy_peak"] = measured
-            r["frac_of_measured_copy"] = r["achieved"] / measured["GB/s"]
+            r["measured_copy_GBs"] = copy_gbs
+            r["frac_of_measured_copy"] = r["achieved"] / copy_gbs
+        if loader is not None:
+            loader["roofline"]["frac_of_measured_copy"] = loader["roofline"]["achieved"] / copy_gbs
         del src, dst
 
     # ---- CPU baseline: the oracle's serial C restatement on a bounded sample of the same workload ------------------
@@ -430,8 +450,8 @@ def main():
                     v1 = int(h1.stats["numVisiblePoints"][0]) + int(h1.stats["numVisibleVoxels"][0])
                     res[kind] = {"insert_M_points_per_s": 1.0 / tc1, "raster_M_samples_per_s": v1 / tr1 / 1e6, "numNodes": int(h1.stats["numNodes"][0]), "numVoxels": int(h1.stats["numVoxels"][0])}
                     del h1
-                cpu["config1_reference_B0"] = {"what": "BASELINE config 1 (1 M uniform points, single batch, 512x512 plain frame), 1 thread: oracle/_ref = the reference's .cu files "
-                                                       "compiled as host C++ (clang -O2) vs the restatement", "kind": "reference", **res}
+                cpu["config1_reference_B0"] = {"what": "BASELINE config 1 (1 M uniform points, one batch, 512x512 plain frame), 1 thread: oracle/_ref (the reference's sources as host code) vs the restatement",
+                                               "kind": "reference", **{k: {kk: round(vv, 2) if isinstance(vv, float) else vv for kk, vv in v.items()} for k, v in res.items()}}
                 # ... and on a prefix of THIS workload (its list walks are quadratic in a leaf's chunk count: the whole 36 M would take hours)
                 mb0 = min(args.b0_points, n_points)
                 if mb0 > 0:
@@ -447,9 +467,8 @@ def main():
                         done = min(i + batch, mb0)
                         if tb > 25.0:
                             break
-                    cpu["workload_prefix_reference_B0"] = {"kind": "reference", "value": done / tb / 1e6, "unit": "M points/s inserted", "cores": 1,
-                                                           "sample": f"first {done} points ({(done + batch - 1) // batch} batches, one per kernel_construct call) of the same terrain through oracle/_ref "
-                                                                     f"(stopped after 25 s)" if done < mb0 else f"all {done} points of the same terrain through oracle/_ref, one batch per kernel_construct call", "seconds": tb}
+                    cpu["workload_reference_B0"] = {"kind": "reference", "value": done / tb / 1e6, "unit": "M points/s inserted", "cores": 1,
+                                                    "sample": f"first {done} points of the same terrain through oracle/_ref, one batch per call" + (" (stopped after 25 s)" if done < mb0 else ""), "seconds": round(tb, 2)}
                     del hb
         except Exception as e:                     # the baseline must never take the bench down
             cpu["config1_reference_B0"] = {"error": repr(e)}
@@ -482,10 +501,8 @@ def main():
             ms2 = (time.perf_counter() - t0) * 1e3 / args.steps
             st2 = dev2.read_stats()
             ok = int(st2["numPoints"]) == n_points and int(st2["dbg"]) == 0 and all(int(st2[k]) == int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels"))
-            coalesced = {"value": n_points / (ms2 * 1e-3) / 1e6, "unit": "M points/s", "ms_per_step": ms2, "launches_per_step": l2 / args.steps, "momentary_mb": mb,
-                         "same_octree_content_counts_as_exact": bool(ok),
-                         "what": "simlod_set_ingest_mode(1): the pending batches of a launch in groups (the same kernels, construct.hip); topology, multisets, bitsets and voxels "
-                                 "equal the exact mode's, the allocator / chunk-pool counters of Stats do not"}
+            coalesced = {"value": n_points / (ms2 * 1e-3) / 1e6, "unit": "M points/s", "ms_per_step": ms2, "momentary_mb": mb, "same_octree_content_counts_as_exact": bool(ok),
+                         "what": "opt-in simlod_set_ingest_mode(1): pending batches in groups of 10; same octree content, other allocator accounting"}
             dev2.close()
             del dev2
         finally:
@@ -498,10 +515,9 @@ def main():
     c3path = os.path.join(pdir, "config3_350m.json") if pdir else ""
     if rank == 0 and os.path.exists(c3path) and json.load(open(c3path)).get("_csrc_sha16") == sha_now:
         c3 = json.load(open(c3path))
-        config3 = {"measured_by": f"tools/config3.py on MI355X (not in this run) on these kernel sources (csrc sha {sha_now}); transcript {os.path.relpath(pdir, ROOT)}/config3_350m_las_scan.txt",
-                   "input": f"{c3['points']} points, fractal terrain {c3['terrain_extent_m'][0]:.0f} m x {c3['terrain_extent_m'][1]:.0f} m, LAS 1.4 format 2 ({c3['las_file_bytes'] / 1e9:.1f} GB), flight lines of 250 m",
-                   "host": "harness/_ref/ref_host_replay: the reference's resetCUDA / updateOctree / renderCUDA / initCudaProgram text, uploader on its own thread + stream, 50-slot ring",
-                   "las_scan_page_locked": c3.get("las_scan_pinned"), "las_scan_pageable": c3.get("las_scan_pageable"), "adversarial_scatter_order": c3.get("adversarial_scatter")}
+        pick = lambda d: {k: d[k] for k in ("kernel_M_points_per_s", "wall_M_points_per_s", "launches", "update_kernel_ms", "wall_ms_incl_h2d") if k in d} if isinstance(d, dict) else d
+        config3 = {"measured_by": f"tools/config3.py (kept under {os.path.relpath(pdir, ROOT)}/, same kernel sources): 350 M-point scan-ordered LAS file through the reference's own host functions",
+                   "las_scan_page_locked": pick(c3.get("las_scan_pinned")), "las_scan_pageable": pick(c3.get("las_scan_pageable"))}
     if rank == 0:
         out = {
             "metric": "M points/sec inserted into octree (raster M samples/s @1080p under 'raster')",
@@ -509,18 +525,17 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+u32 (fp32 quantise/project, fp64 pixel coordinate, integer octree/atomics)", "data": "synthetic",
             "ingest_mode": "coalesced" if args.coalesce else "exact",
-            "config": {"workload": (f"BASELINE config 4 shape: tiled fractal terrain, {n_points} device-generated XYZRGBA points (16 B) per GPU, resident in HBM, "
-                                    f"STREAMED through the 50-slot ring ({n_batches} x 1M batches: uploader stream + back-pressure, main_progressive_octree.cpp:1005-1050), "
-                                    if source is not None else
-                                    f"Morro Bay 36M stand-in: {n_points} XYZRGBA points (16 B) fractal terrain per GPU, {n_batches} x 1M ring batches resident in HBM, ") +
-                                   f"reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step "
-                                   f"(<= 20 batches and <= 10 ms each; " + ("Stats read back after every launch); " if source is not None else "the launches the pending batches need are enqueued back to back, Stats read back after them); ") +
-                                   f"raster 1920x1080", "points_per_gpu": n_points, "record_order": args.order if not use_dist else "device-generated tiles, swath order",
+            "config": {"workload": (f"BASELINE config 4 shape: tiled terrain, {n_points} device-generated 16 B points per GPU streamed through the 50-slot ring ({n_batches} x 1M batches), "
+                                    if source is not None else f"Morro Bay 36M stand-in (BASELINE config 2): {n_points} 16 B points, fractal terrain, {n_batches} x 1M ring batches resident in HBM, ") +
+                                   f"reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step; raster 1920x1080",
+                       "points_per_gpu": n_points, "record_order": args.order if not use_dist else "device-generated tiles, swath order",
                        "parallelism": f"one global cube, level-3 cells dealt to {world} rank(s) by point count"},
-            "profiles_note": profiles_note, "csrc_sha16": sha_now,
-            "coalesced_ingest": coalesced, "config3": config3, "partition": partition, "raster": raster, "roofline": roofline, "roofline_chain": chain, "kernels": kernels, "cpu_baseline": cpu, "loader": loader,
+            "csrc_sha16": sha_now, "profiles_note": profiles_note,
+            "roofline": roofline, "roofline_chain": chain, "cpu_baseline": cpu, "raster": raster, "coalesced_ingest": coalesced, "loader": loader,
+            "collective": collective, "partition": partition, "config3": config3, "kernels": kernels,
             "octree": {k: int(stats[k]) for k in ("numNodes", "numInner", "numLeaves", "numVoxels", "allocatedBytes_persistent")},
         }
+        out = json.loads(json.dumps(out), parse_float=lambda x: float("%.5g" % float(x)))      # five significant digits: the driver keeps 8 KB of the line
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

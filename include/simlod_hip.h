@@ -207,7 +207,7 @@ typedef struct SimlodProfileEntry {
 	uint32_t pad;
 	double   total_ms;
 } SimlodProfileEntry;
-int simlod_profile_enable(int on);
+int simlod_profile_enable(int on);             /* 0 off | 1 every kernel (the builder's two streams become one) | 2 k_voxelize only, on its own stream: the builder's pipeline as in production */
 int simlod_profile_collect(SimlodProfileEntry* out, int capacity, int* count);
 
 /* ---- loader side -------------------------------------------------------------------------------

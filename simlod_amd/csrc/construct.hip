@@ -2340,6 +2340,11 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 				if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);
 				else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
 			}
+			if (profile_dominant()) {      // bench.py's roofline: the dominant kernel timed in the headline configuration, by the launch's own start / stop events
+				hipEvent_t e0, e1;
+				profile_kernel_events("k_voxelize", &e0, &e1);
+				hipExtLaunchKernelGGL(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), 0, back, e0, e1, 0, a, b);
+			} else
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
 		}
 		if (side != nullptr) {

@@ -258,11 +258,12 @@ void frame_feedback_no_bins(Context& ctx, const void* buffer) {
 
 // ---- optional per-kernel profiling ------------------------------------------------------------------------------
 struct ProfileMark { const char* name; hipEvent_t ev; };
-static std::atomic<bool> g_profile{false};
+static std::atomic<int> g_profile{0};          // 0 off | 1 every kernel, one stream | 2 the builder's dominant kernel only, streams as in production
 static std::vector<ProfileMark> g_marks;
 static std::vector<hipEvent_t> g_eventPool;
 
-bool profile_enabled() { return g_profile.load(std::memory_order_relaxed); }
+bool profile_enabled() { return g_profile.load(std::memory_order_relaxed) == 1; }
+bool profile_dominant() { return g_profile.load(std::memory_order_relaxed) == 2; }
 
 static hipEvent_t take_event() {
 	if (!g_eventPool.empty()) { hipEvent_t e = g_eventPool.back(); g_eventPool.pop_back(); return e; }
@@ -276,6 +277,14 @@ void profile_mark(const char* kernelName, hipStream_t stream) {
 }
 
 void profile_close(hipStream_t stream) { profile_mark(nullptr, stream); }
+
+// a pair of events for hipExtLaunchKernelGGL's start / stop slots: the kernel's own begin and end, as the command processor stamps them (what rocprofv3
+// reports) — an event RECORDED in front of a launch is stamped when the stream reaches it, several microseconds before the kernel starts
+void profile_kernel_events(const char* kernelName, hipEvent_t* start, hipEvent_t* stop) {
+	*start = take_event(); *stop = take_event();
+	g_marks.push_back({kernelName, *start});
+	g_marks.push_back({nullptr, *stop});
+}
 
 enum KernelKind { KIND_RESET = 0, KIND_CONSTRUCT = 1, KIND_RENDER = 2, KIND_FILTER = 3 };
 
@@ -556,7 +565,7 @@ int simlod_launch_cooperative(SimlodFunction* fn, unsigned gx, unsigned gy, unsi
 }
 
 int simlod_profile_enable(int on) {
-	g_profile.store(on != 0);
+	g_profile.store(on == 2 ? 2 : on != 0 ? 1 : 0);
 	return 0;
 }
 

@@ -122,8 +122,10 @@ const DeviceInfo& device_info();
 // Optional per-kernel timing with HIP events on the launch stream (simlod_profile_* in simlod_hip.h).  Disabled by
 // default: LAUNCH() then is a bare hipLaunchKernelGGL.
 bool profile_enabled();
+bool profile_dominant();                      // simlod_profile_enable(2): events around k_voxelize alone, on ITS stream — the two-stream pipeline stays as it is in production
 void profile_mark(const char* kernelName, hipStream_t stream);   // records "kernelName starts now"
 void profile_close(hipStream_t stream);                           // records the end of the last kernel of a call
+void profile_kernel_events(const char* kernelName, hipEvent_t* start, hipEvent_t* stop);   // events for a launch's own start / stop slots (hipExtLaunchKernelGGL)
 
 #define SIMLOD_LAUNCH(kernel, grid, block, stream, ...)                           \
 	do {                                                                          \
