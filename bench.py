@@ -247,7 +247,7 @@ def main():
             HQS: all-reduce(MIN) of the depth plane and all-reduce(SUM) of the colour sums between the passes; plain: all-reduce(MIN)
             of the uint64 framebuffer; plus the all-gather of the visible-node records."""
             if use_dist:
-                distributed.render_frame(dev, uc)
+                return distributed.render_frame(dev, uc, check_overflow=False)      # (no host synchronisation inside the frame loop)
             else:
                 dev.render(uc)
 
@@ -257,7 +257,7 @@ def main():
         t0 = time.perf_counter()
         if use_dist and world > 1:
             # two frames in flight: the plane reductions of frame f travel while frame f + 1 is rasterised (distributed.render_frames_pipelined)
-            distributed.render_frames_pipelined(dev, [uc] * args.frames)
+            distributed.render_frames_pipelined(dev, [uc] * args.frames, check_overflow=False)
         else:
             for _ in range(args.frames):
                 frame()
@@ -272,7 +272,8 @@ def main():
         vs = float(samples.item())
         if use_dist and world > 1:
             # one more composed frame, its framebuffer folded into one word per rank: every rank must hold the same frame
-            distributed.render_frame(dev, uc)
+            recs_c, cnts_c = distributed.render_frame(dev, uc, check_overflow=False)
+            assert not distributed.visible_overflowed(cnts_c, 4096), "a rank has more visible nodes than the gather carried"
             fbw = dev.framebuffer_words()
             h = (fbw ^ (fbw >> 29)).sum().reshape(1) if not hqs else (dev.colorbuffer[: W * H].to(torch.int64) * 2654435761 % 1000003).sum().reshape(1)
             hs = [torch.zeros_like(h) for _ in range(world)]

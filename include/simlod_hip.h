@@ -173,10 +173,13 @@ int simlod_render_frame_composed(uint32_t* buffer, const SimlodUniforms* uniform
                                  SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream,
                                  SimlodReduceFn reduce, void* user);
 /* ... with the reductions as ncclAllReduce calls on `ncclComm` (an ncclComm_t of RCCL: one rank per GPU over xGMI), enqueued on `stream`.
- * librccl.so is looked up when this is first called (dlopen: the library itself does not link against it); hipErrorNotSupported if it is
- * not there. */
+ * RCCL is looked up when this is first called — the copy already loaded in the process (the one that made `ncclComm`: a PyTorch process has its own
+ * torch/lib/librccl.so), else dlopen("librccl.so"); the library itself does not link against it.  hipErrorNotSupported if there is none, or if
+ * ncclGetVersion names a release outside 2.10 .. 2.x: the call passes ncclDataType_t / ncclRedOp_t by their 2.x numbers (ncclUint32 = 3,
+ * ncclUint64 = 5, ncclSum = 0, ncclMin = 3).  simlod_rccl_version(): the NCCL_VERSION_CODE found (0: none). */
 int simlod_render_frame_rccl(uint32_t* buffer, const SimlodUniforms* uniforms /*host*/, SimlodNode* nodes, uint32_t* colorbuffer,
                              SimlodStats* stats, uint64_t* frameStartTimestamp, void* cudaprint, void* stream, void* ncclComm);
+int simlod_rccl_version(void);
 
 /* ---- CudaModularProgram-shaped surface ------------------------------------------------------------------- */
 typedef struct SimlodProgram SimlodProgram;

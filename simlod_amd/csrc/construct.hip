@@ -51,7 +51,7 @@ struct BatchCtl {
 	uint32_t active, batchSize, ringSlot, batchIndex;
 	uint32_t ordinal, tag, slotsRound0, numSpilled;   // tag = batch index + 1 (NodeDir); slotsRound0: slots handed out by k_count's tail, snapshot by k_hist: k_expand's first round
 	uint32_t numWork, numClear, numTouched, numCross;    // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_expand allocates their chunks) | leaves k_count saw cross the limit (k_queue)
-	uint32_t barrierCount, unused0, numVoxItems, numVoxSmall;
+	uint32_t barrierCount, rootPieces, numVoxItems, numVoxSmall;     // rootPieces: pieces of a root that is still a leaf (k_voxroot)
 	uint32_t groupBatches, dirCount, pad0, pad1;      // ring batches taken together: 1 in exact mode, up to groupMax in coalesced mode; batchSize = all their samples
 	uint32_t start[SIMLOD_MAX_BATCHES_PER_LAUNCH + 1];   // sample index of the first sample of batch k of the group (start[groupBatches] = batchSize)
 	uint32_t slot[SIMLOD_MAX_BATCHES_PER_LAUNCH];        // its ring slot
@@ -263,10 +263,11 @@ __device__ __forceinline__ BatchCtl* batch_of(Ctl* ctl, uint32_t ordinal) {
 	return bc->active != 0u && bc->ordinal == ordinal ? bc : nullptr;
 }
 
-// phase timer of ONE thread of one workgroup per kernel: adds the time since `t` to slot k and restarts `t`
+// phase timer of ONE thread of one workgroup per kernel: adds the time since `t` to slot k and restarts `t` (builds with SIMLOD_MEASURE only: `on` is a
+// compile-time false in the product library and every mark() folds away)
 struct Phase {
 	Ctl* ctl; bool on; uint64_t t;
-	__device__ __forceinline__ Phase(Ctl* c, bool who) : ctl(c), on(who && threadIdx.x == 0), t(on ? wall_ns() : 0) {}
+	__device__ __forceinline__ Phase(Ctl* c, bool who) : ctl(c), on(SIMLOD_MEASURE != 0 && who && threadIdx.x == 0), t(on ? wall_ns() : 0) {}
 	__device__ __forceinline__ void mark(uint32_t k) { if (on) { const uint64_t n = wall_ns(); ctl->phaseNs[k] += n - t; t = n; } }
 };
 
@@ -335,6 +336,7 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	bc->barrierCount = 0;      // every k_expand instance counts its barrier generations from zero
 	bc->numVoxItems = 0;
 	bc->numVoxSmall = 0;
+	bc->rootPieces = 0;
 	bc->dirCount = 0;
 	bc->reserve = 0;           // (k_count's first workgroup: the node array as k_expand of the group before leaves it)
 	bc->active = 1;
@@ -858,6 +860,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		// voxelize_small's, one wave per leaf (big items: the first VOX_BIG_ITEMS entries of the item array — a piece has at least
 		// VOX_SMALL samples or is the last of its leaf, so they cover 33 M samples; small items behind them: one per leaf at most)
 		const uint32_t pieces = fresh < VOX_SMALL ? 0u : (fresh + VOX_PIECE - 1) / VOX_PIECE;
+		if (i == 0u && pieces != 0u) bc->rootPieces = pieces;          // (the root as a leaf: k_voxroot's pieces)
 		const uint32_t small = need && pieces == 0u ? (fresh + VOX_SMALL_PIECE - 1) / VOX_SMALL_PIECE : 0u;
 		uint32_t totEntries, totAdditional, totPieces, totSmall;
 		const uint32_t exEntries = wave_exclusive(entries, totEntries), exAdditional = wave_exclusive(additional, totAdditional);
@@ -1050,6 +1053,9 @@ __device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, u
 // local node number t of a slot -> depth below the slot's node (1..3) and the octants chosen on the way
 __device__ __forceinline__ uint32_t local_depth(uint32_t t) { return t < 8u ? 1u : t < 72u ? 2u : 3u; }
 
+#ifndef EXPAND_U
+#define EXPAND_U 8
+#endif
 __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
@@ -1083,7 +1089,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	const uint32_t n = bc->batchSize;
 	uint32_t generation = 0;
 
-	const bool timer = blockIdx.x == 0 && threadIdx.x == 0;
+	const bool timer = SIMLOD_MEASURE != 0 && blockIdx.x == 0 && threadIdx.x == 0;
 	if (timer) ctl->expandNs[6] += 1;
 
 	uint32_t sb = 0, se = min(bc->slotsRound0, SLOT_CAP);
@@ -1099,7 +1105,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			// together, then the map words of those that were relabelled, then the points of those whose node was queued again
 			const uint32_t stride = gridDim.x * ETPB;
 			const uint32_t total = n + min(bc->numSpilled, a.spilledCap);
-			constexpr uint32_t U = 8;
+			constexpr uint32_t U = EXPAND_U;
 			for (uint32_t first = blockIdx.x * ETPB + threadIdx.x; first < total; first += U * stride) {
 				uint32_t idx[U], v[U], ent[U];
 				float4 p[U];
@@ -1644,10 +1650,10 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	const VoxItem* items = vox_items(a, bc);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
-	constexpr uint32_t WPT = (CUBE_WORDS + VTPB - 1) / VTPB;        // cube words per thread
+	static_assert(VTPB == 1024 && CUBE_WORDS <= 9216 + VTPB, "k_voxelize: thread t owns the LDS cube words t + 1024 k (k < 8: cube 1), 8192 + t (cube 2), 9216 + t (cubes 3..7)");
 	const uint32_t lane = (uint32_t)lane_id();
 	Phase ph(ctl, blockIdx.x == ((ctl->debugFlags >> 8) & 0xffffu));     // (SIMLOD_DEBUG_PHASE_WG: whose phase times tools/probe.py prints; default workgroup 0)
-	const bool clocked = (ctl->debugFlags & 2u) != 0u;       // SIMLOD_DEBUG_VOXELIZE_CLOCK (tools/probe.py): when the first workgroup came, the last piece was done, the last workgroup left
+	const bool clocked = SIMLOD_MEASURE != 0 && (ctl->debugFlags & 2u) != 0u;       // SIMLOD_DEBUG_VOXELIZE_CLOCK (tools/probe.py): when the first workgroup came, the last piece was done, the last workgroup left
 	if (clocked && blockIdx.x == 0 && threadIdx.x == 0) ctl->voxT[ordinal][0] = wall_ns();
 	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
 		// Global memory is touched in six steps, each one round trip with everything it needs in flight together: the item; the leaf's
@@ -1655,76 +1661,16 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 		VoxItem it = items[item];
 		const uint32_t leafLevel = it.leaf >> 24;
 		it.leaf &= 0xffffffu;
+		if (it.leaf == 0u) continue;                              // (the root as a leaf: k_voxroot)
 		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
 		if (threadIdx.x < PATH_WORDS) {
-			// ancestor d (1 = parent) is anc[d - 1]; a root that is still a leaf samples itself (voxels.cu:449-463: every node of the
-			// path that has a grid is sampled, and the root has one from the reset on)
-			unsigned long long e;
-			if (it.leaf == 0u) { SimlodOccupancyGrid* g = a.nodes[0].grid; e = (threadIdx.x == 0 && g != nullptr) ? path_pack(a.pers, 0u, 0u, g) : 0ull; }
-			else e = threadIdx.x < PATH_WORDS - 1 ? rec[threadIdx.x] : 0ull;
+			// ancestor d (1 = parent) is anc[d - 1].  (A root that is still a leaf samples ITSELF, voxels.cu:449-463 — the whole octree holds fewer
+			// than 50 000 points —: k_voxroot's pieces, skipped here.)
+			const unsigned long long e = threadIdx.x < PATH_WORDS - 1 ? rec[threadIdx.x] : 0ull;
 			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0; sh.rank[threadIdx.x] = 0;
 			if (threadIdx.x < 8u) sh.listCount[threadIdx.x] = 0;
-		}
-		if (it.leaf == 0u) __syncthreads();
-		if (it.leaf == 0u) {
-			// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample, one after the other
-			// (this path runs for the first batch of an octree at most: nothing here is worth a register of the main path); the winners
-			// share ONE voxel list (the root's): one reservation for the whole piece
-			const unsigned long long ent = sh.anc[0];
-			auto sample = [&](uint32_t j, uint32_t& pX, uint32_t& pY, uint32_t& pZ) -> float {
-				const uint32_t i = it.s0 + j * VTPB + threadIdx.x;
-				const float4 q = reinterpret_cast<const float4*>(chunkDir[it.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - it.ptFirst)]->points)[i % SIMLOD_POINTS_PER_CHUNK];
-				pX = quantize(F_FULL, q.x, a.minx, a.size); pY = quantize(F_FULL, q.y, a.miny, a.size); pZ = quantize(F_FULL, q.z, a.minz, a.size);
-				return q.w;
-			};
-			uint32_t wonMask = 0;
-			if (ent != 0ull) {
-#pragma unroll 1
-				for (uint32_t j = 0; j < VOX_SPT; j++) {
-					if (it.s0 + j * VTPB + threadIdx.x >= it.s1) continue;
-					uint32_t pX, pY, pZ;
-					(void)sample(j, pX, pY, pZ);
-					const uint32_t cell = grid_cell(0u, pX, pY, pZ), bit = cell & 31u;
-					uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
-					if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
-					if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
-					wonMask |= 1u << j;
-					atomicAdd(&sh.cnt[1], 1u);
-				}
-			}
-			__syncthreads();
-			if (threadIdx.x == 0u && sh.cnt[1] != 0u) {
-				const uint32_t cnt = sh.cnt[1];
-				const uint32_t first = atomicAdd(&a.nodes[0].numVoxels, cnt);
-				const uint32_t existing = (a.nodes[0].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
-				const uint32_t kFirst = first / SIMLOD_POINTS_PER_CHUNK, kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
-				const uint32_t ownFirst = first % SIMLOD_POINTS_PER_CHUNK == 0u ? kFirst : kFirst + 1u;
-				const uint32_t own = kLast + 1u > ownFirst ? kLast + 1u - ownFirst : 0u;
-				SimlodChunk* mem = own != 0u ? reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), own)) : nullptr;
-				for (uint32_t q = 0; q < own; q++) {
-					SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-					if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
-					vox_chunk_publish(a, ctl, tag, 0u, ownFirst + q, c);
-					sh.chunkOf[1][ownFirst + q - kFirst] = c;
-				}
-				SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[0].voxelChunks) : nullptr;
-				if (own != 0u) vox_chunk_link(a, ctl, tag, 0u, ownFirst, existing, oldTail, mem);
-				if (ownFirst != kFirst) sh.chunkOf[1][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, 0u, kFirst);
-				sh.first[1] = first;
-			}
-			__syncthreads();
-#pragma unroll 1
-			for (uint32_t j = 0; j < VOX_SPT; j++) {
-				if (((wonMask >> j) & 1u) == 0u) continue;
-				uint32_t pX, pY, pZ;
-				const float colour = sample(j, pX, pY, pZ);
-				const uint32_t slot = sh.first[1] + atomicAdd(&sh.rank[1], 1u);
-				SimlodChunk* c = sh.chunkOf[1][slot / SIMLOD_POINTS_PER_CHUNK - sh.first[1] / SIMLOD_POINTS_PER_CHUNK];
-				if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, 0, pX, pY, pZ, colour);
-			}
-			continue;
 		}
 		const SimlodChunk* chunk[VOX_SPT];
 		bool live[VOX_SPT];
@@ -1739,21 +1685,30 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 		uint32_t depth = 0;
 		while (depth < PATH_WORDS - 1 && sh.anc[depth] != 0ull) depth++;
 		// voxels.cu:449: the traverse loop samples levels 0..19 only — an ancestor is at level 19 at most (leaves are at most at 20)
-		const uint32_t ldsDepth = it.leaf == 0u ? 0u : min(depth, LDS_LEVELS);       // a root that is still a leaf: its "cube" is the whole grid
+		const uint32_t ldsDepth = min(depth, LDS_LEVELS);
 
 		// the leaf's cubes, as the grids hold them now (each thread keeps what it loaded: the write-back needs it); the single cells of the
 		// ancestors above; the samples
-		uint32_t snap[WPT];
+		// LDS word w of the cubes belongs to thread w % 1024: eight words of cube 1 (the parent's grid: words g1 + k * 4096 — the 64 x-bits of one
+		// (y, z) row are a pair of words —), one of cube 2 (the grandparent's: g2), and for w >= 9216 one of the small cubes 3..7 (cube_word).
+		// (Round 4 ran the general cube_word() for all ten words, twice, and kept its results: 128 VGPRs and 40 bytes of scratch per lane.)
+		const uint32_t g1 = ((((LX & 1u) * 64u) + 128u * ((LY & 1u) * 64u) + 16384u * ((LZ & 1u) * 64u)) >> 5) + ((threadIdx.x >> 1) & 63u) * 4u + (threadIdx.x >> 7) * 512u + (threadIdx.x & 1u);
+		const uint32_t g2 = (((LX & 3u) * 32u) + 128u * ((LY & 3u) * 32u + (threadIdx.x & 31u)) + 16384u * ((LZ & 3u) * 32u + (threadIdx.x >> 5))) >> 5;
+		const uint32_t w3 = 9216u + threadIdx.x;
+		uint32_t gw3, sft3, msk3;
+		const uint32_t d3 = cube_word(w3, LX, LY, LZ, gw3, sft3, msk3);
+		const bool have3 = d3 != 0u && d3 <= ldsDepth;
+		uint32_t* const grid1 = ldsDepth >= 1u ? path_grid(a.pers, sh.anc[0])->values : nullptr;
+		uint32_t* const grid2 = ldsDepth >= 2u ? path_grid(a.pers, sh.anc[1])->values : nullptr;
+		uint32_t* const grid3 = have3 ? path_grid(a.pers, sh.anc[d3 - 1u])->values : nullptr;
+		uint32_t snap1[8], snap2, snap3;
 		{
-			uint32_t raw[WPT];
 #pragma unroll
-			for (uint32_t k = 0; k < WPT; k++) {
-				uint32_t gw, sft, msk;
-				const uint32_t d = cube_word(k * VTPB + threadIdx.x, LX, LY, LZ, gw, sft, msk);
-				raw[k] = (d == 0u || d > ldsDepth) ? 0u : path_grid(a.pers, sh.anc[d - 1])->values[gw];
-			}
+			for (uint32_t k = 0; k < 8; k++) snap1[k] = ldsDepth >= 1u ? grid1[g1 + k * 4096u] : 0u;
+			snap2 = ldsDepth >= 2u ? grid2[g2] : 0u;
+			snap3 = have3 ? grid3[gw3] : 0u;
 			uint32_t hi = 0;
-			const bool hiMine = it.leaf != 0u && threadIdx.x >= LDS_LEVELS && threadIdx.x < depth;   // d = threadIdx.x + 1 >= 8: every sample of the leaf has the same cell
+			const bool hiMine = threadIdx.x >= LDS_LEVELS && threadIdx.x < depth;   // d = threadIdx.x + 1 >= 8: every sample of the leaf has the same cell
 			if (hiMine) {
 				const unsigned long long ent = sh.anc[threadIdx.x];
 				const uint32_t d = threadIdx.x + 1u, level = path_level(ent);
@@ -1765,14 +1720,11 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 #pragma unroll
 			for (uint32_t j = 0; j < VOX_SPT; j++)
 				p[j] = live[j] ? reinterpret_cast<const float4*>(chunk[j]->points)[(it.s0 + j * VTPB + threadIdx.x) % SIMLOD_POINTS_PER_CHUNK] : make_float4(0, 0, 0, 0);
+			snap3 = have3 ? (snap3 >> sft3) & msk3 : 0u;
 #pragma unroll
-			for (uint32_t k = 0; k < WPT; k++) {
-				const uint32_t w = k * VTPB + threadIdx.x;
-				uint32_t gw, sft, msk;
-				const uint32_t d = cube_word(w, LX, LY, LZ, gw, sft, msk);                  // (recomputed rather than kept: registers)
-				snap[k] = (d == 0u || d > ldsDepth) ? 0u : (raw[k] >> sft) & msk;
-				if (w < CUBE_WORDS) sh.occ[w] = snap[k];
-			}
+			for (uint32_t k = 0; k < 8; k++) sh.occ[k * VTPB + threadIdx.x] = snap1[k];
+			sh.occ[8192u + threadIdx.x] = snap2;
+			if (w3 < CUBE_WORDS) sh.occ[w3] = snap3;
 			if (hiMine) sh.hiOcc[threadIdx.x] = hi;
 			__syncthreads();
 			ph.mark(25);
@@ -1856,22 +1808,26 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 		// write-back: the grids learn the new cells and tell which of them are new for everybody (pieces of one leaf share the cubes):
 		// every thread's atomics are in flight together.  What this piece set in a word = the word now minus the word as it was loaded.
 		{
-			uint32_t f[WPT], old[WPT], gw[WPT], sft[WPT], msk[WPT];
+			uint32_t f1[8], old1[8], f2, old2 = 0, f3, old3 = 0;
 #pragma unroll
-			for (uint32_t k = 0; k < WPT; k++) {
-				const uint32_t w = k * VTPB + threadIdx.x;
-				const uint32_t d = cube_word(w, LX, LY, LZ, gw[k], sft[k], msk[k]);
-				f[k] = (d != 0u && d <= ldsDepth) ? sh.occ[w] & ~snap[k] : 0u;
-				old[k] = f[k] != 0u ? atomicOr(&path_grid(a.pers, sh.anc[d - 1])->values[gw[k]], f[k] << sft[k]) : 0u;   // voxels.cu:96
+			for (uint32_t k = 0; k < 8; k++) {
+				f1[k] = sh.occ[k * VTPB + threadIdx.x] & ~snap1[k];
+				old1[k] = f1[k] != 0u ? atomicOr(&grid1[g1 + k * 4096u], f1[k]) : 0u;                                  // voxels.cu:96
 			}
+			f2 = sh.occ[8192u + threadIdx.x] & ~snap2;
+			if (f2 != 0u) old2 = atomicOr(&grid2[g2], f2);
+			f3 = w3 < CUBE_WORDS ? sh.occ[w3] & ~snap3 : 0u;
+			if (f3 != 0u) old3 = atomicOr(&grid3[gw3], f3 << sft3);
+			uint32_t won1 = 0;
 #pragma unroll
-			for (uint32_t k = 0; k < WPT; k++) {
-				const uint32_t w = k * VTPB + threadIdx.x;
-				if (w >= CUBE_WORDS) continue;
-				const uint32_t won = f[k] & ~(old[k] >> sft[k]);
-				sh.occ[w] = won;                                                   // from here on: the cells this piece won
-				if (won != 0u) atomicAdd(&sh.cnt[w < 8192u ? 1u : w < 9216u ? 2u : w < 9472u ? 3u : w < 9536u ? 4u : w < 9552u ? 5u : w < 9556u ? 6u : 7u], (uint32_t)__popc(won));
+			for (uint32_t k = 0; k < 8; k++) {
+				const uint32_t won = f1[k] & ~old1[k];
+				sh.occ[k * VTPB + threadIdx.x] = won;                               // from here on: the cells this piece won
+				won1 += (uint32_t)__popc(won);
 			}
+			if (won1 != 0u) atomicAdd(&sh.cnt[1], won1);
+			{ const uint32_t won = f2 & ~old2; sh.occ[8192u + threadIdx.x] = won; if (won != 0u) atomicAdd(&sh.cnt[2], (uint32_t)__popc(won)); }
+			if (w3 < CUBE_WORDS) { const uint32_t won = f3 & ~(old3 >> sft3); sh.occ[w3] = won; if (won != 0u) atomicAdd(&sh.cnt[d3], (uint32_t)__popc(won)); }
 			const bool hiMine = threadIdx.x >= LDS_LEVELS && threadIdx.x < depth;
 			if (hiMine && sh.hiFresh[threadIdx.x] != 0u) {
 				const unsigned long long ent = sh.anc[threadIdx.x];
@@ -1948,6 +1904,86 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
 	voxelize_small(a, ctl, bc, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
 	if (clocked) { __syncthreads(); if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&ctl->voxT[ordinal][2]), (unsigned long long)wall_ns()); }
+}
+
+// ---- voxroot: a root that is still a leaf (the whole octree holds fewer than 50 000 points) samples ITSELF (voxels.cu:449-463: every node of the
+// path that has a grid is sampled, and the root has one from the reset on) — into its own grid, sample by sample with device-scope atomics: the
+// first batch or two of an octree, at most seven pieces.  A kernel of its own behind k_voxelize (whose main path it used to share, at the price
+// of scratch memory for all of it); exits at once when the group has no such piece.
+struct VoxRootShared { uint32_t cnt, first, rank; SimlodChunk* chunkOf[VOX_CHUNKS]; };
+__global__ __launch_bounds__(VTPB) void k_voxroot(BuildArgs a, uint32_t ordinal) {
+	Ctl* ctl = ctl_of(a);
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch || bc->rootPieces == 0u) return;
+	const uint32_t numItems = min(bc->numVoxItems, VOX_BIG_ITEMS);
+	__shared__ VoxRootShared shr;
+	const VoxItem* items = vox_items(a, bc);
+	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
+	const uint32_t tag = bc->tag;
+	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
+		VoxItem it = items[item];
+		it.leaf &= 0xffffffu;
+		if (it.leaf != 0u) continue;
+		__syncthreads();
+		if (threadIdx.x == 0u) { shr.cnt = 0; shr.rank = 0; }
+		__syncthreads();
+		SimlodOccupancyGrid* const g = a.nodes[0].grid;
+		const unsigned long long ent = g != nullptr ? path_pack(a.pers, 0u, 0u, g) : 0ull;
+		// a root that is still a leaf (fewer than 50 000 points in the whole octree): its own grid, sample by sample, one after the other
+		// (this path runs for the first batch of an octree at most: nothing here is worth a register of the main path); the winners
+		// share ONE voxel list (the root's): one reservation for the whole piece
+		auto sample = [&](uint32_t j, uint32_t& pX, uint32_t& pY, uint32_t& pZ) -> float {
+			const uint32_t i = it.s0 + j * VTPB + threadIdx.x;
+			const float4 q = reinterpret_cast<const float4*>(chunkDir[it.ptBase + (i / SIMLOD_POINTS_PER_CHUNK - it.ptFirst)]->points)[i % SIMLOD_POINTS_PER_CHUNK];
+			pX = quantize(F_FULL, q.x, a.minx, a.size); pY = quantize(F_FULL, q.y, a.miny, a.size); pZ = quantize(F_FULL, q.z, a.minz, a.size);
+			return q.w;
+		};
+		uint32_t wonMask = 0;
+		if (ent != 0ull) {
+#pragma unroll 1
+			for (uint32_t j = 0; j < VOX_SPT; j++) {
+				if (it.s0 + j * VTPB + threadIdx.x >= it.s1) continue;
+				uint32_t pX, pY, pZ;
+				(void)sample(j, pX, pY, pZ);
+				const uint32_t cell = grid_cell(0u, pX, pY, pZ), bit = cell & 31u;
+				uint32_t* word = &path_grid(a.pers, ent)->values[cell >> 5];
+				if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
+				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
+				wonMask |= 1u << j;
+				atomicAdd(&shr.cnt, 1u);
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0u && shr.cnt != 0u) {
+			const uint32_t cnt = shr.cnt;
+			const uint32_t first = atomicAdd(&a.nodes[0].numVoxels, cnt);
+			const uint32_t existing = (a.nodes[0].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			const uint32_t kFirst = first / SIMLOD_POINTS_PER_CHUNK, kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
+			const uint32_t ownFirst = first % SIMLOD_POINTS_PER_CHUNK == 0u ? kFirst : kFirst + 1u;
+			const uint32_t own = kLast + 1u > ownFirst ? kLast + 1u - ownFirst : 0u;
+			SimlodChunk* mem = own != 0u ? reinterpret_cast<SimlodChunk*>(persistent_alloc(a.pers, sizeof(SimlodChunk), own)) : nullptr;
+			for (uint32_t q = 0; q < own; q++) {
+				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+				vox_chunk_publish(a, ctl, tag, 0u, ownFirst + q, c);
+				shr.chunkOf[ownFirst + q - kFirst] = c;
+			}
+			SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[0].voxelChunks) : nullptr;
+			if (own != 0u) vox_chunk_link(a, ctl, tag, 0u, ownFirst, existing, oldTail, mem);
+			if (ownFirst != kFirst) shr.chunkOf[0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, 0u, kFirst);
+			shr.first = first;
+		}
+		__syncthreads();
+#pragma unroll 1
+		for (uint32_t j = 0; j < VOX_SPT; j++) {
+			if (((wonMask >> j) & 1u) == 0u) continue;
+			uint32_t pX, pY, pZ;
+			const float colour = sample(j, pX, pY, pZ);
+			const uint32_t slot = shr.first + atomicAdd(&shr.rank, 1u);
+			SimlodChunk* c = shr.chunkOf[slot / SIMLOD_POINTS_PER_CHUNK - shr.first / SIMLOD_POINTS_PER_CHUNK];
+			if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, 0, pX, pY, pZ, colour);
+		}
+	}
 }
 
 // ---- alloc: grow the chunk lists to their new lengths, build the per-batch chunk directory ----------------------
@@ -2346,6 +2382,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 				hipExtLaunchKernelGGL(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), 0, back, e0, e1, 0, a, b);
 			} else
 			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
+			SIMLOD_LAUNCH(k_voxroot, dim3(8), dim3(VTPB), back, a, b);      // (exits at once unless the root is still a leaf and got 512 samples or more)
 		}
 		if (side != nullptr) {
 			hipError_t e = hipEventRecord(side->tailDone, back);

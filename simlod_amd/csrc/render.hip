@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 		while (idx >= classEnd[cl]) cl++;
 		const uint64_t itemAt = (uint64_t)cl * a.itemCap + (idx - (cl > 0u ? classEnd[cl - 1u] : 0u));
 		const DrawItem it = items[itemAt];
-		const uint64_t itemStart = threadIdx.x == 0 ? wall_clock64() : 0ull;
+		const uint64_t itemStart = SIMLOD_MEASURE != 0 && threadIdx.x == 0 ? wall_clock64() : 0ull;
 		uint32_t overrideColor = 0; bool useOverride = false;
 		if (MODE != MODE_DEPTH && (a.colorByNode || a.colorByLOD)) {
 			const SimlodNode* node = visible + it.visibleIdx;
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 		else draw_item<MODE>(c, sh_dir, samples, overrideColor, useOverride, outside);
 		if (it.tileX >= 0) { __syncthreads(); tile_flush<MODE>(c); }
 		__syncthreads();
-		if (threadIdx.x == 0) const_cast<DrawItem*>(items)[itemAt].took = (uint32_t)(wall_clock64() - itemStart);
+		if (SIMLOD_MEASURE != 0 && threadIdx.x == 0) const_cast<DrawItem*>(items)[itemAt].took = (uint32_t)(wall_clock64() - itemStart);
 		if (threadIdx.x == 0) sh_idx = gridDim.x + atomicAdd(cursor, 1u);
 		__syncthreads();
 		idx = sh_idx;
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(OTPB) void r_overflow(RenderArgs a) {
 	// in launch order they would all start late, behind a thousand empty ones)
 	const uint32_t T = (uint32_t)(((uint64_t)blockIdx.x * OVERFLOW_STRIDE) % a.binTiles);
 	const uint32_t numSegs = min(segCount[T], BIN_SEG_CAP);
-	const uint64_t started = threadIdx.x == 0u ? wall_clock64() : 0ull;
+	const uint64_t started = SIMLOD_MEASURE != 0 && threadIdx.x == 0u ? wall_clock64() : 0ull;
 	if (T == 0u && threadIdx.x == 0u) work[12] = 0u;                 // (nobody appends in this kernel; this pass's entries stay where they are until the next pass overwrites them)
 	if (numSegs == 0u) return;
 	// (one workgroup per bin of the SCREEN, most of which find nothing.  Round 5 measured the alternative VERDICT r4 asked for — r_draw lists the bins
@@ -1158,10 +1158,12 @@ __global__ __launch_bounds__(OTPB) void r_overflow(RenderArgs a) {
 	}
 	if (threadIdx.x == 0u) {
 		segCount[T] = 0u;
-		uint32_t entries = 0;
-		for (uint32_t k = 0; k < numSegs; k++) entries += sh_segs[k].count;
-		BinSeg* stat = reinterpret_cast<BinSeg*>(segCount + (a.binTiles + 3u) / 4u * 4u);          // measurement aid (tools/raster_bins.py): {entries, segments << 20 | 10 ns}
-		stat[T] = BinSeg{entries, (numSegs << 20) | min((uint32_t)(wall_clock64() - started), 0xfffffu)};
+		if (SIMLOD_MEASURE != 0) {                                     // tools/raster_bins.py: {entries, segments << 20 | 10 ns}
+			uint32_t entries = 0;
+			for (uint32_t k = 0; k < numSegs; k++) entries += sh_segs[k].count;
+			BinSeg* stat = reinterpret_cast<BinSeg*>(segCount + (a.binTiles + 3u) / 4u * 4u);
+			stat[T] = BinSeg{entries, (numSegs << 20) | min((uint32_t)(wall_clock64() - started), 0xfffffu)};
+		}
 	}
 }
 

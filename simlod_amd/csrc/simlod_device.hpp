@@ -19,6 +19,14 @@
 
 #define SIMLOD_WAVE 64
 
+// Measurement aids inside the kernels — the phase clocks of one workgroup per builder kernel (Ctl.phaseNs, Ctl.expandNs[0..6], Ctl.voxT: tools/probe.py),
+// the per-item and per-bin clocks of the rasteriser (DrawItem::took, the bins' stat words: tools/raster_items.py, raster_bins.py) — exist only in
+// builds made with -DSIMLOD_MEASURE=1 (`make -C simlod_amd/csrc variant NAME=measure DEFS=-DSIMLOD_MEASURE=1`, loaded through SIMLOD_HIP_LIB).  The
+// product library carries none of them.
+#ifndef SIMLOD_MEASURE
+#define SIMLOD_MEASURE 0
+#endif
+
 namespace simlod {
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

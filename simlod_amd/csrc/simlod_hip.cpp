@@ -46,7 +46,8 @@ void expand_gate_leave(Context& ctx, hipStream_t stream, hipEvent_t ended, bool 
 	if (!held) return;
 	const int dev = gate_device();
 	ExpandGate& g = g_gate[dev];
-	if (ended == nullptr && live_contexts() > 1u) {           // (one stream, one context: nobody will ever wait for it)
+	if (ended == nullptr) {           // one stream: an event of the context behind the kernel — also while this is the only context (~1 us): one made
+	                                  // a moment later must find the k_expand that is still in flight
 		if (ctx.gateEvent[dev] == nullptr && hipEventCreateWithFlags(&ctx.gateEvent[dev], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx.gateEvent[dev] = nullptr; }
 		ended = ctx.gateEvent[dev];
 		if (ended != nullptr) (void)hipEventRecord(ended, stream);
@@ -463,33 +464,51 @@ int simlod_render_frame_composed(uint32_t* buffer, const SimlodUniforms* u, Siml
 	return rc;
 }
 
-// RCCL, found at run time: ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream)
+// RCCL, found at run time: ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream).
+// The library that made the caller's ncclComm_t must be the one that reduces with it: the copy ALREADY LOADED in the process is looked up first
+// (a PyTorch process carries its own torch/lib/librccl.so, loaded by path; dlopen("librccl.so") beside it would load a second instance and hand the
+// communicator to the wrong one); only a process without one gets a dlopen by name.  The datatype / operator numbers below are the ABI of
+// NCCL / RCCL 2.x (rccl.h ncclDataType_t: ncclUint32 = 3, ncclUint64 = 5; ncclRedOp_t: ncclSum = 0, ncclMin = 3): ncclGetVersion must name a 2.x
+// release from 2.10 on (where the enums took that shape and have stayed) or the entry refuses with hipErrorNotSupported.
 namespace {
 using AllReduceFn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
-AllReduceFn rccl_all_reduce() {
-	static AllReduceFn fn = [] {
-		for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-			if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
-				if (void* f = dlsym(h, "ncclAllReduce")) return reinterpret_cast<AllReduceFn>(f);
+using VersionFn = int (*)(int*);
+struct Rccl { AllReduceFn allReduce = nullptr; int version = 0; bool supported = false; };
+const Rccl* rccl() {
+	static const Rccl r = [] {
+		Rccl x;
+		void* fn = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+		void* ver = fn != nullptr ? dlsym(RTLD_DEFAULT, "ncclGetVersion") : nullptr;
+		if (fn == nullptr) {
+			for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+				void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);             // loaded under that name already?
+				if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+				if (h != nullptr && (fn = dlsym(h, "ncclAllReduce")) != nullptr) { ver = dlsym(h, "ncclGetVersion"); break; }
 			}
 		}
-		return static_cast<AllReduceFn>(nullptr);
+		x.allReduce = reinterpret_cast<AllReduceFn>(fn);
+		if (ver != nullptr && reinterpret_cast<VersionFn>(ver)(&x.version) != 0) x.version = 0;
+		// NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch from 2.9 on (major * 1000 + ... before)
+		x.supported = x.allReduce != nullptr && x.version >= 21000 && x.version < 30000;
+		return x;
 	}();
-	return fn;
+	return &r;
 }
 int reduce_over_rccl(void* comm, uint32_t plane, void* data, uint64_t count, uint32_t elemBytes, uint32_t op, void* stream) {
 	(void)plane;
-	AllReduceFn f = rccl_all_reduce();
-	if (f == nullptr) return (int)hipErrorNotSupported;
-	enum { ncclUint32 = 3, ncclUint64 = 5, ncclSum = 0, ncclMin = 3 };       // rccl.h: ncclDataType_t, ncclRedOp_t
-	return f(data, data, (size_t)count, elemBytes == 8 ? ncclUint64 : ncclUint32, op == SIMLOD_REDUCE_SUM ? ncclSum : ncclMin, comm, (hipStream_t)stream) == 0 ? 0 : (int)hipErrorUnknown;
+	const Rccl& r = *rccl();
+	if (!r.supported) return (int)hipErrorNotSupported;
+	enum { ncclUint32 = 3, ncclUint64 = 5, ncclSum = 0, ncclMin = 3 };       // rccl.h: ncclDataType_t, ncclRedOp_t (2.x ABI, checked above)
+	return r.allReduce(data, data, (size_t)count, elemBytes == 8 ? ncclUint64 : ncclUint32, op == SIMLOD_REDUCE_SUM ? ncclSum : ncclMin, comm, (hipStream_t)stream) == 0 ? 0 : (int)hipErrorUnknown;
 }
 }  // namespace
+
+int simlod_rccl_version(void) { return rccl()->version; }
 
 int simlod_render_frame_rccl(uint32_t* buffer, const SimlodUniforms* u, SimlodNode* nodes, uint32_t* colorbuffer, SimlodStats* stats,
                              uint64_t* frameStartTimestamp, void* cudaprint, void* stream, void* ncclComm) {
 	if (!ncclComm) return (int)hipErrorInvalidValue;
-	if (rccl_all_reduce() == nullptr) return (int)hipErrorNotSupported;
+	if (!rccl()->supported) return (int)hipErrorNotSupported;           // no RCCL in the process, or one whose enum ABI this entry was not written for
 	return simlod_render_frame_composed(buffer, u, nodes, colorbuffer, stats, frameStartTimestamp, cudaprint, stream, reduce_over_rccl, ncclComm);
 }
 

@@ -120,6 +120,7 @@ def partition_and_route(points, box_size, world, level=3, slice_points=32_000_00
     original order inside a source rank — the order route_points leaves).  Peak per rank on top of the input: the result (what the rank
     owns) + 2 slices of records + the slice's index arrays; a rank may free its input afterwards.
     Returns (records this rank owns [n, 16] uint8, owner table, global counts per cell, records received from each rank)."""
+    assert dist.is_initialized() or world == 1, "partition_and_route exchanges records over torch.distributed: initialise a process group first (one rank needs none)"
     rec = points.reshape(-1, 16)
     n = rec.shape[0]
     ncell = 8 ** level
@@ -137,6 +138,8 @@ def partition_and_route(points, box_size, world, level=3, slice_points=32_000_00
         owner[c] = r
         load[r] += counts[c]
     owner_table = torch.from_numpy(owner).to(points.device)
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):      # one rank owns every cell: nothing to exchange
+        return rec, owner_table, counts, [n]
     # what this rank sends to / receives from everybody, in all: from its own histogram
     send_total = torch.zeros(world, dtype=torch.int64, device=points.device).index_add_(0, owner_table, local)
     recv_total = torch.zeros_like(send_total)
@@ -215,7 +218,7 @@ def compose_min(framebuffer_u64_as_i64, group=None):
     return framebuffer_u64_as_i64
 
 
-def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
+def render_frame(renderer, uniforms, group=None, gather_capacity=4096, check_overflow=True):
     """One frame over all ranks, EXACT for plain and for HQS shading: every rank rasterises its own sub-octrees
     and the ranks reduce the planes between the parts of kernel_render (include/simlod_hip.h, simlod_launch_render_part):
         part 0 | HQS: all-reduce(MIN) depth | part 1 | HQS: all-reduce(SUM) {R,G,B,count} | part 2 | all-reduce(MIN) framebuffer | part 3
@@ -231,7 +234,7 @@ def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
     pending = None
     if hasattr(renderer, "visible_records_early"):
         vis, n = renderer.visible_records_early()
-        pending = gather_visible(vis, n, group=group, capacity=gather_capacity, async_op=True)
+        pending = gather_visible(vis, n, group=group, capacity=gather_capacity, async_op=True, check_overflow=check_overflow)
     if hqs:
         dist.all_reduce(renderer.depth_plane(), op=dist.ReduceOp.MIN, group=group)
         renderer.render_part(uniforms, 1)
@@ -243,10 +246,10 @@ def render_frame(renderer, uniforms, group=None, gather_capacity=4096):
     if pending is not None:
         return pending()
     vis, n = renderer.visible_records()
-    return gather_visible(vis, n, group=group, capacity=gather_capacity)
+    return gather_visible(vis, n, group=group, capacity=gather_capacity, check_overflow=check_overflow)
 
 
-def render_frames_pipelined(renderer, frames, group=None, gather_capacity=4096, on_frame=None):
+def render_frames_pipelined(renderer, frames, group=None, gather_capacity=4096, on_frame=None, check_overflow=True):
     """A sequence of frames (`frames`: one Uniforms record each) composed across ranks exactly as render_frame composes one, with TWO frames
     in flight: while the planes of frame f are on the wire, the ranks rasterise the next part of frame f + 1 — on an 8-GPU ring over xGMI the
     reductions of an HQS frame (8.3 + 33.2 MB at 1080p) take about as long as its passes, and inside ONE frame each reduction feeds the very
@@ -267,7 +270,7 @@ def render_frames_pipelined(renderer, frames, group=None, gather_capacity=4096, 
             renderer.render_part(u, 0)
             if hasattr(renderer, "visible_records_early"):
                 vis, n = renderer.visible_records_early()
-                f["vis"] = gather_visible(vis, n, group=group, capacity=gather_capacity, async_op=True)
+                f["vis"] = gather_visible(vis, n, group=group, capacity=gather_capacity, async_op=True, check_overflow=check_overflow)
             if hqs:
                 f["works"].append(dist.all_reduce(renderer.depth_plane(), op=dist.ReduceOp.MIN, group=group, async_op=True)); f["next"] = 1
             else:
@@ -286,7 +289,7 @@ def render_frames_pipelined(renderer, frames, group=None, gather_capacity=4096, 
                 recs, cnts = f["vis"]()
             else:
                 vis, n = renderer.visible_records()
-                recs, cnts = gather_visible(vis, n, group=group, capacity=gather_capacity)
+                recs, cnts = gather_visible(vis, n, group=group, capacity=gather_capacity, check_overflow=check_overflow)
             if on_frame is not None:
                 on_frame(f["index"], renderer, recs, cnts)
             return False
@@ -311,18 +314,28 @@ def render_frames_pipelined(renderer, frames, group=None, gather_capacity=4096, 
             active.pop(0)
 
 
+def visible_overflowed(counts, capacity):
+    """The one look from the host at the counts a gather_visible(..., check_overflow=False) returned: did a rank have more visible nodes than travelled?"""
+    most = int(counts.max().item())
+    if most > abi.MAX_VISIBLE_NODES:
+        raise VisibleOverflow(f"a rank reports {most} visible nodes; the visible-node array holds {abi.MAX_VISIBLE_NODES}")
+    return most > capacity
+
+
 class VisibleOverflow(RuntimeError):
     """A rank has more visible nodes than the visible-node array holds (render.cu:1108: 100 000) — the multi-rank counterpart of
     SIMLOD_ERR_VISIBLE_OVERFLOW in Stats.dbg."""
 
 
-def gather_visible(visible_bytes, count, group=None, capacity=4096, async_op=False):
+def gather_visible(visible_bytes, count, group=None, capacity=4096, async_op=False, check_overflow=True):
     """All-gather the first `count` visible-node records (152 B each) of every rank; returns (records[world, cap, 152], counts) with
     cap >= every rank's count: NOTHING is dropped.  `capacity` records per rank travel at once (no host synchronisation: `count` may be a
     one-element tensor on the records' device); the gathered counts are the TRUE counts, and should one of them exceed `capacity` — BASELINE
     config 5 has 4 097 visible nodes on one GPU — the records are gathered once more with room for the largest (the power of two above it).
     More than the visible-node array can hold (abi.MAX_VISIBLE_NODES) raises VisibleOverflow.  async_op: returns a function that waits for
-    the collectives and hands out the result."""
+    the collectives and hands out the result.  check_overflow=False: no look at the counts from the host — the frame loop stays free of host
+    synchronisation; the caller checks when it suits it (visible_overflowed(counts, capacity): True = the records of that frame were cut at
+    `capacity` per rank and the next gathers want more room)."""
     world = dist.get_world_size(group)
     dev = visible_bytes.device
 
@@ -348,6 +361,8 @@ def gather_visible(visible_bytes, count, group=None, capacity=4096, async_op=Fal
 
     def complete():
         counts = torch.cat(cnts)
+        if not check_overflow:
+            return torch.stack(bufs), counts
         most = int(counts.max().item())                       # (the frame is over by now: this is the one look at the counts from the host)
         if most > abi.MAX_VISIBLE_NODES:
             raise VisibleOverflow(f"a rank reports {most} visible nodes; the visible-node array holds {abi.MAX_VISIBLE_NODES}")

@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "simlod_render_depth_plane_offset", "simlod_render_sum_planes_offset", "simlod_set_ingest_mode", "simlod_set_construct_batch_limit",
     "simlod_context_create", "simlod_context_destroy", "simlod_context_attach", "simlod_context_set_node_capacity", "simlod_context_set_ingest_mode",
     "simlod_context_set_construct_batch_limit", "simlod_context_set_knob", "simlod_context_reload_env", "simlod_context_construct_buffer_min_bytes",
-    "simlod_octree_image_replaced", "simlod_render_frame_composed", "simlod_render_frame_rccl", "simlod_context_set_trunk_mask",
+    "simlod_octree_image_replaced", "simlod_render_frame_composed", "simlod_render_frame_rccl", "simlod_context_set_trunk_mask", "simlod_rccl_version",
     "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_generate_terrain_scan", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 

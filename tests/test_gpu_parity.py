@@ -1499,15 +1499,21 @@ def test_composed_frame_entry_points_call_the_reductions_in_order_and_draw_the_s
     from simlod_amd.runtime import SimlodError
     with pytest.raises(SimlodError):
         dev.render_composed(u, reduce=lambda *a: 7)
-    # RCCL, one rank
+    # RCCL, one rank.  The communicator comes from the copy of RCCL this process already carries (PyTorch's own torch/lib/librccl.so) and the
+    # library must reduce with THAT copy (a second instance loaded by bare name would be handed a foreign communicator): it is made
+    # globally visible here, as a host that links RCCL has it, and the library's lookup (dlsym(RTLD_DEFAULT) first) must then report its version
     rccl = None
-    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+    for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
         try:
-            rccl = ctypes.CDLL(name); break
+            rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL); break
         except OSError:
             pass
     if rccl is None:
         pytest.skip("no librccl.so on this box")
+    ver = ctypes.c_int(0)
+    assert rccl.ncclGetVersion(ctypes.byref(ver)) == 0 and 21000 <= ver.value < 30000, ver.value
+    dev.L.simlod_rccl_version.restype = ctypes.c_int
+    assert dev.L.simlod_rccl_version() == ver.value, "the library found another RCCL than the one that makes the communicator"
     uid = (ctypes.c_char * 128)()
     assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
     comm = ctypes.c_void_p()
@@ -1521,7 +1527,16 @@ def test_composed_frame_entry_points_call_the_reductions_in_order_and_draw_the_s
         dev.render_buffer.fill_(0xA5)
         dev.render_composed(u, rccl_comm=comm.value)
         torch.cuda.synchronize()
+        # one rank: every reduction (MIN of the depth plane, SUM of the colour sums, MIN of the framebuffer) must leave its plane as it was —
+        # a wrong datatype or operator number (the entry passes them by value: the 2.x enum ABI) would not
         assert np.array_equal(dev.framebuffer(Wd, Hd), want_fb) and np.array_equal(dev.color(Wd, Hd), want_color)
+        if variant.startswith("hqs"):
+            dev._frame_size = (Wd, Hd)
+            depth_after, sums_after = dev.depth_plane().cpu().numpy().copy(), dev.sum_planes().cpu().numpy().copy()
+            dev.render_buffer.fill_(0xA5)
+            dev.render_composed(u, reduce=lambda *a: 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.depth_plane().cpu().numpy(), depth_after) and np.array_equal(dev.sum_planes().cpu().numpy(), sums_after)
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
