@@ -508,17 +508,37 @@ __device__ __forceinline__ uint32_t bin_of(uint32_t X, uint32_t Y, uint32_t Z, u
 // batch began — its counter before anybody's add — is the smallest `old` any caller sees: kept per node as tag << 32 | ~old under an
 // atomic max (a newer batch's tag beats an older one, a smaller `old` a larger one).
 static constexpr uint32_t CROSSED = 1u, FIRST = 2u;
-__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCtl* bc, uint32_t leafIdx, uint32_t cnt) {
+// (in two halves, so that a caller with several leaves — the samples of a thread that found no room in the workgroup's table: a batch scattered
+// over thousands of leaves — has all its loads and adds in flight before it looks at any of them)
+struct CountPending { uint32_t touchSeen, old; unsigned long long startSeen; };
+__device__ __forceinline__ CountPending count_issue(const BuildArgs& a, uint32_t leafIdx, uint32_t cnt) {
+	// A batch that is scattered over thousands of leaves (BASELINE config 5: 4 096 leaves, every workgroup meets most of them) makes every workgroup
+	// a caller for every leaf: the add is the work, the two tag words are bookkeeping that only the FIRST callers of a leaf change.  So the tag
+	// words are looked at with plain loads first (in flight beside the add): a word that already carries this batch's tag — and, for the counter
+	// at batch start, a value no larger than this caller's — cannot be changed by this caller, and its atomic is skipped.  A stale read (the
+	// XCDs' L2s are not coherent) can only show an OLDER state: the atomic is then issued as before.  Config 5, 200 M points: k_count issued
+	// 2.0 M memory-side atomics per batch (250 us) before, 0.73 M after; profiles/r05/config5_*.
+	CountPending p;
+	p.touchSeen = __hip_atomic_load(at<uint32_t>(a, a.offTouchTag) + leafIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	p.startSeen = __hip_atomic_load(at<unsigned long long>(a, a.offStartOf) + leafIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	p.old = atomicAdd(&a.nodes[leafIdx].counter, cnt);
+	return p;
+}
+__device__ __forceinline__ uint32_t count_finish(const BuildArgs& a, const BatchCtl* bc, uint32_t leafIdx, uint32_t cnt, const CountPending& p) {
 	SimlodNode* leaf = a.nodes + leafIdx;
-	const uint32_t old = atomicAdd(&leaf->counter, cnt);
-	const uint32_t before = atomicExch(at<uint32_t>(a, a.offTouchTag) + leafIdx, bc->tag);
-	atomicMax(at<unsigned long long>(a, a.offStartOf) + leafIdx, ((unsigned long long)bc->tag << 32) | (0xffffffffu - old));
+	const uint32_t old = p.old;
+	const uint32_t before = p.touchSeen == bc->tag ? bc->tag : atomicExch(at<uint32_t>(a, a.offTouchTag) + leafIdx, bc->tag);
+	const unsigned long long mine = ((unsigned long long)bc->tag << 32) | (0xffffffffu - old);
+	if (p.startSeen < mine) atomicMax(at<unsigned long long>(a, a.offStartOf) + leafIdx, mine);
 	uint32_t flags = before != bc->tag ? FIRST : 0u;
 	bool over = old + cnt > SIMLOD_MAX_POINTS_PER_NODE;
 	if (!over && trunk_any(a)) over = trunk_forced(a, leaf->level, leaf->X, leaf->Y, leaf->Z);      // (a multi-GPU job's shared upper node: splits by the global count)
 	// A node at MAX_DEPTH cannot be subdivided (the descent stops there): it keeps growing instead of spilling.
 	if (over && leaf->level < SIMLOD_MAX_DEPTH && atomicExch(at<uint32_t>(a, a.offRetryTag) + leafIdx, bc->tag) != bc->tag) flags |= CROSSED;
 	return flags;
+}
+__device__ __forceinline__ uint32_t count_into(const BuildArgs& a, const BatchCtl* bc, uint32_t leafIdx, uint32_t cnt) {
+	return count_finish(a, bc, leafIdx, cnt, count_issue(a, leafIdx, cnt));
 }
 // what a leaf held when batch `tag` began (valid once the batch's k_count is complete)
 __device__ __forceinline__ uint32_t stored_at_start(const BuildArgs& a, uint32_t tag, uint32_t leafIdx) {
@@ -739,6 +759,8 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 			if (i >= n) continue;
 			const uint32_t leafIdx = cur[j];
 			leafOf.grp[i] = leafIdx | (bin_of(X[j], Y[j], Z[j], level[j]) << LEAF_BIN_SHIFT);      // the bin is what k_hist needs should this leaf split: it never reads the sample
+			// (no room in the workgroup's table — a batch scattered over more leaves than it has keys —: the leaf's counters directly, one sample after the
+			// other.  Round 5 measured all of a thread's spilled samples with their loads and adds in flight together: config 5 went from 60 to 71 ms)
 			if (!spread_add(tbl, leafIdx, threadIdx.x & (REP - 1u))) counted(leafIdx, count_into(a, bc, leafIdx, 1u));
 		}
 	}
@@ -1538,7 +1560,7 @@ __device__ __forceinline__ void voxelize_small(const BuildArgs& a, Ctl* ctl, Bat
 	const uint32_t tag = bc->tag;
 	const uint32_t lane = (uint32_t)lane_id();
 	constexpr uint32_t U = 4;                              // items a wave works on together when there are more items than waves: a scattered batch leaves ~25 samples in each of tens of thousands of leaves
-	const uint32_t per = numSmall > numWaves ? U : 1u;
+	const uint32_t per = numSmall > numWaves / 4u ? U : 1u;          // (several items of a wave in flight once the items outnumber a quarter of the waves: config 5 has 8 192 items per batch for 8 192 waves of which half are resident — one item per wave took two rounds of ~80 us)
 	for (uint32_t k0 = wave * per; k0 < numSmall; k0 += numWaves * per) {
 		VoxItem it[U];
 		unsigned long long mine[U];

@@ -27,6 +27,11 @@ for first in range(0, n, 50_000_000):
     c = (r * 255.0).to(torch.int32)
     src[first: first + len(r), 3] = c[:, 0] + c[:, 1] * 256 + c[:, 2] * 65536 - 16777216
     del r, c
+# warm-up, as bench.py has one: the first launches of a process load the kernels' code objects and make the context's second stream, its events and
+# its page-locked feedback words (~30 ms, once per process — rounds 2-4 timed them with the ingest: 2.4 / 1.95 G points/s at 200 M, 0.57 at 20 M)
+dev.reset(u)
+dev.stream(u, src.view(torch.uint8).reshape(-1)[: 3_000_000 * 16], 3_000_000)
+dev.render(u)
 dev.reset(u)
 torch.cuda.synchronize()
 t0 = time.time(); launches = dev.stream(u, src.view(torch.uint8).reshape(-1), n); torch.cuda.synchronize(); t_ingest = time.time() - t0
