@@ -495,7 +495,33 @@ struct DrawCtx {
 	int tileX, tileY;            // tile origin; tileX < 0: no tile
 	int tileW, tileH;            // tile extent
 	bool tileExact;              // COLOR: two words per pixel {R | G << 32, B | count << 32} instead of the packed word
+	struct HotTable* hot;        // COLOR, packed tile: the pixels of the item that took more than 64 samples (LDS; nullptr in the other passes)
 };
+
+// The packed tile word of the colour pass holds 64 samples of a pixel (64 x 255 < 2^14); what comes beyond used to go to the pixel's words in the
+// global {R, G, B, count} plane, two device-scope atomics per sample — on ONE address when the pixel is hot, and the memory system retires ~70 M
+// same-address atomics a second: on the 500 M-point octree of BASELINE config 4 a handful of items with a few hot pixels each (ridges seen edge-on:
+// thousands of samples on a pixel) took 100-300 us where their neighbours took 20, and set the colour pass's length (bird: 220 us against 64 for the
+// depth pass; tools/raster_big.py).  Now the 65th sample onwards of a pixel goes into a small LDS table of the item's hot pixels — tile index ->
+// exact 32-bit sums — which the flush adds to the global plane with two atomics per hot PIXEL.  No room in the table: the global words, as before.
+static constexpr uint32_t HOT_CAP = 512, HOT_EMPTY = 0xffffffffu;
+struct HotTable { uint32_t key[HOT_CAP]; unsigned long long rg[HOT_CAP], bc[HOT_CAP]; };
+template <int MODE> struct HotStore { __device__ __forceinline__ HotTable* table() { return nullptr; } };
+template <> struct HotStore<2> { HotTable t; __device__ __forceinline__ HotTable* table() { return &t; } };      // (MODE_COLOR)
+__device__ __forceinline__ void beyond_64(const DrawCtx& c, uint32_t t, uint32_t pixel, unsigned long long r, unsigned long long g, unsigned long long b) {
+	if (c.hot != nullptr) {
+		uint32_t h = (t * 2654435761u) >> (32 - 9);
+#pragma unroll 1
+		for (int probe = 0; probe < 8; probe++) {
+			uint32_t k = c.hot->key[h];
+			if (k == HOT_EMPTY) { k = atomicCAS(&c.hot->key[h], HOT_EMPTY, t); if (k == HOT_EMPTY) k = t; }
+			if (k == t) { atomicAdd(&c.hot->rg[h], r | (g << 32)); atomicAdd(&c.hot->bc[h], b | (1ull << 32)); return; }
+			h = (h + 1u) & (HOT_CAP - 1u);
+		}
+	}
+	atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
+	atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
+}
 
 template <int MODE>
 __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, const uint32_t overrideColor, const bool useOverride, uint32_t& outside) {
@@ -535,11 +561,7 @@ __device__ __forceinline__ void draw_sample(const DrawCtx& c, const float4 p, co
 					const unsigned long long r = color & 0xffu, g = (color >> 8) & 0xffu, b = (color >> 16) & 0xffu;
 					const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
 					const unsigned long long old = atomicAdd(&c.tile[t], pk);
-					if ((old >> 42) >= 64ull) {
-						atomicAdd(&c.tile[t], 0ull - pk);
-						atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
-						atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
-					}
+					if ((old >> 42) >= 64ull) { atomicAdd(&c.tile[t], 0ull - pk); beyond_64(c, t, pixel, r, g, b); }
 				}
 				continue;
 			}
@@ -644,11 +666,7 @@ __device__ __forceinline__ void draw_wave(const DrawCtx& c, const float4 p, cons
 			const unsigned long long r = color & 0xffu, g = (color >> 8) & 0xffu, b = (color >> 16) & 0xffu;
 			const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
 			const unsigned long long old = atomicAdd(&c.tile[t], pk);
-			if ((old >> 42) >= 64ull) {
-				atomicAdd(&c.tile[t], 0ull - pk);
-				atomicAdd(&c.overflow[2 * pixel + 0], r | (g << 32));
-				atomicAdd(&c.overflow[2 * pixel + 1], b | (1ull << 32));
-			}
+			if ((old >> 42) >= 64ull) { atomicAdd(&c.tile[t], 0ull - pk); beyond_64(c, t, pixel, r, g, b); }
 		}
 	}
 	if (valid && !inTile) {                          // outside the tile: the global path of draw_sample
@@ -724,11 +742,7 @@ __device__ __forceinline__ void draw_staged(const DrawCtx& c, const float4 (&p)[
 				const unsigned long long r = color[u] & 0xffu, g = (color[u] >> 8) & 0xffu, b = (color[u] >> 16) & 0xffu;
 				const unsigned long long pk = b | (g << 14) | (r << 28) | (1ull << 42);
 				const unsigned long long old = atomicAdd(&c.tile[t[u]], pk);
-				if ((old >> 42) >= 64ull) {
-					atomicAdd(&c.tile[t[u]], 0ull - pk);
-					atomicAdd(&c.overflow[2 * pixel[u] + 0], r | (g << 32));
-					atomicAdd(&c.overflow[2 * pixel[u] + 1], b | (1ull << 32));
-				}
+				if ((old >> 42) >= 64ull) { atomicAdd(&c.tile[t[u]], 0ull - pk); beyond_64(c, t[u], pixel[u], r, g, b); }
 			}
 		}
 	}
@@ -936,6 +950,8 @@ __device__ __forceinline__ void tile_clear(const DrawCtx& c) {
 	for (int t = threadIdx.x; t < words; t += DTPB) {
 		if (MODE == MODE_DEPTH) c.tile32[t] = 0xffffffffu; else c.tile[t] = MODE == MODE_COLOR ? 0ull : ~0ull;
 	}
+	if (MODE == MODE_COLOR && c.hot != nullptr && !c.tileExact)
+		for (uint32_t h = threadIdx.x; h < HOT_CAP; h += DTPB) { c.hot->key[h] = HOT_EMPTY; c.hot->rg[h] = 0ull; c.hot->bc[h] = 0ull; }
 }
 
 // One global atomic per TOUCHED pixel of the tile.
@@ -965,6 +981,15 @@ __device__ __forceinline__ void tile_flush(const DrawCtx& c) {
 			}
 		}
 	}
+	if (MODE == MODE_COLOR && c.hot != nullptr && !c.tileExact) {      // the item's hot pixels: what they took beyond their 64th sample
+		for (uint32_t h = threadIdx.x; h < HOT_CAP; h += DTPB) {
+			const uint32_t t = c.hot->key[h];
+			if (t == HOT_EMPTY) continue;
+			const uint32_t pixel = (uint32_t)(c.tileX + (int)(t % (uint32_t)c.tileW)) + (uint32_t)c.W * (uint32_t)(c.tileY + (int)(t / (uint32_t)c.tileW));
+			atomicAdd(&c.overflow[2 * pixel + 0], c.hot->rg[h]);
+			atomicAdd(&c.overflow[2 * pixel + 1], c.hot->bc[h]);
+		}
+	}
 }
 
 template <int MODE>
@@ -975,7 +1000,9 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 	__shared__ const SimlodChunk* sh_dir[ITEM_CHUNKS];
 	constexpr uint32_t BIN_WORDS = 2 * BIN_MAX_TILES + 32;                                  // bin_item's counters, in the tile's place
 	__shared__ unsigned long long sh_tile[MODE == MODE_DEPTH ? (TILE * TILE > BIN_WORDS ? TILE * TILE : BIN_WORDS) / 2 : TILE * TILE];
+	__shared__ HotStore<MODE> sh_hot;
 	DrawCtx c;
+	c.hot = sh_hot.table();
 	c.tile = sh_tile; c.tile32 = reinterpret_cast<uint32_t*>(sh_tile); c.tileX = -1; c.tileY = -1; c.tileW = TILE; c.tileH = TILE; c.tileExact = false;
 	c.r0 = a.transform.rows[0]; c.r1 = a.transform.rows[1]; c.r3 = a.transform.rows[3];
 	c.width = a.width; c.height = a.height;
