@@ -105,7 +105,14 @@ int simlod_set_construct_batch_limit(uint32_t maxBatches);
 int simlod_octree_image_replaced(const SimlodNode* nodes);
 
 /* Byte offset of the uint64 framebuffer inside kernel_render's momentary `buffer` (identical to where the
- * reference's bump allocator places it, render.cu:1108-1123) and the minimum size of that buffer. */
+ * reference's bump allocator places it, render.cu:1108-1123) and the size of that buffer's full layout: planes, draw items, chunk directory
+ * and, last, the screen bins (a 48 MB pool of 16-byte entries + per-bin tables) that frames with very large nodes sort their samples into.
+ * 1920 x 1080: 193.5 MB — inside the 200 000 000 bytes the reference host allocates whatever its window's size (main_progressive_octree.cpp:555).
+ * Larger frames need more for the full layout (1920 x 1200: 202 MB, 2560 x 1440: 255 MB); a buffer that is smaller is still fine as long as it
+ * holds everything in front of the bin pool (2560 x 1440: 199.2 MB): kernel_render asks the runtime how large the ALLOCATION behind `buffer` is
+ * (hipMemGetAddressRange) and sizes the pool by what is left — with less than 1 MB left it draws without bins (same frame, the samples of
+ * screen-filling nodes take device-scope atomics).  A host that carves `buffer` out of a larger allocation of its own must therefore give it
+ * simlod_render_buffer_bytes(width, height): what lies behind `buffer` inside that allocation is taken for the pool. */
 uint64_t simlod_render_framebuffer_offset(void);
 uint64_t simlod_render_buffer_bytes(uint32_t width, uint32_t height);
 /* Minimum size of kernel_construct's momentary `buffer` (the host allocates 300 MB, main_progressive_octree.cpp:554). */

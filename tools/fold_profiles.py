@@ -30,7 +30,7 @@ json.dump({"_csrc_sha16": summ.get("_csrc_sha16"), "what": "simlod_amd.fingerpri
 for k, v in summ["hbm_traffic"].items():
     total = v["fetch_bytes_x2"] + v["write_bytes"]
     base = k.split("<")[0]
-    if k.startswith("k_") and base not in ("k_begin", "k_finish", "k_stats", "k_parents", "k_paths", "k_reset", "k_end", "k_voxdone"):
+    if k.startswith("k_") and base not in ("k_begin", "k_finish", "k_stats", "k_parents", "k_rebuild", "k_voxroot", "k_paths", "k_reset", "k_end", "k_voxdone"):
         out[base] = total / (n_ingests * n_batches * per_batch.get(base, 1))
     elif k in names:
         out[names[k]] = total / frames

@@ -8,13 +8,14 @@ from simlod_amd.runtime import DeviceOctree
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 span_px = float(sys.argv[2]) if len(sys.argv) > 2 else 128.0
+momentary = int(sys.argv[3]) * 1_000_000 if len(sys.argv) > 3 else 4_000_000_000      # the reference host gives kernel_construct 300 MB (main_progressive_octree.cpp:554): argv[3] = 300
 box = np.array([1.0, 1.0, 1.0], dtype=np.float32)
 W, H = 1920, 1080
 cell = np.array([21, 40, 13], dtype=np.float64) / 64 + 1 / 128          # centre of the level-6 cell
 size = 1 / 64
 dist = size * (H / span_px) / (2 * np.tan(np.radians(30)))             # the cell spans ~span_px pixels vertically
 T = camera.lookat_transform(cell + np.array([0.6, -0.7, 0.4]) / np.linalg.norm([0.6, -0.7, 0.4]) * dist, cell, W, H)
-dev = DeviceOctree("cuda:0", persistent_bytes=(96 << 30) if n > 50_000_000 else (6 << 30), momentary_bytes=4_000_000_000, max_pixels=W * H)
+dev = DeviceOctree("cuda:0", persistent_bytes=(96 << 30) if n > 50_000_000 else (6 << 30), momentary_bytes=momentary, max_pixels=W * H)
 u = dev.uniforms(W, H, T, box, min_node_size=8.0)
 # the points on the device (uniform inside the cell, colour from the position inside it; the host generator takes minutes at 200 M), streamed
 # through the ring like config 4's: uploader + back-pressure + one kernel_construct per frame
@@ -39,7 +40,7 @@ del src
 st = dev.read_stats()
 from simlod_amd.fingerprint import csrc_sha16
 out = {"_csrc_sha16": csrc_sha16(), "points": n, "span_px": span_px, "ingest_s_resident_points_streamed_through_the_ring": t_ingest, "ingest_M_points_per_s": n / t_ingest / 1e6, "launches": launches,
-       "momentary_bytes": 4_000_000_000, "dbg": int(st["dbg"]), "numNodes": int(st["numNodes"]), "numVoxels": int(st["numVoxels"])}
+       "momentary_bytes": momentary, "dbg": int(st["dbg"]), "dbg_says": "0x2 = spill space ran out: splits DEFERRED to later batches, no point lost" if int(st["dbg"]) & 2 else None, "numPoints": int(st["numPoints"]), "numNodes": int(st["numNodes"]), "numVoxels": int(st["numVoxels"])}
 fbs = {}
 for tiles in (1, 0):
     dev.tune("SIMLOD_RASTER_LDS_TILES", tiles)
