@@ -480,6 +480,21 @@ struct LeafWords {
 };
 static constexpr uint32_t SLOT_CAP = 2048;                  // slots per batch (12 bits of a relabelled word and of the reservation word)
 static constexpr uint32_t HIST_BINS = 512;
+// The histograms exist HIST_SHARDS times: a workgroup flushes its LDS counts into copy blockIdx & 3 (consecutive workgroups run on different XCDs), the
+// readers (k_expand) add the copies.  A batch's splitting leaves are a dozen, their hot bins a few hundred words, and five hundred workgroups flush
+// into them within the same microseconds: a memory-side atomic of k_hist spent ~3 000 cycles in flight against 500-700 in every other kernel
+// (profiles/r04, TCC_EA0_ATOMIC_LEVEL / TCC_EA0_ATOMIC: same-address atomics retire one after the other).
+// Only the first HIST_SHARDED slots of a batch have the copies — a batch of a stream splits a dozen leaves; a batch that splits hundreds
+// (a coalesced group, scattered points) spreads its adds over that many histograms anyway —: 1.5 MB of the momentary buffer instead of 12.
+#ifndef HIST_SHARDS_N
+#define HIST_SHARDS_N 4          // measured on one box, ms per 36 M ingest: 1 copy 3.69, 4 copies 3.65, 8 copies 3.79 (cycles in flight per memory-side atomic of k_hist: 2 965 / 1 150 / 846)
+#endif
+static constexpr uint32_t HIST_SHARDS = HIST_SHARDS_N, HIST_SHARDED = 256;
+static constexpr uint64_t HIST_EXTRA_WORDS = (uint64_t)(HIST_SHARDS - 1u) * HIST_SHARDED * HIST_BINS;      // copies 1..3 of slots 0..255, behind the SLOT_CAP x HIST_BINS words of copy 0
+// word of (slot << 9 | bin) in copy `shard`
+__device__ __forceinline__ uint64_t hist_word(uint32_t key, uint32_t shard) {
+	return (shard == 0u || (key >> 9) >= HIST_SHARDED) ? (uint64_t)key : (uint64_t)SLOT_CAP * HIST_BINS + (uint64_t)(shard - 1u) * HIST_SHARDED * HIST_BINS + key;
+}
 static constexpr uint32_t LEAF_FLAG = 0x80000000u;          // cached-leaf word: FLAG | slot << 9 | bin   (else: node index | bin below that node << 19, as k_count left it)
 static constexpr uint32_t LEAF_BIN_SHIFT = 19;              // node indices travel in 19 bits (simlod_context_set_node_capacity: <= 2^19 nodes)
 static constexpr uint32_t LEAF_NODE_MASK = (1u << LEAF_BIN_SHIFT) - 1u;
@@ -633,8 +648,10 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 	top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
 	// the slot's histogram starts from zero
 	{
-		uint4* h = reinterpret_cast<uint4*>(at<uint32_t>(a, a.offHist) + (uint64_t)slot * HIST_BINS);
-		h[lane] = make_uint4(0, 0, 0, 0); h[lane + 64] = make_uint4(0, 0, 0, 0);
+		for (uint32_t sd = 0; sd < (slot < HIST_SHARDED ? HIST_SHARDS : 1u); sd++) {
+			uint4* h = reinterpret_cast<uint4*>(at<uint32_t>(a, a.offHist) + hist_word(slot << 9, sd));
+			h[lane] = make_uint4(0, 0, 0, 0); h[lane + 64] = make_uint4(0, 0, 0, 0);
+		}
 	}
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SpillWork* work = at<SpillWork>(a, a.offWork);
@@ -966,6 +983,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	const LeafWords leafOf(a, ordinal);
 	const unsigned long long* slotOf = at<const unsigned long long>(a, a.offSplitTag);   // per node: batch tag << 32 | level << 16 | slot
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
+	const uint32_t shard = blockIdx.x & (HIST_SHARDS - 1u);                                    // this workgroup's copy
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
 	const uint32_t n = bc->batchSize;
@@ -979,7 +997,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	__syncthreads();
 	auto add = [&](uint32_t key) {
 		uint32_t rank;
-		if (table_add(tbl, key, 1u, &rank) < 0) atomicAdd(hist + key, 1u);
+		if (table_add(tbl, key, 1u, &rank) < 0) atomicAdd(hist + hist_word(key, shard), 1u);
 	};
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		// stage by stage, eight elements per thread.  A SAMPLE of the group is never read here: its word holds the leaf k_count found and the
@@ -1023,7 +1041,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	ph.mark(4);
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) atomicAdd(hist + key, tbl.vals[e]);
+		if (key != TBL_EMPTY) atomicAdd(hist + hist_word(key, shard), tbl.vals[e]);
 	}
 	ph.mark(5);
 	if (ph.on) ctl->phaseNs[6] += 1;
@@ -1045,6 +1063,15 @@ static constexpr uint32_t ETPB = 1024;             // k_expand: at most one work
 static constexpr int HT_BITS = 12;
 static constexpr uint32_t HT_CAP = 1u << HT_BITS;
 static constexpr uint32_t LOCAL_NODES = 8 + 64 + 512;          // nodes a slot can create: local numbering t = 0..7 | 8..71 | 72..583
+
+__device__ __forceinline__ uint32_t hist_sum(const uint32_t* hist, uint64_t word) {      // a bin's count: the sum of its copies
+	uint32_t v = hist[word];
+	if ((word >> 9) < HIST_SHARDED) {
+#pragma unroll
+		for (uint32_t sd = 1; sd < HIST_SHARDS; sd++) v += hist[hist_word((uint32_t)word, sd)];
+	}
+	return v;
+}
 
 struct ExpandShared {
 	uint32_t keys[HT_CAP], vals[HT_CAP];           // H: (slot << 9 | bin) -> count
@@ -1070,7 +1097,7 @@ __device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, u
 		if (k == key) { atomicAdd(&sh.vals[h], cnt); return; }
 		h = (h + 1) & (HT_CAP - 1);
 	}
-	atomicAdd(at<uint32_t>(a, a.offHist) + key, cnt);          // no room in the table: straight to the histogram
+	atomicAdd(at<uint32_t>(a, a.offHist) + hist_word(key, blockIdx.x & (HIST_SHARDS - 1u)), cnt);          // no room in the table: straight to the histogram (this workgroup's copy)
 }
 // local node number t of a slot -> depth below the slot's node (1..3) and the octants chosen on the way
 __device__ __forceinline__ uint32_t local_depth(uint32_t t) { return t < 8u ? 1u : t < 72u ? 2u : 3u; }
@@ -1164,7 +1191,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			__syncthreads();
 			for (uint32_t e = threadIdx.x; e < HT_CAP; e += ETPB) {
 				const uint32_t key = sh.keys[e];
-				if (key != TBL_EMPTY) atomicAdd(hist + key, sh.vals[e]);
+				if (key != TBL_EMPTY) atomicAdd(hist + hist_word(key, blockIdx.x & (HIST_SHARDS - 1u)), sh.vals[e]);
 			}
 			if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
 			if (!grid_barrier(&bc->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
@@ -1180,7 +1207,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			bool mine = false;
 			for (uint32_t i = threadIdx.x; i < (se - sb) * HIST_BINS; i += ETPB) {
 				const uint32_t s = sb + i / HIST_BINS;
-				if (hist[(uint64_t)s * HIST_BINS + (i % HIST_BINS)] > SIMLOD_MAX_POINTS_PER_NODE && slots[s].node != NONE && slots[s].level + 3u < (uint32_t)SIMLOD_MAX_DEPTH) mine = true;
+				if (hist_sum(hist, (uint64_t)s * HIST_BINS + (i % HIST_BINS)) > SIMLOD_MAX_POINTS_PER_NODE && slots[s].node != NONE && slots[s].level + 3u < (uint32_t)SIMLOD_MAX_DEPTH) mine = true;
 			}
 			if (mine) sh.more = 1;
 		}
@@ -1196,7 +1223,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			const uint32_t K = min(3u, (uint32_t)SIMLOD_MAX_DEPTH - l);         // levels below L that exist
 			const uint32_t t = threadIdx.x;
 			__syncthreads();
-			if (t < HIST_BINS) sh.bins[t] = hist[(uint64_t)s * HIST_BINS + t];
+			if (t < HIST_BINS) sh.bins[t] = hist_sum(hist, (uint64_t)s * HIST_BINS + t);
 			if (t < PATH_WORDS) sh.pathL[t] = t + 1 < PATH_WORDS ? paths[(uint64_t)L * PATH_WORDS + t] : 0ull;
 			for (uint32_t i = t; i < LOCAL_NODES; i += ETPB) sh.listed[i] = NONE;
 			if (t < 72u) sh.grid[t] = nullptr;
@@ -1248,8 +1275,10 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 					// still too full after three levels: a slot of its own for the next round (its eight children reserved now, no stored points)
 					uint32_t slot = 0, childBase = 0, dummy;
 					if (reserve(a, ctl, bc, 1u, 8u, 0u, slot, childBase, dummy)) {
-						uint4* h = reinterpret_cast<uint4*>(hist + (uint64_t)slot * HIST_BINS);
-						for (uint32_t i = 0; i < HIST_BINS / 4; i++) h[i] = make_uint4(0, 0, 0, 0);
+						for (uint32_t sd = 0; sd < (slot < HIST_SHARDED ? HIST_SHARDS : 1u); sd++) {
+							uint4* h = reinterpret_cast<uint4*>(hist + hist_word(slot << 9, sd));
+							for (uint32_t i = 0; i < HIST_BINS / 4; i++) h[i] = make_uint4(0, 0, 0, 0);
+						}
 						slots[slot] = SlotRec{indexOf(t), level, childBase, 0u, 0u, 0u, 0u, 0u};
 						sh.listed[t] = MAP_LISTED | (level << 16) | slot;
 					}
@@ -2229,7 +2258,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t g
 	uint64_t off = 4096;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	a.offSlots = off;    off += align_up((uint64_t)2 * SLOT_CAP * sizeof(SlotRec), 256);
-	a.offHist = off;     off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
+	a.offHist = off;     off += align_up(((uint64_t)SLOT_CAP * HIST_BINS + HIST_EXTRA_WORDS) * 4, 256);      // (+ three more copies of the first 256 slots)
 	a.offMap = off;      off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
 	a.clearCap = 65536;
 	a.offClear = off;    off += align_up((uint64_t)2 * a.clearCap * 8, 256);

@@ -106,3 +106,24 @@ def test_kept_profiles_are_quoted_only_for_the_sources_they_were_measured_on(tmp
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     newest = sorted(d for d in os.listdir(os.path.join(here, "profiles")) if d.startswith("r") and d[1:].isdigit())[-1]
     assert os.path.exists(os.path.join(here, "profiles", newest, "fingerprint.json"))
+
+
+def test_trunk_mask_names_the_upper_nodes_whose_global_count_exceeds_the_limit():
+    """distributed.trunk_mask (multi-GPU: the shared levels 0-2 split by GLOBAL counts): bit 0 the root, 1 + c the level-1 node with cell code c,
+    9 + c the level-2 node; a node is named iff more than 50 000 points lie under it; a named node's parents are named (counts are monotone)."""
+    from simlod_amd import distributed
+    c = np.zeros(512, dtype=np.int64)
+    assert distributed.trunk_mask(c) == (0, 0)
+    c[0] = 50_000                                   # exactly the limit: a leaf holds up to 50 000 (progressive_octree_voxels.cu:209-217: splits when it holds MORE)
+    assert distributed.trunk_mask(c) == (0, 0)
+    c[0] = 50_001                                   # level-3 cell 0: under root, level-1 node 0, level-2 node 0
+    lo, hi = distributed.trunk_mask(c)
+    assert (lo, hi) == (1 | (1 << 1) | (1 << 9), 0)
+    c[:] = 0
+    c[511] = 30_000; c[510] = 30_000                # two cells of level-2 node 63 (cells 504..511), level-1 node 7: 60 000 under each of them and the root
+    lo, hi = distributed.trunk_mask(c)
+    mask = lo | (hi << 64)
+    assert mask == 1 | (1 << (1 + 7)) | (1 << (9 + 63)) and hi == 1 << 8
+    c[:] = 0
+    c[64 * 3: 64 * 3 + 64] = 1000                   # 64 000 points spread over level-1 node 3: the node and the root split, none of its level-2 nodes (8 000 each)
+    assert distributed.trunk_mask(c) == (1 | (1 << 4), 0)
