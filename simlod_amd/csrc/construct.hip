@@ -861,11 +861,12 @@ struct AllocRec {
 	SimlodChunk* head; SimlodChunk* tail;                   // the list as it is (nullptr: empty)
 };
 struct AllocShared { AllocRec rec[ALLOC_LEAVES]; uint32_t total; };
+struct FreshLeaf { uint32_t node, samples, level, X, Y, Z; };      // a leaf a cascade has just made: what alloc_points would otherwise read back from the node it was written to a moment ago
 
 // Entry k is taken when firstEntry + lane < numEntries.  `touched` (global memory): the leaves k_count found new samples for — what
 // each held when the batch began comes from stored_at_start().  `fresh` (LDS): {node, samples} of the empty leaves a cascade has
 // just made (nothing about them has to be read back).  One of the two lists is given.
-__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint32_t* touched, const uint2* fresh, uint32_t firstEntry, uint32_t numEntries) {
+__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint32_t* touched, const FreshLeaf* fresh, uint32_t firstEntry, uint32_t numEntries) {
 	const bool fresh_leaves = fresh != nullptr;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = chunk_dir(a, bc);
@@ -874,8 +875,10 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 	if (threadIdx.x < 64u) {
 		const uint32_t lane = threadIdx.x;
 		// (Node.numPoints is not looked at: the back half of the batch before may still be advancing it)
-		uint2 entry = make_uint2(NONE, 0u);
-		if (firstEntry + lane < numEntries) entry = fresh_leaves ? fresh[firstEntry + lane] : make_uint2(touched[firstEntry + lane], 0u);
+		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by prepare_batch, between the groups' allocations (asked for here: in flight beside everything below)
+		FreshLeaf fl = FreshLeaf{NONE, 0u, 0u, 0u, 0u, 0u};
+		if (firstEntry + lane < numEntries) { if (fresh_leaves) fl = fresh[firstEntry + lane]; else fl.node = touched[firstEntry + lane]; }
+		const uint2 entry = make_uint2(fl.node, fl.samples);
 		const uint32_t i = entry.x, stored = (fresh_leaves || i == NONE) ? 0u : stored_at_start(a, bc->tag, i);
 		SimlodNode* node = a.nodes + (i != NONE ? i : 0u);
 		uint32_t counter = 0;
@@ -915,7 +918,6 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		}
 		dirBase = (uint32_t)__shfl((int)dirBase, 0, 64); itemBase = (uint32_t)__shfl((int)itemBase, 0, 64); smallBase = (uint32_t)__shfl((int)smallBase, 0, 64);
 		chunkBase = shfl64(chunkBase, 0);
-		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by prepare_batch, between the groups' allocations
 		// pop from the recycle stack, allocate what the stack cannot serve
 		const unsigned long long firstIdx = chunkBase + exAdditional;
 		const uint32_t fromPool = firstIdx >= pool ? 0u : (uint32_t)min((unsigned long long)additional, pool - firstIdx);
@@ -935,8 +937,9 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 			NodeDir& d = nodeDir[i];
 			d.ptBase = base; d.ptFirst = first; d.ptTag = bc->tag;
 			VoxItem* items = vox_items(a, bc);
-			if (pieces == 0u) for (uint32_t q = 0; q < small; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_SMALL_PIECE, min(stored + (q + 1u) * VOX_SMALL_PIECE, counter), base, first, node->X, node->Y, node->Z};
-			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | node->level << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, node->X, node->Y, node->Z};
+			const uint32_t nl = fresh_leaves ? fl.level : node->level, nX = fresh_leaves ? fl.X : node->X, nY = fresh_leaves ? fl.Y : node->Y, nZ = fresh_leaves ? fl.Z : node->Z;
+			if (pieces == 0u) for (uint32_t q = 0; q < small; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_SMALL_PIECE, min(stored + (q + 1u) * VOX_SMALL_PIECE, counter), base, first, nX, nY, nZ};
+			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, nX, nY, nZ};
 		}
 		AllocRec& r = sh.rec[lane];
 		r.node = i; r.existing = existing; r.additional = ok ? additional : 0u; r.fromPool = fromPool; r.dirNew = base + e; r.prefix = exAdditional;
@@ -1078,7 +1081,10 @@ struct ExpandShared {
 	uint32_t bins[HIST_BINS], c2[64], c1[8];
 	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
 	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
-	uint2 fresh[LOCAL_NODES];                      // the cascade's nodes that hold samples: {node, samples} — they get their chunks before the kernel ends
+	FreshLeaf fresh[LOCAL_NODES];                  // the cascade's nodes that hold samples — they get their chunks before the kernel ends
+	uint32_t LX, LY, LZ;                           // the slot node's own coordinates, name and grid, read once per slot
+	uint8_t nameL[20];
+	SimlodOccupancyGrid* gridL;
 	uint32_t numFresh, numFill;
 	uint4 fill[8 + 64];                            // new leaves at level <= 3 whose cells of the top table the whole workgroup fills: {node | level << 19, X, Y, Z}
 	AllocShared alloc;
@@ -1217,14 +1223,18 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 
 		// -- D: decide and build ---------------------------------------------------------------------------------------------
 		for (uint32_t s = sb + blockIdx.x; s < se; s += gridDim.x) {
+			const uint32_t t = threadIdx.x;
+			const uint32_t myBin = t < HIST_BINS ? hist_sum(hist, (uint64_t)s * HIST_BINS + t) : 0u;      // (needs the slot's number only: in flight beside its record)
 			const SlotRec rec = slots[s];
 			if (rec.node == NONE) continue;                                     // nothing could be reserved for this leaf
 			const uint32_t L = rec.node, l = rec.level;
 			const uint32_t K = min(3u, (uint32_t)SIMLOD_MAX_DEPTH - l);         // levels below L that exist
-			const uint32_t t = threadIdx.x;
 			__syncthreads();
-			if (t < HIST_BINS) sh.bins[t] = hist_sum(hist, (uint64_t)s * HIST_BINS + t);
+			if (t < HIST_BINS) sh.bins[t] = myBin;
 			if (t < PATH_WORDS) sh.pathL[t] = t + 1 < PATH_WORDS ? paths[(uint64_t)L * PATH_WORDS + t] : 0ull;
+			// the slot node's coordinates, name and grid: one round trip here, beside its path, instead of one in every phase that wants them
+			if (t == 64u) { const SimlodNode* nl = a.nodes + L; sh.LX = nl->X; sh.LY = nl->Y; sh.LZ = nl->Z; sh.gridL = nl->grid; }
+			if (t >= 96u && t < 116u) sh.nameL[t - 96u] = a.nodes[L].name[t - 96u];
 			for (uint32_t i = t; i < LOCAL_NODES; i += ETPB) sh.listed[i] = NONE;
 			if (t < 72u) sh.grid[t] = nullptr;
 			if (t == 0u) { sh.numFresh = 0; sh.numFill = 0; }
@@ -1238,9 +1248,8 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				// (or when it is an upper node of a multi-GPU job that the host's mask names: trunk_forced)
 				bool f1 = false, f2 = false;
 				if (trunk_any(a) && l + 1u < TRUNK_LEVELS) {
-					const SimlodNode* nodeL = a.nodes + L;
 					// lane t < 8 as child t; every lane as grandchild t = child (t >> 3), octant (t & 7) below it
-					const uint32_t LX = nodeL->X, LY = nodeL->Y, LZ = nodeL->Z, j = t >> 3, k = t & 7u;
+					const uint32_t LX = sh.LX, LY = sh.LY, LZ = sh.LZ, j = t >> 3, k = t & 7u;
 					f1 = t < 8u && trunk_forced(a, l + 1u, 2u * LX + ((t >> 2) & 1u), 2u * LY + ((t >> 1) & 1u), 2u * LZ + (t & 1u));
 					f2 = trunk_forced(a, l + 2u, 4u * LX + 2u * ((j >> 2) & 1u) + ((k >> 2) & 1u), 4u * LY + 2u * ((j >> 1) & 1u) + ((k >> 1) & 1u), 4u * LZ + 2u * (j & 1u) + (k & 1u));
 				}
@@ -1291,8 +1300,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				const uint32_t rel = t < 8u ? t : t < 72u ? t - 8u : t - 72u;
 				uint32_t oct[3] = {0, 0, 0};
 				for (uint32_t k = 0; k < depth; k++) oct[k] = (rel >> (3u * (depth - 1u - k))) & 7u;
-				const SimlodNode* nodeL = a.nodes + L;
-				uint32_t X = nodeL->X, Y = nodeL->Y, Z = nodeL->Z;
+				uint32_t X = sh.LX, Y = sh.LY, Z = sh.LZ;
 				for (uint32_t k = 0; k < depth; k++) { X = 2u * X + ((oct[k] >> 2) & 1u); Y = 2u * Y + ((oct[k] >> 1) & 1u); Z = 2u * Z + (oct[k] & 1u); }
 				const bool split = splits(t);
 				const bool nextRound = sh.listed[t] != NONE;
@@ -1303,7 +1311,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				c.counter = countOf(t); c.numPoints = 0;
 				c.level = level; c.X = X; c.Y = Y; c.Z = Z;
 				c.countIteration = 0; c.countFlag = 0;
-				for (int k = 0; k < 20; k++) c.name[k] = nodeL->name[k];
+				for (int k = 0; k < 20; k++) c.name[k] = sh.nameL[k];
 				for (uint32_t k = 0; k < depth; k++) if (l + 1u + k < 20u) c.name[l + 1u + k] = (uint8_t)('0' + oct[k]);
 				c.visible = 0; c.isFiltered = 0; c.isLeaf = 1; c.isLarge = 0;
 				c.grid = split ? sh.grid[t] : nullptr; c.points = nullptr; c.voxelChunks = nullptr;
@@ -1319,13 +1327,15 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				uint32_t w = 0;
 				if (depth >= 3u) { const uint32_t g = 8u + ((t - 72u) >> 3); mine[w++] = path_pack(a.pers, indexOf(g), l + 2u, sh.grid[g]); }
 				if (depth >= 2u) { const uint32_t ch = depth == 2u ? (t - 8u) >> 3 : (t - 72u) >> 6; mine[w++] = path_pack(a.pers, indexOf(ch), l + 1u, sh.grid[ch]); }
-				mine[w++] = path_pack(a.pers, L, l, nodeL->grid);
+				mine[w++] = path_pack(a.pers, L, l, sh.gridL);
 				for (uint32_t k = 0; w < PATH_WORDS; k++) {
 					const unsigned long long e = w + 1 < PATH_WORDS ? sh.pathL[k] : 0ull;
 					mine[w++] = e;
 					if (e == 0ull) break;
 				}
 				if (t < 8u) a.nodes[L].children[t] = a.nodes + idx;
+				// the nodes of the cascade that hold samples and stay leaves (one that was queued again is none by the time its chunks would be used)
+				if (!split && countOf(t) != 0u && !nextRound) sh.fresh[atomicAdd(&sh.numFresh, 1u)] = FreshLeaf{idx, countOf(t), level, X, Y, Z};
 				// the top table (where k_count's descent starts): a new node at level <= 5 that has no children in the table's range takes over the cells it covers
 				// (a node two or more levels above the table's — 64 to 4096 cells, the first batches over a region — is filled by the whole workgroup, below)
 				if (level <= TOP_LEVEL && (!split || level == TOP_LEVEL)) {
@@ -1334,8 +1344,6 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				}
 			}
 			if (t == 0u) { a.nodes[L].numPoints = 0; a.nodes[L].points = nullptr; }          // voxels.cu:359-360 (its points are in the spill buffer, its chunks on the recycle stack: k_queue, k_hist)
-			// the nodes of the cascade that hold samples and stay leaves (one that was queued again is none by the time its chunks would be used)
-			if (t < LOCAL_NODES && exists(t) && !splits(t) && countOf(t) != 0u && sh.listed[t] == NONE) sh.fresh[atomicAdd(&sh.numFresh, 1u)] = make_uint2(indexOf(t), countOf(t));
 			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
 			if (t < HIST_BINS) {
 				const uint32_t j = t >> 6, jk = t >> 3;
