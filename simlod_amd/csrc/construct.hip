@@ -215,6 +215,7 @@ struct NodeDir {          // per node, valid for the batch whose tag it carries:
 // launches like the recycle stack does, and is refilled by k_rebuild whenever k_begin finds its stamp stale.
 static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
 static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
+static_assert(LEAF_SLOTS <= 64, "queue_split hands a leaf's chunks out one per lane");
 
 // Ancestor paths: PATH_WORDS 64-bit entries per node, entry k = the k-th ancestor (parent first), zero-terminated.
 // An entry packs everything `sample` and `insert` need to know about that ancestor — its occupancy grid (offset into the
@@ -613,6 +614,9 @@ __device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& 
 __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t nodeIdx) {
 	const uint32_t lane = (uint32_t)lane_id();
 	SimlodNode* node = a.nodes + nodeIdx;
+	// the leaf's row of the chunk table, a lane per chunk: asked for now, needed after the reservation (one round trip less on a kernel that is a
+	// chain of them)
+	SimlodChunk* const rowChunk = lane < LEAF_SLOTS ? at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)nodeIdx * LEAF_SLOTS + lane] : nullptr;
 	uint32_t ok = 0, slot = 0, spillBase = 0, stored = 0, level = 0, w0 = 0;
 	unsigned long long top = 0;
 	uint32_t numChunks = 0;
@@ -668,10 +672,9 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 	};
 	SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
 	if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
-	for (uint32_t ci = lane; ci < min(numChunks, LEAF_SLOTS); ci += 64) {
-		SimlodChunk* chunk = slots[ci];
-		emit(ci, chunk);
-		chunk->next = nullptr;
+	if (lane < min(numChunks, LEAF_SLOTS)) {                          // (LEAF_SLOTS <= 64: one chunk per lane)
+		emit(lane, rowChunk);
+		rowChunk->next = nullptr;
 	}
 	if (lane == 0) {
 		for (uint32_t ci = LEAF_SLOTS; ci < numChunks && beyond != nullptr; ci++) {   // the table has no slot for these: walk
@@ -978,6 +981,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr || ctl->abortBatch) return;
+	const uint32_t n = bc->batchSize, tag = bc->tag, numWork = bc->numWork;      // (asked for beside the slot count: one round trip, not two)
 	const uint32_t slots0 = slots_in_use(bc);
 	if (blockIdx.x == 0 && threadIdx.x == 0) bc->slotsRound0 = slots0;
 	if (blockIdx.x + 1u == gridDim.x && threadIdx.x == 0) prepare_batch(a, ctl, ordinal + 1u);     // (a workgroup without samples, as a rule)
@@ -989,9 +993,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	const uint32_t shard = blockIdx.x & (HIST_SHARDS - 1u);                                    // this workgroup's copy
 	const SpillWork* work = at<const SpillWork>(a, a.offWork);
 	float4* spilled = at<float4>(a, a.offSpilled);
-	const uint32_t n = bc->batchSize;
-	const uint32_t tag = bc->tag;
-	const uint32_t moved = min(bc->numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
+	const uint32_t moved = min(numWork, a.workCap) * SIMLOD_POINTS_PER_CHUNK;
 	const uint32_t total = moved + n;
 	const uint32_t numChunks = (total + CPB - 1) / CPB;
 	if (blockIdx.x >= numChunks) return;
