@@ -688,8 +688,14 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 
 // k_count takes more points per thread than k_insert (PPT): its cost is the flush of the per-workgroup counts into a few dozen
 // hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
-static constexpr uint32_t CPT = 8;
-static constexpr uint32_t CPB = TPB * CPT;         // (k_hist)
+#ifndef COUNT_CPT
+#define COUNT_CPT 8
+#endif
+#ifndef HIST_CPT
+#define HIST_CPT 8
+#endif
+static constexpr uint32_t CPT = COUNT_CPT;
+static constexpr uint32_t HCPT = HIST_CPT, CPB = TPB * HCPT;         // (k_hist)
 
 static constexpr uint32_t TOUCH_CAP = 512;         // leaves one workgroup can be the first to touch in one batch (more: appended one by one)
 
@@ -1008,10 +1014,10 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 		// stage by stage, eight elements per thread.  A SAMPLE of the group is never read here: its word holds the leaf k_count found and the
 		// bin below that leaf (node | bin << 19) — if the leaf was queued, the word becomes FLAG | slot | bin and the bin is counted.  A STORED
 		// point of a queued leaf is read, binned and moved to the spill buffer.
-		uint32_t ent[CPT], dst[CPT], v[CPT];              // moved points: ent = level << 16 | slot (or NONE), dst = spill index; samples: v = the cached-leaf word (or NONE)
-		const float4* src[CPT];
+		uint32_t ent[HCPT], dst[HCPT], v[HCPT];              // moved points: ent = level << 16 | slot (or NONE), dst = spill index; samples: v = the cached-leaf word (or NONE)
+		const float4* src[HCPT];
 #pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) {
+		for (uint32_t j = 0; j < HCPT; j++) {
 			const uint32_t e = chunk * CPB + j * TPB + threadIdx.x;
 			ent[j] = NONE; src[j] = nullptr; dst[j] = 0; v[j] = NONE;
 			if (e < moved) {
@@ -1020,21 +1026,21 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 				if (k < item.count) { ent[j] = (item.level << 16) | item.slot; src[j] = reinterpret_cast<const float4*>(item.chunk->points) + k; dst[j] = item.dstBase + k; }
 			} else if (e < total) v[j] = leafOf.grp[e - moved];
 		}
-		unsigned long long info[CPT];
+		unsigned long long info[HCPT];
 #pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) info[j] = v[j] != NONE ? slotOf[v[j] & LEAF_NODE_MASK] : 0ull;
-		float4 p[CPT];
+		for (uint32_t j = 0; j < HCPT; j++) info[j] = v[j] != NONE ? slotOf[v[j] & LEAF_NODE_MASK] : 0ull;
+		float4 p[HCPT];
 #pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) p[j] = ent[j] != NONE ? *src[j] : make_float4(0, 0, 0, 0);
+		for (uint32_t j = 0; j < HCPT; j++) p[j] = ent[j] != NONE ? *src[j] : make_float4(0, 0, 0, 0);
 #pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) {
+		for (uint32_t j = 0; j < HCPT; j++) {
 			if (v[j] == NONE || (uint32_t)(info[j] >> 32) != tag) continue;
 			const uint32_t key = (((uint32_t)info[j] & 0xffffu) << 9) | (v[j] >> LEAF_BIN_SHIFT);
 			leafOf.grp[chunk * CPB + j * TPB + threadIdx.x - moved] = LEAF_FLAG | key;
 			add(key);
 		}
 #pragma unroll
-		for (uint32_t j = 0; j < CPT; j++) {
+		for (uint32_t j = 0; j < HCPT; j++) {
 			if (ent[j] == NONE) continue;
 			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
 			const uint32_t key = ((ent[j] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[j] >> 16);
