@@ -366,82 +366,37 @@ __host__ __device__ inline uint64_t layout_signature(const BuildArgs& a) {
 	return a.scratchBytes ^ ((uint64_t)a.nodeCapacity << 40) ^ ((uint64_t)a.groupMax << 59) ^ (a.offSpilled * 0x9E3779B97F4A7C15ull);
 }
 
-// ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885) -------------------
-__global__ void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs, uint32_t groupMax) {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	Ctl* ctl = ctl_of(a);
-	const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
-	ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
-	ctl->stop = (momentaryTooSmall || fatal) ? 1u : 0u;
-	ctl->abortBatch = 0;
-	ctl->processed = 0;
-	ctl->consumed = 0;
-	ctl->groupMax = groupMax;
-	ctl->debugFlags = debugFlags;
-	ctl->budgetUs = budgetUs != 0u ? budgetUs : (uint32_t)(SIMLOD_MAX_PROCESSING_MS * 1000.0f);
-	ctl->startNs = wall_ns();
-	*a.frameStart = ctl->startNs;
-	// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
-	const uint32_t uploaded = __hip_atomic_load(a.numBatchesUploaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- begin: snapshot the upload counter, stamp the frame start (voxels.cu:823-825, 870-885); restore the side tables when they are stale -------
+// The side tables — parents, ancestor paths, the top table, the chunk table, the recycle stack — and the per-node tag words survive between
+// launches: k_expand keeps them current split by split, and every tag is a batch index + 1, which only grows while an octree lives.  They
+// are rebuilt only when the stamp k_finish left does not name THIS octree in THIS state in THIS layout: the first launch, after a reset, an
+// uploaded image, an aborted batch, a wiped or resized momentary buffer.  (Tags travel in 20 bits through the hash directory of voxel chunks: a
+// full clear every 2^19 batches keeps them unambiguous.)  Every thread of the launch reads the stamp for itself — nobody writes those words
+// while k_begin runs: the stamp is taken off by the launch's first k_count —, so the decision needs no second kernel (round 4: a memset and two
+// kernels per launch; round 5, first: two kernels that exited at once; 9 us each on a chain that is one batch long).
+__device__ __forceinline__ bool stamp_is_stale(const BuildArgs& a, const Ctl* ctl) {
 	const uint32_t first = a.stats->batchletIndex;
-	uint32_t n = uploaded - first;
-	if ((int32_t)n < 0) n = 0;
-	if (n > SIMLOD_MAX_BATCHES_PER_LAUNCH) n = SIMLOD_MAX_BATCHES_PER_LAUNCH;
-	if (n > batchLimit) n = batchLimit;
-	ctl->uploaded = uploaded;
-	ctl->firstBatch = first;
-	ctl->numBatches = n;
-	for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
-	// The side tables — parents, ancestor paths, the top table, the chunk table, the recycle stack — and the per-node tag words survive between
-	// launches: k_expand keeps them current split by split, and every tag is a batch index + 1, which only grows while an octree lives.  They
-	// are rebuilt (k_rebuild, k_paths) only when the stamp k_finish left does not name THIS octree in THIS state in THIS layout: the first launch,
-	// after a reset, an uploaded image, an aborted batch, a wiped or resized momentary buffer.  (Tags travel in 20 bits through the hash directory
-	// of voxel chunks: a full clear every 2^19 batches keeps them unambiguous.)
-	ctl->rebuildLeafChunks = (ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers ||
-	                          ctl->tableLayout != layout_signature(a) || ctl->tableSig != table_signature(a.stats) ||
-	                          (first >= 0x80000u && (first & 0x7ffffu) < SIMLOD_MAX_BATCHES_PER_LAUNCH)) ? 1u : 0u;
-	ctl->tableMagic = 0;                        // valid again once k_finish has run
-	for (uint32_t i = 0; i < BATCH_COPIES; i++) ctl->batch[i].active = 0;
-	for (uint32_t i = 0; i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++) { ctl->voxT[i][0] = ~0ull; ctl->voxT[i][1] = 0; ctl->voxT[i][2] = 0; }
-	prepare_batch(a, ctl, 0);
+	return ctl->tableMagic != TABLE_MAGIC || ctl->tableBatch != first || ctl->tableNodes != (uint64_t)a.nodes || ctl->tablePers != (uint64_t)a.pers ||
+	       ctl->tableLayout != layout_signature(a) || ctl->tableSig != table_signature(a.stats) ||
+	       (first >= 0x80000u && (first & 0x7ffffu) < SIMLOD_MAX_BATCHES_PER_LAUNCH);
 }
 
-// ---- rebuild: the side tables of an octree this buffer does not describe (see k_begin) --------------------------------------------------
-// k_rebuild: the per-node tag words and the hash directory are zeroed (offSplitTag .. offParent: a stale word could pass for a tag of this
-// octree's batches), parents come from the children pointers, the rows of the chunk table from the lists.  k_paths (needs the parents):
-// every node's ancestor list and the top table.  Both exit at once when the stamp is good — every launch but the first, as a rule: a launch
-// used to pay an 8 MB memset and two passes over the node CAPACITY (1 028 workgroups each) for tables that were valid.
-__global__ __launch_bounds__(TPB) void k_rebuild(BuildArgs a) {
-	if (ctl_of(a)->rebuildLeafChunks == 0u) return;
+// The side tables of an octree this buffer does not describe.  The per-node tag words and the hash directory are zeroed (offSplitTag .. offParent:
+// a stale word could pass for a tag of this octree's batches), parents come from the children pointers, the rows of the chunk table from the
+// lists, the top table and every node's ancestor list from a descent from the root (a node knows its level and cell: the ancestor at level l is
+// entry level - 1 - l of its list — no pass has to wait for the parent table).
+__device__ void rebuild_side_tables(const BuildArgs& a) {
+	const uint64_t first = (uint64_t)blockIdx.x * TPB + threadIdx.x, stride = (uint64_t)gridDim.x * TPB;
 	{
 		uint4* w = reinterpret_cast<uint4*>(a.mom + a.offSplitTag);
 		const uint64_t n = (a.offParent - a.offSplitTag) / 16;                 // (the offsets are 256-byte aligned)
-		for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) w[i] = make_uint4(0, 0, 0, 0);
+		for (uint64_t i = first; i < n; i += stride) w[i] = make_uint4(0, 0, 0, 0);
 	}
 	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
-		if (i == 0) parentOf[0] = 0xffffffffu;
-		const SimlodNode* n = a.nodes + i;
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const SimlodNode* c = n->children[k];
-			if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = i;
-		}
-		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser)
-		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)i * LEAF_SLOTS;
-		const SimlodChunk* c = node_is_leaf(n) ? n->points : n->voxelChunks;
-		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
-	}
-}
-
-// ---- paths: every node's ancestor list, from the parent table (one thread per node, depth <= 20 steps) ---------------------
-__global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
-	if (ctl_of(a)->rebuildLeafChunks == 0u) return;
-	const uint32_t numNodes = min(a.stats->numNodes, a.nodeCapacity);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < TOP_CELLS; i += gridDim.x * TPB) {      // the top table: cell i's deepest node at level <= TOP_LEVEL, by descent from the root
+	for (uint64_t i = first; i < TOP_CELLS; i += stride) {      // the top table: cell i's deepest node at level <= TOP_LEVEL
 		const uint32_t s = (uint32_t)SIMLOD_MAX_DEPTH - TOP_LEVEL;
-		const uint32_t X = (i >> (2u * TOP_LEVEL)) << s, Y = ((i >> TOP_LEVEL) & (TOP_SIDE - 1u)) << s, Z = (i & (TOP_SIDE - 1u)) << s;
+		const uint32_t X = ((uint32_t)i >> (2u * TOP_LEVEL)) << s, Y = (((uint32_t)i >> TOP_LEVEL) & (TOP_SIDE - 1u)) << s, Z = ((uint32_t)i & (TOP_SIDE - 1u)) << s;
 		uint32_t cur = 0, level = 0;
 		while (level < TOP_LEVEL) {
 			const SimlodNode* c = a.nodes[cur].children[child_index(X, Y, Z, (int)level)];
@@ -450,16 +405,67 @@ __global__ __launch_bounds__(TPB) void k_paths(BuildArgs a) {
 		}
 		at<uint32_t>(a, a.offTop)[i] = cur | (level << 19);
 	}
-	const uint32_t* parentOf = at<const uint32_t>(a, a.offParent);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < numNodes; i += gridDim.x * TPB) {
-		unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + (uint64_t)i * PATH_WORDS;
-		uint32_t k = 0;
-		for (uint32_t cur = parentOf[i]; cur != 0xffffffffu && k < PATH_WORDS - 1; cur = parentOf[cur]) {
-			const SimlodNode* n = a.nodes + cur;
-			rec[k++] = path_pack(a.pers, cur, n->level, n->grid);
+	for (uint64_t i = first; i < numNodes; i += stride) {
+		if (i == 0) parentOf[0] = 0xffffffffu;
+		const SimlodNode* n = a.nodes + i;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const SimlodNode* c = n->children[k];
+			if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = (uint32_t)i;
 		}
-		rec[k] = 0;
+		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser)
+		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + i * LEAF_SLOTS;
+		const SimlodChunk* c = node_is_leaf(n) ? n->points : n->voxelChunks;
+		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
+		// the ancestors, parent first, zero-terminated
+		unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + i * PATH_WORDS;
+		const uint32_t L = min(n->level, PATH_WORDS - 1u), s = (uint32_t)SIMLOD_MAX_DEPTH - L;
+		const uint32_t X = n->X << s, Y = n->Y << s, Z = n->Z << s;        // (child_index() takes coordinates at full depth)
+		uint32_t cur = 0, l = 0;
+		for (; l < L; l++) {
+			const SimlodNode* anc = a.nodes + cur;
+			rec[L - 1u - l] = path_pack(a.pers, cur, anc->level, anc->grid);
+			const SimlodNode* c = anc->children[child_index(X, Y, Z, (int)l)];
+			if (c == nullptr) break;                                         // (an image whose node is not where its coordinates say: entries below stay as they are, the list ends)
+			cur = (uint32_t)(c - a.nodes);
+		}
+		rec[L] = 0;
 	}
+}
+
+__global__ __launch_bounds__(TPB) void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs, uint32_t groupMax) {
+	Ctl* ctl = ctl_of(a);
+	const bool stale = momentaryTooSmall != 0u || stamp_is_stale(a, ctl);
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
+		ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
+		ctl->stop = (momentaryTooSmall || fatal) ? 1u : 0u;
+		ctl->abortBatch = 0;
+		ctl->processed = 0;
+		ctl->consumed = 0;
+		ctl->groupMax = groupMax;
+		ctl->debugFlags = debugFlags;
+		ctl->budgetUs = budgetUs != 0u ? budgetUs : (uint32_t)(SIMLOD_MAX_PROCESSING_MS * 1000.0f);
+		ctl->startNs = wall_ns();
+		*a.frameStart = ctl->startNs;
+		// written concurrently by the upload stream (main_progressive_octree.cpp:1047-1050): device-scope load
+		const uint32_t uploaded = __hip_atomic_load(a.numBatchesUploaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t first = a.stats->batchletIndex;
+		uint32_t n = uploaded - first;
+		if ((int32_t)n < 0) n = 0;
+		if (n > SIMLOD_MAX_BATCHES_PER_LAUNCH) n = SIMLOD_MAX_BATCHES_PER_LAUNCH;
+		if (n > batchLimit) n = batchLimit;
+		ctl->uploaded = uploaded;
+		ctl->firstBatch = first;
+		ctl->numBatches = n;
+		for (int i = 0; i < 8; i++) ctl->statCounters[i] = 0;
+		ctl->rebuildLeafChunks = stale ? 1u : 0u;
+		if (momentaryTooSmall != 0u) ctl->tableMagic = 0;    // (a launch that does nothing: its k_finish leaves no stamp)
+		for (uint32_t i = 0; i < BATCH_COPIES; i++) ctl->batch[i].active = 0;
+		for (uint32_t i = 0; i < SIMLOD_MAX_BATCHES_PER_LAUNCH; i++) { ctl->voxT[i][0] = ~0ull; ctl->voxT[i][1] = 0; ctl->voxT[i][2] = 0; }
+		prepare_batch(a, ctl, 0);
+	}
+	if (stale && momentaryTooSmall == 0u) rebuild_side_tables(a);
 }
 
 // ---- count: leaf lookup + per-leaf arrival counters + spill detection (voxels.cu:124-229) ---------------------
@@ -720,6 +726,7 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 		// allocations, before this one recycles or takes a chunk — and the node array's fill, where this group's reservations start (k_queue)
 		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
 		bc->reserve = (unsigned long long)a.stats->numNodes << 32;
+		if (ordinal == 0u) ctl->tableMagic = 0;     // the octree changes from here on: the side tables' stamp is valid again once k_finish has run (k_begin only reads it)
 	}
 	const bool trunkPass = blockIdx.x == 0 && trunk_any(a);     // (also for a group without samples: how a host flushes a mask it has just widened)
 	if (blockIdx.x >= numChunks && !trunkPass) return;
@@ -1706,14 +1713,22 @@ __device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
 // octree holds fewer than 50 000 points) is sampled here like every other leaf — into its own grid: the next batch may split that root, but
 // the grid is cleared by that batch's k_insert (voxels.cu:371-382), which waits for this kernel.  No other grid is touched by both: a leaf
 // that k_expand splits gets a NEW grid, and nothing samples into a leaf's own grid.
+static constexpr uint32_t VOXROOT_WGS = 8;         // the last workgroups of k_voxelize's grid: the pieces of a root that is still a leaf (voxroot_pieces)
+__device__ __forceinline__ void voxroot_pieces(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, VoxShared& sh, uint32_t wg, uint32_t numWgs);
+
 __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal) {
 	Ctl* ctl = ctl_of(a);
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr || ctl->abortBatch) return;
+	__shared__ VoxShared sh;
+	const uint32_t numWgs = gridDim.x - VOXROOT_WGS;          // (the host launches VOXROOT_WGS more than it has pieces for)
+	if (blockIdx.x >= numWgs) {
+		if (bc->rootPieces != 0u) voxroot_pieces(a, ctl, bc, sh, blockIdx.x - numWgs, VOXROOT_WGS);
+		return;
+	}
 	// the group's points are stored (k_insert has ended: nobody reads its ring slots any more): voxels.cu:925-949
 	if (blockIdx.x == 0 && threadIdx.x == 0) end_of_batch(a, ctl, bc);
 	const uint32_t numItems = min(bc->numVoxItems, VOX_BIG_ITEMS);
-	__shared__ VoxShared sh;
 	const VoxItem* items = vox_items(a, bc);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
@@ -1722,19 +1737,19 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	Phase ph(ctl, blockIdx.x == ((ctl->debugFlags >> 8) & 0xffffu));     // (SIMLOD_DEBUG_PHASE_WG: whose phase times tools/probe.py prints; default workgroup 0)
 	const bool clocked = SIMLOD_MEASURE != 0 && (ctl->debugFlags & 2u) != 0u;       // SIMLOD_DEBUG_VOXELIZE_CLOCK (tools/probe.py): when the first workgroup came, the last piece was done, the last workgroup left
 	if (clocked && blockIdx.x == 0 && threadIdx.x == 0) ctl->voxT[ordinal][0] = wall_ns();
-	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
+	for (uint32_t item = blockIdx.x; item < numItems; item += numWgs) {
 		// Global memory is touched in six steps, each one round trip with everything it needs in flight together: the item; the leaf's
 		// path; chunk addresses + cube words; the samples; the write-back atomics; the slot reservations and voxel chunks.
 		VoxItem it = items[item];
 		const uint32_t leafLevel = it.leaf >> 24;
 		it.leaf &= 0xffffffu;
-		if (it.leaf == 0u) continue;                              // (the root as a leaf: k_voxroot)
+		if (it.leaf == 0u) continue;                              // (the root as a leaf: voxroot_pieces)
 		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
 		if (threadIdx.x < PATH_WORDS) {
 			// ancestor d (1 = parent) is anc[d - 1].  (A root that is still a leaf samples ITSELF, voxels.cu:449-463 — the whole octree holds fewer
-			// than 50 000 points —: k_voxroot's pieces, skipped here.)
+			// than 50 000 points —: voxroot_pieces, skipped here.)
 			const unsigned long long e = threadIdx.x < PATH_WORDS - 1 ? rec[threadIdx.x] : 0ull;
 			sh.anc[threadIdx.x] = e; sh.cnt[threadIdx.x] = 0; sh.hiOcc[threadIdx.x] = 0; sh.hiFresh[threadIdx.x] = 0; sh.rank[threadIdx.x] = 0;
 			if (threadIdx.x < 8u) sh.listCount[threadIdx.x] = 0;
@@ -1969,30 +1984,26 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 	}
 	if (clocked && threadIdx.x == 0 && blockIdx.x < numItems) atomicMax(reinterpret_cast<unsigned long long*>(&ctl->voxT[ordinal][1]), (unsigned long long)wall_ns());
 	// then, wave by wave, the leaves with few new samples — handed out from the LAST wave down: the workgroups that had no piece start at once
-	voxelize_small(a, ctl, bc, gridDim.x * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, gridDim.x * VTPB / 64u);
+	voxelize_small(a, ctl, bc, numWgs * VTPB / 64u - 1u - (blockIdx.x * VTPB + threadIdx.x) / 64u, numWgs * VTPB / 64u);
 	if (clocked) { __syncthreads(); if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&ctl->voxT[ordinal][2]), (unsigned long long)wall_ns()); }
 }
 
 // ---- voxroot: a root that is still a leaf (the whole octree holds fewer than 50 000 points) samples ITSELF (voxels.cu:449-463: every node of the
 // path that has a grid is sampled, and the root has one from the reset on) — into its own grid, sample by sample with device-scope atomics: the
-// first batch or two of an octree, at most seven pieces.  A kernel of its own behind k_voxelize (whose main path it used to share, at the price
-// of scratch memory for all of it); exits at once when the group has no such piece.
-struct VoxRootShared { uint32_t cnt, first, rank; SimlodChunk* chunkOf[VOX_CHUNKS]; };
-__global__ __launch_bounds__(VTPB) void k_voxroot(BuildArgs a, uint32_t ordinal) {
-	Ctl* ctl = ctl_of(a);
-	BatchCtl* bc = batch_of(ctl, ordinal);
-	if (bc == nullptr || ctl->abortBatch || bc->rootPieces == 0u) return;
+// first batch or two of an octree, at most seven pieces.  The LAST workgroups of k_voxelize's launch (a path of its own, not a case of the main
+// path: that cost the main path scratch memory; as a kernel of its own behind k_voxelize it cost every batch a launch); they leave at once when
+// the group has no such piece.  Uses entry 0 of the piece state (cnt, first, rank, chunkOf).
+__device__ __forceinline__ void voxroot_pieces(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, VoxShared& sh, uint32_t wg, uint32_t numWgs) {
 	const uint32_t numItems = min(bc->numVoxItems, VOX_BIG_ITEMS);
-	__shared__ VoxRootShared shr;
 	const VoxItem* items = vox_items(a, bc);
 	SimlodChunk* const* chunkDir = chunk_dir(a, bc);
 	const uint32_t tag = bc->tag;
-	for (uint32_t item = blockIdx.x; item < numItems; item += gridDim.x) {
+	for (uint32_t item = wg; item < numItems; item += numWgs) {
 		VoxItem it = items[item];
 		it.leaf &= 0xffffffu;
 		if (it.leaf != 0u) continue;
 		__syncthreads();
-		if (threadIdx.x == 0u) { shr.cnt = 0; shr.rank = 0; }
+		if (threadIdx.x == 0u) { sh.cnt[0] = 0; sh.rank[0] = 0; }
 		__syncthreads();
 		SimlodOccupancyGrid* const g = a.nodes[0].grid;
 		const unsigned long long ent = g != nullptr ? path_pack(a.pers, 0u, 0u, g) : 0ull;
@@ -2017,12 +2028,12 @@ __global__ __launch_bounds__(VTPB) void k_voxroot(BuildArgs a, uint32_t ordinal)
 				if (((*word >> bit) & 1u) != 0u) continue;                                         // voxels.cu:93-94
 				if (((atomicOr(word, 1u << bit) >> bit) & 1u) != 0u) continue;                     // voxels.cu:96
 				wonMask |= 1u << j;
-				atomicAdd(&shr.cnt, 1u);
+				atomicAdd(&sh.cnt[0], 1u);
 			}
 		}
 		__syncthreads();
-		if (threadIdx.x == 0u && shr.cnt != 0u) {
-			const uint32_t cnt = shr.cnt;
+		if (threadIdx.x == 0u && sh.cnt[0] != 0u) {
+			const uint32_t cnt = sh.cnt[0];
 			const uint32_t first = atomicAdd(&a.nodes[0].numVoxels, cnt);
 			const uint32_t existing = (a.nodes[0].numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 			const uint32_t kFirst = first / SIMLOD_POINTS_PER_CHUNK, kLast = (first + cnt - 1u) / SIMLOD_POINTS_PER_CHUNK;
@@ -2033,12 +2044,12 @@ __global__ __launch_bounds__(VTPB) void k_voxroot(BuildArgs a, uint32_t ordinal)
 				SimlodChunk* c = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(mem) + (uint64_t)q * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
 				if (q + 1u < own) c->next = reinterpret_cast<SimlodChunk*>(reinterpret_cast<uint8_t*>(c) + SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
 				vox_chunk_publish(a, ctl, tag, 0u, ownFirst + q, c);
-				shr.chunkOf[ownFirst + q - kFirst] = c;
+				sh.chunkOf[0][ownFirst + q - kFirst] = c;
 			}
 			SimlodChunk* oldTail = existing > 0u ? tail_of(a.nodes[0].voxelChunks) : nullptr;
 			if (own != 0u) vox_chunk_link(a, ctl, tag, 0u, ownFirst, existing, oldTail, mem);
-			if (ownFirst != kFirst) shr.chunkOf[0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, 0u, kFirst);
-			shr.first = first;
+			if (ownFirst != kFirst) sh.chunkOf[0][0] = kFirst < existing ? oldTail : dir_wait(a, ctl, tag, 0u, kFirst);
+			sh.first[0] = first;
 		}
 		__syncthreads();
 #pragma unroll 1
@@ -2046,8 +2057,8 @@ __global__ __launch_bounds__(VTPB) void k_voxroot(BuildArgs a, uint32_t ordinal)
 			if (((wonMask >> j) & 1u) == 0u) continue;
 			uint32_t pX, pY, pZ;
 			const float colour = sample(j, pX, pY, pZ);
-			const uint32_t slot = shr.first + atomicAdd(&shr.rank, 1u);
-			SimlodChunk* c = shr.chunkOf[slot / SIMLOD_POINTS_PER_CHUNK - shr.first / SIMLOD_POINTS_PER_CHUNK];
+			const uint32_t slot = sh.first[0] + atomicAdd(&sh.rank[0], 1u);
+			SimlodChunk* c = sh.chunkOf[0][slot / SIMLOD_POINTS_PER_CHUNK - sh.first[0] / SIMLOD_POINTS_PER_CHUNK];
 			if (c != nullptr) reinterpret_cast<float4*>(c->points)[slot % SIMLOD_POINTS_PER_CHUNK] = voxel_of(a, 0, pX, pY, pZ, colour);
 		}
 	}
@@ -2383,22 +2394,20 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	const DeviceInfo& dev = device_info();
 
 	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(ctx.batchLimit.load(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(ctx, stats));
-	SIMLOD_LAUNCH(k_begin, dim3(1), dim3(64), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
+	// (one workgroup does the launch's bookkeeping; all of them restore the side tables when the stamp is stale: the first launch of an octree, as a rule)
+	SIMLOD_LAUNCH(k_begin, dim3(fits ? dev.numCUs * 2 : 1u), dim3(TPB), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
 	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), a.groupMax);
 	if (fits) {
-		// (both exit at once unless k_begin found the side tables stale: the first launch of an octree, as a rule)
-		SIMLOD_LAUNCH(k_rebuild, dim3(dev.numCUs * 2), dim3(TPB), stream, a);
-		SIMLOD_LAUNCH(k_paths, dim3(dev.numCUs), dim3(TPB), stream, a);
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
 		// measured optimum on MI355X (36 M terrain, us per batch: 256 -> 104, 192 -> 93, 128 -> 83, 96 -> 82, 64 -> 84, 32 -> 107):
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
 		// (with the previous batch's voxel half running beside it on the side stream: one per FOUR CUs — 256: 8.3 ms per ingest, 128: 7.8,
 		// 96: 7.5, 64: 7.2, 48: 7.3, 32: 7.5)
-		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled();
+		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
+		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled() && numGroups > 1u;   // (two streams: see below)
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
 		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
-		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		// A batch has a FRONT half — k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
 		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
 		// the caller's stream, the back half on a second stream of the library, two dependencies per batch between them:
@@ -2409,16 +2418,18 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		// k_count does not look at Node.numPoints (stored_at_start()).  Per batch the chain is as long as its longest cycle — k_insert,
 		// event, k_queue + k_hist + k_expand, event: ~90 us — instead of the sum of all seven kernels (~190 us on one stream).
 		// Off while per-kernel profiling is on (one stream, one timeline) or with SIMLOD_OVERLAP_TAIL=0.
-		SideStream* side = (ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled()) ? side_stream(ctx) : nullptr;
+		// A launch of ONE group has nothing to overlap: its seven kernels on the caller's stream, without the two event hops (13 + 12 us) and the stop
+		// event's gap (6 us) — a launch that finds one batch: 166 -> ~135 us (tools/launch_cost.py; the reference's frame loop while the loader is the bottleneck).
+		SideStream* side = overlap ? side_stream(ctx) : nullptr;
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
 		const int countTpb = ctx.tune(KNOB_COUNT_TPB, 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
 		const bool single = a.groupMax == 1u;
-		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
 		hipStream_t back = side != nullptr ? side->stream : stream;
 		// an enqueue that fails in the middle of the chain: the second stream may hold kernels that read and write the caller's buffers — the
 		// call does not return before they have ended (the caller may free or reset those buffers next)
 		auto fail = [&](hipError_t e) { if (side != nullptr) (void)hipStreamSynchronize(side->stream); (void)hipGetLastError(); return (int)(e != hipSuccess ? e : hipErrorUnknown); };
+		const uint32_t voxWgs = (uint32_t)max(1, ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)) + VOXROOT_WGS;     // (+ the workgroups of a root that is still a leaf)
 		for (uint32_t b = 0; b < numGroups; b++) {
 			if (single) {
 				if (countTpb == 256) SIMLOD_LAUNCH((k_count<TPB, true>), dim3(gridPoints), dim3(TPB), stream, a, b);
@@ -2446,16 +2457,18 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 			if (profile_dominant()) {      // bench.py's roofline: the dominant kernel timed in the headline configuration, by the launch's own start / stop events
 				hipEvent_t e0, e1;
 				profile_kernel_events("k_voxelize", &e0, &e1);
-				hipExtLaunchKernelGGL(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), 0, back, e0, e1, 0, a, b);
+				hipExtLaunchKernelGGL(k_voxelize, dim3(voxWgs), dim3(VTPB), 0, back, e0, e1, 0, a, b);
 			} else
-			SIMLOD_LAUNCH(k_voxelize, dim3((uint32_t)ctx.tune(KNOB_VOXELIZE_WGS, (int)dev.numCUs * 2)), dim3(VTPB), back, a, b);
-			SIMLOD_LAUNCH(k_voxroot, dim3(8), dim3(VTPB), back, a, b);      // (exits at once unless the root is still a leaf and got 512 samples or more)
+			SIMLOD_LAUNCH(k_voxelize, dim3(voxWgs), dim3(VTPB), back, a, b);
 		}
 		if (side != nullptr) {
 			hipError_t e = hipEventRecord(side->tailDone, back);
 			if (e == hipSuccess) e = hipStreamWaitEvent(stream, side->tailDone, 0);
 			if (e != hipSuccess) return fail(e);
 		}
+		// (kernels that follow each other on one queue start where the one before ends: three small kernels cost what one does — merged into one,
+		// with an arrival counter and its fence, this tail took 22 us instead of 19)
+		const uint32_t gridNodes = (a.nodeCapacity + TPB - 1) / TPB;
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
 	}

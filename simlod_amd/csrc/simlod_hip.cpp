@@ -176,10 +176,17 @@ static LaunchHistory* history_of(Context& ctx, const void* stats, bool create) {
 		seen = static_cast<volatile uint32_t*>(pinned);
 	}
 	seen[0] = NOTHING_SEEN; seen[1] = NOTHING_SEEN;
-	g_history.push_back(LaunchHistory{stats, seen, 0u, false});
+	g_history.push_back(LaunchHistory{stats, seen, 0u, 0u, 0u, false});
 	return &g_history.back();
 }
 
+// How many groups of kernels a launch enqueues.  The reference's kernel loops over whatever has been uploaded when it starts (voxels.cu:870-885);
+// here every batch is seven kernel launches the HOST enqueues before it can know that number.  A group without a batch is not free: its kernels
+// leave at once, but the two event hops between its halves stand in line behind the real batches — ~45 us per empty group at the end of a launch
+// (rocprofv3, tools/trace_launch.sh: a launch that found ONE batch among three groups took 233 us, of which the batch's own kernels end at 137).
+// So: what the latest feedback saw pending + as many as were uploaded between the last two feedbacks (the uploader's pace per launch), at least
+// one; everything (20) while nothing is known — the first launches after a reset.  A batch that arrives beyond that waits for the next launch,
+// where it counts as pending.  A host that knows the number says so (simlod_context_set_construct_batch_limit: the launch takes the smaller).
 uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
 	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
 	std::lock_guard<std::mutex> hold(ctx.historyLock);
@@ -188,10 +195,12 @@ uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
 	const uint32_t index = h->seen[0], uploaded = h->seen[1];
 	if (index == NOTHING_SEEN || uploaded == NOTHING_SEEN) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
 	const uint32_t pending = uploaded > index ? uploaded - index : 0u;
-	const uint32_t recent = h->havePrev && index >= h->prevIndex ? index - h->prevIndex : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (a smaller index: reset by other means)
-	h->prevIndex = index; h->havePrev = true;
-	const uint32_t want = pending + recent + 2u;
-	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want;
+	if (!h->havePrev) h->arrivals = SIMLOD_MAX_BATCHES_PER_LAUNCH;                                  // (one feedback says nothing about the pace)
+	else if (index != h->prevIndex || uploaded != h->prevUploaded)                                   // (the same feedback as last time: launches are enqueued faster than they end — keep the pace)
+		h->arrivals = uploaded >= h->prevUploaded && index >= h->prevIndex ? uploaded - h->prevUploaded : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (counters that went back: reset by other means)
+	h->prevIndex = index; h->prevUploaded = uploaded; h->havePrev = true;
+	const uint32_t want = pending + h->arrivals;
+	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want < 1u ? 1u : want;
 }
 
 uint32_t* launch_feedback_words(Context& ctx, const SimlodStats* stats) {

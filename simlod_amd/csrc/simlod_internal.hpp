@@ -50,7 +50,7 @@ enum Knob : int {
 static constexpr int KNOB_UNSET = INT_MIN;
 extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...
 
-struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter
+struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex, prevUploaded, arrivals; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter (as the latest launch whose end the host has seen left them); arrivals: batches uploaded between the last two
 struct FrameFeedback { const void* buffer; volatile uint32_t* seen; bool bins; uint64_t bytes; bool possible, open; };                       // render.hip launch_render: seen[0] = nodes of the buffer's latest frame that sort (or would)
 struct SideStream;                                           // construct.hip: the second stream of kernel_construct and its events
 void destroy_side_stream(SideStream* s);

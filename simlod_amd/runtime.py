@@ -139,6 +139,11 @@ class DeviceOctree:
         _check(self.L.simlod_context_set_node_capacity(ctx, max_nodes), "simlod_context_set_node_capacity")
         _check(self.L.simlod_context_set_ingest_mode(ctx, 1 if coalesce else 0), "simlod_context_set_ingest_mode")
         _check(self.L.simlod_context_set_construct_batch_limit(ctx, abi.MAX_BATCHES_PER_LAUNCH), "simlod_context_set_construct_batch_limit")
+        self.batch_limit = abi.MAX_BATCHES_PER_LAUNCH
+        # drain() and stream() know how many batches are pending — the reference's host does too (its upload index and the batchletIndex it reads
+        # back every frame) — and say so before a launch: a launch enqueues no kernels for batches that do not exist (an empty group costs ~45 us
+        # at a launch's end, simlod_hip.cpp groups_for_launch).  SIMLOD_HOST_HINT=0: launches sized by the library's own prediction only.
+        self.hint_pending = os.environ.get("SIMLOD_HOST_HINT", "1") != "0"
         z = dict(dtype=torch.uint8, device=self.device)
         # H11: the reference renders before any reset and relies on fresh VRAM reading as zero
         self.nodes = torch.zeros(max_nodes * 152, **z)
@@ -194,7 +199,14 @@ class DeviceOctree:
         self.drain(uniforms)
 
     def set_batch_limit(self, max_batches):
+        self.batch_limit = max(1, min(int(max_batches), abi.MAX_BATCHES_PER_LAUNCH))
         _check(self.L.simlod_context_set_construct_batch_limit(self.ctx, max_batches), "simlod_context_set_construct_batch_limit")
+
+    def _hint(self, pending=None):
+        """Tell the library how many batches the next launch can find at most (None: back to the caller's limit)."""
+        if self.hint_pending:
+            n = self.batch_limit if pending is None else max(1, min(int(pending), self.batch_limit))
+            _check(self.L.simlod_context_set_construct_batch_limit(self.ctx, n), "simlod_context_set_construct_batch_limit")
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def uniforms(self, width, height, transform, box_size, **kw):
@@ -427,9 +439,11 @@ class DeviceOctree:
         while before < self.uploaded_host and launches < max_launches:
             # as many launches as the pending batches need at 20 per launch, enqueued back to back (the reference's frame loop does not wait
             # for a launch either before it enqueues the next frame's); then ONE look at Stats
-            need = -(-(self.uploaded_host - before) // abi.MAX_BATCHES_PER_LAUNCH)
-            for _ in range(need):
+            need = -(-(self.uploaded_host - before) // self.batch_limit)
+            for k in range(need):
+                self._hint(self.uploaded_host - before - k * self.batch_limit)
                 self.construct(uniforms)
+            self._hint()
             launches += need
             after = self.processed()
             stalled, before = after == before, after
@@ -476,6 +490,7 @@ class DeviceOctree:
         top_up()
         while processed < nb:
             self.uploaded_host = base + uploaded
+            self._hint(uploaded - processed)
             self.construct(uniforms)              # takes what has been published by now (k_begin reads the counter with a device-scope load)
             launches += 1
             top_up()                              # ... and the uploader refills behind it while it runs
@@ -489,6 +504,7 @@ class DeviceOctree:
             if stalls > 1:
                 st = self.read_stats()
                 raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, memCapacityReached={int(st['memCapacityReached'])})")
+        self._hint()
         self.uploaded_host = base + uploaded
         self.processed_host = self.uploaded_host
         return launches
