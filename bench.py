@@ -211,6 +211,21 @@ def main():
     assert int(stats["numPointsProcessed"]) == my_points and int(stats["numPoints"]) == my_points, "ingest lost points"
     assert int(stats["dbg"]) == 0, f"device error bits {int(stats['dbg']):#x}"
     value = world * n_points / (ms_per_step * 1e-3) / 1e6
+    # The host mirror tells the library how many batches a launch can find (DeviceOctree._hint: simlod_context_set_construct_batch_limit — the
+    # reference's host has the same two numbers, its upload index and the batchletIndex it reads back); the same steps WITHOUT that hint — launches
+    # sized by the library's own prediction, what the reference's unchanged host gets — are reported beside the headline.
+    without_hint = None
+    if source is None and dev.hint_pending and rank == 0 and not use_dist:
+        dev.hint_pending = False
+        ingest_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ingest_step()
+        torch.cuda.synchronize()
+        ms_nohint = (time.perf_counter() - t0) * 1e3 / args.steps
+        dev.hint_pending = True
+        without_hint = {"ms_per_step": ms_nohint, "value": n_points / (ms_nohint * 1e-3) / 1e6, "what": "launches sized by the library's prediction alone (SIMLOD_HOST_HINT=0): the second launch of a step enqueues 20 groups for 16 batches"}
     collective = None
     if use_dist:
         # what the process group really was: every rank adds 1 (ranks_seen must be the world size) and its point count (the octrees of all
@@ -526,6 +541,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+u32 (fp32 quantise/project, fp64 pixel coordinate, integer octree/atomics)", "data": "synthetic",
             "ingest_mode": "coalesced" if args.coalesce else "exact",
+            "host_hint": "the host mirror passes its pending-batch count to every launch (simlod_context_set_construct_batch_limit)" if dev.hint_pending else None,
+            "ingest_without_host_hint": without_hint,
             "config": {"workload": (f"BASELINE config 4 shape: tiled terrain, {n_points} device-generated 16 B points per GPU streamed through the 50-slot ring ({n_batches} x 1M batches), "
                                     if source is not None else f"Morro Bay 36M stand-in (BASELINE config 2): {n_points} 16 B points, fractal terrain, {n_batches} x 1M ring batches resident in HBM, ") +
                                    f"reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step; raster 1920x1080",

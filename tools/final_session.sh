@@ -24,6 +24,8 @@ tools/trace.sh final_$TAG > $F/ingest_timeline.txt 2>&1
 SIMLOD_HIP_LIB=$MEASURE timeout 200 python tools/probe.py "" "SIMLOD_DEBUG_VOXELIZE_CLOCK=1" 2>&1 | grep -v amdgpu > $F/ingest_phases_measure_build.txt
 timeout 200 python tools/probe.py "" "" 2>&1 | grep -v amdgpu > $F/ingest_probe_product_build.txt
 timeout 200 python tools/launch_cost.py 2>&1 | grep -v amdgpu > $F/launch_cost.txt
+timeout 200 tools/trace_launch.sh final_$TAG > $F/launch_timeline.txt 2>&1
+SIMLOD_HOST_HINT=0 timeout 200 python tools/probe.py "" "" 2>&1 | grep "ms/ingest" | cut -c1-110 > $F/ingest_probe_without_host_hint.txt
 timeout 200 python tools/las_bench.py 2>&1 | grep -v amdgpu > $F/las_decode.txt
 timeout 200 python tools/batch_shape.py 2>&1 | grep -v amdgpu > $F/batch_shape.txt
 python tools/fold_profiles.py $TAG > $F/fold.txt 2>&1
