@@ -33,6 +33,21 @@ for fmt, bpp in ((2, 26), (3, 34), (7, 36)):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (3 * NSET)
     print(f"format {fmt} ({bpp} B records): {us:6.2f} us per 1 M-point launch (back to back) = {batch / us:7.0f} M points/s, {(bpp + 16) * batch / us / 1e6:6.2f} TB/s of {bpp} + 16 B per point", flush=True)
+    # the same bytes in launches of 6 M points (six batches that lie back to back): what the kernel does when the ~3 us between two launches of a
+    # stream are a twentieth of a launch instead of a quarter
+    G = 6
+    big = lambda k: L.simlod_decode_las(ctypes.c_void_p(d_raw[k].data_ptr()), ctypes.c_uint64(G * batch), ctypes.c_uint32(bpp), ctypes.c_uint32(fmt), scale3, off3,
+                                        ctypes.c_void_p(d_out[k].data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for k in range(0, NSET, G):
+        big(k)
+    torch.cuda.synchronize()
+    e0.record()
+    for rep in range(3):
+        for k in range(0, NSET, G):
+            big(k)
+    e1.record(); torch.cuda.synchronize()
+    usb = e0.elapsed_time(e1) * 1e3 / (3 * NSET // G)
+    print(f"format {fmt} ({bpp} B records): {usb:6.2f} us per {G} M-point launch               = {G * batch / usb:7.0f} M points/s, {(bpp + 16) * G * batch / usb / 1e6:6.2f} TB/s", flush=True)
     del d_raw, d_out
 src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0"); dst = torch.empty_like(src)
 for _ in range(2):
