@@ -215,7 +215,7 @@ def main():
     # reference's host has the same two numbers, its upload index and the batchletIndex it reads back); the same steps WITHOUT that hint — launches
     # sized by the library's own prediction, what the reference's unchanged host gets — are reported beside the headline.
     without_hint = None
-    if source is None and dev.hint_pending and rank == 0 and not use_dist:
+    if source is None and dev.hint_pending and rank == 0 and not use_dist and not args.no_cpu_baseline:      # (not in the profiling passes: their per-launch figures count three ingests)
         dev.hint_pending = False
         ingest_step()
         torch.cuda.synchronize()
