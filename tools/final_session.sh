@@ -12,7 +12,6 @@ cp gpurun_out/config5_$TAG/kernels.txt $F/config5_200m_kernels.txt; cp gpurun_ou
 timeout 300 python tools/hotspot_ab.py 200000000 > $F/config5_200m.json 2> $F/config5_200m.err
 timeout 300 python tools/hotspot_ab.py 200000000 128 300 > $F/config5_200m_host_300mb.json 2>> $F/config5_200m.err
 timeout 300 python tools/hotspot_ab.py 20000000 > $F/config5_20m.json 2>> $F/config5_200m.err
-timeout 300 python bench.py --stream --steps 2 --warmup 1 --no-cpu-baseline --no-profile --profiles $TAG > $F/bench_stream_500m_1gpu.json 2> $F/bench_stream.err
 timeout 200 python tools/raster_close.py 30 "" "X=1" "SIMLOD_RASTER_SCREEN_BINS=0" 2>&1 | grep -v amdgpu > $F/raster_presets.txt
 SIMLOD_HIP_LIB=$MEASURE PRESETS=close timeout 100 python tools/raster_items.py 2>&1 | grep -v amdgpu > $F/raster_items_close.txt
 SIMLOD_HIP_LIB=$MEASURE PRESETS=bird timeout 100 python tools/raster_items.py 2>&1 | grep -v amdgpu > $F/raster_items_bird.txt
@@ -31,4 +30,5 @@ timeout 200 python tools/batch_shape.py 2>&1 | grep -v amdgpu > $F/batch_shape.t
 python tools/fold_profiles.py $TAG > $F/fold.txt 2>&1
 mkdir -p profiles/$TAG; cp gpurun_out/final_$TAG/config3_350m* profiles/$TAG/ 2>/dev/null
 timeout 900 python bench.py --profiles $TAG > $F/bench_final.json 2> $F/bench_final.err
+timeout 300 python bench.py --stream --steps 2 --warmup 1 --no-cpu-baseline --no-profile --profiles $TAG > $F/bench_stream_500m_1gpu.json 2> $F/bench_stream.err
 tail -c 600 $F/bench_final.json; ls $F
