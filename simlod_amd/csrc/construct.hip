@@ -381,6 +381,9 @@ __device__ __forceinline__ bool stamp_is_stale(const BuildArgs& a, const Ctl* ct
 	       (first >= 0x80000u && (first & 0x7ffffu) < SIMLOD_MAX_BATCHES_PER_LAUNCH);
 }
 
+// (the 8 spare bytes Chunk::size / padding_0 of a list's HEAD chunk: the address of the list's last chunk)
+__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
+
 // The side tables of an octree this buffer does not describe.  The per-node tag words and the hash directory are zeroed (offSplitTag .. offParent:
 // a stale word could pass for a tag of this octree's batches), parents come from the children pointers, the rows of the chunk table from the
 // lists, the top table and every node's ancestor list from a descent from the root (a node knows its level and cell: the ancestor at level l is
@@ -413,10 +416,19 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 			const SimlodNode* c = n->children[k];
 			if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = (uint32_t)i;
 		}
-		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser)
+		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser).  And the word this builder keeps in the spare
+		// bytes of a list's HEAD chunk, the address of the list's last chunk (O(1) append): an image built elsewhere — by the reference — has
+		// none; found by walking the list once, here.
 		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + i * LEAF_SLOTS;
-		const SimlodChunk* c = node_is_leaf(n) ? n->points : n->voxelChunks;
-		for (uint32_t k = 0; k < LEAF_SLOTS && c != nullptr; k++) { slots[k] = const_cast<SimlodChunk*>(c); c = c->next; }
+		const bool leaf = node_is_leaf(n);
+		SimlodChunk* const head = leaf ? n->points : n->voxelChunks;
+		const uint32_t inList = ((leaf ? n->numPoints : n->numVoxelsStored) + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+		SimlodChunk* c = head;
+		for (uint32_t k = 0; c != nullptr && (k < LEAF_SLOTS || k < inList); k++) {
+			if (k < LEAF_SLOTS) slots[k] = c;
+			if (k + 1u == inList) tail_of(head) = c;
+			c = c->next;
+		}
 		// the ancestors, parent first, zero-terminated
 		unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + i * PATH_WORDS;
 		const uint32_t L = min(n->level, PATH_WORDS - 1u), s = (uint32_t)SIMLOD_MAX_DEPTH - L;
@@ -846,7 +858,6 @@ struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // sample
 __device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl* bc) { return at<VoxItem>(a, a.offVoxItems) + (uint64_t)(bc->ordinal & 1u) * a.voxItemCap; }
 
 // ---- chunks for the leaves with new samples ----------------------------------------------------------------------------
-__device__ __forceinline__ SimlodChunk*& tail_of(SimlodChunk* head) { return *reinterpret_cast<SimlodChunk**>(&head->size); }
 // sum over the wave and the sum of the lanes below (every lane of the wave calls)
 __device__ __forceinline__ uint32_t wave_exclusive(uint32_t v, uint32_t& total) {
 	const uint32_t lane = (uint32_t)lane_id();
