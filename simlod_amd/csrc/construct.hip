@@ -424,7 +424,7 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 		SimlodChunk* const head = leaf ? n->points : n->voxelChunks;
 		const uint32_t inList = ((leaf ? n->numPoints : n->numVoxelsStored) + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		SimlodChunk* c = head;
-		for (uint32_t k = 0; c != nullptr && (k < LEAF_SLOTS || k < inList); k++) {
+		for (uint32_t k = 0; c != nullptr && k < max(inList, 1u); k++) {      // (not beyond the list's last chunk: whether its `next` is null is the other builder's business)
 			if (k < LEAF_SLOTS) slots[k] = c;
 			if (k + 1u == inList) tail_of(head) = c;
 			c = c->next;

@@ -184,8 +184,8 @@ static LaunchHistory* history_of(Context& ctx, const void* stats, bool create) {
 // here every batch is seven kernel launches the HOST enqueues before it can know that number.  A group without a batch is not free: its kernels
 // leave at once, but the two event hops between its halves stand in line behind the real batches — ~45 us per empty group at the end of a launch
 // (rocprofv3, tools/trace_launch.sh: a launch that found ONE batch among three groups took 233 us, of which the batch's own kernels end at 137).
-// So: what the latest feedback saw pending + as many as were uploaded between the last two feedbacks (the uploader's pace per launch), at least
-// one; everything (20) while nothing is known — the first launches after a reset.  A batch that arrives beyond that waits for the next launch,
+// So: what the latest feedback saw pending + as many as were uploaded between the last two feedbacks (the uploader's pace per launch);
+// everything (20) while nothing is known — the first launches after a reset.  A batch that arrives beyond that waits for the next launch,
 // where it counts as pending.  A host that knows the number says so (simlod_context_set_construct_batch_limit: the launch takes the smaller).
 uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
 	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
@@ -200,7 +200,12 @@ uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
 		h->arrivals = uploaded >= h->prevUploaded && index >= h->prevIndex ? uploaded - h->prevUploaded : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (counters that went back: reset by other means)
 	h->prevIndex = index; h->prevUploaded = uploaded; h->havePrev = true;
 	const uint32_t want = pending + h->arrivals;
-	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want < 1u ? 1u : want;
+	// Nothing pending and nothing uploaded between the last two reports: the loader is idle (or done — the viewer's steady state: every frame launches
+	// kernel_construct, main_progressive_octree.cpp:364-428).  Such a launch enqueues NO group — k_begin, the Stats pass, k_finish: ~22 us instead of ~55 —; the first
+	// batch of a new burst is seen by that launch's report and taken by the next launch.  Not for a host that sizes its launches itself
+	// (simlod_context_set_construct_batch_limit): the launch takes the smaller of the two numbers, and its number must not meet a zero here.
+	if (want == 0u) return ctx.batchLimitGiven.load() ? 1u : 0u;
+	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want;
 }
 
 uint32_t* launch_feedback_words(Context& ctx, const SimlodStats* stats) {
@@ -356,6 +361,7 @@ int simlod_context_set_ingest_mode(SimlodContext* c, uint32_t mode) {
 int simlod_context_set_construct_batch_limit(SimlodContext* c, uint32_t maxBatches) {
 	if (maxBatches == 0u) return (int)hipErrorInvalidValue;
 	ctx_or_default(c).batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
+	ctx_or_default(c).batchLimitGiven.store(true);
 	return 0;
 }
 int simlod_context_set_trunk_mask(SimlodContext* c, uint64_t lo, uint64_t hi) {

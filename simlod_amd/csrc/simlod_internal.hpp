@@ -59,6 +59,7 @@ struct Context {
 	std::atomic<uint32_t> nodeCapacity{263157u};             // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
 	std::atomic<uint32_t> ingestMode{0u};                    // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
 	std::atomic<uint32_t> batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};   // host hint: at most this many batches are pending (<= 20)
+	std::atomic<bool>     batchLimitGiven{false};                       // the host has called simlod_context_set_construct_batch_limit at least once: it sizes its launches itself (groups_for_launch never answers 0 then)
 	std::atomic<uint64_t> trunkLo{0u}, trunkHi{0u};          // simlod_context_set_trunk_mask: upper nodes (levels 0-2) that split whatever they hold; zero: the reference's rule alone
 	int knob[KNOB_COUNT_];
 	std::mutex sideLock;
