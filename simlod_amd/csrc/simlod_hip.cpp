@@ -196,8 +196,12 @@ uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
 	if (index == NOTHING_SEEN || uploaded == NOTHING_SEEN) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
 	const uint32_t pending = uploaded > index ? uploaded - index : 0u;
 	if (!h->havePrev) h->arrivals = SIMLOD_MAX_BATCHES_PER_LAUNCH;                                  // (one feedback says nothing about the pace)
-	else if (index != h->prevIndex || uploaded != h->prevUploaded)                                   // (the same feedback as last time: launches are enqueued faster than they end — keep the pace)
+	else if (index != h->prevIndex || uploaded != h->prevUploaded)
 		h->arrivals = uploaded >= h->prevUploaded && index >= h->prevIndex ? uploaded - h->prevUploaded : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (counters that went back: reset by other means)
+	// The same two numbers as last time: either no launch has ended in between (launches enqueued faster than they end — keep the pace) or one has and
+	// found the counters where they were.  With nothing pending the second reading is the safe one: a loader that has finished must not leave its
+	// last pace behind in every later frame's launch (20 groups without a batch: 0.6 ms per frame).
+	else if (pending == 0u) h->arrivals = 0u;
 	h->prevIndex = index; h->prevUploaded = uploaded; h->havePrev = true;
 	const uint32_t want = pending + h->arrivals;
 	// Nothing pending and nothing uploaded between the last two reports: the loader is idle (or done — the viewer's steady state: every frame launches

@@ -123,7 +123,7 @@ class DeviceOctree:
     """Device buffers of initCudaProgram() + the three launches, on one GPU."""
 
     def __init__(self, device="cuda:0", *, persistent_bytes=4 << 30, momentary_bytes=300_000_000, max_nodes=263_157,
-                 ring_slots=abi.BATCH_STREAM_SIZE, max_pixels=1920 * 1080, coalesce=False):
+                 ring_slots=abi.BATCH_STREAM_SIZE, max_pixels=1920 * 1080, coalesce=False, sizes_launches=True):
         if not torch.cuda.is_available():
             raise SimlodError("no GPU visible: the SimLOD hot paths only exist as gfx950 kernels")
         self.L = lib()
@@ -138,12 +138,14 @@ class DeviceOctree:
         self.ctx = ctx
         _check(self.L.simlod_context_set_node_capacity(ctx, max_nodes), "simlod_context_set_node_capacity")
         _check(self.L.simlod_context_set_ingest_mode(ctx, 1 if coalesce else 0), "simlod_context_set_ingest_mode")
-        _check(self.L.simlod_context_set_construct_batch_limit(ctx, abi.MAX_BATCHES_PER_LAUNCH), "simlod_context_set_construct_batch_limit")
+        # (sizes_launches=False: a host like the reference's own, which never tells the library how many batches a launch can find — the library's prediction alone)
+        if sizes_launches:
+            _check(self.L.simlod_context_set_construct_batch_limit(ctx, abi.MAX_BATCHES_PER_LAUNCH), "simlod_context_set_construct_batch_limit")
         self.batch_limit = abi.MAX_BATCHES_PER_LAUNCH
         # drain() and stream() know how many batches are pending — the reference's host does too (its upload index and the batchletIndex it reads
         # back every frame) — and say so before a launch: a launch enqueues no kernels for batches that do not exist (an empty group costs ~45 us
         # at a launch's end, simlod_hip.cpp groups_for_launch).  SIMLOD_HOST_HINT=0: launches sized by the library's own prediction only.
-        self.hint_pending = os.environ.get("SIMLOD_HOST_HINT", "1") != "0"
+        self.hint_pending = sizes_launches and os.environ.get("SIMLOD_HOST_HINT", "1") != "0"
         z = dict(dtype=torch.uint8, device=self.device)
         # H11: the reference renders before any reset and relies on fresh VRAM reading as zero
         self.nodes = torch.zeros(max_nodes * 152, **z)
