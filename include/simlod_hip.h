@@ -40,6 +40,7 @@ extern "C" {
 #define SIMLOD_ERR_BARRIER_TIMEOUT     0x040u /* FATAL: in-kernel grid barrier of the split cascade gave up (sticky until reset) */
 #define SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW 0x080u /* > 1 000 000 recycled chunks (voxels.cu:856)                        */
 #define SIMLOD_ERR_VISIBLE_OVERFLOW    0x100u /* > 100 000 visible nodes (render.cu:1108)                           */
+#define SIMLOD_ERR_ACCOUNTING          0x200u /* exact mode, launches of several batches: the per-batch chunk accounting of a group did not end at the chunk count the octree has (Stats.allocatedBytes_persistent / chunkPoolSize may differ from the reference's; the octree itself is sound) */
 
 /* ---- per-octree contexts --------------------------------------------------------------------------------------------------------
  * The reference host keeps ONE octree per process and its launch signatures carry no handle (main_progressive_octree.cpp:337-345,

@@ -52,12 +52,16 @@ struct BatchCtl {
 	uint32_t ordinal, tag, slotsRound0, numSpilled;   // tag = batch index + 1 (NodeDir); slotsRound0: slots handed out by k_count's tail, snapshot by k_hist: k_expand's first round
 	uint32_t numWork, numClear, numTouched, numCross;    // spill-copy work items | grids k_insert has to clear | leaves with new samples (k_expand allocates their chunks) | leaves k_count saw cross the limit (k_queue)
 	uint32_t barrierCount, rootPieces, numVoxItems, numVoxSmall;     // rootPieces: pieces of a root that is still a leaf (k_voxroot)
-	uint32_t groupBatches, dirCount, pad0, pad1;      // ring batches taken together: 1 in exact mode, up to groupMax in coalesced mode; batchSize = all their samples
+	uint32_t groupBatches, dirCount, acct, accounted;      // ring batches taken together: 1 in exact mode, up to groupMax in coalesced mode; batchSize = all their samples | acct: an EXACT group of several batches — counts and histograms are kept per batch, the allocator / chunk-pool counters are brought to what batch-by-batch ingestion leaves (account_group) | accounted: that has happened
 	uint32_t start[SIMLOD_MAX_BATCHES_PER_LAUNCH + 1];   // sample index of the first sample of batch k of the group (start[groupBatches] = batchSize)
 	uint32_t slot[SIMLOD_MAX_BATCHES_PER_LAUNCH];        // its ring slot
 	uint32_t pad3;
 	unsigned long long reserve;        // split slots << 52 | nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves all or nothing
 	unsigned long long pad2;
+	// per-batch chunk accounting of an exact group (acct): point chunks batch k of the group would have taken / given back had the batches been ingested one
+	// by one (voxels.cu:346-357, 485-538), filled by k_expand; the chunk counters as they stood when the group began (k_count's first workgroup)
+	uint32_t acctAlloc0, acctPool0, pad4, pad5;
+	uint32_t acctD[SIMLOD_MAX_BATCHES_PER_LAUNCH], acctF[SIMLOD_MAX_BATCHES_PER_LAUNCH];
 };
 
 // Control block at byte 0 of kernel_construct's momentary buffer.  Lives only for the duration of one launch
@@ -72,7 +76,8 @@ struct Ctl {
 	uint64_t tableNodes, tablePers;    // ... of THIS octree (node array, persistent buffer)
 	uint64_t tableSig;                 // table_signature() of the Stats the table belongs to
 	uint64_t tableLayout;              // layout_signature() of the momentary buffer the side tables were built in
-	uint64_t unused1[3];
+	uint64_t pointsTaken;              // samples of all batches taken so far, this launch's included (Stats.numPointsProcessed follows when their back halves have run)
+	uint64_t unused1[2];
 	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
 	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 216: k_voxelize of group #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
 	uint64_t phaseNs[48];              // byte 696: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
@@ -81,7 +86,7 @@ struct Ctl {
 };
 static_assert(offsetof(Ctl, voxT) == 216 && offsetof(Ctl, phaseNs) == 696, "tools/probe.py reads Ctl.voxT at byte 216, Ctl.phaseNs at byte 696");
 static_assert(offsetof(Ctl, expandNs) == 152, "bench.py / tools read Ctl.expandNs at byte 152");
-static_assert(offsetof(Ctl, batch) == 1080 && sizeof(BatchCtl) == 264, "tools/batch_shape.py reads Ctl.batch at byte 1080");
+static_assert(offsetof(Ctl, batch) == 1080 && sizeof(BatchCtl) == 440, "tools/batch_shape.py reads Ctl.batch at byte 1080");
 static_assert(sizeof(Ctl) <= 4096, "control block");
 
 struct BuildArgs {
@@ -98,6 +103,8 @@ struct BuildArgs {
 	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, offTop, leafOfStride;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax, crossCap;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
 	uint64_t     trunkLo, trunkHi;   // simlod_context_set_trunk_mask: nodes of levels 0-2 that split whatever they hold (multi-GPU: the shared upper levels); zero on one GPU
+	uint64_t     offCntB, offHistB;  // exact groups (acct): per node, samples of batch k of the group (groupMax words) | per (slot, bin), likewise
+	uint32_t     acct, pad;          // exact mode with groups of several batches (groupMax > 1): see account_group
 };
 
 // ---- the shared upper levels of a multi-GPU job (include/simlod_hip.h simlod_context_set_trunk_mask; no counterpart in the reference, which is
@@ -286,11 +293,13 @@ __device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->e
 // level, every inner node can start one more chunk).  The memory guard of voxels.cu:896-912 looks at the allocator after the WHOLE previous
 // batch; here a batch is prepared while the voxel halves of the TWO batches before it may still be running, so within this distance of the
 // guard a launch takes one batch only: the next launch's k_begin runs after everything and decides exactly.
-__device__ __forceinline__ unsigned long long voxel_half_slack(const BuildArgs& a, const BatchCtl* prev) {
-	const unsigned long long samples = (unsigned long long)prev->batchSize + prev->numSpilled;
+__device__ __forceinline__ unsigned long long slack_for(const BuildArgs& a, unsigned long long samples) {
 	// (+ the point chunks and grids the group before has yet to allocate: its k_expand runs after this look at the allocator)
 	return (2ull * (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + a.stats->numNodes + 1ull) + samples / SIMLOD_POINTS_PER_CHUNK + 4096ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk))
 	       + (unsigned long long)SLOT_CAP_GRIDS * SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid));
+}
+__device__ __forceinline__ unsigned long long voxel_half_slack(const BuildArgs& a, const BatchCtl* prev) {
+	return slack_for(a, (unsigned long long)prev->batchSize + prev->numSpilled);
 }
 
 // Make group #ordinal of this launch current (in copy ordinal & 3), or leave it inactive (progressive_octree_voxels.cu:890-912).  Runs on the
@@ -310,7 +319,20 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	a.stats->memCapacityReached = full ? 1 : 0;
 	if (full) { ctl->stop = 1; return; }
 	const uint32_t batchIndex = ctl->firstBatch + ctl->consumed;       // (Stats.batchletIndex itself is advanced by the back half, which may lag)
-	const uint32_t take = min(ctl->groupMax, ctl->numBatches - ctl->consumed);
+	uint32_t take = min(ctl->groupMax, ctl->numBatches - ctl->consumed);
+	// A root that is still a leaf samples ITSELF (voxels.cu:449-463) and is sampled AGAIN, from nothing, by the batch that splits it (:371-382): what its
+	// voxel list holds then depends on which batch that was — batch by batch until the root has children (the first 50 000 points of an octree)
+	if (a.acct != 0u && take > 1u && node_is_leaf(a.nodes)) take = 1u;
+	if (a.acct != 0u && take > 1u) {
+		// An EXACT group of several batches is taken only where the reference's guard — looked at before EVERY batch (voxels.cu:896-912) — cannot
+		// trip inside it: the allocator must be a worst-case group away from it.  Closer than that, the launch goes batch by batch as before.
+		unsigned long long samples = 0;
+		for (uint32_t k = 0; k < take; k++) samples += min(a.batchSizes[(batchIndex + k) % SIMLOD_BATCH_STREAM_SIZE], (uint32_t)SIMLOD_MAX_BATCH_SIZE);
+		// (stored points a split moves are sampled again: at most what the octree holds, at most what the spill buffer takes)
+		samples += min((unsigned long long)a.spilledCap, (unsigned long long)ctl->pointsTaken);
+		const unsigned long long before = ordinal > 0u ? voxel_half_slack(a, &ctl->batch[(ordinal - 1u) % BATCH_COPIES]) : 0ull;
+		if (alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + before + slack_for(a, samples) >= a.persCapacity) take = 1u;
+	}
 	uint32_t total = 0;
 	for (uint32_t k = 0; k < take; k++) {
 		const uint32_t slot = (batchIndex + k) % SIMLOD_BATCH_STREAM_SIZE;
@@ -321,6 +343,7 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	}
 	bc->start[take] = total;
 	ctl->consumed += take;
+	ctl->pointsTaken += total;
 	bc->groupBatches = take;
 	bc->batchIndex = batchIndex;
 	bc->ringSlot = bc->slot[0];
@@ -340,6 +363,9 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	bc->rootPieces = 0;
 	bc->dirCount = 0;
 	bc->reserve = 0;           // (k_count's first workgroup: the node array as k_expand of the group before leaves it)
+	bc->acct = a.acct != 0u && take > 1u ? 1u : 0u;
+	bc->accounted = 0;
+	for (uint32_t k = 0; k < SIMLOD_MAX_BATCHES_PER_LAUNCH; k++) { bc->acctD[k] = 0; bc->acctF[k] = 0; }
 	bc->active = 1;
 }
 
@@ -455,6 +481,7 @@ __global__ __launch_bounds__(TPB) void k_begin(BuildArgs a, uint32_t momentaryTo
 		ctl->abortBatch = 0;
 		ctl->processed = 0;
 		ctl->consumed = 0;
+		ctl->pointsTaken = a.stats->numPointsProcessed;
 		ctl->groupMax = groupMax;
 		ctl->debugFlags = debugFlags;
 		ctl->budgetUs = budgetUs != 0u ? budgetUs : (uint32_t)(SIMLOD_MAX_PROCESSING_MS * 1000.0f);
@@ -519,7 +546,7 @@ static constexpr uint32_t LEAF_BIN_SHIFT = 19;              // node indices trav
 static constexpr uint32_t LEAF_NODE_MASK = (1u << LEAF_BIN_SHIFT) - 1u;
 static constexpr uint32_t MAP_LISTED = 0x80000000u;         // map entry: LISTED | level << 16 | slot of the NEXT round   (else: a node index)
 static constexpr uint32_t NONE = 0xffffffffu;
-struct SlotRec { uint32_t node, level, childBase, spillBase, stored, pad0, pad1, pad2; };   // node == NONE: nothing could be reserved, the leaf stays as it is
+struct SlotRec { uint32_t node, level, childBase, spillBase, stored, born, pad1, pad2; };   // node == NONE: nothing could be reserved, the leaf stays as it is | born: NONE for a leaf that existed when the group began; else (an exact group, a node the cascade queued for its next round) the batch of the group in which the node split — when its children were created
 __device__ __forceinline__ SlotRec* slot_recs(const BuildArgs& a, uint32_t ordinal) { return at<SlotRec>(a, a.offSlots) + (uint64_t)(ordinal & 1u) * SLOT_CAP; }   // (by parity, as the clear list)
 
 // the three child choices below a node at `level`, most significant first (levels beyond MAX_DEPTH contribute zero bits)
@@ -660,7 +687,7 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 			atomicAdd(&bc->numSpilled, stored);
 			if (grid == nullptr) { grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + gridAt); node->grid = grid; }
 			note_clear(a, bc, c, grid);
-			slot_recs(a, bc->ordinal)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, 0u, 0u, 0u};
+			slot_recs(a, bc->ordinal)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, NONE, 0u, 0u};
 			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)bc->tag << 32) | (level << 16) | slot;      // (the group's tag: unique while the octree lives, like every tag word)
 		}
 	}
@@ -673,6 +700,10 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 		for (uint32_t sd = 0; sd < (slot < HIST_SHARDED ? HIST_SHARDS : 1u); sd++) {
 			uint4* h = reinterpret_cast<uint4*>(at<uint32_t>(a, a.offHist) + hist_word(slot << 9, sd));
 			h[lane] = make_uint4(0, 0, 0, 0); h[lane + 64] = make_uint4(0, 0, 0, 0);
+		}
+		if (bc->acct != 0u) {      // (an exact group: the slot's histograms per batch)
+			uint4* hb = reinterpret_cast<uint4*>(at<uint32_t>(a, a.offHistB) + (uint64_t)slot * HIST_BINS * a.groupMax);
+			for (uint32_t i = lane; i < HIST_BINS / 4u * a.groupMax; i += 64u) hb[i] = make_uint4(0, 0, 0, 0);
 		}
 	}
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
@@ -704,6 +735,62 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 	}
 }
 
+// ---- exact groups of several batches: the allocator / chunk-pool counters of batch-by-batch ingestion -----------------------------------
+// In EXACT mode a launch that finds several pending batches ingests up to groupMax of them as ONE group — one descent, one insert, one voxel
+// pass over all their samples, the throughput regime of the chip — where the reference ingests them one after the other (voxels.cu:883-949).
+// Topology, per-node sample multisets, occupancy grids, voxel positions and counts do not depend on that granularity (a leaf splits iff what
+// lies in its cell exceeds 50 000; a grid holds the cells of every sample that passed through the node).  What does:
+//   * Node.counter of an inner node — what lay in its cell after the batch in which it split (voxels.cu:203-218: later batches descend past it);
+//   * Stats.numAllocatedChunks' excursions, hence Stats.chunkPoolSize (its high-water mark, voxels.cu:535-537) and how many point chunks came
+//     FRESH from the allocator instead of the recycle stack, hence Stats.allocatedBytes_persistent: a node that is created by one batch of the
+//     group and split by a later one held chunks in between; a leaf takes its chunks batch by batch.
+// Both follow from COUNTS PER BATCH alone: k_count keeps the samples per (leaf, batch of the group), k_hist / k_expand the 512-bin histograms
+// per batch, and k_expand derives, for every node of a cascade, the batch it was created in (= the batch its parent split in), the batch it
+// split in (the first in which its running count exceeds the limit), its counter at that moment, and the chunks it took and gave back in every
+// batch: BatchCtl.acctD[k] / acctF[k] = point chunks batch k of the group takes / returns, summed over all nodes.  account_group() then replays
+// voxels.cu:346-357 / 505-516 on those numbers — a stack pointer and a high-water mark — and makes the real counters agree: the chunks the
+// batch-by-batch run would have taken fresh beyond what the group did are allocated now and put on the recycle stack, where that run would have
+// left them.  The replay must end at the chunk count the octree really has (every chunk in use is in use in both runs): SIMLOD_ERR_ACCOUNTING otherwise.
+struct Phantom { uint32_t base, count; unsigned long long mem; };      // recycle-stack entries [base, base + count) = fresh chunks from `mem` on (written by the whole workgroup)
+__device__ Phantom account_group(const BuildArgs& a, Ctl* ctl, BatchCtl* g) {
+	SimlodStats* s = a.stats;
+	Phantom ph{0u, 0u, 0ull};
+	if (g != nullptr && g->acct != 0u && g->accounted == 0u && ctl->abortBatch == 0u) {
+		long long A = (long long)g->acctAlloc0, P = (long long)g->acctPool0;
+		for (uint32_t k = 0; k < g->groupBatches; k++) {
+			A -= (long long)g->acctF[k];            // voxels.cu:346-357: the batch's splits return their leaves' chunks first ...
+			A += (long long)g->acctD[k];            // ... then its leaves take what they need (voxels.cu:505-516), from the stack while it has any
+			if (A > P) P = A;                       // voxels.cu:535-537
+		}
+		const long long Areal = (long long)s->numAllocatedChunks;
+		if (A != Areal) raise(ctl, SIMLOD_ERR_ACCOUNTING);
+		const long long Preal = max((long long)g->acctPool0, Areal);          // what the group's own allocations made of the pool
+		if (P > Preal && P <= (long long)CHUNK_QUEUE_CAPACITY) {
+			ph.base = (uint32_t)Preal; ph.count = (uint32_t)(P - Preal);
+			ph.mem = (unsigned long long)persistent_alloc(a.pers, sizeof(SimlodChunk), ph.count);
+		}
+		s->chunkPoolSize = (uint64_t)max(P, Preal);
+		g->accounted = 1u;
+	} else if (s->numAllocatedChunks > s->chunkPoolSize) s->chunkPoolSize = s->numAllocatedChunks;      // voxels.cu:535-537
+	return ph;
+}
+__device__ __forceinline__ void phantom_fill(const BuildArgs& a, const Phantom& ph) {      // (every thread of the workgroup)
+	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
+	for (uint32_t i = threadIdx.x; i < ph.count; i += blockDim.x) {
+		SimlodChunk* c = reinterpret_cast<SimlodChunk*>(ph.mem + (unsigned long long)i * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk)));
+		c->next = nullptr;
+		chunkQueue[ph.base + i] = c;
+	}
+}
+// batch of the group that sample i belongs to
+__device__ __forceinline__ uint32_t batch_of_sample(const BatchCtl* bc, uint32_t i) {
+	uint32_t k = min(i / (uint32_t)SIMLOD_MAX_BATCH_SIZE, bc->groupBatches - 1u);
+	while (k + 1u < bc->groupBatches && i >= bc->start[k + 1u]) k++;
+	return k;
+}
+static constexpr uint32_t ACCT_BATCH_SHIFT = 21;       // keys of an exact group's LDS tables: (slot << 9 | bin) | batch << 21  (k_hist, k_expand); leaf | batch << 19 (k_count)
+static constexpr uint32_t ACCT_MOVED = 31u;            // "batch" of a stored point a split moves: it was there before the group
+
 // k_count takes more points per thread than k_insert (PPT): its cost is the flush of the per-workgroup counts into a few dozen
 // hot leaf counters, and fewer, fatter workgroups mean fewer same-address atomics (measured: 8 -> -3.5 us, in k_insert +14 us)
 #ifndef COUNT_CPT
@@ -733,13 +820,22 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	uint32_t* touched = at<uint32_t>(a, a.offTouched);
 	uint32_t* crossList = at<uint32_t>(a, a.offCross);
 	const uint32_t numChunks = (n + CPB - 1) / CPB;
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		// what had to wait for k_expand of the group before: voxels.cu:535-537 — the chunk pool's high-water mark follows that group's
-		// allocations, before this one recycles or takes a chunk — and the node array's fill, where this group's reservations start (k_queue)
-		if (a.stats->numAllocatedChunks > a.stats->chunkPoolSize) a.stats->chunkPoolSize = a.stats->numAllocatedChunks;
-		bc->reserve = (unsigned long long)a.stats->numNodes << 32;
-		if (ordinal == 0u) ctl->tableMagic = 0;     // the octree changes from here on: the side tables' stamp is valid again once k_finish has run (k_begin only reads it)
+	if (blockIdx.x == 0) {
+		__shared__ Phantom sh_phantom;
+		if (threadIdx.x == 0) {
+			// what had to wait for k_expand of the group before: voxels.cu:535-537 — the chunk pool's high-water mark follows that group's
+			// allocations, before this one recycles or takes a chunk (an exact group of several batches: account_group) — and the node array's fill,
+			// where this group's reservations start (k_queue)
+			sh_phantom = account_group(a, ctl, ordinal > 0u ? batch_of(ctl, ordinal - 1u) : nullptr);
+			bc->acctAlloc0 = (uint32_t)a.stats->numAllocatedChunks; bc->acctPool0 = (uint32_t)a.stats->chunkPoolSize;
+			bc->reserve = (unsigned long long)a.stats->numNodes << 32;
+			if (ordinal == 0u) ctl->tableMagic = 0;     // the octree changes from here on: the side tables' stamp is valid again once k_finish has run (k_begin only reads it)
+		}
+		__syncthreads();
+		phantom_fill(a, sh_phantom);
 	}
+	const bool acct = bc->acct != 0u;
+	uint32_t* cntB = at<uint32_t>(a, a.offCntB);
 	const bool trunkPass = blockIdx.x == 0 && trunk_any(a);     // (also for a group without samples: how a host flushes a mask it has just widened)
 	if (blockIdx.x >= numChunks && !trunkPass) return;
 	Phase ph(ctl, blockIdx.x == 0);
@@ -806,14 +902,21 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 			leafOf.grp[i] = leafIdx | (bin_of(X[j], Y[j], Z[j], level[j]) << LEAF_BIN_SHIFT);      // the bin is what k_hist needs should this leaf split: it never reads the sample
 			// (no room in the workgroup's table — a batch scattered over more leaves than it has keys —: the leaf's counters directly, one sample after the
 			// other.  Round 5 measured all of a thread's spilled samples with their loads and adds in flight together: config 5 went from 60 to 71 ms)
-			if (!spread_add(tbl, leafIdx, threadIdx.x & (REP - 1u))) counted(leafIdx, count_into(a, bc, leafIdx, 1u));
+			const uint32_t kb = acct ? batch_of_sample(bc, i) : 0u;                                   // (an exact group: counts per leaf AND batch)
+			if (!spread_add(tbl, leafIdx | (kb << LEAF_BIN_SHIFT), threadIdx.x & (REP - 1u))) {
+				counted(leafIdx, count_into(a, bc, leafIdx, 1u));
+				if (acct) atomicAdd(cntB + (uint64_t)leafIdx * a.groupMax + kb, 1u);
+			}
 		}
 	}
 	__syncthreads();
 	ph.mark(0);
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += BT) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) counted(key, count_into(a, bc, key, spread_sum(tbl, e)));
+		if (key == TBL_EMPTY) continue;
+		const uint32_t leafIdx = key & LEAF_NODE_MASK, cnt = spread_sum(tbl, e);
+		counted(leafIdx, count_into(a, bc, leafIdx, cnt));
+		if (acct) atomicAdd(cntB + (uint64_t)leafIdx * a.groupMax + (key >> LEAF_BIN_SHIFT), cnt);
 	}
 	__syncthreads();
 	ph.mark(1);
@@ -916,6 +1019,25 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 			// (a leaf that k_count's tail has queued for splitting still looks like a leaf until k_expand gives it children: not this one's business)
 			const bool queued = (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[i] >> 32) == bc->tag;
 			counter = node->counter; head = node->points; need = !queued && stored < counter && node_is_leaf(node);
+		}
+		if (bc->acct != 0u && !fresh_leaves) {
+			// An exact group of several batches: a leaf takes its chunks batch by batch (voxels.cu:485-538) — batch k of the group brings it from
+			// ceil(count before / 1000) to ceil(count after / 1000) chunks; k_count kept the leaf's samples per batch.  Summed over the wave, one add per
+			// batch (account_group replays them).  The row is left as it was found: zero.  (The nodes of a cascade: k_expand, from the histograms.)
+			uint32_t* row = at<uint32_t>(a, a.offCntB) + (uint64_t)(i != NONE ? i : 0u) * a.groupMax;
+			uint32_t c = stored, have = (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			for (uint32_t k = 0; k < bc->groupBatches; k++) {
+				uint32_t delta = 0;
+				if (i != NONE) {
+					c += row[k]; row[k] = 0u;
+					const uint32_t want = (c + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+					if (need) delta = want - have;
+					have = want;
+				}
+				uint32_t sum;
+				(void)wave_exclusive(delta, sum);
+				if (lane == 0u && sum != 0u) atomicAdd(&bc->acctD[k], sum);
+			}
 		}
 		const uint32_t required = (counter + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		const uint32_t existing = need ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
@@ -1024,9 +1146,21 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 	Phase ph(ctl, blockIdx.x == 0);
 	table_init(tbl);
 	__syncthreads();
-	auto add = [&](uint32_t key) {
+	// An exact group of several batches (acct) keeps a slot's histogram PER BATCH: a sample of batch k of the group goes into histB[(slot, bin)][k], a
+	// stored point that moves — it was there before the group — into the plain histogram; a bin's count is the sum of both (bin_total).  The LDS
+	// table's key carries the batch above the (slot, bin) bits.
+	const bool acct = bc->acct != 0u;
+	uint32_t* histB = at<uint32_t>(a, a.offHistB);
+	const uint32_t GB = a.groupMax;
+	auto flush = [&](uint32_t key, uint32_t cnt) {
+		const uint32_t kb = key >> ACCT_BATCH_SHIFT, k21 = key & 0x1fffffu;
+		if (acct && kb != ACCT_MOVED) atomicAdd(histB + (uint64_t)k21 * GB + kb, cnt);
+		else atomicAdd(hist + hist_word(k21, shard), cnt);
+	};
+	auto add = [&](uint32_t key, uint32_t kb) {
 		uint32_t rank;
-		if (table_add(tbl, key, 1u, &rank) < 0) atomicAdd(hist + hist_word(key, shard), 1u);
+		if (acct) key |= kb << ACCT_BATCH_SHIFT;
+		if (table_add(tbl, key, 1u, &rank) < 0) flush(key, 1u);
 	};
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		// stage by stage, eight elements per thread.  A SAMPLE of the group is never read here: its word holds the leaf k_count found and the
@@ -1054,8 +1188,9 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 		for (uint32_t j = 0; j < HCPT; j++) {
 			if (v[j] == NONE || (uint32_t)(info[j] >> 32) != tag) continue;
 			const uint32_t key = (((uint32_t)info[j] & 0xffffu) << 9) | (v[j] >> LEAF_BIN_SHIFT);
-			leafOf.grp[chunk * CPB + j * TPB + threadIdx.x - moved] = LEAF_FLAG | key;
-			add(key);
+			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x - moved;
+			leafOf.grp[i] = LEAF_FLAG | key;
+			add(key, acct ? batch_of_sample(bc, i) : 0u);
 		}
 #pragma unroll
 		for (uint32_t j = 0; j < HCPT; j++) {
@@ -1063,14 +1198,14 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 			const uint32_t X = quantize(F_GRID, p[j].x, a.minx, a.size), Y = quantize(F_GRID, p[j].y, a.miny, a.size), Z = quantize(F_GRID, p[j].z, a.minz, a.size);
 			const uint32_t key = ((ent[j] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[j] >> 16);
 			spilled[dst[j]] = p[j]; leafOf.mov[dst[j]] = LEAF_FLAG | key;                       // a stored point moves
-			add(key);
+			add(key, ACCT_MOVED);
 		}
 	}
 	__syncthreads();
 	ph.mark(4);
 	for (uint32_t e = threadIdx.x; e < (uint32_t)TBL_CAP; e += TPB) {
 		const uint32_t key = tbl.keys[e];
-		if (key != TBL_EMPTY) atomicAdd(hist + hist_word(key, shard), tbl.vals[e]);
+		if (key != TBL_EMPTY) flush(key, tbl.vals[e]);
 	}
 	ph.mark(5);
 	if (ph.on) ctl->phaseNs[6] += 1;
@@ -1102,8 +1237,20 @@ __device__ __forceinline__ uint32_t hist_sum(const uint32_t* hist, uint64_t word
 	return v;
 }
 
+// ... of an exact group of several batches (acct): the stored points that moved (the plain histogram) + the group's samples, kept per batch
+__device__ __forceinline__ uint32_t bin_total(const BuildArgs& a, const uint32_t* hist, uint64_t word, bool acct) {
+	uint32_t v = hist_sum(hist, word);
+	if (acct) {
+		const uint32_t* hb = at<const uint32_t>(a, a.offHistB) + word * a.groupMax;
+		for (uint32_t k = 0; k < a.groupMax; k++) v += hb[k];
+	}
+	return v;
+}
+static constexpr uint32_t ACCT_MAX_GROUP = 12;     // batches an exact group can have: k_expand keeps a slot's 512 + 64 + 8 per-batch rows in the LDS words of its hash table
+static constexpr uint32_t NEVER = 0xffu;
+
 struct ExpandShared {
-	uint32_t keys[HT_CAP], vals[HT_CAP];           // H: (slot << 9 | bin) -> count
+	uint32_t keys[HT_CAP], vals[HT_CAP];           // H: (slot << 9 | bin) -> count.  D, exact groups: rows of per-batch counts (keys and vals as one array: acct_rows)
 	uint32_t bins[HIST_BINS], c2[64], c1[8];
 	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
 	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
@@ -1118,9 +1265,24 @@ struct ExpandShared {
 	unsigned long long pathL[PATH_WORDS];          // the slot node's own ancestor path
 	uint32_t mask1, extraBase, ok, more;
 	unsigned long long mask2;
+	// exact groups of several batches (acct): per local node, the batch of the group in which it split (NEVER: it did not) and its counter after that batch;
+	// [LOCAL_NODES] = the slot's own node.  The upper nodes the trunk mask names (they split as soon as they exist).  Chunks taken / returned per batch.
+	uint8_t splitAt[LOCAL_NODES + 8];
+	uint32_t counterAt[LOCAL_NODES + 1];
+	uint32_t forced1;
+	unsigned long long forced2;
+	uint32_t accD[SIMLOD_MAX_BATCHES_PER_LAUNCH], accF[SIMLOD_MAX_BATCHES_PER_LAUNCH];
 };
+static_assert(offsetof(ExpandShared, vals) == offsetof(ExpandShared, keys) + sizeof(uint32_t) * HT_CAP && (HIST_BINS + 64u + 8u) * ACCT_MAX_GROUP <= 2u * HT_CAP, "acct_rows");
 
-__device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, uint32_t key, uint32_t cnt) {
+// one table entry of k_expand's in-kernel histogram pass -> global memory.  key: slot << 9 | bin, and in an exact group (acct) above them the batch the
+// samples belong to (ACCT_MOVED: stored points that moved): a sample of batch k counts in histB[(slot, bin)][k], a moved point in the plain histogram
+__device__ __forceinline__ void hist_flush(const BuildArgs& a, uint32_t key, uint32_t cnt, bool acct) {
+	const uint32_t kb = key >> ACCT_BATCH_SHIFT, k21 = key & 0x1fffffu;
+	if (acct && kb != ACCT_MOVED) atomicAdd(at<uint32_t>(a, a.offHistB) + (uint64_t)k21 * a.groupMax + kb, cnt);
+	else atomicAdd(at<uint32_t>(a, a.offHist) + hist_word(k21, blockIdx.x & (HIST_SHARDS - 1u)), cnt);
+}
+__device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, uint32_t key, uint32_t cnt, bool acct) {
 	uint32_t h = (key * 2654435761u) >> (32 - HT_BITS);
 #pragma unroll 1
 	for (int probe = 0; probe < 16; ++probe) {
@@ -1129,7 +1291,7 @@ __device__ __forceinline__ void hist_add(const BuildArgs& a, ExpandShared& sh, u
 		if (k == key) { atomicAdd(&sh.vals[h], cnt); return; }
 		h = (h + 1) & (HT_CAP - 1);
 	}
-	atomicAdd(at<uint32_t>(a, a.offHist) + hist_word(key, blockIdx.x & (HIST_SHARDS - 1u)), cnt);          // no room in the table: straight to the histogram (this workgroup's copy)
+	hist_flush(a, key, cnt, acct);          // no room in the table: straight to the histogram (this workgroup's copy)
 }
 // local node number t of a slot -> depth below the slot's node (1..3) and the octants chosen on the way
 __device__ __forceinline__ uint32_t local_depth(uint32_t t) { return t < 8u ? 1u : t < 72u ? 2u : 3u; }
@@ -1169,6 +1331,8 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	const Samples<false> pts(a, bc);
 	const uint32_t n = bc->batchSize;
 	uint32_t generation = 0;
+	const bool acct = bc->acct != 0u;                      // an exact group of several batches: histograms per batch, counters and chunk accounting as batch-by-batch ingestion leaves them (account_group)
+	const uint32_t GB = bc->groupBatches, GBS = a.groupMax;      // batches of the group | stride of the per-batch rows
 
 	const bool timer = SIMLOD_MEASURE != 0 && blockIdx.x == 0 && threadIdx.x == 0;
 	if (timer) ctl->expandNs[6] += 1;
@@ -1215,7 +1379,8 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 					const uint32_t X = quantize(F_GRID, p[q].x, a.minx, a.size), Y = quantize(F_GRID, p[q].y, a.miny, a.size), Z = quantize(F_GRID, p[q].z, a.minz, a.size);
 					const uint32_t key = ((ent[q] & 0xffffu) << 9) | bin_of(X, Y, Z, ent[q] >> 16);
 					leafOf[idx[q]] = LEAF_FLAG | key;
-					hist_add(a, sh, key, 1u);
+					const uint32_t t = first + q * stride;
+					hist_add(a, sh, acct ? key | ((t < n ? batch_of_sample(bc, t) : ACCT_MOVED) << ACCT_BATCH_SHIFT) : key, 1u, acct);
 				}
 			}
 		}
@@ -1223,7 +1388,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			__syncthreads();
 			for (uint32_t e = threadIdx.x; e < HT_CAP; e += ETPB) {
 				const uint32_t key = sh.keys[e];
-				if (key != TBL_EMPTY) atomicAdd(hist + hist_word(key, blockIdx.x & (HIST_SHARDS - 1u)), sh.vals[e]);
+				if (key != TBL_EMPTY) hist_flush(a, key, sh.vals[e], acct);
 			}
 			if (timer) { t1 = wall_ns(); ctl->expandNs[0] += t1 - t0; t0 = t1; }
 			if (!grid_barrier(&bc->barrierCount, generation, gridDim.x)) { if (threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
@@ -1239,7 +1404,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			bool mine = false;
 			for (uint32_t i = threadIdx.x; i < (se - sb) * HIST_BINS; i += ETPB) {
 				const uint32_t s = sb + i / HIST_BINS;
-				if (hist_sum(hist, (uint64_t)s * HIST_BINS + (i % HIST_BINS)) > SIMLOD_MAX_POINTS_PER_NODE && slots[s].node != NONE && slots[s].level + 3u < (uint32_t)SIMLOD_MAX_DEPTH) mine = true;
+				if (bin_total(a, hist, (uint64_t)s * HIST_BINS + (i % HIST_BINS), acct) > SIMLOD_MAX_POINTS_PER_NODE && slots[s].node != NONE && slots[s].level + 3u < (uint32_t)SIMLOD_MAX_DEPTH) mine = true;
 			}
 			if (mine) sh.more = 1;
 		}
@@ -1256,7 +1421,14 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			const uint32_t L = rec.node, l = rec.level;
 			const uint32_t K = min(3u, (uint32_t)SIMLOD_MAX_DEPTH - l);         // levels below L that exist
 			__syncthreads();
-			if (t < HIST_BINS) sh.bins[t] = myBin;
+			uint32_t* const B3 = sh.keys; uint32_t* const B2 = B3 + HIST_BINS * GBS; uint32_t* const B1 = B2 + 64u * GBS;      // acct_rows: per-batch counts of the 512 bins, the 64 grandchildren, the 8 children
+			uint32_t binTotal = myBin;
+			if (acct && t < HIST_BINS) {       // an exact group: myBin = the stored points that moved; the group's samples per batch
+				const uint32_t* hb = at<const uint32_t>(a, a.offHistB) + ((uint64_t)s * HIST_BINS + t) * GBS;
+				for (uint32_t k = 0; k < GB; k++) { const uint32_t r = hb[k]; B3[t * GBS + k] = r; binTotal += r; }
+			}
+			if (t < HIST_BINS) sh.bins[t] = binTotal;
+			if (t < SIMLOD_MAX_BATCHES_PER_LAUNCH) { sh.accD[t] = 0; sh.accF[t] = 0; }
 			if (t < PATH_WORDS) sh.pathL[t] = t + 1 < PATH_WORDS ? paths[(uint64_t)L * PATH_WORDS + t] : 0ull;
 			// the slot node's coordinates, name and grid: one round trip here, beside its path, instead of one in every phase that wants them
 			if (t == 64u) { const SimlodNode* nl = a.nodes + L; sh.LX = nl->X; sh.LY = nl->Y; sh.LZ = nl->Z; sh.gridL = nl->grid; }
@@ -1279,6 +1451,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 					f1 = t < 8u && trunk_forced(a, l + 1u, 2u * LX + ((t >> 2) & 1u), 2u * LY + ((t >> 1) & 1u), 2u * LZ + (t & 1u));
 					f2 = trunk_forced(a, l + 2u, 4u * LX + 2u * ((j >> 2) & 1u) + ((k >> 2) & 1u), 4u * LY + 2u * ((j >> 1) & 1u) + ((k >> 1) & 1u), 4u * LZ + 2u * (j & 1u) + (k & 1u));
 				}
+				{ const unsigned long long bf1 = __ballot(f1), bf2 = __ballot(f2); if (t == 0u) { sh.forced1 = (uint32_t)bf1 & 0xffu; sh.forced2 = bf2; } }
 				const bool s1 = t < 8u && K >= 2u && (sh.c1[t & 7u] > SIMLOD_MAX_POINTS_PER_NODE || f1);
 				uint32_t mask1 = (uint32_t)__ballot(s1) & 0xffu;
 				const bool s2 = K >= 3u && ((mask1 >> (t >> 3)) & 1u) != 0u && (sh.c2[t] > SIMLOD_MAX_POINTS_PER_NODE || f2);
@@ -1303,6 +1476,92 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			auto countOf = [&](uint32_t u) { return u < 8u ? sh.c1[u] : u < 72u ? sh.c2[u - 8u] : sh.bins[u - 72u]; };
 			auto splits = [&](uint32_t u) { return u < 8u ? ((mask1 >> u) & 1u) != 0u : u < 72u ? ((mask2 >> (u - 8u)) & 1ull) != 0ull : false; };
 			auto indexOf = [&](uint32_t u) { return u < 8u ? rec.childBase + u : u < 72u ? sh.base2[(u - 8u) >> 3] + ((u - 8u) & 7u) : sh.base3[(u - 72u) >> 3] + ((u - 72u) & 7u); };
+			// ---- an exact group of several batches: WHEN each node of the cascade split, what it held then, the chunks it took and returned meanwhile ----
+			// Local node u's row: its samples per batch of the group.  The node is created in the batch its parent split in (`born`), holds what lay in its
+			// cell up to and including that batch (the stored points that moved + the group's samples so far), and — if it splits at all — splits in the first
+			// batch from then on after which it holds more than 50 000 (a node the trunk mask names: at once).  While it is a leaf it has ceil(count / 1000)
+			// chunks (voxels.cu:485-538), all of which it returns when it splits (voxels.cu:346-357).
+			auto rowOf = [&](uint32_t u) -> const uint32_t* { return u < 8u ? B1 + u * GBS : u < 72u ? B2 + (u - 8u) * GBS : B3 + (u - 72u) * GBS; };
+			// -> the batch in which u splits (`willSplit`: it does, in this round or as a slot of the next) and its counter after that batch
+			auto split_time = [&](uint32_t u, uint32_t born, bool forced, uint32_t& counterThen) -> uint32_t {
+				const uint32_t* row = rowOf(u);
+				uint32_t c = countOf(u);
+				for (uint32_t k = 0; k < GB; k++) c -= row[k];                     // the stored points that moved into u's cell
+				for (uint32_t k = 0; k <= born; k++) c += row[k];                   // what u is created with
+				uint32_t k = born;
+				while (!forced && c <= SIMLOD_MAX_POINTS_PER_NODE && k + 1u < GB) { k++; c += row[k]; }
+				counterThen = c;
+				return k;
+			};
+			// the chunks u takes, batch by batch, while it is a leaf: from `born` until `splitAt` (NEVER: the end of the group), and returns then
+			auto leaf_chunks = [&](uint32_t u, uint32_t born, uint32_t splitAt) {
+				const uint32_t* row = rowOf(u);
+				uint32_t c = countOf(u);
+				for (uint32_t k = 0; k < GB; k++) c -= row[k];
+				for (uint32_t k = 0; k < born; k++) c += row[k];
+				uint32_t have = 0;
+				for (uint32_t k = born; k < min(splitAt, GB); k++) {
+					c += row[k];
+					const uint32_t want = (c + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+					if (want != have) atomicAdd(&sh.accD[k], want - have);
+					have = want;
+				}
+				if (splitAt < GB && have != 0u) atomicAdd(&sh.accF[splitAt], have);
+			};
+			if (acct) {
+				for (uint32_t i = t; i < 64u * GB; i += ETPB) { const uint32_t jk = i / GB, k = i % GB; uint32_t c = 0; for (uint32_t q = 0; q < 8; q++) c += B3[(jk * 8u + q) * GBS + k]; B2[jk * GBS + k] = c; }
+				__syncthreads();
+				for (uint32_t i = t; i < 8u * GB; i += ETPB) { const uint32_t j = i / GB, k = i % GB; uint32_t c = 0; for (uint32_t q = 0; q < 8; q++) c += B2[(j * 8u + q) * GBS + k]; B1[j * GBS + k] = c; }
+				__syncthreads();
+				if (t == 0u) {
+					// the slot's own node.  One the cascade queued for this round (born != NONE): settled by the round that queued it.  A leaf of the octree as the
+					// group found it: it holds rec.stored points in ceil(stored / 1000) chunks, grows batch by batch, and splits in the first batch that takes it
+					// over the limit (a leaf already over it — a split that had to wait —: in the first batch that touches it; one the trunk mask names: at once)
+					uint32_t sL = rec.born, cThen = 0;
+					if (rec.born == NONE) {
+						const bool forcedL = trunk_any(a) && trunk_forced(a, l, sh.LX, sh.LY, sh.LZ);
+						uint32_t c = rec.stored;
+						sL = GB - 1u;
+						for (uint32_t k = 0; k < GB; k++) {
+							uint32_t g = 0;
+							for (uint32_t j = 0; j < 8; j++) g += B1[j * GBS + k];
+							if (forcedL || (g != 0u && c + g > SIMLOD_MAX_POINTS_PER_NODE)) { sL = k; break; }
+							c += g;
+						}
+						c = rec.stored;
+						uint32_t have = (c + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+						for (uint32_t k = 0; k <= sL; k++) {
+							uint32_t g = 0;
+							for (uint32_t j = 0; j < 8; j++) g += B1[j * GBS + k];
+							c += g;
+							if (k == sL) break;
+							const uint32_t want = (c + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+							if (want != have) atomicAdd(&sh.accD[k], want - have);
+							have = want;
+						}
+						if (have != 0u) atomicAdd(&sh.accF[sL], have);
+						cThen = c;
+					}
+					sh.splitAt[LOCAL_NODES] = (uint8_t)sL; sh.counterAt[LOCAL_NODES] = cThen;
+				}
+				__syncthreads();
+				if (t < 8u) {                                                      // the children: created when the slot's node split
+					const uint32_t born = sh.splitAt[LOCAL_NODES];
+					uint32_t cThen = 0;
+					const uint32_t at = splits(t) ? split_time(t, born, ((sh.forced1 >> t) & 1u) != 0u, cThen) : NEVER;
+					sh.splitAt[t] = (uint8_t)at; sh.counterAt[t] = cThen;
+					leaf_chunks(t, born, at);
+				}
+				__syncthreads();
+				if (t >= 8u && t < 72u && exists(t)) {                             // the grandchildren: created when their parent split
+					const uint32_t born = sh.splitAt[(t - 8u) >> 3];
+					uint32_t cThen = 0;
+					const uint32_t at = splits(t) ? split_time(t, born, ((sh.forced2 >> (t - 8u)) & 1ull) != 0ull, cThen) : NEVER;
+					sh.splitAt[t] = (uint8_t)at; sh.counterAt[t] = cThen;
+					leaf_chunks(t, born, at);
+				}
+				__syncthreads();
+			}
 			if (t < LOCAL_NODES && exists(t)) {
 				const uint32_t level = l + local_depth(t);
 				if (splits(t)) sh.grid[t] = grid_for_split(a, bc);
@@ -1314,7 +1573,13 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 							uint4* h = reinterpret_cast<uint4*>(hist + hist_word(slot << 9, sd));
 							for (uint32_t i = 0; i < HIST_BINS / 4; i++) h[i] = make_uint4(0, 0, 0, 0);
 						}
-						slots[slot] = SlotRec{indexOf(t), level, childBase, 0u, 0u, 0u, 0u, 0u};
+						uint32_t born = NONE, cThen = 0;
+						if (acct) {      // (an exact group: the slot's histograms per batch; the batch in which this node splits — when its children are created)
+							uint4* hb = reinterpret_cast<uint4*>(at<uint32_t>(a, a.offHistB) + (uint64_t)slot * HIST_BINS * GBS);
+							for (uint32_t i = 0; i < HIST_BINS / 4u * GBS; i++) hb[i] = make_uint4(0, 0, 0, 0);
+							born = split_time(t, sh.splitAt[8u + ((t - 72u) >> 3)], false, cThen);
+						}
+						slots[slot] = SlotRec{indexOf(t), level, childBase, 0u, 0u, born, 0u, 0u};
 						sh.listed[t] = MAP_LISTED | (level << 16) | slot;
 					}
 				}
@@ -1334,7 +1599,20 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				SimlodNode& c = a.nodes[idx];
 				const uint32_t firstChild = !split ? 0u : t < 8u ? sh.base2[t] : sh.base3[t - 8u];
 				for (uint32_t k = 0; k < 8; k++) c.children[k] = split ? a.nodes + firstChild + k : nullptr;
-				c.counter = countOf(t); c.numPoints = 0;
+				uint32_t counter = countOf(t);
+				if (acct) {
+					// what the node held after the batch in which it split (later batches of the group went past it, voxels.cu:169-187); a great-grandchild
+					// is settled here (whether it got a slot for the next round is known now), the levels above it were on the way
+					if (depth == 3u) {
+						const uint32_t born = sh.splitAt[8u + ((t - 72u) >> 3)];
+						uint32_t cThen = 0;
+						const uint32_t at = nextRound ? split_time(t, born, false, cThen) : NEVER;
+						sh.splitAt[t] = (uint8_t)at; sh.counterAt[t] = cThen;
+						leaf_chunks(t, born, at);
+					}
+					if (sh.splitAt[t] != NEVER) counter = sh.counterAt[t];
+				}
+				c.counter = counter; c.numPoints = 0;
 				c.level = level; c.X = X; c.Y = Y; c.Z = Z;
 				c.countIteration = 0; c.countFlag = 0;
 				for (int k = 0; k < 20; k++) c.name[k] = sh.nameL[k];
@@ -1369,7 +1647,10 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 					else sh.fill[atomicAdd(&sh.numFill, 1u)] = make_uint4(idx | (level << 19), X, Y, Z);
 				}
 			}
-			if (t == 0u) { a.nodes[L].numPoints = 0; a.nodes[L].points = nullptr; }          // voxels.cu:359-360 (its points are in the spill buffer, its chunks on the recycle stack: k_queue, k_hist)
+			if (t == 0u) {
+				a.nodes[L].numPoints = 0; a.nodes[L].points = nullptr;          // voxels.cu:359-360 (its points are in the spill buffer, its chunks on the recycle stack: k_queue, k_hist)
+				if (acct && rec.born == NONE) a.nodes[L].counter = sh.counterAt[LOCAL_NODES];      // (k_count added the whole group's samples: the batches after the split went to the children)
+			}
 			// the slot's map: bin -> the deepest node that exists above it (or the slot that node got for the next round)
 			if (t < HIST_BINS) {
 				const uint32_t j = t >> 6, jk = t >> 3;
@@ -1379,6 +1660,10 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			}
 			// ... and their chunks, 64 leaves at a time (voxels.cu:485-538; the nodes written above are this workgroup's own stores: visible after the barrier)
 			__syncthreads();
+			if (acct && t < GB) {
+				if (sh.accD[t] != 0u) atomicAdd(&bc->acctD[t], sh.accD[t]);
+				if (sh.accF[t] != 0u) atomicAdd(&bc->acctF[t], sh.accF[t]);
+			}
 			for (uint32_t j = 0; j < sh.numFill; j++) {                          // the top table's cells under the big new leaves, all threads
 				const uint4 f = sh.fill[j];
 				const uint32_t flevel = f.x >> 19, k = TOP_LEVEL - flevel, side = 1u << k;
@@ -2262,9 +2547,15 @@ __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 }
 
 __global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const uint32_t* numBatchesUploaded) {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	if (blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
 	SimlodStats* s = a.stats;
+	__shared__ Phantom sh_phantom;
+	// voxels.cu:535-537 for the launch's last group (k_count's first workgroup: the others); an exact group of several batches: account_group
+	if (threadIdx.x == 0) sh_phantom = account_group(a, ctl, ctl->processed != 0u ? batch_of(ctl, ctl->processed - 1u) : nullptr);
+	__syncthreads();
+	phantom_fill(a, sh_phantom);
+	if (threadIdx.x != 0) return;
 	if (feedback != nullptr) { feedback[0] = s->batchletIndex; feedback[1] = *numBatchesUploaded; }      // what the next launch sizes itself by (groups_for_launch): page-locked host memory
 	s->numInner = ctl->statCounters[0];
 	s->numLeaves = ctl->statCounters[1];
@@ -2273,7 +2564,6 @@ __global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const u
 	s->numVoxels = ctl->statCounters[4];
 	s->numChunksPoints = ctl->statCounters[5];
 	s->numChunksVoxels = ctl->statCounters[6];
-	if (s->numAllocatedChunks > s->chunkPoolSize) s->chunkPoolSize = s->numAllocatedChunks;       // voxels.cu:535-537, for the launch's last group (prepare_batch: the others)
 	s->allocatedBytes_momentary = a.scratchBytes;
 	s->allocatedBytes_persistent = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers)->offset;
 	s->frameID = (uint32_t)a.frameCounter;
@@ -2291,13 +2581,18 @@ __global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const u
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t groupLimit = SIMLOD_MAX_BATCHES_PER_LAUNCH) {
+// exactGroup > 1: EXACT mode in groups of that many batches (account_group) — the per-batch count rows are part of the layout; false when the buffer
+// does not hold them beside ACCT_SPILL_FLOOR moved points (the caller then lays out plain exact mode: one batch per group)
+static constexpr uint64_t ACCT_SPILL_FLOOR = 3500000;      // moved points an exact group must have room for: what one BATCH has in the plain exact layout of the reference host's 300 MB
+bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t groupLimit = SIMLOD_MAX_BATCHES_PER_LAUNCH, uint32_t exactGroup = 1) {
 	a.dirCap = 2 * a.nodeCapacity + 65536;
+	a.acct = exactGroup > 1u ? 1u : 0u;
 	uint64_t off = 4096;
 	a.offQueue = off;    off += align_up((uint64_t)CHUNK_QUEUE_CAPACITY * 8, 256);
 	a.offSlots = off;    off += align_up((uint64_t)2 * SLOT_CAP * sizeof(SlotRec), 256);
 	a.offHist = off;     off += align_up(((uint64_t)SLOT_CAP * HIST_BINS + HIST_EXTRA_WORDS) * 4, 256);      // (+ three more copies of the first 256 slots)
 	a.offMap = off;      off += align_up((uint64_t)SLOT_CAP * HIST_BINS * 4, 256);
+	a.offHistB = off;    off += align_up((uint64_t)(a.acct ? SLOT_CAP : 0u) * HIST_BINS * exactGroup * 4, 256);
 	a.clearCap = 65536;
 	a.offClear = off;    off += align_up((uint64_t)2 * a.clearCap * 8, 256);
 	a.offTouched = off;  off += align_up((uint64_t)a.nodeCapacity * 4, 256);
@@ -2309,6 +2604,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t g
 	a.offRetryTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offTouchTag = off; off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offStartOf = off;  off += align_up((uint64_t)a.nodeCapacity * 8, 256);
+	a.offCntB = off;     off += align_up((uint64_t)(a.acct ? a.nodeCapacity : 0u) * exactGroup * 4, 256);      // (zero between groups: whoever reads a row clears it)
 	a.hashCap = 1u << 17;
 	a.offHashDir = off;  off += align_up((uint64_t)a.hashCap * sizeof(DirEntry), 256);
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
@@ -2328,6 +2624,10 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t g
 	if (capacity < off + 2 * perBatch + fixedWork + 4096 + 25ull * 65536) { a.spilledCap = 0; a.scratchBytes = off + 2 * perBatch + fixedWork; return false; }
 	const uint64_t freeBytes = capacity - off - fixedWork - 4096;
 	if (coalesce) a.groupMax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(groupLimit, SIMLOD_MAX_BATCHES_PER_LAUNCH), freeBytes / (2 * perBatch + 20ull * SIMLOD_MAX_BATCH_SIZE)));
+	if (a.acct) {
+		if (freeBytes < 2ull * exactGroup * perBatch + 512 + ACCT_SPILL_FLOOR * 20032 / 1000) return false;
+		a.groupMax = exactGroup;
+	}
 	a.groupCap = a.groupMax * SIMLOD_MAX_BATCH_SIZE;
 	// (the group samples' cached-leaf words exist twice, by group parity; 4 + 16 B per moved point)
 	uint64_t cap = (freeBytes - 2ull * a.groupMax * perBatch - 512) * 1000 / (20 * 1000 + 32);   // + one 32-byte work item per 1000 moved points
@@ -2396,7 +2696,13 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	a.nodeCapacity = ctx.nodeCapacity.load();
 	a.trunkLo = ctx.trunkLo.load(); a.trunkHi = ctx.trunkHi.load();
 	const bool coalesce = ctx.ingestMode.load() != 0u;
-	const bool fits = layout_construct(a, u->momentaryBufferCapacity, coalesce, (uint32_t)std::max(1, ctx.tune(KNOB_GROUP_BATCHES, 10)));   // coalesced mode: groups of 10 (36 M terrain: 20: 3.17 ms, 10: 2.95, 5: 3.10, 2: 3.66 — two groups per launch overlap front and back halves)
+	// EXACT mode: a launch that finds several batches pending ingests them in groups of up to SIMLOD_EXACT_GROUP (default 5; 1: one by one) wherever the
+	// momentary buffer holds the largest such layout that leaves room for ACCT_SPILL_FLOOR moved points — every Node and Stats field comes out as batch-by-batch
+	// ingestion leaves it (account_group).  Not with a forced time budget (the budget is looked at per group: voxels.cu:936-949 looks per batch).
+	uint32_t exactGroup = coalesce || ctx.tune(KNOB_DEBUG_BUDGET_US, 0) > 0 ? 1u : (uint32_t)std::min<int>(std::max(1, ctx.tune(KNOB_EXACT_GROUP, 5)), (int)ACCT_MAX_GROUP);
+	bool fits = false;
+	for (; exactGroup > 1u && !fits; exactGroup -= fits ? 0u : 1u) fits = layout_construct(a, u->momentaryBufferCapacity, false, 1, exactGroup);
+	if (!fits) fits = layout_construct(a, u->momentaryBufferCapacity, coalesce, (uint32_t)std::max(1, ctx.tune(KNOB_GROUP_BATCHES, 10)));   // coalesced mode: groups of 10 (36 M terrain: 20: 3.17 ms, 10: 2.95, 5: 3.10, 2: 3.66 — two groups per launch overlap front and back halves)
 	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
 		note_leaf_table(ctx, LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
@@ -2418,7 +2724,8 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
 		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled() && numGroups > 1u;   // (two streams: see below)
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
-		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, a.groupMax > 1u ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
+		const bool single = a.groupMax == 1u || limit <= 1u;      // every group of this launch is ONE ring batch (k_begin takes no more than `limit` batches)
+		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, !single ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		// A batch has a FRONT half — k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
 		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
 		// the caller's stream, the back half on a second stream of the library, two dependencies per batch between them:
@@ -2435,7 +2742,6 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		std::unique_lock<std::mutex> block;
 		if (side != nullptr) block = std::unique_lock<std::mutex>(side->enqueue);      // (host threads building two octrees on one device)
 		const int countTpb = ctx.tune(KNOB_COUNT_TPB, 512);   // fewer, fatter workgroups: fewer adds on the hot leaf counters (flush 7.5 -> 2.7 us at 512, main loop 11.1 -> 12.7)
-		const bool single = a.groupMax == 1u;
 		hipStream_t back = side != nullptr ? side->stream : stream;
 		// an enqueue that fails in the middle of the chain: the second stream may hold kernels that read and write the caller's buffers — the
 		// call does not return before they have ended (the caller may free or reset those buffers next)

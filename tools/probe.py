@@ -23,6 +23,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--points", type=int, default=36_000_000)
 ap.add_argument("--order", default="shuffled")
 ap.add_argument("--coalesce", action="store_true")
+ap.add_argument("--momentary-mb", type=int, default=None)
 ap.add_argument("variants", nargs="*", default=[""])
 args = ap.parse_args()
 
@@ -32,7 +33,7 @@ pts, box = gen(args.points, seed=7)
 batch = abi.MAX_BATCH_SIZE
 nb = (args.points + batch - 1) // batch
 T = camera.world_view_proj(camera.orbit_view(-0.207, -0.797, 3866.886 * float(box[0]) / 6000.0, (box[0] / 2, box[1] / 2, 0.35 * box[2])), camera.perspective(aspect=W / H))
-dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, momentary_bytes=(700 if args.coalesce else 300) * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
+dev = DeviceOctree("cuda:0", persistent_bytes=64 << 30, momentary_bytes=(args.momentary_mb or (700 if args.coalesce else 300)) * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
 u = dev.uniforms(W, H, T, box, hqs=True)
 rv = dev.ring.view(torch.uint8)
 for i in range(nb):
