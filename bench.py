@@ -190,7 +190,7 @@ def main():
         if source is not None:                        # config 4: through the 50-slot ring, uploader + back-pressure + one launch per frame
             return dev.stream(u, source, my_points)
         dev.batch_sizes[:n_batches] = sizes           # what the uploader's cuMemsetD32Async pair publishes
-        dev.num_uploaded.fill_(n_batches)
+        dev.publish(n_batches)                        # (... and what shim/cuda.h tells the library about it: simlod_upload_counter_written)
         dev.uploaded_host = n_batches
         return dev.drain(u)      # ceil(36 / 20) launches back to back, one look at Stats.batchletIndex; more launches if a time budget cut one short
 
@@ -211,21 +211,30 @@ def main():
     assert int(stats["numPointsProcessed"]) == my_points and int(stats["numPoints"]) == my_points, "ingest lost points"
     assert int(stats["dbg"]) == 0, f"device error bits {int(stats['dbg']):#x}"
     value = world * n_points / (ms_per_step * 1e-3) / 1e6
-    # The host mirror tells the library how many batches a launch can find (DeviceOctree._hint: simlod_context_set_construct_batch_limit — the
-    # reference's host has the same two numbers, its upload index and the batchletIndex it reads back); the same steps WITHOUT that hint — launches
-    # sized by the library's own prediction, what the reference's unchanged host gets — are reported beside the headline.
+    # The headline is what the UNCHANGED reference host gets: the library sizes its launches by the upload-counter writes it is told about (shim/cuda.h
+    # forwards the uploader's cuMemsetD32Async, main_progressive_octree.cpp:1047-1050; the Python mirror's publish() does the same) and by what its
+    # earlier launches reported.  Beside it: the same steps with the host ALSO saying how many batches are pending in front of every launch
+    # (simlod_context_hint_pending_batches) — the two must agree — and with a host that tells nothing at all (the library's prediction alone).
     without_hint = None
-    if source is None and dev.hint_pending and rank == 0 and not use_dist and not args.no_cpu_baseline:      # (not in the profiling passes: their per-launch figures count three ingests)
-        dev.hint_pending = False
-        ingest_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+    if source is None and rank == 0 and not use_dist and not args.no_cpu_baseline:      # (not in the profiling passes: their per-launch figures count three ingests)
+        def timed():
             ingest_step()
-        torch.cuda.synchronize()
-        ms_nohint = (time.perf_counter() - t0) * 1e3 / args.steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ingest_step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / args.steps
+            return {"ms_per_step": ms, "value": n_points / (ms * 1e-3) / 1e6}
+        was = dev.hint_pending, dev.notifies
         dev.hint_pending = True
-        without_hint = {"ms_per_step": ms_nohint, "value": n_points / (ms_nohint * 1e-3) / 1e6, "what": "launches sized by the library's prediction alone (SIMLOD_HOST_HINT=0): the second launch of a step enqueues 20 groups for 16 batches"}
+        with_hint = timed()
+        dev.hint_pending, dev.notifies = False, False
+        blind = timed()
+        dev.hint_pending, dev.notifies = was
+        ingest_step(); torch.cuda.synchronize()
+        without_hint = {"with_host_hint": with_hint, "host_tells_nothing": blind,
+                        "what": "headline: launches sized by the upload-counter writes the shim forwards; with_host_hint: + simlod_context_hint_pending_batches per launch; host_tells_nothing: neither (prediction from the launches' own reports)"}
     collective = None
     if use_dist:
         # what the process group really was: every rank adds 1 (ranks_seen must be the world size) and its point count (the octrees of all
@@ -506,7 +515,7 @@ def main():
             def step2():
                 dev2.reset(u2)
                 dev2.batch_sizes[:n_batches] = sizes
-                dev2.num_uploaded.fill_(n_batches)
+                dev2.publish(n_batches)
                 dev2.uploaded_host = n_batches
                 return dev2.drain(u2)
             step2()
@@ -541,8 +550,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+u32 (fp32 quantise/project, fp64 pixel coordinate, integer octree/atomics)", "data": "synthetic",
             "ingest_mode": "coalesced" if args.coalesce else "exact",
-            "host_hint": "the host mirror passes its pending-batch count to every launch (simlod_context_set_construct_batch_limit)" if dev.hint_pending else None,
-            "ingest_without_host_hint": without_hint,
+            "host_hint": "simlod_context_hint_pending_batches per launch" if dev.hint_pending else None,
+            "ingest_other_hosts": without_hint,
             "config": {"workload": (f"BASELINE config 4 shape: tiled terrain, {n_points} device-generated 16 B points per GPU streamed through the 50-slot ring ({n_batches} x 1M batches), "
                                     if source is not None else f"Morro Bay 36M stand-in (BASELINE config 2): {n_points} 16 B points, fractal terrain, {n_batches} x 1M ring batches resident in HBM, ") +
                                    f"reset + {launches / max(args.steps, 1):.1f} kernel_construct launches per step; raster 1920x1080",

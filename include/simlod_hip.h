@@ -65,6 +65,16 @@ int simlod_context_attach(SimlodContext* ctx, const SimlodNode* nodes);       /*
 int simlod_context_set_node_capacity(SimlodContext* ctx, uint32_t numNodes);
 int simlod_context_set_ingest_mode(SimlodContext* ctx, uint32_t mode);
 int simlod_context_set_construct_batch_limit(SimlodContext* ctx, uint32_t maxBatches);
+/* "That many ring batches are pending right now" (uploaded and not ingested, not counting what launches already enqueued will take): for the NEXT
+ * kernel_construct launch of the context only — it enqueues kernels for that many batches (0: none, an idle frame), whatever the library would have
+ * guessed.  Optional: hosts whose upload-counter writes reach simlod_upload_counter_written (shim/cuda.h does that for the reference's) need not call it. */
+int simlod_context_hint_pending_batches(SimlodContext* ctx, uint32_t pending);
+/* The host has enqueued a write of `value` to the 4-byte upload counter at `numBatchesUploaded` (main_progressive_octree.cpp:1047-1050:
+ * cuMemsetD32Async(cptr_numBatchesUploaded, batchStreamUploadIndex + 1, 1, stream_upload)).  kernel_construct reads the counter on the device when it
+ * runs (voxels.cu:870-885); the library, which has to enqueue a group of kernels per batch BEFORE that, sizes its launches by what it is told here and by
+ * what its earlier launches reported.  Addresses that no reset / construct launch has been given as `numBatchesUploaded` are ignored (the shims forward
+ * every 4-byte memset).  Without it the library predicts from its launches' own reports alone: at least one group per launch, a burst picked up a launch late. */
+int simlod_upload_counter_written(const void* numBatchesUploaded, uint32_t value);
 /* Multi-GPU jobs (no counterpart in the reference, which is single-GPU: main_progressive_octree.cpp:274, CudaModularProgram.h:215).  Ranks own
  * level-3 cells of ONE global cube; the nodes of levels 0-2 exist on every rank.  The single-GPU octree of the whole data set splits such a
  * node when the GLOBAL count under it crosses 50 000 (progressive_octree_voxels.cu:209-217); a rank that looked at its own count would keep it

@@ -62,8 +62,9 @@ inline CUresult cuMemGetInfo(size_t* freeBytes, size_t* total) { return (CUresul
 inline CUresult cuMemcpyHtoDAsync(CUdeviceptr dst, const void* src, size_t n, CUstream s) { return (CUresult)hipMemcpyAsync((void*)(uintptr_t)dst, src, n, hipMemcpyHostToDevice, s); }
 inline CUresult cuMemcpyDtoHAsync(void* dst, CUdeviceptr src, size_t n, CUstream s) { return (CUresult)hipMemcpyAsync(dst, (const void*)(uintptr_t)src, n, hipMemcpyDeviceToHost, s); }
 inline CUresult cuMemcpyDtoH(void* dst, CUdeviceptr src, size_t n) { return (CUresult)hipMemcpy(dst, (const void*)(uintptr_t)src, n, hipMemcpyDeviceToHost); }
-inline CUresult cuMemsetD32(CUdeviceptr dst, unsigned v, size_t count) { return (CUresult)hipMemsetD32((hipDeviceptr_t)(uintptr_t)dst, (int)v, count); }
-inline CUresult cuMemsetD32Async(CUdeviceptr dst, unsigned v, size_t count, CUstream s) { return (CUresult)hipMemsetD32Async((hipDeviceptr_t)(uintptr_t)dst, (int)v, count, s); }
+// (a one-word memset may be the uploader publishing its batch count, main_progressive_octree.cpp:1047-1050: the library sizes its launches by it — it ignores every other address)
+inline CUresult cuMemsetD32(CUdeviceptr dst, unsigned v, size_t count) { if (count == 1) (void)simlod_upload_counter_written((const void*)(uintptr_t)dst, v); return (CUresult)hipMemsetD32((hipDeviceptr_t)(uintptr_t)dst, (int)v, count); }
+inline CUresult cuMemsetD32Async(CUdeviceptr dst, unsigned v, size_t count, CUstream s) { if (count == 1) (void)simlod_upload_counter_written((const void*)(uintptr_t)dst, v); return (CUresult)hipMemsetD32Async((hipDeviceptr_t)(uintptr_t)dst, (int)v, count, s); }
 inline CUresult cuMemsetD8(CUdeviceptr dst, unsigned char v, size_t count) { return (CUresult)hipMemset((void*)(uintptr_t)dst, v, count); }
 inline CUresult cuEventCreate(CUevent* e, unsigned) { return (CUresult)hipEventCreate(e); }
 inline CUresult cuEventRecord(CUevent e, CUstream s) { return (CUresult)hipEventRecord(e, s); }

@@ -57,7 +57,7 @@ struct BatchCtl {
 	uint32_t slot[SIMLOD_MAX_BATCHES_PER_LAUNCH];        // its ring slot
 	uint32_t pad3;
 	unsigned long long reserve;        // split slots << 52 | nodes in use << 32 | spilled points of this batch — ONE word, so a split reserves all or nothing
-	unsigned long long pad2;
+	unsigned long long reserve0;       // ... as the group began (k_count's first workgroup): what k_queue's entries count from
 	// per-batch chunk accounting of an exact group (acct): point chunks batch k of the group would have taken / given back had the batches been ingested one
 	// by one (voxels.cu:346-357, 485-538), filled by k_expand; the chunk counters as they stood when the group began (k_count's first workgroup)
 	uint32_t acctAlloc0, acctPool0, pad4, pad5;
@@ -220,7 +220,7 @@ struct NodeDir {          // per node, valid for the batch whose tag it carries:
 // at most MAX_POINTS_PER_NODE points between batches (= 50 chunks), so the split reads its whole list from here with all
 // lanes at once instead of chasing 50 `next` pointers (~1 us each) with one.  Kept up to date by alloc_points (k_expand); survives between
 // launches like the recycle stack does, and is refilled by k_rebuild whenever k_begin finds its stamp stale.
-static constexpr uint32_t LEAF_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK;
+static constexpr uint32_t LEAF_SLOTS = LEAF_ROW_SLOTS;      // (rows are packed: simlod_internal.hpp leaf_row_get / leaf_row_set)
 static constexpr uint32_t TABLE_MAGIC = 0x51ab1e05u;
 static_assert(LEAF_SLOTS <= 64, "queue_split hands a leaf's chunks out one per lane");
 
@@ -322,7 +322,9 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	uint32_t take = min(ctl->groupMax, ctl->numBatches - ctl->consumed);
 	// A root that is still a leaf samples ITSELF (voxels.cu:449-463) and is sampled AGAIN, from nothing, by the batch that splits it (:371-382): what its
 	// voxel list holds then depends on which batch that was — batch by batch until the root has children (the first 50 000 points of an octree)
-	if (a.acct != 0u && take > 1u && node_is_leaf(a.nodes)) take = 1u;
+	// (... or the group before — whose k_queue has run, whose k_expand has not: this runs in its k_hist — is about to give it some)
+	if (a.acct != 0u && take > 1u && node_is_leaf(a.nodes) &&
+	    !(ordinal > 0u && (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[0] >> 32) == ctl->tagOf[ordinal - 1u])) take = 1u;
 	if (a.acct != 0u && take > 1u) {
 		// An EXACT group of several batches is taken only where the reference's guard — looked at before EVERY batch (voxels.cu:896-912) — cannot
 		// trip inside it: the allocator must be a worst-case group away from it.  Closer than that, the launch goes batch by batch as before.
@@ -445,13 +447,13 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser).  And the word this builder keeps in the spare
 		// bytes of a list's HEAD chunk, the address of the list's last chunk (O(1) append): an image built elsewhere — by the reference — has
 		// none; found by walking the list once, here.
-		SimlodChunk** slots = at<SimlodChunk*>(a, a.offLeafChunks) + i * LEAF_SLOTS;
+		uint8_t* const table = a.mom + a.offLeafChunks;
 		const bool leaf = node_is_leaf(n);
 		SimlodChunk* const head = leaf ? n->points : n->voxelChunks;
 		const uint32_t inList = ((leaf ? n->numPoints : n->numVoxelsStored) + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
 		SimlodChunk* c = head;
 		for (uint32_t k = 0; c != nullptr && k < max(inList, 1u); k++) {      // (not beyond the list's last chunk: whether its `next` is null is the other builder's business)
-			if (k < LEAF_SLOTS) slots[k] = c;
+			if (k < LEAF_SLOTS) leaf_row_set(table, a.pers, i, k, c);
 			if (k + 1u == inList) tail_of(head) = c;
 			c = c->next;
 		}
@@ -656,45 +658,81 @@ __device__ __forceinline__ SimlodOccupancyGrid* grid_for_split(const BuildArgs& 
 // with it a histogram), eight node slots and the spill space for the stored points together, the occupancy grid.  Then the leaf's
 // chunk list becomes spill-copy work items (chunk k comes from the leaf chunk table, not from a walk) and goes back to the recycle
 // stack (voxels.cu:346-357; nothing pops before alloc_points in k_expand).  (voxels.cu:308-383 doSplitting, first half)
-__device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t nodeIdx) {
+// sum over the wave and the sum of the lanes below (every lane of the wave calls)
+__device__ __forceinline__ uint32_t wave_exclusive(uint32_t v, uint32_t& total) {
 	const uint32_t lane = (uint32_t)lane_id();
-	SimlodNode* node = a.nodes + nodeIdx;
-	// the leaf's row of the chunk table, a lane per chunk: asked for now, needed after the reservation (one round trip less on a kernel that is a
-	// chain of them)
-	SimlodChunk* const rowChunk = lane < LEAF_SLOTS ? at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)nodeIdx * LEAF_SLOTS + lane] : nullptr;
-	uint32_t ok = 0, slot = 0, spillBase = 0, stored = 0, level = 0, w0 = 0;
-	unsigned long long top = 0;
-	uint32_t numChunks = 0;
-	SimlodChunk* head = nullptr;
-	if (lane == 0) {
-		// (not Node.numPoints, which the back half of the group before may still be advancing — and which is reset, with the list's head,
-		// by k_expand, after that back half: this kernel runs beside it)
-		stored = stored_at_start(a, bc->tag, nodeIdx); level = node->level; head = node->points;
-		SimlodOccupancyGrid* grid = node->grid;
-		// between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
-		numChunks = head != nullptr ? (stored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
-		uint32_t childBase = 0;
-		if (reserve(a, ctl, bc, 1u, 8u, stored, slot, childBase, spillBase)) {
-			ok = 1;
-			// (four independent atomics with a return value: issued together, one round trip)
-			SimlodAllocatorGlobal* alloc = reinterpret_cast<SimlodAllocatorGlobal*>(a.pers);
-			const unsigned long long gridAt = grid == nullptr ? atomicAdd(reinterpret_cast<unsigned long long*>(&alloc->offset), (unsigned long long)SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid))) : 0ull;   // voxels.cu:363-365
-			const uint32_t c = atomicAdd(&bc->numClear, 1u);
-			if (numChunks > 0) {
-				w0 = atomicAdd(&bc->numWork, numChunks);      // cannot run out: workCap covers spilledCap / 1000 + one item per node slot
-				top = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)numChunks));
-			}
-			atomicAdd(&bc->numSpilled, stored);
-			if (grid == nullptr) { grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + gridAt); node->grid = grid; }
-			note_clear(a, bc, c, grid);
-			slot_recs(a, bc->ordinal)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, NONE, 0u, 0u};
-			at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)bc->tag << 32) | (level << 16) | slot;      // (the group's tag: unique while the octree lives, like every tag word)
+	uint32_t x = v;
+#pragma unroll
+	for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
+	total = (uint32_t)__shfl((int)x, 63, 64);
+	return x - v;
+}
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+}
+
+// What a crossing leaf needs reserved — a slot, eight node slots, spill space for its stored points, places in the work list and on the recycle
+// stack for its chunks — follows from ITS PLACE IN THE LIST: entry e takes slot e, the nodes from 8 e on, and the spill / work / stack ranges behind
+// those of the entries before it (a prefix sum over the list, which every wave computes for itself from the leaves' stored counts: plain loads, no
+// atomic).  Round 5 reserved per leaf with a compare-and-swap on one word: forty leaves of a group of batches queued behind each other, a round trip
+// each (k_queue: 55 us per group of five batches).  An entry is served iff everything up to and including it fits (slots, node array, spill
+// space): once one does not, none behind it does — those leaves stay as they are, too full but intact, and are queued again by a later batch.
+struct CrossPrefix { uint32_t stored, chunks, storedBefore, chunksBefore; bool ok; };
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+	return v;
+}
+// entry e of the list: its own numbers and the sums over the entries before it (every lane of the wave calls; all get the result)
+__device__ CrossPrefix cross_prefix(const BuildArgs& a, const BatchCtl* bc, const uint32_t* crossList, uint32_t numCross, uint32_t e, uint32_t slots0, uint32_t nodes0, uint32_t spill0) {
+	const uint32_t lane = (uint32_t)lane_id();
+	CrossPrefix r{0u, 0u, 0u, 0u, false};
+	for (uint32_t c0 = 0; c0 <= e; c0 += 64u) {
+		const uint32_t idx = c0 + lane;
+		uint32_t st = 0, ch = 0;
+		if (idx < numCross && idx <= e) {
+			const uint32_t leaf = crossList[idx];
+			// (not Node.numPoints, which the back half of the group before may still be advancing — and which is reset, with the list's head,
+			// by k_expand, after that back half: this kernel runs beside it); between batches stored == counter, so the list holds exactly ceil(stored / 1000) chunks
+			st = stored_at_start(a, bc->tag, leaf);
+			ch = a.nodes[leaf].points != nullptr ? (st + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
 		}
+		if (e - c0 < 64u) {        // the chunk that holds entry e
+			r.stored = (uint32_t)__shfl((int)st, (int)(e - c0), 64); r.chunks = (uint32_t)__shfl((int)ch, (int)(e - c0), 64);
+			r.storedBefore += wave_sum_u32(idx < e ? st : 0u); r.chunksBefore += wave_sum_u32(idx < e ? ch : 0u);
+		} else { r.storedBefore += wave_sum_u32(st); r.chunksBefore += wave_sum_u32(ch); }
 	}
-	ok = __shfl(ok, 0);
-	if (!ok) return;
-	slot = __shfl(slot, 0); spillBase = __shfl(spillBase, 0); stored = __shfl(stored, 0); level = __shfl(level, 0); w0 = __shfl(w0, 0); numChunks = __shfl(numChunks, 0);
-	top = ((unsigned long long)__shfl((uint32_t)(top >> 32), 0) << 32) | __shfl((uint32_t)top, 0);
+	r.ok = slots0 + e + 1u <= SLOT_CAP && nodes0 + 8u * (e + 1u) <= a.nodeCapacity && (unsigned long long)spill0 + r.storedBefore + r.stored <= a.spilledCap;
+	return r;
+}
+
+__device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, const uint32_t* crossList, uint32_t numCross, uint32_t e) {
+	const uint32_t lane = (uint32_t)lane_id();
+	const uint32_t nodeIdx = crossList[e];
+	SimlodNode* node = a.nodes + nodeIdx;
+	// the leaf's row of the chunk table, a lane per chunk: asked for now, needed after the prefix (one round trip less on a kernel that is a chain of them)
+	SimlodChunk* const rowChunk = lane < LEAF_SLOTS ? const_cast<SimlodChunk*>(leaf_row_get(a.mom + a.offLeafChunks, a.pers, nodeIdx, lane)) : nullptr;
+	const uint32_t level = node->level;
+	SimlodOccupancyGrid* grid = node->grid;
+	const unsigned long long base = bc->reserve0;          // as k_count's first workgroup left it (bc->reserve itself: the list's totals, written below by the wave of entry 0)
+	const uint32_t slots0 = (uint32_t)(base >> RSV_SLOT_SHIFT), nodes0 = (uint32_t)(base >> 32) & 0xfffffu, spill0 = (uint32_t)base;
+	const CrossPrefix cp = cross_prefix(a, bc, crossList, numCross, e, slots0, nodes0, spill0);
+	if (!cp.ok) {
+		if (lane == 0u) raise(ctl, slots0 + e + 1u > SLOT_CAP ? SIMLOD_ERR_SPILLING_OVERFLOW : nodes0 + 8u * (e + 1u) > a.nodeCapacity ? SIMLOD_ERR_NODES_EXHAUSTED : SIMLOD_ERR_SPILLED_OVERFLOW);
+		return;
+	}
+	const uint32_t slot = slots0 + e, childBase = nodes0 + 8u * e, spillBase = spill0 + cp.storedBefore, stored = cp.stored, numChunks = cp.chunks, w0 = cp.chunksBefore;
+	const unsigned long long top = (unsigned long long)bc->acctAlloc0 - cp.chunksBefore;      // Stats.numAllocatedChunks as this leaf's turn finds it (voxels.cu:346-357)
+	if (lane == 0u) {
+		if (grid == nullptr) {                                                               // voxels.cu:363-365
+			SimlodAllocatorGlobal* alloc = reinterpret_cast<SimlodAllocatorGlobal*>(a.pers);
+			grid = reinterpret_cast<SimlodOccupancyGrid*>(a.pers + atomicAdd(reinterpret_cast<unsigned long long*>(&alloc->offset), (unsigned long long)SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid))));
+			node->grid = grid;
+		}
+		note_clear(a, bc, e, grid);
+		slot_recs(a, bc->ordinal)[slot] = SlotRec{nodeIdx, level, childBase, spillBase, stored, NONE, 0u, 0u};
+		at<unsigned long long>(a, a.offSplitTag)[nodeIdx] = ((unsigned long long)bc->tag << 32) | (level << 16) | slot;      // (the group's tag: unique while the octree lives, like every tag word)
+	}
 	// the slot's histogram starts from zero
 	{
 		for (uint32_t sd = 0; sd < (slot < HIST_SHARDED ? HIST_SHARDS : 1u); sd++) {
@@ -708,7 +746,6 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 	}
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	SpillWork* work = at<SpillWork>(a, a.offWork);
-	SimlodChunk* const* slots = at<SimlodChunk*>(a, a.offLeafChunks) + (uint64_t)nodeIdx * LEAF_SLOTS;
 	auto emit = [&](uint32_t ci, SimlodChunk* chunk) {
 		if (w0 + ci < a.workCap) {
 			SpillWork w;
@@ -720,7 +757,7 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 		if (q < CHUNK_QUEUE_CAPACITY) chunkQueue[q] = chunk; else raise(ctl, SIMLOD_ERR_CHUNK_QUEUE_OVERFLOW);
 	};
 	SimlodChunk* beyond = nullptr;                      // chunk #LEAF_SLOTS of a leaf whose split was deferred and that kept growing
-	if (lane == 0 && numChunks > LEAF_SLOTS) beyond = slots[LEAF_SLOTS - 1]->next;
+	if (lane == 0 && numChunks > LEAF_SLOTS) beyond = leaf_row_get(a.mom + a.offLeafChunks, a.pers, nodeIdx, LEAF_SLOTS - 1)->next;
 	if (lane < min(numChunks, LEAF_SLOTS)) {                          // (LEAF_SLOTS <= 64: one chunk per lane)
 		emit(lane, rowChunk);
 		rowChunk->next = nullptr;
@@ -732,6 +769,39 @@ __device__ void queue_split(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t
 			beyond->next = nullptr;
 			beyond = next;
 		}
+	}
+}
+// the list's totals (the wave that takes entry 0): how many entries are served — everything up to the first that does not fit — and what they take
+__device__ void queue_totals(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, const uint32_t* crossList, uint32_t numCross) {
+	const uint32_t lane = (uint32_t)lane_id();
+	const unsigned long long base = bc->reserve0;
+	const uint32_t slots0 = (uint32_t)(base >> RSV_SLOT_SHIFT), nodes0 = (uint32_t)(base >> 32) & 0xfffffu, spill0 = (uint32_t)base;
+	uint32_t served = 0, stored = 0, chunks = 0;
+	bool open = true;
+	for (uint32_t c0 = 0; c0 < numCross && open; c0 += 64u) {
+		const uint32_t idx = c0 + lane;
+		uint32_t st = 0, ch = 0;
+		if (idx < numCross) {
+			const uint32_t leaf = crossList[idx];
+			st = stored_at_start(a, bc->tag, leaf);
+			ch = a.nodes[leaf].points != nullptr ? (st + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK : 0u;
+		}
+		uint32_t totSt, totCh;
+		const uint32_t exSt = wave_exclusive(st, totSt), exCh = wave_exclusive(ch, totCh);
+		const bool ok = idx < numCross && slots0 + idx + 1u <= SLOT_CAP && nodes0 + 8u * (idx + 1u) <= a.nodeCapacity && (unsigned long long)spill0 + stored + exSt + st <= a.spilledCap;
+		// the served entries of this chunk are a prefix of it: the lanes below the first that does not fit
+		const unsigned long long okMask = __ballot(ok), valid = __ballot(idx < numCross), firstFail = ~okMask & valid;
+		const uint32_t here = firstFail != 0ull ? (uint32_t)__ffsll((long long)firstFail) - 1u : (uint32_t)__popcll(valid);
+		served += here;
+		stored += here < 64u ? (uint32_t)__shfl((int)exSt, (int)here, 64) : totSt;
+		chunks += here < 64u ? (uint32_t)__shfl((int)exCh, (int)here, 64) : totCh;
+		if (firstFail != 0ull) open = false;
+	}
+	if (lane == 0u) {
+		bc->reserve = base + ((unsigned long long)served << RSV_SLOT_SHIFT) + ((unsigned long long)(8u * served) << 32) + stored;
+		if (served != 0u) atomicAdd(&a.stats->numNodes, 8u * served);                        // voxels.cu:317
+		if (chunks != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)(-(long long)chunks));   // voxels.cu:346-357
+		bc->numClear = served; bc->numWork = chunks; bc->numSpilled = stored;
 	}
 }
 
@@ -828,7 +898,7 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 			// where this group's reservations start (k_queue)
 			sh_phantom = account_group(a, ctl, ordinal > 0u ? batch_of(ctl, ordinal - 1u) : nullptr);
 			bc->acctAlloc0 = (uint32_t)a.stats->numAllocatedChunks; bc->acctPool0 = (uint32_t)a.stats->chunkPoolSize;
-			bc->reserve = (unsigned long long)a.stats->numNodes << 32;
+			bc->reserve = (unsigned long long)a.stats->numNodes << 32; bc->reserve0 = bc->reserve;
 			if (ordinal == 0u) ctl->tableMagic = 0;     // the octree changes from here on: the side tables' stamp is valid again once k_finish has run (k_begin only reads it)
 		}
 		__syncthreads();
@@ -942,7 +1012,8 @@ __global__ __launch_bounds__(TPB) void k_queue(BuildArgs a, uint32_t ordinal) {
 	if ((ctl->debugFlags & 1u) != 0u) { if (blockIdx.x == 0 && threadIdx.x == 0) panic(ctl, SIMLOD_ERR_BARRIER_TIMEOUT); return; }
 	const uint32_t* crossList = at<const uint32_t>(a, a.offCross);
 	const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) / 64u, numWaves = gridDim.x * TPB / 64u;
-	for (uint32_t e = wave; e < numCross; e += numWaves) queue_split(a, ctl, bc, crossList[e]);
+	for (uint32_t e = wave; e < numCross; e += numWaves) queue_split(a, ctl, bc, crossList, numCross, e);
+	if (wave == 0u) queue_totals(a, ctl, bc, crossList, numCross);
 }
 
 // ---- k_voxelize's work items (filled by the chunk allocation below) -----------------------------------------------------
@@ -957,23 +1028,10 @@ static constexpr uint32_t VOX_SMALL = 512;                      // a leaf with f
 static constexpr uint32_t VOX_SMALL_PIECE = 128;                // ... in items of at most this many samples (two steps of a wave)
 static constexpr uint32_t LDS_LEVELS = 7;                       // ancestors d = 1..7 own a cube of side 128 >> d; from d = 8 on: one cell
 static constexpr uint32_t CUBE_WORDS = 8192 + 1024 + 256 + 64 + 16 + 4 + 4;
-struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst, X, Y, Z; };   // samples [s0, s1) of the leaf's storage; its chunk directory, its coordinates; leaf = node index | level << 24
+struct VoxItem { uint32_t leaf, s0, s1, ptBase, ptFirst; };   // samples [s0, s1) of the leaf's storage; its chunk directory; leaf = node index | level << 24   (20 bytes: the leaf's coordinates come from its node)
 __device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl* bc) { return at<VoxItem>(a, a.offVoxItems) + (uint64_t)(bc->ordinal & 1u) * a.voxItemCap; }
 
 // ---- chunks for the leaves with new samples ----------------------------------------------------------------------------
-// sum over the wave and the sum of the lanes below (every lane of the wave calls)
-__device__ __forceinline__ uint32_t wave_exclusive(uint32_t v, uint32_t& total) {
-	const uint32_t lane = (uint32_t)lane_id();
-	uint32_t x = v;
-#pragma unroll
-	for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
-	total = (uint32_t)__shfl((int)x, 63, 64);
-	return x - v;
-}
-__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
-	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
-}
-
 // The point chunks of the leaves with new samples and their share of k_voxelize's work list (voxels.cu:485-538), for ALLOC_LEAVES entries
 // of the batch's list: ONE WORKGROUP.
 //   phase 1, wave 0, one leaf per lane: how many chunks, directory entries and work items each leaf needs; the reservations of the wave's
@@ -1001,7 +1059,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = chunk_dir(a, bc);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
-	SimlodChunk** leafChunks = at<SimlodChunk*>(a, a.offLeafChunks);
+	uint8_t* const leafChunks = a.mom + a.offLeafChunks;
 	if (threadIdx.x < 64u) {
 		const uint32_t lane = threadIdx.x;
 		// (Node.numPoints is not looked at: the back half of the batch before may still be advancing it)
@@ -1086,9 +1144,9 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 			NodeDir& d = nodeDir[i];
 			d.ptBase = base; d.ptFirst = first; d.ptTag = bc->tag;
 			VoxItem* items = vox_items(a, bc);
-			const uint32_t nl = fresh_leaves ? fl.level : node->level, nX = fresh_leaves ? fl.X : node->X, nY = fresh_leaves ? fl.Y : node->Y, nZ = fresh_leaves ? fl.Z : node->Z;
-			if (pieces == 0u) for (uint32_t q = 0; q < small; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_SMALL_PIECE, min(stored + (q + 1u) * VOX_SMALL_PIECE, counter), base, first, nX, nY, nZ};
-			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first, nX, nY, nZ};
+			const uint32_t nl = fresh_leaves ? fl.level : node->level;
+			if (pieces == 0u) for (uint32_t q = 0; q < small; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_SMALL_PIECE, min(stored + (q + 1u) * VOX_SMALL_PIECE, counter), base, first};
+			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first};
 		}
 		AllocRec& r = sh.rec[lane];
 		r.node = i; r.existing = existing; r.additional = ok ? additional : 0u; r.fromPool = fromPool; r.dirNew = base + e; r.prefix = exAdditional;
@@ -1111,7 +1169,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 		SimlodChunk* first = r.head != nullptr ? r.head : (k == 0u ? c : (k + 1u == r.additional ? chunk_at(0u) : nullptr));
 		c->next = next;
 		chunkDir[r.dirNew + k] = c;
-		if (r.existing + k < LEAF_SLOTS) leafChunks[(uint64_t)r.node * LEAF_SLOTS + r.existing + k] = c;
+		if (r.existing + k < LEAF_SLOTS) leaf_row_set(leafChunks, a.pers, r.node, r.existing + k, c);
 		if (k == 0u) { if (r.tail == nullptr) a.nodes[r.node].points = c; else r.tail->next = c; }
 		if (k + 1u == r.additional) tail_of(first) = c;
 	}
@@ -1780,7 +1838,7 @@ __device__ SimlodChunk* dir_wait(const BuildArgs& a, Ctl* ctl, uint32_t tag, uin
 __device__ __forceinline__ void vox_chunk_publish(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t node, uint32_t k, SimlodChunk* c) {
 	// an inner node's row of the leaf chunk table lists its voxel chunks: the rasteriser reads the list from there (render.hip r_visible) — never
 	// the root's: its row may still be read as a LEAF's by the next batch's k_count, which splits a root that was still a leaf
-	if (k < LEAF_SLOTS && node != 0u) at<SimlodChunk*>(a, a.offLeafChunks)[(uint64_t)node * LEAF_SLOTS + k] = c;
+	if (k < LEAF_SLOTS && node != 0u) leaf_row_set(a.mom + a.offLeafChunks, a.pers, node, k, c);
 	dir_insert(a, ctl, tag, node, k, c);
 }
 // ... and hangs behind its predecessor: the head pointer, the old tail, or a chunk of this batch (which may have to be waited for).
@@ -2040,7 +2098,7 @@ __global__ __launch_bounds__(VTPB) void k_voxelize(BuildArgs a, uint32_t ordinal
 		const uint32_t leafLevel = it.leaf >> 24;
 		it.leaf &= 0xffffffu;
 		if (it.leaf == 0u) continue;                              // (the root as a leaf: voxroot_pieces)
-		const uint32_t LX = it.X, LY = it.Y, LZ = it.Z;
+		const uint32_t LX = a.nodes[it.leaf].X, LY = a.nodes[it.leaf].Y, LZ = a.nodes[it.leaf].Z;      // (in flight beside the leaf's path)
 		const unsigned long long* rec = at<const unsigned long long>(a, a.offPaths) + (uint64_t)it.leaf * PATH_WORDS;
 		__syncthreads();                                       // the previous item's LDS state is no longer read
 		if (threadIdx.x < PATH_WORDS) {
@@ -2546,7 +2604,7 @@ __global__ __launch_bounds__(TPB) void k_stats(BuildArgs a) {
 	}
 }
 
-__global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const uint32_t* numBatchesUploaded) {
+__global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const uint32_t* numBatchesUploaded, uint32_t launchSeq) {
 	if (blockIdx.x != 0) return;
 	Ctl* ctl = ctl_of(a);
 	SimlodStats* s = a.stats;
@@ -2556,7 +2614,15 @@ __global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const u
 	__syncthreads();
 	phantom_fill(a, sh_phantom);
 	if (threadIdx.x != 0) return;
-	if (feedback != nullptr) { feedback[0] = s->batchletIndex; feedback[1] = *numBatchesUploaded; }      // what the next launch sizes itself by (groups_for_launch): page-locked host memory
+	if (feedback != nullptr) {      // what the next launch sizes itself by (groups_for_launch): page-locked host memory
+		feedback[0] = s->batchletIndex; feedback[1] = *numBatchesUploaded;
+		// ... and whether its batches can go in groups (exact mode, prepare_batch decides for every group; a launch whose groups would each be cut down to
+		// one batch had better enqueue one group of kernels per batch): the root has children, the allocator is a worst-case full group away from the guard
+		const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
+		feedback[2] = a.acct != 0u && !node_is_leaf(a.nodes) &&
+		              alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + slack_for(a, (unsigned long long)a.groupCap + min((unsigned long long)a.spilledCap, (unsigned long long)s->numPointsProcessed)) < a.persCapacity ? 1u : 0u;
+		__hip_atomic_store(feedback + 3, launchSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (last: a reader that sees this launch's number sees its report)
+	}
 	s->numInner = ctl->statCounters[0];
 	s->numLeaves = ctl->statCounters[1];
 	s->numNonemptyLeaves = ctl->statCounters[2];
@@ -2610,7 +2676,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t g
 	a.offParent = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.offNodeDir = off;  off += align_up((uint64_t)a.nodeCapacity * sizeof(NodeDir), 256);
 	a.offChunkDir = off; off += align_up(2ull * a.dirCap * 8, 256);            // (two copies, by batch parity)
-	a.offLeafChunks = off; off += align_up((uint64_t)a.nodeCapacity * LEAF_SLOTS * 8, 256);
+	a.offLeafChunks = off; off += (uint64_t)a.nodeCapacity * LEAF_ROW_BYTES;
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	a.offTop = off;   off += align_up((uint64_t)TOP_CELLS * 4, 256);
 	a.voxItemCap = min(a.nodeCapacity + 2u * VOX_BIG_ITEMS, 1u << 20);         // VOX_BIG_ITEMS pieces + small items: a leaf has one more than its new samples / 128, and 65 536 x 128 = 8 M samples
@@ -2703,17 +2769,22 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	bool fits = false;
 	for (; exactGroup > 1u && !fits; exactGroup -= fits ? 0u : 1u) fits = layout_construct(a, u->momentaryBufferCapacity, false, 1, exactGroup);
 	if (!fits) fits = layout_construct(a, u->momentaryBufferCapacity, coalesce, (uint32_t)std::max(1, ctx.tune(KNOB_GROUP_BATCHES, 10)));   // coalesced mode: groups of 10 (36 M terrain: 20: 3.17 ms, 10: 2.95, 5: 3.10, 2: 3.66 — two groups per launch overlap front and back halves)
-	if (fits) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible)
+	if (fits && ((uint64_t)a.mom & (LEAF_ROW_BYTES - 1u)) == 0ull) {   // the rasteriser reads leaf lists through the table while its stamp matches the octree (render.hip r_visible; a draw item names a row by its address, 256-byte aligned)
 		const Ctl* ctl = reinterpret_cast<const Ctl*>(a.mom);
-		note_leaf_table(ctx, LeafTableRef{nodes, a.mom, reinterpret_cast<const SimlodChunk* const*>(a.mom + a.offLeafChunks), &ctl->tableMagic, &ctl->tableBatch,
+		note_leaf_table(ctx, LeafTableRef{nodes, a.mom, a.mom + a.offLeafChunks, a.pers, &ctl->tableMagic, &ctl->tableBatch,
 		                             &ctl->tableNodes, &ctl->tableSig, TABLE_MAGIC, LEAF_SLOTS, a.nodeCapacity});
 	} else forget_leaf_table(ctx, nodes);
 	const DeviceInfo& dev = device_info();
 
-	const uint32_t limit = std::min<uint32_t>(std::min<uint32_t>(ctx.batchLimit.load(), SIMLOD_MAX_BATCHES_PER_LAUNCH), groups_for_launch(ctx, stats));
+	note_upload_counter(numBatchesUploaded, 0u, false, true);
+	const LaunchPlan plan = launch_plan(ctx, stats, numBatchesUploaded);
+	const uint32_t limit = plan.batches;
+	// batches per group this launch aims at: the layout's, or — exact mode, when the latest launch reported that groups of several batches are out of the
+	// question for now (LaunchPlan::mayGroup) — one, with one group of kernels per batch
+	const uint32_t take = a.acct != 0u && !plan.mayGroup ? 1u : a.groupMax;
 	// (one workgroup does the launch's bookkeeping; all of them restore the side tables when the stamp is stale: the first launch of an octree, as a rule)
 	SIMLOD_LAUNCH(k_begin, dim3(fits ? dev.numCUs * 2 : 1u), dim3(TPB), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
-	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), a.groupMax);
+	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), take);
 	if (fits) {
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);
 		// k_expand's workgroups meet at grid barriers: never more than one per CU (all must be resident).  One per TWO CUs is the
@@ -2721,10 +2792,11 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
 		// (with the previous batch's voxel half running beside it on the side stream: one per FOUR CUs — 256: 8.3 ms per ingest, 128: 7.8,
 		// 96: 7.5, 64: 7.2, 48: 7.3, 32: 7.5)
-		const uint32_t numGroups = (limit + a.groupMax - 1) / a.groupMax;            // kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode)
+		// kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode, exact mode in groups; the first group of an octree's first launch is one batch: prepare_batch)
+		const uint32_t numGroups = a.acct != 0u && take > 1u && plan.fresh && limit > 1u ? 1u + (limit - 1u + take - 1u) / take : (limit + take - 1u) / take;
 		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled() && numGroups > 1u;   // (two streams: see below)
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
-		const bool single = a.groupMax == 1u || limit <= 1u;      // every group of this launch is ONE ring batch (k_begin takes no more than `limit` batches)
+		const bool single = take == 1u || limit <= 1u;      // every group of this launch is ONE ring batch (k_begin takes no more than `limit` batches)
 		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, !single ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		// A batch has a FRONT half — k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
 		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
@@ -2789,7 +2861,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		SIMLOD_LAUNCH(k_voxdone, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);   // the last batch's voxel lists (the others: by the following batch's k_insert)
 		SIMLOD_LAUNCH(k_stats, dim3(min(gridNodes, dev.numCUs)), dim3(TPB), stream, a);
 	}
-	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u, launch_feedback_words(ctx, stats), (const uint32_t*)numBatchesUploaded);
+	SIMLOD_LAUNCH(k_finish, dim3(1), dim3(64), stream, a, fits ? 1u : 0u, plan.feedback, (const uint32_t*)numBatchesUploaded, plan.seq);
 	if (profile_enabled()) profile_close(stream);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return (int)e;

@@ -45,7 +45,8 @@ struct RenderArgs {
 	uint32_t     useBins, binTilesX, binTiles, binPoolCap, binMinArea, binsPossible;
 	uint32_t*    binFeedback;                       // page-locked: the frame's first draw pass stores here how many nodes sort, or would (launch_render)      // screen bins of the samples that leave their item's tile (r_overflow): tiles per row, tiles in all, entries in the pool
 	// the builder's leaf chunk table (simlod_internal.hpp LeafTableRef), or table == nullptr: r_visible walks every list
-	const SimlodChunk* const* leafTable;
+	const uint8_t* leafTable;                          // packed rows (simlod_internal.hpp leaf_row_get), offsets into leafTablePers
+	const uint8_t* leafTablePers;
 	const uint32_t* leafTableMagic;
 	const uint32_t* leafTableBatch;
 	const uint64_t* leafTableNodes;
@@ -272,7 +273,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	if (a.leafTable != nullptr) {
 		const uint32_t magic = *a.leafTableMagic, batch = *a.leafTableBatch, batchNow = a.stats->batchletIndex;
 		const uint64_t tableNodes = *a.leafTableNodes, sig = *a.leafTableSig, sigNow = table_signature(a.stats);
-		if (a.leafTableSlots <= 64u && a.leafTableRows != 0u) rowHead = a.leafTable[(uint64_t)(active && i < a.leafTableRows ? i : 0u) * a.leafTableSlots];
+		if (a.leafTableSlots <= 64u && a.leafTableRows != 0u) rowHead = leaf_row_get(a.leafTable, a.leafTablePers, active && i < a.leafTableRows ? i : 0u, 0u);
 		tableValid = (magic == a.leafTableMagicValue) & (batch == batchNow) & (tableNodes == (uint64_t)a.nodes) & (sig == sigNow);
 	}
 	const uint32_t level = n->level, X = n->X, Y = n->Y, Z = n->Z;
@@ -347,7 +348,8 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 	const uint32_t myChunks = numChunks[0] + numChunks[1];
 	// A node has one list worth drawing (a leaf its points, an inner node its voxels): that one may come from the builder's chunk table
 	const int rowList = numChunks[0] != 0u ? 0 : 1;
-	const SimlodChunk* const* slots = tableValid && draws && a.leafTableSlots <= 64u && i < a.leafTableRows ? a.leafTable + (uint64_t)i * a.leafTableSlots : nullptr;
+	// (a draw item that reads its chunks straight from the row names the row — 256-byte aligned — with bit 0 set and its first slot in bits 1..7: item_chunk)
+	const uint8_t* const slots = tableValid && draws && a.leafTableSlots <= 64u && i < a.leafTableRows ? a.leafTable + (uint64_t)i * LEAF_ROW_BYTES : nullptr;
 	const uint32_t fromTable = slots != nullptr ? min(numChunks[rowList], a.leafTableSlots) : 0u;
 	uint32_t myClass[ITEM_CLASSES] = {0u, 0u, 0u, 0u};                                   // a list's pieces: full ones (class 0), then the rest
 #pragma unroll
@@ -423,7 +425,7 @@ __device__ __forceinline__ void visible_nodes(const RenderArgs& a, const float (
 				for (int q = 0; q < ITEM_CLASSES; q++) if (cl == (uint32_t)q) at = classBase[q]++;
 				if (at >= a.itemCap) { atomicOr(&a.stats->dbg, SIMLOD_ERR_VISIBLE_OVERFLOW); continue; }
 				DrawItem it;
-				it.chunks = (l == rowList && rowDirect ? slots : dir + dirBase) + p * perItem;
+				it.chunks = l == rowList && rowDirect ? reinterpret_cast<const SimlodChunk* const*>((uint64_t)slots | 1ull | (uint64_t)(p * perItem) << 1) : dir + dirBase + p * perItem;
 				it.samples = have > firstSample ? min(have - firstSample, perItem * SIMLOD_POINTS_PER_CHUNK) : 0u;
 				it.visibleIdx = slot; it.tileX = tileX; it.tileY = tileY; it.tileWH = tileW | (tileH << 16); it.took = 0u;
 				items[(uint64_t)cl * a.itemCap + at] = it;
@@ -1042,7 +1044,9 @@ __global__ __launch_bounds__(DTPB) void r_draw(RenderArgs a) {
 		c.tileExact = c.tileW * c.tileH <= TILE_EXACT_AREA;
 		bool gap = false;
 		if (threadIdx.x < ITEM_CHUNKS && threadIdx.x * SIMLOD_POINTS_PER_CHUNK < it.samples) {
-			const SimlodChunk* ch = it.chunks[threadIdx.x];
+			const uint64_t where = (uint64_t)it.chunks;           // the frame's chunk directory, or (bit 0) a row of the builder's packed chunk table from slot (bits 1..7) on
+			const SimlodChunk* ch = (where & 1ull) != 0ull ? leaf_row_get(reinterpret_cast<const uint8_t*>(where & ~255ull), a.leafTablePers, 0, (uint32_t)((where >> 1) & 127ull) + threadIdx.x)
+			                                               : it.chunks[threadIdx.x];
 			sh_dir[threadIdx.x] = ch;
 			gap = ch == nullptr;
 		}
@@ -1493,7 +1497,7 @@ __global__ __launch_bounds__(TPB) void r_output(RenderArgs a) {
 
 // ---- reset.cu:20-86 -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_reset(uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
-                                               uint32_t* batchSizes, uint32_t frameCounter) {
+                                               uint32_t* batchSizes, uint32_t frameCounter, uint32_t* feedback, uint32_t resetSeq) {
 	// The allocator starts at offset 16 and the root's occupancy grid is its first allocation (reset.cu:42-67), so the
 	// grid sits at pers + 16: every workgroup can clear its share without waiting for thread 0.
 	uint4* grid = reinterpret_cast<uint4*>(pers + 16);
@@ -1520,6 +1524,8 @@ __global__ __launch_bounds__(TPB) void k_reset(uint8_t* pers, SimlodNode* nodes,
 	root->grid = reinterpret_cast<SimlodOccupancyGrid*>(pers + 16);
 	*numBatchesUploaded = 0;
 	for (uint32_t k = 0; k < SIMLOD_BATCH_STREAM_SIZE; k++) batchSizes[k] = 0;
+	// what the next kernel_construct launches size themselves by (simlod_hip.cpp launch_plan; page-locked): nothing ingested, nothing uploaded, as of this reset
+	if (feedback != nullptr) { feedback[0] = 0u; feedback[1] = 0u; feedback[2] = 1u; __hip_atomic_store(feedback + 3, resetSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
@@ -1546,8 +1552,9 @@ uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 int launch_reset(Context& ctx, const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream) {
 	forget_leaf_table(ctx, nodes);
-	forget_launch_history(ctx, stats);
-	SIMLOD_LAUNCH(k_reset, dim3(64), dim3(TPB), stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter);
+	uint32_t* words = nullptr; uint32_t seq = 0;
+	forget_launch_history(ctx, stats, numBatchesUploaded, &words, &seq);
+	SIMLOD_LAUNCH(k_reset, dim3(64), dim3(TPB), stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter, words, seq);
 	return (int)hipGetLastError();
 }
 
@@ -1589,7 +1596,7 @@ int launch_render(Context& ctx, uint32_t* buffer, const SimlodUniforms* u, Simlo
 	render_plane_offsets(a.numPixels, a.offWork, a.offItems, a.offDepth, a.offColor, a.offOverflow, &a.offDir);
 	LeafTableRef lt;
 	if (ctx.tune(KNOB_RASTER_LEAF_TABLE, 1) && find_leaf_table(ctx, nodes, lt)) {
-		a.leafTable = lt.table; a.leafTableMagic = lt.magic; a.leafTableBatch = lt.batch; a.leafTableNodes = lt.tableNodes; a.leafTableSig = lt.sig;
+		a.leafTable = lt.table; a.leafTablePers = lt.pers; a.leafTableMagic = lt.magic; a.leafTableBatch = lt.batch; a.leafTableNodes = lt.tableNodes; a.leafTableSig = lt.sig;
 		a.leafTableMagicValue = lt.magicValue; a.leafTableSlots = lt.slots; a.leafTableRows = lt.rows;
 	}
 	a.itemCap = MAX_DRAW_ITEMS;

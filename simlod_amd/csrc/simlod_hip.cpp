@@ -157,8 +157,38 @@ bool find_leaf_table(Context& ctx, const void* nodes, LeafTableRef& ref) {
 	return false;
 }
 
-// ---- launch feedback: how many batches the recent kernel_construct launches found (simlod_internal.hpp groups_for_launch) ----------
+// ---- launch sizing: how many batches a kernel_construct launch can find (simlod_internal.hpp launch_plan) ---------------------------------
+// The reference's kernel loops over whatever has been uploaded when it starts (voxels.cu:870-885); here every group of batches is a handful of kernel
+// launches the HOST enqueues before it can read that number (the upload counter lives on the device).  Kernels of a group without a batch leave at
+// once, but its event hops stand in line behind the real work (~45 us per empty group).  What the host can know:
+//   * the upload counter itself: the reference's uploader publishes it with cuMemsetD32Async(cptr_numBatchesUploaded, n, 1, stream_upload)
+//     (main_progressive_octree.cpp:1047-1050) — shim/cuda.h passes every such write on (simlod_upload_counter_written), the Python mirror does the same;
+//   * Stats.batchletIndex as the latest launch whose end the host has seen left it (k_finish stores it, the upload counter, whether the octree is
+//     fit for exact groups, and the launch's sequence number into page-locked memory: no synchronisation), and how many batches the launches
+//     enqueued since then were sized for.
+// pending = uploaded - index - (what those launches will take).  A host that does not say (no shim, no hint): the counter the latest report saw + the
+// uploader's pace, and never less than one group — a host that uploads, launches once and waits must not wait for ever.
 static constexpr uint32_t NOTHING_SEEN = 0xffffffffu;
+
+namespace {
+struct UploadCounter { const void* ptr; uint32_t value; bool known; };      // known: the host has said what it wrote there (a reset: zero)
+std::mutex g_countersLock;
+std::vector<UploadCounter> g_counters;          // the upload counters the host has told about (simlod_upload_counter_written), by address
+bool host_uploaded(const void* counter, uint32_t& value) {
+	std::lock_guard<std::mutex> hold(g_countersLock);
+	for (const UploadCounter& c : g_counters) if (c.ptr == counter) { value = c.value; return c.known; }
+	return false;
+}
+}  // namespace
+// written: the host has enqueued a write of `value` (remembered only for addresses a reset or a launch has named as an upload counter: the shims pass on
+// every one-word memset); else: a launch names `counter` as its upload counter (what it holds stays unknown until the host says)
+void note_upload_counter(const void* counter, uint32_t value, bool written, bool create) {
+	std::lock_guard<std::mutex> hold(g_countersLock);
+	for (UploadCounter& c : g_counters) if (c.ptr == counter) { if (written) { c.value = value; c.known = true; } return; }
+	if (!create) return;
+	if (g_counters.size() >= 64) g_counters.erase(g_counters.begin());
+	g_counters.push_back(UploadCounter{counter, value, written});
+}
 
 static LaunchHistory* history_of(Context& ctx, const void* stats, bool create) {
 	std::vector<LaunchHistory>& g_history = ctx.history;
@@ -175,54 +205,67 @@ static LaunchHistory* history_of(Context& ctx, const void* stats, bool create) {
 		if (hipHostMalloc(&pinned, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 		seen = static_cast<volatile uint32_t*>(pinned);
 	}
-	seen[0] = NOTHING_SEEN; seen[1] = NOTHING_SEEN;
-	g_history.push_back(LaunchHistory{stats, seen, 0u, 0u, 0u, false});
+	seen[0] = NOTHING_SEEN; seen[1] = NOTHING_SEEN; seen[2] = 1u; seen[3] = 0u;
+	LaunchHistory h{};
+	h.stats = stats; h.seen = seen;
+	g_history.push_back(h);
 	return &g_history.back();
 }
 
-// How many groups of kernels a launch enqueues.  The reference's kernel loops over whatever has been uploaded when it starts (voxels.cu:870-885);
-// here every batch is seven kernel launches the HOST enqueues before it can know that number.  A group without a batch is not free: its kernels
-// leave at once, but the two event hops between its halves stand in line behind the real batches — ~45 us per empty group at the end of a launch
-// (rocprofv3, tools/trace_launch.sh: a launch that found ONE batch among three groups took 233 us, of which the batch's own kernels end at 137).
-// So: what the latest feedback saw pending + as many as were uploaded between the last two feedbacks (the uploader's pace per launch);
-// everything (20) while nothing is known — the first launches after a reset.  A batch that arrives beyond that waits for the next launch,
-// where it counts as pending.  A host that knows the number says so (simlod_context_set_construct_batch_limit: the launch takes the smaller).
-uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats) {
-	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
+LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploadCounter) {
+	LaunchPlan plan{SIMLOD_MAX_BATCHES_PER_LAUNCH, true, false, nullptr, 0u};
+	const uint32_t limit = std::min<uint32_t>(ctx.batchLimit.load(), SIMLOD_MAX_BATCHES_PER_LAUNCH);
+	const int hinted = ctx.hintPending.exchange(-1);                      // simlod_context_hint_pending_batches: for THIS launch
 	std::lock_guard<std::mutex> hold(ctx.historyLock);
-	LaunchHistory* h = history_of(ctx, stats, false);
-	if (h == nullptr) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
-	const uint32_t index = h->seen[0], uploaded = h->seen[1];
-	if (index == NOTHING_SEEN || uploaded == NOTHING_SEEN) return SIMLOD_MAX_BATCHES_PER_LAUNCH;
-	const uint32_t pending = uploaded > index ? uploaded - index : 0u;
-	if (!h->havePrev) h->arrivals = SIMLOD_MAX_BATCHES_PER_LAUNCH;                                  // (one feedback says nothing about the pace)
-	else if (index != h->prevIndex || uploaded != h->prevUploaded)
-		h->arrivals = uploaded >= h->prevUploaded && index >= h->prevIndex ? uploaded - h->prevUploaded : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (counters that went back: reset by other means)
-	// The same two numbers as last time: either no launch has ended in between (launches enqueued faster than they end — keep the pace) or one has and
-	// found the counters where they were.  With nothing pending the second reading is the safe one: a loader that has finished must not leave its
-	// last pace behind in every later frame's launch (20 groups without a batch: 0.6 ms per frame).
-	else if (pending == 0u) h->arrivals = 0u;
-	h->prevIndex = index; h->prevUploaded = uploaded; h->havePrev = true;
-	const uint32_t want = pending + h->arrivals;
-	// Nothing pending and nothing uploaded between the last two reports: the loader is idle (or done — the viewer's steady state: every frame launches
-	// kernel_construct, main_progressive_octree.cpp:364-428).  Such a launch enqueues NO group — k_begin, the Stats pass, k_finish: ~22 us instead of ~55 —; the first
-	// batch of a new burst is seen by that launch's report and taken by the next launch.  Not for a host that sizes its launches itself
-	// (simlod_context_set_construct_batch_limit): the launch takes the smaller of the two numbers, and its number must not meet a zero here.
-	if (want == 0u) return ctx.batchLimitGiven.load() ? 1u : 0u;
-	return want > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : want;
+	LaunchHistory* h = ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) != 0 ? history_of(ctx, stats, true) : nullptr;
+	if (h == nullptr) { plan.batches = hinted >= 0 ? std::min<uint32_t>((uint32_t)hinted, limit) : limit; return plan; }
+	const uint32_t seq = ++h->seq;
+	plan.feedback = const_cast<uint32_t*>(h->seen); plan.seq = seq;
+	const uint32_t index = h->seen[0], uploadedSeen = h->seen[1], reportSeq = h->seen[3];
+	const bool reported = index != NOTHING_SEEN && uploadedSeen != NOTHING_SEEN;        // a launch of this octree, or its reset, has ended and said so
+	plan.mayGroup = !reported || h->seen[2] != 0u;
+	// what the launches enqueued behind the reporting one (or behind the reset, while nothing has reported) were sized for
+	const uint32_t since = reported ? reportSeq : h->resetSeq;
+	uint32_t inflight = 0;
+	if (seq - since > 32u) inflight = NOTHING_SEEN;
+	else for (uint32_t q = since + 1u; q != seq; q++) inflight += h->enq[q % 32u];
+	const bool knowsStart = reported || h->resetKnown;                                  // index is known: the report's, or zero (a reset is in the stream ahead of this launch)
+	const uint32_t indexNow = reported ? index : 0u;
+	uint32_t want, uploadedHost = 0;
+	if (hinted >= 0) want = (uint32_t)hinted;
+	else if (knowsStart && inflight != NOTHING_SEEN && host_uploaded(uploadCounter, uploadedHost)) {
+		const uint32_t pending = uploadedHost > indexNow ? uploadedHost - indexNow : 0u;
+		want = pending > inflight ? pending - inflight : 0u;
+	} else if (!reported) want = SIMLOD_MAX_BATCHES_PER_LAUNCH;                          // nothing is known: everything
+	else {
+		// the host says nothing: what the latest report saw pending + what was uploaded between the last two reports (the uploader's pace per launch)
+		const uint32_t pending = uploadedSeen > index ? uploadedSeen - index : 0u;
+		if (!h->havePrev) h->arrivals = SIMLOD_MAX_BATCHES_PER_LAUNCH;                  // (one report says nothing about the pace)
+		else if (index != h->prevIndex || uploadedSeen != h->prevUploaded)
+			h->arrivals = uploadedSeen >= h->prevUploaded && index >= h->prevIndex ? uploadedSeen - h->prevUploaded : SIMLOD_MAX_BATCHES_PER_LAUNCH;   // (counters that went back: reset by other means)
+		else if (pending == 0u) h->arrivals = 0u;                                       // the same numbers again and nothing pending: the loader is idle or done
+		h->prevIndex = index; h->prevUploaded = uploadedSeen; h->havePrev = true;
+		want = std::max<uint32_t>(1u, pending + h->arrivals);                           // (never nothing: such a host may upload, launch once and wait)
+	}
+	plan.batches = std::min<uint32_t>(want, limit);
+	// the first launch of an octree (index 0, nothing in flight): its first group is ONE batch whatever the layout says (the root is still a leaf:
+	// construct.hip prepare_batch) — one more group of kernels, so that the launch still takes what it was sized for
+	plan.fresh = knowsStart && indexNow == 0u && inflight == 0u;
+	h->enq[seq % 32u] = plan.batches;
+	return plan;
 }
 
-uint32_t* launch_feedback_words(Context& ctx, const SimlodStats* stats) {
-	if (ctx.tune(KNOB_ADAPTIVE_GROUPS, 1) == 0) return nullptr;
+void forget_launch_history(Context& ctx, const SimlodStats* stats, const void* uploadCounter, uint32_t** words, uint32_t* seq) {
+	if (uploadCounter != nullptr) note_upload_counter(uploadCounter, 0u, true, true);        // reset.cu:84: the reset zeroes the upload counter
 	std::lock_guard<std::mutex> hold(ctx.historyLock);
-	LaunchHistory* h = history_of(ctx, stats, true);
-	return h != nullptr ? const_cast<uint32_t*>(h->seen) : nullptr;      // (a slot that changes hands before the launch's last kernel stores into it: a stale hint for the new owner)
-}
-
-void forget_launch_history(Context& ctx, const SimlodStats* stats) {
-	std::lock_guard<std::mutex> hold(ctx.historyLock);
-	LaunchHistory* h = history_of(ctx, stats, false);
-	if (h != nullptr) { h->seen[0] = NOTHING_SEEN; h->seen[1] = NOTHING_SEEN; h->havePrev = false; }
+	LaunchHistory* h = history_of(ctx, stats, words != nullptr);
+	if (words != nullptr) { *words = nullptr; *seq = 0u; }
+	if (h == nullptr) return;
+	h->seen[0] = NOTHING_SEEN; h->seen[1] = NOTHING_SEEN; h->seen[2] = 1u;
+	h->havePrev = false;
+	h->resetSeq = ++h->seq; h->resetKnown = words != nullptr;
+	h->enq[h->seq % 32u] = 0u;
+	if (words != nullptr) { *words = const_cast<uint32_t*>(h->seen); *seq = h->seq; }  // (k_reset reports in stream order: index 0, uploaded 0)
 }
 
 // ---- frame feedback: did the render buffer's previous frame have nodes that sort into the screen bins (render.hip r_overflow) ----------
@@ -365,7 +408,15 @@ int simlod_context_set_ingest_mode(SimlodContext* c, uint32_t mode) {
 int simlod_context_set_construct_batch_limit(SimlodContext* c, uint32_t maxBatches) {
 	if (maxBatches == 0u) return (int)hipErrorInvalidValue;
 	ctx_or_default(c).batchLimit.store(maxBatches > SIMLOD_MAX_BATCHES_PER_LAUNCH ? SIMLOD_MAX_BATCHES_PER_LAUNCH : maxBatches);
-	ctx_or_default(c).batchLimitGiven.store(true);
+	return 0;
+}
+int simlod_context_hint_pending_batches(SimlodContext* c, uint32_t pending) {
+	ctx_or_default(c).hintPending.store((int)std::min<uint32_t>(pending, SIMLOD_MAX_BATCHES_PER_LAUNCH));
+	return 0;
+}
+int simlod_upload_counter_written(const void* numBatchesUploaded, uint32_t value) {
+	if (!numBatchesUploaded) return (int)hipErrorInvalidValue;
+	note_upload_counter(numBatchesUploaded, value, true, false);      // (only addresses a reset or a launch has named as an upload counter are remembered)
 	return 0;
 }
 int simlod_context_set_trunk_mask(SimlodContext* c, uint64_t lo, uint64_t hi) {

@@ -22,10 +22,28 @@ static constexpr uint32_t SPILLING_CAPACITY = 100000u;       // progressive_octr
 // The three stamp words live in the builder's control block on the device; the table describes the octree `nodes` as it is NOW only
 // while *magic == magicValue, *batch == Stats.batchletIndex and *tableNodes == nodes and *sig == table_signature(Stats) (the builder clears the stamp while it works and
 // re-stamps in k_finish), which r_visible checks on the device every frame.
+// A row is 256 bytes: LEAF_ROW_SLOTS chunk addresses as offsets into the persistent buffer in units of 16 bytes (every allocation there is a multiple of 16
+// from a base that is: utils.h.cu:185-197), 40 bits each — the low words as 50 x u32, the high bytes as 50 x u8 behind them; 0 = no chunk (offset 0 is the
+// allocator's own header).  8-byte pointers cost 105 MB of the momentary buffer for the reference host's 263 157 nodes, this 67 MB: the difference is
+// what lets EXACT mode ingest a launch's batches in groups inside the reference host's 300 MB (construct.hip account_group).
+static constexpr uint32_t LEAF_ROW_SLOTS = SIMLOD_MAX_POINTS_PER_NODE / SIMLOD_POINTS_PER_CHUNK, LEAF_ROW_BYTES = 256;
+static_assert(LEAF_ROW_SLOTS * 5u <= LEAF_ROW_BYTES && LEAF_ROW_SLOTS * 4u % 4u == 0u, "leaf chunk table row");
+__host__ __device__ inline const SimlodChunk* leaf_row_get(const uint8_t* table, const uint8_t* pers, uint64_t row, uint32_t k) {
+	const uint8_t* r = table + row * LEAF_ROW_BYTES;
+	const uint64_t v = (uint64_t)reinterpret_cast<const uint32_t*>(r)[k] | (uint64_t)r[LEAF_ROW_SLOTS * 4u + k] << 32;
+	return v != 0ull ? reinterpret_cast<const SimlodChunk*>(pers + (v << 4)) : nullptr;
+}
+__host__ __device__ inline void leaf_row_set(uint8_t* table, const uint8_t* pers, uint64_t row, uint32_t k, const SimlodChunk* c) {
+	uint8_t* r = table + row * LEAF_ROW_BYTES;
+	const uint64_t v = c != nullptr ? (uint64_t)(reinterpret_cast<const uint8_t*>(c) - pers) >> 4 : 0ull;
+	reinterpret_cast<uint32_t*>(r)[k] = (uint32_t)v;
+	r[LEAF_ROW_SLOTS * 4u + k] = (uint8_t)(v >> 32);
+}
 struct LeafTableRef {
 	const void*               nodes;
 	const void*               block;       // start of the buffer the table lives in (the construct kernel's momentary buffer)
-	const SimlodChunk* const* table;
+	const uint8_t*            table;       // rows of LEAF_ROW_BYTES (leaf_row_get)
+	const uint8_t*            pers;        // the persistent buffer the rows' offsets refer to
 	const uint32_t*           magic;
 	const uint32_t*           batch;
 	const uint64_t*           tableNodes;
@@ -50,7 +68,12 @@ enum Knob : int {
 static constexpr int KNOB_UNSET = INT_MIN;
 extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...
 
-struct LaunchHistory { const void* stats; volatile uint32_t* seen; uint32_t prevIndex, prevUploaded, arrivals; bool havePrev; };   // seen[0] = batchletIndex, seen[1] = upload counter (as the latest launch whose end the host has seen left them); arrivals: batches uploaded between the last two
+struct LaunchHistory {      // seen (page-locked, written by the launches' last kernels and by k_reset): [0] batchletIndex, [1] the upload counter, [2] fit for exact groups, [3] sequence number of the launch that wrote them
+	const void* stats; volatile uint32_t* seen; uint32_t prevIndex, prevUploaded, arrivals; bool havePrev;
+	uint32_t seq, resetSeq; bool resetKnown;      // launches (and resets) of this octree so far | the latest reset's number | ... and it ran through this library (index 0 from there on)
+	uint32_t enq[32];                             // batches launch #seq was sized for
+};
+struct LaunchPlan { uint32_t batches; bool mayGroup, fresh; uint32_t* feedback; uint32_t seq; };   // batches this launch can find (0: none — an idle frame) | exact groups allowed | first launch of an octree | where its last kernel reports, and as which launch
 struct FrameFeedback { const void* buffer; volatile uint32_t* seen; bool bins; uint64_t bytes; bool possible, open; };                       // render.hip launch_render: seen[0] = nodes of the buffer's latest frame that sort (or would)
 struct SideStream;                                           // construct.hip: the second stream of kernel_construct and its events
 void destroy_side_stream(SideStream* s);
@@ -58,8 +81,8 @@ void destroy_side_stream(SideStream* s);
 struct Context {
 	std::atomic<uint32_t> nodeCapacity{263157u};             // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
 	std::atomic<uint32_t> ingestMode{0u};                    // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
-	std::atomic<uint32_t> batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};   // host hint: at most this many batches are pending (<= 20)
-	std::atomic<bool>     batchLimitGiven{false};                       // the host has called simlod_context_set_construct_batch_limit at least once: it sizes its launches itself (groups_for_launch never answers 0 then)
+	std::atomic<uint32_t> batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};   // simlod_context_set_construct_batch_limit: a launch never takes more than this many batches (<= 20)
+	std::atomic<int>      hintPending{-1};                              // simlod_context_hint_pending_batches: that many batches are pending NOW — for the next launch, then forgotten
 	std::atomic<uint64_t> trunkLo{0u}, trunkHi{0u};          // simlod_context_set_trunk_mask: upper nodes (levels 0-2) that split whatever they hold; zero: the reference's rule alone
 	int knob[KNOB_COUNT_];
 	std::mutex sideLock;
@@ -104,14 +127,10 @@ void note_leaf_table(Context& ctx, const LeafTableRef& ref);                 // 
 void forget_leaf_table(Context& ctx, const void* nodes);                     // reset
 bool find_leaf_table(Context& ctx, const void* nodes, LeafTableRef& ref);    // false also when the table's buffer is no longer a live device allocation
 
-// How many per-batch kernel groups a kernel_construct launch should enqueue (the host cannot see how many batches are pending: the
-// upload counter lives on the device).  Every launch ends with two 4-byte copies — Stats.batchletIndex and the upload counter — into
-// page-locked host memory; the next launch reads whatever has arrived (no synchronisation) and enqueues what was left pending + what
-// the recent launches processed + 2, at least 2, at most 20.  Unknown octree, or just reset: 20.  An idle frame loop pays for 2
-// groups instead of 20 (0.84 ms -> 0.1 ms per launch on MI355X, tools/idle_launch.py); a burst is picked up one launch late.
-uint32_t groups_for_launch(Context& ctx, const SimlodStats* stats);
-uint32_t* launch_feedback_words(Context& ctx, const SimlodStats* stats);      // page-locked {batchletIndex, upload counter} the launch's last kernel stores into (two 4-byte copies behind it were 10 us of every launch); nullptr: no feedback
-void forget_launch_history(Context& ctx, const SimlodStats* stats);
+// How many batches a kernel_construct launch should enqueue kernels for (simlod_hip.cpp: launch sizing).
+LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploadCounter);
+void forget_launch_history(Context& ctx, const SimlodStats* stats, const void* uploadCounter = nullptr, uint32_t** words = nullptr, uint32_t* seq = nullptr);   // reset (words: where k_reset reports, as launch *seq)
+void note_upload_counter(const void* counter, uint32_t value, bool written, bool create);     // written: the host has enqueued a write of `value` to the upload counter at `counter`; else: `counter` is named as one
 
 struct DeviceInfo {
 	int      device;

@@ -47,6 +47,8 @@ def lib():
         L.simlod_context_set_node_capacity.argtypes = [vp, u32]
         L.simlod_context_set_ingest_mode.argtypes = [vp, u32]
         L.simlod_context_set_construct_batch_limit.argtypes = [vp, u32]
+        L.simlod_context_hint_pending_batches.argtypes = [vp, u32]
+        L.simlod_upload_counter_written.argtypes = [vp, u32]
         L.simlod_context_set_knob.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         L.simlod_context_reload_env.argtypes = [vp]
         L.simlod_context_set_trunk_mask.argtypes = [vp, u64, u64]
@@ -93,6 +95,7 @@ EXPORTED_SYMBOLS = [
     "simlod_context_create", "simlod_context_destroy", "simlod_context_attach", "simlod_context_set_node_capacity", "simlod_context_set_ingest_mode",
     "simlod_context_set_construct_batch_limit", "simlod_context_set_knob", "simlod_context_reload_env", "simlod_context_construct_buffer_min_bytes",
     "simlod_octree_image_replaced", "simlod_render_frame_composed", "simlod_render_frame_rccl", "simlod_context_set_trunk_mask", "simlod_rccl_version",
+    "simlod_context_hint_pending_batches", "simlod_upload_counter_written",
     "simlod_profile_enable", "simlod_profile_collect", "simlod_generate_terrain", "simlod_generate_terrain_scan", "simlod_launch_colorfilter", "simlod_colorfilter_buffer_min_bytes",
 ]
 
@@ -138,14 +141,14 @@ class DeviceOctree:
         self.ctx = ctx
         _check(self.L.simlod_context_set_node_capacity(ctx, max_nodes), "simlod_context_set_node_capacity")
         _check(self.L.simlod_context_set_ingest_mode(ctx, 1 if coalesce else 0), "simlod_context_set_ingest_mode")
-        # (sizes_launches=False: a host like the reference's own, which never tells the library how many batches a launch can find — the library's prediction alone)
-        if sizes_launches:
-            _check(self.L.simlod_context_set_construct_batch_limit(ctx, abi.MAX_BATCHES_PER_LAUNCH), "simlod_context_set_construct_batch_limit")
         self.batch_limit = abi.MAX_BATCHES_PER_LAUNCH
-        # drain() and stream() know how many batches are pending — the reference's host does too (its upload index and the batchletIndex it reads
-        # back every frame) — and say so before a launch: a launch enqueues no kernels for batches that do not exist (an empty group costs ~45 us
-        # at a launch's end, simlod_hip.cpp groups_for_launch).  SIMLOD_HOST_HINT=0: launches sized by the library's own prediction only.
-        self.hint_pending = sizes_launches and os.environ.get("SIMLOD_HOST_HINT", "1") != "0"
+        # How many batches a launch can find.  Every write of the upload counter goes past the library (publish -> simlod_upload_counter_written), as
+        # shim/cuda.h does with the cuMemsetD32Async of the reference's uploader (main_progressive_octree.cpp:1047-1050): the library sizes its launches
+        # by that and by what its earlier launches reported — the unchanged reference host gets the same.  sizes_launches=False: a host that tells
+        # nothing (the library predicts from its launches' reports alone).  SIMLOD_HOST_HINT=1: drain() / stream() also say how many batches are
+        # pending in front of every launch (simlod_context_hint_pending_batches): the two must give the same rates (bench.py reports both).
+        self.notifies = sizes_launches
+        self.hint_pending = sizes_launches and os.environ.get("SIMLOD_HOST_HINT", "0") == "1"
         z = dict(dtype=torch.uint8, device=self.device)
         # H11: the reference renders before any reset and relies on fresh VRAM reading as zero
         self.nodes = torch.zeros(max_nodes * 152, **z)
@@ -205,10 +208,9 @@ class DeviceOctree:
         _check(self.L.simlod_context_set_construct_batch_limit(self.ctx, max_batches), "simlod_context_set_construct_batch_limit")
 
     def _hint(self, pending=None):
-        """Tell the library how many batches the next launch can find at most (None: back to the caller's limit)."""
-        if self.hint_pending:
-            n = self.batch_limit if pending is None else max(1, min(int(pending), self.batch_limit))
-            _check(self.L.simlod_context_set_construct_batch_limit(self.ctx, n), "simlod_context_set_construct_batch_limit")
+        """Tell the library how many batches are pending for the next launch (SIMLOD_HOST_HINT=1 only; None: nothing to say)."""
+        if self.hint_pending and pending is not None:
+            _check(self.L.simlod_context_hint_pending_batches(self.ctx, max(0, min(int(pending), self.batch_limit))), "simlod_context_hint_pending_batches")
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def uniforms(self, width, height, transform, box_size, **kw):
@@ -248,7 +250,14 @@ class DeviceOctree:
             dst.copy_(torch.from_numpy(np.ascontiguousarray(points).view(np.uint8).reshape(-1)), non_blocking=True)
         self.batch_sizes[slot] = n
         self.uploaded_host += 1
-        self.num_uploaded.fill_(self.uploaded_host)
+        self.publish(self.uploaded_host)
+
+    def publish(self, num_batches):
+        """The upload counter: `num_batches` ring batches are complete (in stream order behind their copies and their batchSizes entries), and the
+        library is told so (main_progressive_octree.cpp:1047-1050 + shim/cuda.h: cuMemsetD32Async(cptr_numBatchesUploaded, ...))."""
+        self.num_uploaded.fill_(num_batches)
+        if self.notifies:
+            _check(self.L.simlod_upload_counter_written(self._p(self.num_uploaded), int(num_batches)), "simlod_upload_counter_written")
 
     def upload_las(self, records, header, translation):
         """One batch of RAW LAS point records (uint8 host array or device tensor) into the next ring slot, decoded on the
@@ -270,7 +279,7 @@ class DeviceOctree:
                                         scale, offset, ctypes.c_void_p(dst), self._stream()), "simlod_decode_las")
         self.batch_sizes[slot] = n
         self.uploaded_host += 1
-        self.num_uploaded.fill_(self.uploaded_host)
+        self.publish(self.uploaded_host)
 
     def add_las(self, uniforms, path, translation=None, batch=abi.MAX_BATCH_SIZE):
         """Stream a LAS file through the ring: read raw bytes, decode on the device, ingest."""
@@ -486,7 +495,7 @@ class DeviceOctree:
                     self.ring[slot * abi.MAX_BATCH_SIZE * 16: slot * abi.MAX_BATCH_SIZE * 16 + n * 16].copy_(src[uploaded * batch * 16: uploaded * batch * 16 + n * 16], non_blocking=True)
                     self.batch_sizes[slot: slot + run].fill_(min(batch, n))
                     uploaded += run
-                    self.num_uploaded.fill_(base + uploaded)
+                    self.publish(base + uploaded)
 
         self.upload_stream.wait_stream(torch.cuda.current_stream())     # (a reset enqueued just before zeroes batchSizes: the uploader starts behind it)
         top_up()

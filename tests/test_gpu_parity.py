@@ -1608,7 +1608,7 @@ def test_repeated_ingests_leave_identical_counters(built_libs):
     for p in range(40):
         dev.reset(u)
         dev.batch_sizes[: len(batches)] = sizes
-        dev.num_uploaded.fill_(len(batches))
+        dev.publish(len(batches))
         dev.uploaded_host = len(batches)
         dev.drain(u)
         st = dev.read_stats()

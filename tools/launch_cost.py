@@ -42,7 +42,7 @@ for var in args.variants:
         dev.batch_sizes[:nb] = sizes
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nb)]
         for b in range(nb):
-            dev.num_uploaded.fill_(b + 1)
+            dev.publish(b + 1)
             dev.uploaded_host = b + 1
             ev[b][0].record()
             dev.construct(u)

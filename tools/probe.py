@@ -45,7 +45,7 @@ sizes = torch.tensor([min(batch, args.points - i * batch) for i in range(nb)], d
 def step():
     dev.reset(u)
     dev.batch_sizes[:nb] = sizes
-    dev.num_uploaded.fill_(nb)
+    dev.publish(nb)
     dev.uploaded_host = nb
     return dev.drain(u)
 

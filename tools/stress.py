@@ -47,7 +47,7 @@ for p in range(args.passes):
         dev.stream(u, src, args.points)
     else:
         dev.batch_sizes[:nb] = sizes
-        dev.num_uploaded.fill_(nb)
+        dev.publish(nb)
         dev.uploaded_host = nb
         dev.drain(u)
     st = dev.read_stats()
