@@ -60,7 +60,7 @@ struct BatchCtl {
 	unsigned long long reserve0;       // ... as the group began (k_count's first workgroup): what k_queue's entries count from
 	// per-batch chunk accounting of an exact group (acct): point chunks batch k of the group would have taken / given back had the batches been ingested one
 	// by one (voxels.cu:346-357, 485-538), filled by k_expand; the chunk counters as they stood when the group began (k_count's first workgroup)
-	uint32_t acctAlloc0, acctPool0, pad4, pad5;
+	uint32_t acctAlloc0, acctPool0, rootSplitAt, pad5;      // rootSplitAt: an exact group in which the ROOT splits: the batch of the group it splits in (k_rootpre); NONE otherwise
 	uint32_t acctD[SIMLOD_MAX_BATCHES_PER_LAUNCH], acctF[SIMLOD_MAX_BATCHES_PER_LAUNCH];
 };
 
@@ -293,9 +293,11 @@ __device__ __forceinline__ void panic(Ctl* ctl, uint32_t bit) { atomicOr(&ctl->e
 // level, every inner node can start one more chunk).  The memory guard of voxels.cu:896-912 looks at the allocator after the WHOLE previous
 // batch; here a batch is prepared while the voxel halves of the TWO batches before it may still be running, so within this distance of the
 // guard a launch takes one batch only: the next launch's k_begin runs after everything and decides exactly.
-__device__ __forceinline__ unsigned long long slack_for(const BuildArgs& a, unsigned long long samples) {
+__host__ __device__ inline unsigned long long group_slack_bytes(unsigned long long samples, unsigned long long numNodes);
+__device__ __forceinline__ unsigned long long slack_for(const BuildArgs& a, unsigned long long samples) { return group_slack_bytes(samples, a.stats->numNodes); }
+__host__ __device__ inline unsigned long long group_slack_bytes(unsigned long long samples, unsigned long long numNodes) {
 	// (+ the point chunks and grids the group before has yet to allocate: its k_expand runs after this look at the allocator)
-	return (2ull * (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + a.stats->numNodes + 1ull) + samples / SIMLOD_POINTS_PER_CHUNK + 4096ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk))
+	return (2ull * (samples * SIMLOD_MAX_DEPTH / SIMLOD_POINTS_PER_CHUNK + numNodes + 1ull) + samples / SIMLOD_POINTS_PER_CHUNK + 4096ull) * SIMLOD_ALLOC_ROUND(sizeof(SimlodChunk))
 	       + (unsigned long long)SLOT_CAP_GRIDS * SIMLOD_ALLOC_ROUND(sizeof(SimlodOccupancyGrid));
 }
 __device__ __forceinline__ unsigned long long voxel_half_slack(const BuildArgs& a, const BatchCtl* prev) {
@@ -320,11 +322,6 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	if (full) { ctl->stop = 1; return; }
 	const uint32_t batchIndex = ctl->firstBatch + ctl->consumed;       // (Stats.batchletIndex itself is advanced by the back half, which may lag)
 	uint32_t take = min(ctl->groupMax, ctl->numBatches - ctl->consumed);
-	// A root that is still a leaf samples ITSELF (voxels.cu:449-463) and is sampled AGAIN, from nothing, by the batch that splits it (:371-382): what its
-	// voxel list holds then depends on which batch that was — batch by batch until the root has children (the first 50 000 points of an octree)
-	// (... or the group before — whose k_queue has run, whose k_expand has not: this runs in its k_hist — is about to give it some)
-	if (a.acct != 0u && take > 1u && node_is_leaf(a.nodes) &&
-	    !(ordinal > 0u && (uint32_t)(at<const unsigned long long>(a, a.offSplitTag)[0] >> 32) == ctl->tagOf[ordinal - 1u])) take = 1u;
 	if (a.acct != 0u && take > 1u) {
 		// An EXACT group of several batches is taken only where the reference's guard — looked at before EVERY batch (voxels.cu:896-912) — cannot
 		// trip inside it: the allocator must be a worst-case group away from it.  Closer than that, the launch goes batch by batch as before.
@@ -367,6 +364,7 @@ __device__ void prepare_batch(const BuildArgs& a, Ctl* ctl, uint32_t ordinal) {
 	bc->reserve = 0;           // (k_count's first workgroup: the node array as k_expand of the group before leaves it)
 	bc->acct = a.acct != 0u && take > 1u ? 1u : 0u;
 	bc->accounted = 0;
+	bc->rootSplitAt = 0xffffffffu;
 	for (uint32_t k = 0; k < SIMLOD_MAX_BATCHES_PER_LAUNCH; k++) { bc->acctD[k] = 0; bc->acctF[k] = 0; }
 	bc->active = 1;
 }
@@ -1515,12 +1513,25 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				const bool s2 = K >= 3u && ((mask1 >> (t >> 3)) & 1u) != 0u && (sh.c2[t] > SIMLOD_MAX_POINTS_PER_NODE || f2);
 				unsigned long long mask2 = __ballot(s2);
 				uint32_t n1 = (uint32_t)__popc(mask1), n2 = (uint32_t)__popcll(mask2);
-				uint32_t extraBase = 0;
+				uint32_t extraBase = 0, granted = n1 + n2;
 				if (t == 0 && n1 + n2 > 0u) {
 					uint32_t noSlot, noSpill;
-					if (!reserve(a, ctl, bc, 0u, 8u * (n1 + n2), 0u, noSlot, extraBase, noSpill)) extraBase = NONE;    // no room for the cascade: the children stay too full (deferred)
+					if (!reserve(a, ctl, bc, 0u, 8u * (n1 + n2), 0u, noSlot, extraBase, noSpill)) {
+						// no room in the node array for the whole cascade: as many of its splits as still fit, children first (the others stay too full: deferred)
+						const uint32_t inUse = (uint32_t)(__hip_atomic_load(&bc->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) & 0xfffffu;
+						granted = a.nodeCapacity > inUse ? min((a.nodeCapacity - inUse) / 8u, n1 + n2) : 0u;
+						if (granted == 0u || !reserve(a, ctl, bc, 0u, 8u * granted, 0u, noSlot, extraBase, noSpill)) { granted = 0u; extraBase = NONE; }
+					}
 				}
-				extraBase = __shfl(extraBase, 0);
+				extraBase = __shfl(extraBase, 0); granted = __shfl(granted, 0);
+				if (granted < n1 + n2) {
+					// the first `granted` splits in order: the children by octant, then the grandchildren of the children that do split
+					uint32_t keep1 = 0, left = granted;
+					for (uint32_t j = 0; j < 8u && left != 0u; j++) if (((mask1 >> j) & 1u) != 0u) { keep1 |= 1u << j; left--; }
+					unsigned long long keep2 = 0ull;
+					for (uint32_t jk = 0; jk < 64u && left != 0u; jk++) if (((mask2 >> jk) & 1ull) != 0ull && ((keep1 >> (jk >> 3)) & 1u) != 0u) { keep2 |= 1ull << jk; left--; }
+					mask1 = keep1; mask2 = keep2; n1 = (uint32_t)__popc(mask1); n2 = (uint32_t)__popcll(mask2);
+				}
 				if (extraBase == NONE) { mask1 = 0; mask2 = 0ull; n1 = 0; n2 = 0; }
 				if (t < 8u) sh.base2[t] = extraBase + 8u * (uint32_t)__popc(mask1 & ((1u << t) - 1u));
 				sh.base3[t] = extraBase + 8u * (n1 + (uint32_t)__popcll(mask2 & ((1ull << t) - 1ull)));
@@ -1601,6 +1612,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 						cThen = c;
 					}
 					sh.splitAt[LOCAL_NODES] = (uint8_t)sL; sh.counterAt[LOCAL_NODES] = cThen;
+					if (L == 0u && rec.born == NONE) bc->rootSplitAt = sL;      // (the batches before it found the root a leaf: k_rootpre)
 				}
 				__syncthreads();
 				if (t < 8u) {                                                      // the children: created when the slot's node split
@@ -2426,8 +2438,9 @@ __device__ __forceinline__ void voxroot_pieces(const BuildArgs& a, Ctl* ctl, Bat
 // (O(1) append next time).  `tag`: the batch whose hash directory names the new chunks.  Runs as part of the NEXT batch's k_insert (the
 // first kernel on the caller's stream that has waited for the side stream; some workgroups at the end of its grid, which have no samples)
 // and once more, as a kernel of its own, at the end of the launch.  Nodes the next batch has created meanwhile have no voxels: skipped.
-__device__ void voxdone_nodes(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t numNodes, uint32_t first, uint32_t stride) {
+__device__ void voxdone_nodes(const BuildArgs& a, Ctl* ctl, uint32_t tag, uint32_t numNodes, uint32_t first, uint32_t stride, bool skipRoot = false) {
 	for (uint32_t i = first; i < numNodes; i += stride) {
+		if (skipRoot && i == 0u) continue;
 		SimlodNode* node = a.nodes + i;
 		const uint32_t numVoxels = node->numVoxels, stored = node->numVoxelsStored;
 		if (numVoxels == stored) continue;
@@ -2443,6 +2456,44 @@ __global__ __launch_bounds__(TPB) void k_voxdone(BuildArgs a) {
 	Ctl* ctl = ctl_of(a);
 	if (ctl->processed == 0u || ctl->abortBatch) return;
 	voxdone_nodes(a, ctl, ctl->tagOf[ctl->processed - 1u], min(a.stats->numNodes, a.nodeCapacity), blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB);   // (the launch's last group)
+}
+
+// ---- rootpre: an exact group of several batches in which the ROOT splits ------------------------------------------------------------------
+// A root that is still a leaf samples ITSELF (voxels.cu:449-463: every node of the path that has a grid, and the root has one from the reset on), and the
+// batch that splits it clears that grid and samples everything again from nothing (voxels.cu:371-382): the root's voxel list keeps what the batches
+// before the split put there AND gets every cell again.  Ingested batch by batch that is what happens; in a group, the batches in front of the
+// splitting one (k_expand knows which: BatchCtl.rootSplitAt) have to meet the root's grid as those batches would have — before k_insert clears it.
+// One workgroup on the back stream in front of k_insert; leaves at once in every group but the one or two of an octree's life that split its root.
+__global__ __launch_bounds__(1024) void k_rootpre(BuildArgs a, uint32_t ordinal) {
+	Ctl* ctl = ctl_of(a);
+	BatchCtl* bc = batch_of(ctl, ordinal);
+	if (bc == nullptr || ctl->abortBatch || bc->acct == 0u) return;
+	const uint32_t sR = bc->rootSplitAt;
+	if (sR == NONE || sR == 0u) return;
+	// the root's voxel list as the group before left it (its k_voxelize has ended: stream order): closed here, in front of this group's first voxels
+	if (threadIdx.x == 0u && ordinal > 0u) voxdone_nodes(a, ctl, ctl->tagOf[ordinal - 1u], 1u, 0u, 1u);
+	__threadfence();
+	__syncthreads();
+	const uint32_t n = bc->start[min(sR, bc->groupBatches)], lane = (uint32_t)lane_id();
+	const Samples<false> pts(a, bc);
+	SimlodOccupancyGrid* const g = a.nodes[0].grid;
+	if (g == nullptr) return;
+	for (uint32_t base = 0; base < n; base += blockDim.x) {
+		const uint32_t i = base + threadIdx.x;
+		bool go = i < n;
+		const float4 p = go ? pts[i] : make_float4(0, 0, 0, 0);
+		const uint32_t pX = quantize(F_FULL, p.x, a.minx, a.size), pY = quantize(F_FULL, p.y, a.miny, a.size), pZ = quantize(F_FULL, p.z, a.minz, a.size);
+		const uint32_t cell = grid_cell(0u, pX, pY, pZ), bit = cell & 31u;
+		uint32_t* word = &g->values[cell >> 5];
+		go = go && ((*word >> bit) & 1u) == 0u;                                                  // voxels.cu:93-94
+		go = go && ((atomicOr(word, go ? 1u << bit : 0u) >> bit) & 1u) == 0u;                      // voxels.cu:96
+		const unsigned long long wm = __ballot(go);
+		if (wm == 0ull) continue;
+		uint32_t first = 0;
+		if (lane == 0u) first = atomicAdd(&a.nodes[0].numVoxels, (uint32_t)__popcll(wm));       // voxels.cu:101
+		first = (uint32_t)__shfl((int)first, 0, 64);
+		store_voxels_wave(a, ctl, bc->tag, go, 0u, first + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull)), voxel_of(a, 0, pX, pY, pZ, p.w));
+	}
 }
 
 // ---- insert: points into leaf chunks, regenerated voxels into voxel chunks (voxels.cu:540-639, 674-698) --------
@@ -2491,7 +2542,8 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 			constexpr uint32_t DONE_WGS = 32;
 			const uint32_t back = gridDim.x - 1u - blockIdx.x;
 			if (back >= 1u && back <= DONE_WGS && bc->ordinal != 0u)
-				voxdone_nodes(a, ctl, ctl->tagOf[bc->ordinal - 1u], min(a.stats->numNodes, a.nodeCapacity), (back - 1u) * TPB + threadIdx.x, DONE_WGS * TPB);
+				voxdone_nodes(a, ctl, ctl->tagOf[bc->ordinal - 1u], min(a.stats->numNodes, a.nodeCapacity), (back - 1u) * TPB + threadIdx.x, DONE_WGS * TPB,
+				              bc->acct != 0u && bc->rootSplitAt != 0xffffffffu && bc->rootSplitAt != 0u);      // (k_rootpre has closed the root's list and appended to it since)
 		}
 		ph.mark(pb + 0);
 		// the occupancy grids of the nodes this batch split (k_count's tail and k_expand listed them): cleared here, by everybody, before
@@ -2617,9 +2669,9 @@ __global__ void k_finish(BuildArgs a, uint32_t fits, uint32_t* feedback, const u
 	if (feedback != nullptr) {      // what the next launch sizes itself by (groups_for_launch): page-locked host memory
 		feedback[0] = s->batchletIndex; feedback[1] = *numBatchesUploaded;
 		// ... and whether its batches can go in groups (exact mode, prepare_batch decides for every group; a launch whose groups would each be cut down to
-		// one batch had better enqueue one group of kernels per batch): the root has children, the allocator is a worst-case full group away from the guard
+		// one batch had better enqueue one group of kernels per batch): the allocator is a worst-case full group away from the guard
 		const SimlodAllocatorGlobal* alloc = reinterpret_cast<const SimlodAllocatorGlobal*>(a.pers);
-		feedback[2] = a.acct != 0u && !node_is_leaf(a.nodes) &&
+		feedback[2] = a.acct != 0u &&
 		              alloc->offset + SIMLOD_MEM_SAFETY_MARGIN + slack_for(a, (unsigned long long)a.groupCap + min((unsigned long long)a.spilledCap, (unsigned long long)s->numPointsProcessed)) < a.persCapacity ? 1u : 0u;
 		__hip_atomic_store(feedback + 3, launchSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (last: a reader that sees this launch's number sees its report)
 	}
@@ -2766,6 +2818,9 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	// momentary buffer holds the largest such layout that leaves room for ACCT_SPILL_FLOOR moved points — every Node and Stats field comes out as batch-by-batch
 	// ingestion leaves it (account_group).  Not with a forced time budget (the budget is looked at per group: voxels.cu:936-949 looks per batch).
 	uint32_t exactGroup = coalesce || ctx.tune(KNOB_DEBUG_BUDGET_US, 0) > 0 ? 1u : (uint32_t)std::min<int>(std::max(1, ctx.tune(KNOB_EXACT_GROUP, 5)), (int)ACCT_MAX_GROUP);
+	// (a persistent buffer so small that even an empty octree is closer to the reference's memory guard than a worst-case group of two batches: prepare_batch
+	// would cut every group down to one batch — plain exact mode, without the groups' bookkeeping)
+	if (exactGroup > 1u && SIMLOD_MEM_SAFETY_MARGIN + group_slack_bytes(2ull * SIMLOD_MAX_BATCH_SIZE, 0u) >= a.persCapacity) exactGroup = 1u;
 	bool fits = false;
 	for (; exactGroup > 1u && !fits; exactGroup -= fits ? 0u : 1u) fits = layout_construct(a, u->momentaryBufferCapacity, false, 1, exactGroup);
 	if (!fits) fits = layout_construct(a, u->momentaryBufferCapacity, coalesce, (uint32_t)std::max(1, ctx.tune(KNOB_GROUP_BATCHES, 10)));   // coalesced mode: groups of 10 (36 M terrain: 20: 3.17 ms, 10: 2.95, 5: 3.10, 2: 3.66 — two groups per launch overlap front and back halves)
@@ -2792,8 +2847,8 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		// the barrier's agent-scope release / acquire and the polling cost grow with the participants, the work does not need them
 		// (with the previous batch's voxel half running beside it on the side stream: one per FOUR CUs — 256: 8.3 ms per ingest, 128: 7.8,
 		// 96: 7.5, 64: 7.2, 48: 7.3, 32: 7.5)
-		// kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode, exact mode in groups; the first group of an octree's first launch is one batch: prepare_batch)
-		const uint32_t numGroups = a.acct != 0u && take > 1u && plan.fresh && limit > 1u ? 1u + (limit - 1u + take - 1u) / take : (limit + take - 1u) / take;
+		// kernel groups to enqueue: one per ring batch, or per groupMax of them (coalesced mode, exact mode in groups)
+		const uint32_t numGroups = (limit + take - 1u) / take;
 		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled() && numGroups > 1u;   // (two streams: see below)
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
 		const bool single = take == 1u || limit <= 1u;      // every group of this launch is ONE ring batch (k_begin takes no more than `limit` batches)
@@ -2834,12 +2889,14 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 				SIMLOD_LAUNCH_STOP(k_expand, dim3(expandWgs), dim3(ETPB), stream, side->expanded[b], a, b);
 				expand_gate_leave(ctx, stream, side->expanded[b], gated);
 				{ const hipError_t e = hipStreamWaitEvent(back, side->expanded[b], 0); if (e != hipSuccess) return fail(e); }
+				if (!single && a.acct != 0u) SIMLOD_LAUNCH(k_rootpre, dim3(1), dim3(1024), back, a, b);
 				if (single) SIMLOD_LAUNCH_STOP(k_insert<true>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
 				else SIMLOD_LAUNCH_STOP(k_insert<false>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);
 			} else {
 				const bool gated = expand_gate_enter(ctx, stream);
 				SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
 				expand_gate_leave(ctx, stream, nullptr, gated);
+				if (!single && a.acct != 0u) SIMLOD_LAUNCH(k_rootpre, dim3(1), dim3(1024), back, a, b);
 				if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);
 				else SIMLOD_LAUNCH(k_insert<false>, dim3(gridPoints), dim3(TPB), back, a, b);
 			}

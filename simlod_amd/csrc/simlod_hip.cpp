@@ -213,7 +213,7 @@ static LaunchHistory* history_of(Context& ctx, const void* stats, bool create) {
 }
 
 LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploadCounter) {
-	LaunchPlan plan{SIMLOD_MAX_BATCHES_PER_LAUNCH, true, false, nullptr, 0u};
+	LaunchPlan plan{SIMLOD_MAX_BATCHES_PER_LAUNCH, true, nullptr, 0u};
 	const uint32_t limit = std::min<uint32_t>(ctx.batchLimit.load(), SIMLOD_MAX_BATCHES_PER_LAUNCH);
 	const int hinted = ctx.hintPending.exchange(-1);                      // simlod_context_hint_pending_batches: for THIS launch
 	std::lock_guard<std::mutex> hold(ctx.historyLock);
@@ -236,6 +236,9 @@ LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploa
 	else if (knowsStart && inflight != NOTHING_SEEN && host_uploaded(uploadCounter, uploadedHost)) {
 		const uint32_t pending = uploadedHost > indexNow ? uploadedHost - indexNow : 0u;
 		want = pending > inflight ? pending - inflight : 0u;
+		// (a launch may take less than it was sized for — the memory guard, the time budget —: while the launches in flight have not reported, they
+		// cannot be counted on to have taken everything, and this one enqueues one group: a frame loop must not stand still with batches pending)
+		if (want == 0u && pending != 0u) want = 1u;
 	} else if (!reported) want = SIMLOD_MAX_BATCHES_PER_LAUNCH;                          // nothing is known: everything
 	else {
 		// the host says nothing: what the latest report saw pending + what was uploaded between the last two reports (the uploader's pace per launch)
@@ -248,9 +251,6 @@ LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploa
 		want = std::max<uint32_t>(1u, pending + h->arrivals);                           // (never nothing: such a host may upload, launch once and wait)
 	}
 	plan.batches = std::min<uint32_t>(want, limit);
-	// the first launch of an octree (index 0, nothing in flight): its first group is ONE batch whatever the layout says (the root is still a leaf:
-	// construct.hip prepare_batch) — one more group of kernels, so that the launch still takes what it was sized for
-	plan.fresh = knowsStart && indexNow == 0u && inflight == 0u;
 	h->enq[seq % 32u] = plan.batches;
 	return plan;
 }

@@ -73,7 +73,7 @@ struct LaunchHistory {      // seen (page-locked, written by the launches' last 
 	uint32_t seq, resetSeq; bool resetKnown;      // launches (and resets) of this octree so far | the latest reset's number | ... and it ran through this library (index 0 from there on)
 	uint32_t enq[32];                             // batches launch #seq was sized for
 };
-struct LaunchPlan { uint32_t batches; bool mayGroup, fresh; uint32_t* feedback; uint32_t seq; };   // batches this launch can find (0: none — an idle frame) | exact groups allowed | first launch of an octree | where its last kernel reports, and as which launch
+struct LaunchPlan { uint32_t batches; bool mayGroup; uint32_t* feedback; uint32_t seq; };   // batches this launch can find (0: none — an idle frame) | exact groups allowed | where its last kernel reports, and as which launch
 struct FrameFeedback { const void* buffer; volatile uint32_t* seen; bool bins; uint64_t bytes; bool possible, open; };                       // render.hip launch_render: seen[0] = nodes of the buffer's latest frame that sort (or would)
 struct SideStream;                                           // construct.hip: the second stream of kernel_construct and its events
 void destroy_side_stream(SideStream* s);

@@ -25,7 +25,7 @@ def _device(**kw):
     from simlod_amd.runtime import DeviceOctree
     # (SIMLOD_TEST_MOMENTARY_MB / SIMLOD_TEST_PERSISTENT_MB: the same tests with other default buffer sizes — exact mode ingests a launch's batches in
     # groups where the momentary buffer has room for it and the persistent buffer is far from the reference's guard: construct.hip account_group)
-    kw.setdefault("persistent_bytes", int(os.environ.get("SIMLOD_TEST_PERSISTENT_MB", "1024")) << 20)
+    kw.setdefault("persistent_bytes", int(os.environ.get("SIMLOD_TEST_PERSISTENT_MB", "8192")) << 20)
     if "SIMLOD_TEST_MOMENTARY_MB" in os.environ:
         kw.setdefault("momentary_bytes", int(os.environ["SIMLOD_TEST_MOMENTARY_MB"]) * 1_000_000)
     kw.setdefault("max_pixels", 1920 * 1080)
