@@ -87,8 +87,24 @@ def collect_profile(L):
     return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(cnt.value)}
 
 
+def relaunch_through_torchrun(args):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment) with N > 1: start it again the way the driver does — one process per
+    GPU through torch.distributed.run on 127.0.0.1 — instead of giving up: the first hardware SCALE run must not die on a launch detail."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_through_torchrun(args)
     import torch
     import torch.distributed as dist
     from simlod_amd import abi, camera, synthetic
@@ -328,11 +344,14 @@ def main():
     roofline, chain, kernels = None, None, {}
     # measurement aid in the control block at byte 0 of the momentary buffer: construct.hip Ctl.expandNs[7] (stored points moved by splits) at byte 208
     CTL_COUNTERS = slice(208, 216)
+    CTL_GROUPS = slice(184, 192)           # Ctl.expandNs[4]: groups of batches ingested (every per-group kernel had that many launches with work)
     if rank == 0 and not args.no_profile:
         L.simlod_profile_enable(2)
+        dev.momentary[CTL_GROUPS].zero_()
         ingest_step()
         torch.cuda.synchronize()
         prof_dom = collect_profile(L)
+        groups_with_work = int(dev.momentary[CTL_GROUPS].cpu().numpy().view(np.uint64)[0])
         L.simlod_profile_enable(1)
         dev.momentary[CTL_COUNTERS].zero_()
         ingest_step()
@@ -359,16 +378,21 @@ def main():
         per_ingest = {"k_count": 16.0 * my_points, "k_hist": 32.0 * moved, "k_insert": 32.0 * (my_points + moved), "k_voxelize": 16.0 * (my_points + moved) + 16.0 * new_voxels}
         dom = "k_voxelize"
         n_dom, ms_dom = prof_dom.get(dom, (0, 0.0))
-        # launches with a batch: the timed pass ingested n_batches groups; what the events saw beyond that are early exits (a few us each)
-        active = max(1, min(n_dom, n_batches if not args.coalesce else n_dom))
+        # launches with work: the groups of batches the pass ingested (counted on the device: Ctl.expandNs[4]) — exact mode takes a launch's batches in
+        # groups (construct.hip account_group), so a launch of the kernel covers several 1 M-point batches; what the events saw beyond that are early
+        # exits of groups without a batch.  `avg_launch_us` is the RAW event time over the launches with work (the early exits' few us each are in it);
+        # `avg_launch_us_less_idle` takes 4 us per early exit off (a model, reported beside the measurement, not instead of it).
+        active = max(1, min(n_dom, groups_with_work))
         idle = max(0, n_dom - active)
-        avg_ms = max(ms_dom - idle * 0.004, 1e-6) / active                  # (a launch without a batch: ~4 us)
+        avg_ms = max(ms_dom, 1e-6) / active
+        avg_ms_less_idle = max(ms_dom - idle * 0.004, 1e-6) / active
         bytes_per_launch = per_ingest[dom] / active
-        traffic = rtraffic.get(dom) if (tfile and dom in rtraffic) else None     # HBM bytes per launch from the PMC passes (kept profile, same sources)
+        traffic = rtraffic.get(dom) * n_batches / active if (tfile and dom in rtraffic) else None     # HBM bytes per launch from the PMC passes (kept profile, same sources; the file holds bytes per 1 M-point batch)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
-                    "avg_launch_us": avg_ms * 1e3, "bytes_per_launch": bytes_per_launch, "launches_with_work": active,
+                    "avg_launch_us": avg_ms * 1e3, "avg_launch_us_less_idle": avg_ms_less_idle * 1e3, "bytes_per_launch": bytes_per_launch, "launches_with_work": active, "launches_without": idle,
+                    "batches_per_launch": n_batches / active,
                     "measured_with": "HIP events in the launch's own start/stop slots (hipExtLaunchKernelGGL) on the stream the kernel runs on; two-stream pipeline as in the timed region",
                     "per_kernel_wasted_traffic_ratio": {k: round(rtraffic[k] * n_batches / per_ingest[k], 2) for k in per_ingest if rtraffic.get(k) and per_ingest[k] > 0} or None,
                     "moved_points": moved, "new_voxels": new_voxels}

@@ -78,7 +78,7 @@ struct Ctl {
 	uint64_t tableLayout;              // layout_signature() of the momentary buffer the side tables were built in
 	uint64_t pointsTaken;              // samples of all batches taken so far, this launch's included (Stats.numPointsProcessed follows when their back halves have run)
 	uint64_t unused1[2];
-	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, -, rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
+	uint64_t expandNs[8];              // byte 152: k_expand phase times of workgroup 0 (in-kernel histogram pass, barrier, decide + build, barrier, [4] = groups ingested so far (bench.py), rounds, calls; tools/probe.py), [7] = spilled points so far (bench.py)
 	uint64_t voxT[SIMLOD_MAX_BATCHES_PER_LAUNCH][3];   // byte 216: k_voxelize of group #ordinal of the last launch: first workgroup in, last piece done, last workgroup out (tools/probe.py)
 	uint64_t phaseNs[48];              // byte 696: phase times of one workgroup per kernel, summed over the launches since the host last cleared them (tools/probe.py)
 	BatchCtl batch[BATCH_COPIES];
@@ -455,6 +455,16 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 			if (k + 1u == inList) tail_of(head) = c;
 			c = c->next;
 		}
+		// (a LEAF that also has a voxel list — the root while it is still a leaf samples itself, voxels.cu:449-463 —: that list's tail word too;
+		// voxroot_pieces / voxelize_small append behind it.  ADVICE r5: an image built elsewhere with fewer than 50 000 points)
+		if (leaf && n->voxelChunks != nullptr) {
+			const uint32_t inVox = (n->numVoxelsStored + SIMLOD_POINTS_PER_CHUNK - 1) / SIMLOD_POINTS_PER_CHUNK;
+			SimlodChunk* v = n->voxelChunks;
+			for (uint32_t k = 0; v != nullptr && k < max(inVox, 1u); k++) {
+				if (k + 1u >= inVox) { tail_of(n->voxelChunks) = v; break; }
+				v = v->next;
+			}
+		}
 		// the ancestors, parent first, zero-terminated
 		unsigned long long* rec = at<unsigned long long>(a, a.offPaths) + i * PATH_WORDS;
 		const uint32_t L = min(n->level, PATH_WORDS - 1u), s = (uint32_t)SIMLOD_MAX_DEPTH - L;
@@ -473,7 +483,7 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 
 __global__ __launch_bounds__(TPB) void k_begin(BuildArgs a, uint32_t momentaryTooSmall, uint32_t batchLimit, uint32_t debugFlags, uint32_t budgetUs, uint32_t groupMax) {
 	Ctl* ctl = ctl_of(a);
-	const bool stale = momentaryTooSmall != 0u || stamp_is_stale(a, ctl);
+	const bool stale = momentaryTooSmall != 0u || (debugFlags & 4u) != 0u || stamp_is_stale(a, ctl);      // (debugFlags bit 2: the host knows the image was replaced — simlod_octree_image_replaced, a reset)
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
 		const uint32_t fatal = a.stats->dbg & (SIMLOD_ERR_BARRIER_TIMEOUT | SIMLOD_ERR_DIRECTORY_FULL);   // sticky until the host resets the octree
 		ctl->errors = momentaryTooSmall ? SIMLOD_ERR_MOMENTARY_TOO_SMALL : 0u;
@@ -536,6 +546,7 @@ static constexpr uint32_t HIST_BINS = 512;
 #define HIST_SHARDS_N 4          // measured on one box, ms per 36 M ingest: 1 copy 3.69, 4 copies 3.65, 8 copies 3.79 (cycles in flight per memory-side atomic of k_hist: 2 965 / 1 150 / 846)
 #endif
 static constexpr uint32_t HIST_SHARDS = HIST_SHARDS_N, HIST_SHARDED = 256;
+static_assert(HIST_SHARDS >= 1u && (HIST_SHARDS & (HIST_SHARDS - 1u)) == 0u, "a workgroup picks its copy with blockIdx & (HIST_SHARDS - 1)");
 static constexpr uint64_t HIST_EXTRA_WORDS = (uint64_t)(HIST_SHARDS - 1u) * HIST_SHARDED * HIST_BINS;      // copies 1..3 of slots 0..255, behind the SLOT_CAP x HIST_BINS words of copy 0
 // word of (slot << 9 | bin) in copy `shard`
 __device__ __forceinline__ uint64_t hist_word(uint32_t key, uint32_t shard) {
@@ -2068,6 +2079,7 @@ __device__ void end_of_batch(const BuildArgs& a, Ctl* ctl, BatchCtl* bc) {
 		a.stats->numPointsProcessed += bc->batchSize;
 		ctl->processed += 1;
 		ctl->expandNs[7] += min(bc->numSpilled, a.spilledCap);   // measurement aid: stored points moved by splits so far (bench.py)
+		ctl->expandNs[4] += 1;                                   // ... and groups of batches ingested so far: the launches of a per-group kernel that had work (bench.py's roofline)
 		// voxels.cu:936-949: no further batch once the launch has run for 10 ms.  The front half of the next batch (or two) may be under way
 		// already; what has been prepared is completed, nothing more is prepared.
 		const float elapsedMs = (float)(wall_ns() - ctl->startNs) / 1000000.0f;
@@ -2838,7 +2850,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	// question for now (LaunchPlan::mayGroup) — one, with one group of kernels per batch
 	const uint32_t take = a.acct != 0u && !plan.mayGroup ? 1u : a.groupMax;
 	// (one workgroup does the launch's bookkeeping; all of them restore the side tables when the stamp is stale: the first launch of an octree, as a rule)
-	SIMLOD_LAUNCH(k_begin, dim3(fits ? dev.numCUs * 2 : 1u), dim3(TPB), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
+	SIMLOD_LAUNCH(k_begin, dim3(fits ? dev.numCUs * 2 : 1u), dim3(TPB), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (ctx.sideTablesStale.exchange(false) ? 4u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
 	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), take);
 	if (fits) {
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);
@@ -2904,6 +2916,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 				hipEvent_t e0, e1;
 				profile_kernel_events("k_voxelize", &e0, &e1);
 				hipExtLaunchKernelGGL(k_voxelize, dim3(voxWgs), dim3(VTPB), 0, back, e0, e1, 0, a, b);
+				{ const hipError_t e = hipGetLastError(); if (e != hipSuccess) return fail(e); }
 			} else
 			SIMLOD_LAUNCH(k_voxelize, dim3(voxWgs), dim3(VTPB), back, a, b);
 		}

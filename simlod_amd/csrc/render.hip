@@ -1552,6 +1552,7 @@ uint64_t render_buffer_bytes(uint32_t width, uint32_t height) {
 int launch_reset(Context& ctx, const SimlodUniforms* u, uint8_t* pers, SimlodNode* nodes, SimlodStats* stats, uint32_t* numBatchesUploaded,
                  uint32_t* batchSizes, hipStream_t stream) {
 	forget_leaf_table(ctx, nodes);
+	ctx.sideTablesStale.store(true);
 	uint32_t* words = nullptr; uint32_t seq = 0;
 	forget_launch_history(ctx, stats, numBatchesUploaded, &words, &seq);
 	SIMLOD_LAUNCH(k_reset, dim3(64), dim3(TPB), stream, pers, nodes, stats, numBatchesUploaded, batchSizes, (uint32_t)u->frameCounter, words, seq);

@@ -455,7 +455,9 @@ int simlod_set_ingest_mode(uint32_t mode) { return simlod_context_set_ingest_mod
 int simlod_set_construct_batch_limit(uint32_t maxBatches) { return simlod_context_set_construct_batch_limit(nullptr, maxBatches); }
 
 int simlod_octree_image_replaced(const SimlodNode* nodes) {
-	forget_leaf_table(context_of(nodes), nodes);
+	Context& ctx = context_of(nodes);
+	forget_leaf_table(ctx, nodes);
+	ctx.sideTablesStale.store(true);
 	return 0;
 }
 

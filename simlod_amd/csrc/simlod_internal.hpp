@@ -82,6 +82,7 @@ struct Context {
 	std::atomic<uint32_t> nodeCapacity{263157u};             // 40 000 000 B / 152 B, main_progressive_octree.cpp:552
 	std::atomic<uint32_t> ingestMode{0u};                    // 0 = exact (one batch at a time, the reference's granularity), 1 = coalesced
 	std::atomic<uint32_t> batchLimit{SIMLOD_MAX_BATCHES_PER_LAUNCH};   // simlod_context_set_construct_batch_limit: a launch never takes more than this many batches (<= 20)
+	std::atomic<bool>     sideTablesStale{false};                       // simlod_octree_image_replaced / a reset: the next kernel_construct rebuilds its side tables whatever the stamp in the buffer says (an uploaded image with the same counters as the one it replaces: ADVICE r5)
 	std::atomic<int>      hintPending{-1};                              // simlod_context_hint_pending_batches: that many batches are pending NOW — for the next launch, then forgotten
 	std::atomic<uint64_t> trunkLo{0u}, trunkHi{0u};          // simlod_context_set_trunk_mask: upper nodes (levels 0-2) that split whatever they hold; zero: the reference's rule alone
 	int knob[KNOB_COUNT_];

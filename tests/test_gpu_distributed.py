@@ -174,6 +174,24 @@ def test_two_ranks_on_one_gpu_partition_ingest_and_compose_frames_like_the_oracl
     single.close()
 
 
+def test_bench_started_bare_with_gpus_2_relaunches_itself_through_torch_distributed_run(built_libs):
+    """`python bench.py --gpus 2 ...` without torch.distributed.run (no WORLD_SIZE in the environment): bench.py starts itself again through
+    `python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1` and still prints ONE JSON line (a bare start used
+    to die on an assert)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "2", "--points", "3000000", "--backend", "gloo", "--one-device",
+           "--no-cpu-baseline", "--no-profile"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["collective"]["ranks_seen"] == 2
+
+
 def test_bench_n2_runs_its_multi_rank_path_with_two_processes_on_one_gpu_over_gloo(built_libs):
     """`bench.py --gpus 2` — generation per rank, partition in slices, streamed ingest of what each rank owns, composed frames with two in
     flight, max-over-ranks timing, ONE JSON line from rank 0 — launched the way the driver launches it (torch.distributed.run, one process
