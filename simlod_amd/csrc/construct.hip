@@ -100,7 +100,7 @@ struct BuildArgs {
 	uint32_t*    batchSizes;
 	float        minx, miny, minz, size;
 	uint64_t     persCapacity, frameCounter, scratchBytes;
-	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, offTop, leafOfStride;
+	uint64_t     offQueue, offSlots, offHist, offMap, offClear, offTouched, offSplitTag, offRetryTag, offParent, offNodeDir, offChunkDir, offLeafChunks, offPaths, offWork, offLeafOf, offVoxItems, offSpilled, offHashDir, offTouchTag, offStartOf, offCross, offTop, offKid, leafOfStride;
 	uint32_t     nodeCapacity, spilledCap, dirCap, workCap, voxItemCap, clearCap, hashCap, groupCap, groupMax, crossCap;   // groupCap = groupMax * 1 000 000: where the moved points' words start in leafOf
 	uint64_t     trunkLo, trunkHi;   // simlod_context_set_trunk_mask: nodes of levels 0-2 that split whatever they hold (multi-GPU: the shared upper levels); zero on one GPU
 	uint64_t     offCntB, offHistB;  // exact groups (acct): per node, samples of batch k of the group (groupMax words) | per (slot, bin), likewise
@@ -253,13 +253,23 @@ __device__ __forceinline__ uint32_t top_cell(uint32_t X, uint32_t Y, uint32_t Z)
 	return (((X >> s) & (TOP_SIDE - 1u)) << (2u * TOP_LEVEL)) | (((Y >> s) & (TOP_SIDE - 1u)) << TOP_LEVEL) | ((Z >> s) & (TOP_SIDE - 1u));
 }
 // node `idx` at `level` <= TOP_LEVEL with coordinates (X, Y, Z) becomes the entry of every cell it covers
-__device__ __forceinline__ void top_fill(uint32_t* top, uint32_t idx, uint32_t level, uint32_t X, uint32_t Y, uint32_t Z) {
-	const uint32_t k = TOP_LEVEL - level, side = 1u << k, x0 = X << k, y0 = Y << k, z0 = Z << k, e = idx | (level << 19);      // (sides are powers of two: shifts, no division)
+__device__ __forceinline__ void top_fill(uint32_t* top, uint32_t idx, uint32_t level, uint32_t X, uint32_t Y, uint32_t Z, uint32_t mark) {      // mark: TOP_LEAF for a node without children
+	const uint32_t k = TOP_LEVEL - level, side = 1u << k, x0 = X << k, y0 = Y << k, z0 = Z << k, e = idx | (level << 19) | mark;      // (sides are powers of two: shifts, no division)
 	for (uint32_t i = 0; i < (1u << (3u * k)); i++) {
 		const uint32_t dx = i >> (2u * k), dy = (i >> k) & (side - 1u), dz = i & (side - 1u);
 		top[((x0 + dx) << (2u * TOP_LEVEL)) | ((y0 + dy) << TOP_LEVEL) | (z0 + dz)] = e;
 	}
 }
+
+// Child words: ONE 32-bit word per node instead of its eight 8-byte child pointers spread over a 152-byte record — what k_count's descent reads.  A node that
+// splits gets all eight children at once, in eight consecutive node slots (voxels.cu:316-343: atomicAdd(&stats->numNodes, 8); here: k_queue / reserve()), so
+// the word holds the FIRST child's index (19 bits) and, above it, which of the eight are leaves (8 bits): a sample that steps into a child marked as a leaf
+// is done without looking at that child.  0: the node has no children.  KID_IRREGULAR: children that are not eight consecutive nodes (an image neither this
+// builder nor the reference made): that node is descended through Node.children as before.  The 36 M terrain's 4 425 nodes: 17 KB, L1-resident, against
+// 4 425 x 152 B of records of which a step used 8 bytes.  Kept current by k_expand (a node that splits clears its bit in its parent's word), restored from
+// the node array with the other side tables (rebuild_side_tables).  The top table's entries carry the same mark (TOP_LEAF).
+static constexpr uint32_t KID_IRREGULAR = 0xffffffffu, KID_LEAF_SHIFT = 19, TOP_LEAF = 0x80000000u;
+__device__ __forceinline__ uint32_t octant_of(uint32_t X, uint32_t Y, uint32_t Z) { return ((X & 1u) << 2) | ((Y & 1u) << 1) | (Z & 1u); }      // a node's place among its parent's children (voxels.cu:320-322)
 
 __device__ __forceinline__ Ctl* ctl_of(const BuildArgs& a) { return reinterpret_cast<Ctl*>(a.mom); }
 template <class T> __device__ __forceinline__ T* at(const BuildArgs& a, uint64_t off) { return reinterpret_cast<T*>(a.mom + off); }
@@ -385,6 +395,17 @@ struct Samples {
 		return ring + (size_t)bc->slot[k] * SIMLOD_MAX_BATCH_SIZE + (i - bc->start[k]);
 	}
 	__device__ __forceinline__ float4 operator[](uint32_t i) const { return *ptr(i); }
+	// Do the samples i0 .. i1 of the group lie in ONE ring batch (a workgroup's tile of consecutive samples does, as a rule: a batch has up to a million)?
+	// Then sample i is base[i] and its batch of the group is k — without a lookup per sample (the walk through start[] in front of every load was a
+	// dependent round trip in front of the kernels' first HBM access).
+	__device__ __forceinline__ bool span(uint32_t i0, uint32_t i1, const float4*& base, uint32_t& k) const {
+		k = 0; base = only;
+		if (SINGLE || batches == 1u) return true;
+		k = min(i0 / SIMLOD_MAX_BATCH_SIZE, batches - 1u);
+		while (k + 1u < batches && i0 >= bc->start[k + 1u]) k++;
+		base = ring + (size_t)bc->slot[k] * SIMLOD_MAX_BATCH_SIZE - bc->start[k];
+		return i1 < bc->start[k + 1u];
+	}
 };
 
 // what the stamp remembers of the momentary buffer's layout: side tables of another node capacity / buffer size / group size are not these
@@ -432,7 +453,7 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 			if (c == nullptr) break;
 			cur = (uint32_t)(c - a.nodes); level++;
 		}
-		at<uint32_t>(a, a.offTop)[i] = cur | (level << 19);
+		at<uint32_t>(a, a.offTop)[i] = cur | (level << 19) | (node_is_leaf(a.nodes + cur) ? TOP_LEAF : 0u);
 	}
 	for (uint64_t i = first; i < numNodes; i += stride) {
 		if (i == 0) parentOf[0] = 0xffffffffu;
@@ -441,6 +462,19 @@ __device__ void rebuild_side_tables(const BuildArgs& a) {
 		for (int k = 0; k < 8; k++) {
 			const SimlodNode* c = n->children[k];
 			if (c != nullptr) parentOf[(uint32_t)(c - a.nodes)] = (uint32_t)i;
+		}
+		{   // the node's child word
+			const SimlodNode* c0 = n->children[0];
+			uint32_t word = 0u, some = 0u;
+			bool regular = c0 != nullptr;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const SimlodNode* c = n->children[k];
+				if (c != nullptr) some++;
+				if (c == nullptr || c != c0 + k) regular = false;
+				else if (node_is_leaf(c)) word |= 1u << (KID_LEAF_SHIFT + (uint32_t)k);
+			}
+			at<uint32_t>(a, a.offKid)[i] = some == 0u ? 0u : regular ? (word | (uint32_t)(c0 - a.nodes)) : KID_IRREGULAR;
 		}
 		// a leaf's row: its point chunks; an inner node's row: its voxel chunks (for the rasteriser).  And the word this builder keeps in the spare
 		// bytes of a list's HEAD chunk, the address of the list's last chunk (O(1) append): an image built elsewhere — by the reference — has
@@ -632,16 +666,20 @@ __device__ __forceinline__ uint32_t slots_in_use(const BatchCtl* bc) {
 	return (uint32_t)(__hip_atomic_load(&bc->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> RSV_SLOT_SHIFT);
 }
 __device__ __forceinline__ bool reserve(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, uint32_t slots, uint32_t nodes, uint32_t spill, uint32_t& slotBase, uint32_t& nodeBase, uint32_t& spillBase) {
-	unsigned long long cur = __hip_atomic_load(&bc->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	for (;;) {
-		slotBase = (uint32_t)(cur >> RSV_SLOT_SHIFT); nodeBase = (uint32_t)(cur >> 32) & 0xfffffu; spillBase = (uint32_t)cur;
-		if (slotBase + slots > SLOT_CAP) { raise(ctl, SIMLOD_ERR_SPILLING_OVERFLOW); return false; }     // more leaves cross the limit at once than a batch has slots for
-		if (nodeBase + nodes > a.nodeCapacity) { raise(ctl, SIMLOD_ERR_NODES_EXHAUSTED); return false; }
-		if ((unsigned long long)spillBase + spill > a.spilledCap) { raise(ctl, SIMLOD_ERR_SPILLED_OVERFLOW); return false; }
-		const unsigned long long prev = atomicCAS(&bc->reserve, cur, cur + ((unsigned long long)slots << RSV_SLOT_SHIFT) + ((unsigned long long)nodes << 32) + spill);
-		if (prev == cur) { atomicAdd(&a.stats->numNodes, nodes); return true; }       // voxels.cu:317
-		cur = prev;
-	}
+	// ONE add on the packed word hands out the three ranges; a caller that finds any of them beyond its capacity takes its add back and fails.  While such
+	// a failed add stands, every other caller sees that field beyond its capacity too and fails as well (conservatively: the leaf stays as it is and is
+	// queued again later) — so a caller that SUCCEEDS never got its ranges on top of amounts that are taken back afterwards.  The fields have room for
+	// what can stand at once: a round has at most (group + moved samples) / 50 000 nodes that ask for a slot, and at most one cascade per workgroup
+	// (<= 8 x 72 nodes each) that asks for nodes.  (Rounds 2-5: a compare-and-swap loop — forty cascades of a group of batches queued behind each other
+	// on this word, a round trip each: 35 of k_expand's 56 us per slot.)
+	const unsigned long long inc = ((unsigned long long)slots << RSV_SLOT_SHIFT) + ((unsigned long long)nodes << 32) + spill;
+	const unsigned long long old = atomicAdd(&bc->reserve, inc);
+	slotBase = (uint32_t)(old >> RSV_SLOT_SHIFT); nodeBase = (uint32_t)(old >> 32) & 0xfffffu; spillBase = (uint32_t)old;
+	const bool okSlots = slotBase + slots <= SLOT_CAP, okNodes = nodeBase + nodes <= a.nodeCapacity, okSpill = (unsigned long long)spillBase + spill <= a.spilledCap;
+	if (okSlots && okNodes && okSpill) { atomicAdd(&a.stats->numNodes, nodes); return true; }       // voxels.cu:317
+	atomicAdd(&bc->reserve, 0ull - inc);
+	raise(ctl, !okSlots ? SIMLOD_ERR_SPILLING_OVERFLOW : !okNodes ? SIMLOD_ERR_NODES_EXHAUSTED : SIMLOD_ERR_SPILLED_OVERFLOW);      // more leaves cross the limit at once than a batch has slots for | node array full | spill space
+	return false;
 }
 
 // the occupancy grid of a node that splits in this batch: allocated if the node has none (voxels.cu:363-365), cleared in any case
@@ -883,6 +921,34 @@ static constexpr uint32_t HCPT = HIST_CPT, CPB = TPB * HCPT;         // (k_hist)
 
 static constexpr uint32_t TOUCH_CAP = 512;         // leaves one workgroup can be the first to touch in one batch (more: appended one by one)
 
+// The descents of a thread's P samples in lockstep, one level per step, through the child words (KID_*): P independent 4-byte loads in flight per step, and a
+// step into a child that its parent's word marks as a leaf ends the descent without a load of its own.
+template <int P>
+__device__ __forceinline__ void descend_kids(const SimlodNode* nodes, const uint32_t* kid, uint32_t (&cur)[P], uint32_t (&level)[P], const uint32_t (&X)[P], const uint32_t (&Y)[P],
+                                             const uint32_t (&Z)[P], bool (&walking)[P]) {
+	bool any = true;
+#pragma unroll 1
+	for (int step = 0; step < SIMLOD_MAX_DEPTH && any; ++step) {
+		uint32_t w[P];
+#pragma unroll
+		for (int j = 0; j < P; j++) w[j] = walking[j] && level[j] < (uint32_t)SIMLOD_MAX_DEPTH ? kid[cur[j]] : 0u;
+		any = false;
+#pragma unroll
+		for (int j = 0; j < P; j++) {
+			if (w[j] == 0u) { walking[j] = false; continue; }
+			const uint32_t ci = (uint32_t)child_index(X[j], Y[j], Z[j], (int)level[j]);
+			if (w[j] == KID_IRREGULAR) {                                      // (an image whose children are not eight consecutive nodes)
+				const SimlodNode* c = nodes[cur[j]].children[ci];
+				if (c == nullptr) { walking[j] = false; continue; }
+				cur[j] = (uint32_t)(c - nodes); level[j] += 1u; any = true;
+				continue;
+			}
+			cur[j] = (w[j] & LEAF_NODE_MASK) + ci; level[j] += 1u;
+			if (((w[j] >> (KID_LEAF_SHIFT + ci)) & 1u) != 0u) walking[j] = false; else any = true;
+		}
+	}
+}
+
 template <uint32_t BT, bool SINGLE>
 __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	constexpr uint32_t CPB = BT * CPT;
@@ -950,10 +1016,12 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 	}
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 		float4 p[CPT];
+		const float4* base; uint32_t kspan;
+		const bool oneBatch = pts.span(chunk * CPB, min(n, (chunk + 1u) * CPB) - 1u, base, kspan);      // (workgroup-uniform)
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
 			const uint32_t i = chunk * CPB + j * BT + threadIdx.x;
-			p[j] = i < n ? pts[i] : make_float4(0, 0, 0, 0);
+			p[j] = i < n ? (oneBatch ? base[i] : pts[i]) : make_float4(0, 0, 0, 0);
 		}
 		// the eight descents of a thread in lockstep, one level per step: eight L2 round trips in flight instead of eight chains of 5-8
 		// dependent loads one after the other (that was the kernel: 21 us)
@@ -970,9 +1038,9 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 #pragma unroll
 			for (uint32_t j = 0; j < CPT; j++) e[j] = walking[j] ? top[top_cell(X[j], Y[j], Z[j])] : 0u;
 #pragma unroll
-			for (uint32_t j = 0; j < CPT; j++) { cur[j] = e[j] & LEAF_NODE_MASK; level[j] = e[j] >> 19; }
+			for (uint32_t j = 0; j < CPT; j++) { cur[j] = e[j] & LEAF_NODE_MASK; level[j] = (e[j] >> 19) & 31u; walking[j] = walking[j] && (e[j] & TOP_LEAF) == 0u; }
 		}
-		descend_lockstep<(int)CPT>(a.nodes, cur, level, X, Y, Z, walking);
+		descend_kids<(int)CPT>(a.nodes, at<const uint32_t>(a, a.offKid), cur, level, X, Y, Z, walking);
 #pragma unroll
 		for (uint32_t j = 0; j < CPT; j++) {
 			const uint32_t i = chunk * CPB + j * BT + threadIdx.x;
@@ -981,7 +1049,7 @@ __global__ __launch_bounds__(BT) void k_count(BuildArgs a, uint32_t ordinal) {
 			leafOf.grp[i] = leafIdx | (bin_of(X[j], Y[j], Z[j], level[j]) << LEAF_BIN_SHIFT);      // the bin is what k_hist needs should this leaf split: it never reads the sample
 			// (no room in the workgroup's table — a batch scattered over more leaves than it has keys —: the leaf's counters directly, one sample after the
 			// other.  Round 5 measured all of a thread's spilled samples with their loads and adds in flight together: config 5 went from 60 to 71 ms)
-			const uint32_t kb = acct ? batch_of_sample(bc, i) : 0u;                                   // (an exact group: counts per leaf AND batch)
+			const uint32_t kb = !acct ? 0u : oneBatch ? kspan : batch_of_sample(bc, i);              // (an exact group: counts per leaf AND batch)
 			if (!spread_add(tbl, leafIdx | (kb << LEAF_BIN_SHIFT), threadIdx.x & (REP - 1u))) {
 				counted(leafIdx, count_into(a, bc, leafIdx, 1u));
 				if (acct) atomicAdd(cntB + (uint64_t)leafIdx * a.groupMax + kb, 1u);
@@ -1050,27 +1118,32 @@ __device__ __forceinline__ VoxItem* vox_items(const BuildArgs& a, const BatchCtl
 //   phase 2, all waves, one NEW CHUNK per lane: fetch it (stack or fresh memory), link it, enter it in the chunk directory and the leaf
 //     chunk table.  A leaf the batch has filled from nothing needs 50 chunks; taken one after the other by the leaf's lane that was 50
 //     dependent round trips (the whole of round 2's allocation kernel: 13 us), taken side by side it is two.
-static constexpr uint32_t ALLOC_LEAVES = 64;
+#ifndef ALLOC_WAVES_N
+#define ALLOC_WAVES_N 1      /* (8: a wave per 64 leaves — measured: no gain, k_expand's build phase is not bound by this loop; and a fault in plain exact mode with the trunk mask that was not understood) */
+#endif
+static constexpr uint32_t ALLOC_WAVES = ALLOC_WAVES_N, ALLOC_LEAVES = 64 * ALLOC_WAVES;      // leaves per call: a wave per 64 (a group of several batches hands a cascade's 584 nodes over at once: one wave took nine turns, 45 us of k_expand's 61 per slot)
 struct AllocRec {
 	uint32_t node, existing, additional, fromPool;
 	uint32_t dirNew, prefix;                                // directory entry of the leaf's first new chunk | new chunks of the lanes below
 	unsigned long long firstIdx, mem;                       // recycle-stack index of the first new chunk | memory of the first one the stack could not serve
 	SimlodChunk* head; SimlodChunk* tail;                   // the list as it is (nullptr: empty)
 };
-struct AllocShared { AllocRec rec[ALLOC_LEAVES]; uint32_t total; };
+struct AllocShared { uint32_t waveTotal[ALLOC_WAVES]; };
 struct FreshLeaf { uint32_t node, samples, level, X, Y, Z; };      // a leaf a cascade has just made: what alloc_points would otherwise read back from the node it was written to a moment ago
 
 // Entry k is taken when firstEntry + lane < numEntries.  `touched` (global memory): the leaves k_count found new samples for — what
 // each held when the batch began comes from stored_at_start().  `fresh` (LDS): {node, samples} of the empty leaves a cascade has
 // just made (nothing about them has to be read back).  One of the two lists is given.
-__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, const uint32_t* touched, const FreshLeaf* fresh, uint32_t firstEntry, uint32_t numEntries) {
+// (rec: ALLOC_LEAVES records in LDS — k_expand lends the words of its hash table)
+__device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocShared& sh, AllocRec* rec, const uint32_t* touched, const FreshLeaf* fresh, uint32_t firstEntry, uint32_t numEntries) {
 	const bool fresh_leaves = fresh != nullptr;
 	NodeDir* nodeDir = at<NodeDir>(a, a.offNodeDir);
 	SimlodChunk** chunkDir = chunk_dir(a, bc);
 	SimlodChunk** chunkQueue = at<SimlodChunk*>(a, a.offQueue);
 	uint8_t* const leafChunks = a.mom + a.offLeafChunks;
-	if (threadIdx.x < 64u) {
-		const uint32_t lane = threadIdx.x;
+	if (threadIdx.x < 64u * ALLOC_WAVES) {
+		const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+		firstEntry += wv * 64u;                                         // (this wave's 64 entries)
 		// (Node.numPoints is not looked at: the back half of the batch before may still be advancing it)
 		const unsigned long long pool = a.stats->chunkPoolSize;         // raised only by prepare_batch, between the groups' allocations (asked for here: in flight beside everything below)
 		FreshLeaf fl = FreshLeaf{NONE, 0u, 0u, 0u, 0u, 0u};
@@ -1130,7 +1203,7 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 			if (totAdditional != 0u) chunkBase = atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats->numAllocatedChunks), (unsigned long long)totAdditional);
 			if (totPieces != 0u) itemBase = atomicAdd(&bc->numVoxItems, totPieces);
 			if (totSmall != 0u) smallBase = atomicAdd(&bc->numVoxSmall, totSmall);
-			sh.total = totAdditional;
+			sh.waveTotal[wv] = totAdditional;
 		}
 		dirBase = (uint32_t)__shfl((int)dirBase, 0, 64); itemBase = (uint32_t)__shfl((int)itemBase, 0, 64); smallBase = (uint32_t)__shfl((int)smallBase, 0, 64);
 		chunkBase = shfl64(chunkBase, 0);
@@ -1157,17 +1230,20 @@ __device__ void alloc_points(const BuildArgs& a, Ctl* ctl, BatchCtl* bc, AllocSh
 			if (pieces == 0u) for (uint32_t q = 0; q < small; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_SMALL_PIECE, min(stored + (q + 1u) * VOX_SMALL_PIECE, counter), base, first};
 			else for (uint32_t q = 0; q < pieces; q++) items[itemAt + q] = VoxItem{i | nl << 24, stored + q * VOX_PIECE, min(stored + (q + 1u) * VOX_PIECE, counter), base, first};
 		}
-		AllocRec& r = sh.rec[lane];
+		AllocRec& r = rec[threadIdx.x];
 		r.node = i; r.existing = existing; r.additional = ok ? additional : 0u; r.fromPool = fromPool; r.dirNew = base + e; r.prefix = exAdditional;
 		r.firstIdx = firstIdx; r.mem = mem; r.head = head; r.tail = tail;
 	}
 	__syncthreads();
 	// phase 2: new chunk q of the workgroup = chunk k of the leaf whose prefix covers q
-	const uint32_t total = sh.total;
-	for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
-		uint32_t lo = 0, hi = ALLOC_LEAVES;                              // the last leaf with prefix <= q (leaves without new chunks share their successor's prefix)
-		while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (sh.rec[mid].prefix <= q) lo = mid; else hi = mid; }
-		const AllocRec r = sh.rec[lo];
+	uint32_t total = 0;
+	for (uint32_t w = 0; w < ALLOC_WAVES; w++) total += sh.waveTotal[w];
+	for (uint32_t q0 = threadIdx.x; q0 < total; q0 += blockDim.x) {
+		uint32_t q = q0, wv = 0;                                         // the wave whose leaves new chunk q0 belongs to, and its number among that wave's
+		while (wv + 1u < ALLOC_WAVES && q >= sh.waveTotal[wv]) { q -= sh.waveTotal[wv]; wv++; }
+		uint32_t lo = wv * 64u, hi = lo + 64u;                           // the last leaf with prefix <= q (leaves without new chunks share their successor's prefix)
+		while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (rec[mid].prefix <= q) lo = mid; else hi = mid; }
+		const AllocRec r = rec[lo];
 		const uint32_t k = q - r.prefix;
 		if (k >= r.additional) continue;                                 // (a leaf that could not be served: its reservation stays unused)
 		auto chunk_at = [&](uint32_t j) -> SimlodChunk* {
@@ -1229,7 +1305,12 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 		if (acct) key |= kb << ACCT_BATCH_SHIFT;
 		if (table_add(tbl, key, 1u, &rank) < 0) flush(key, 1u);
 	};
+	const Samples<false> grp(a, bc);
 	for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+		// (an exact group: which batch of the group the tile's samples belong to — one lookup per tile where the tile lies in one batch)
+		const float4* unusedBase; uint32_t kspan = 0;
+		const uint32_t e0 = max(chunk * CPB, moved), e1 = min(total, (chunk + 1u) * CPB);
+		const bool oneBatch = acct && e0 < e1 && grp.span(e0 - moved, e1 - 1u - moved, unusedBase, kspan);      // (workgroup-uniform)
 		// stage by stage, eight elements per thread.  A SAMPLE of the group is never read here: its word holds the leaf k_count found and the
 		// bin below that leaf (node | bin << 19) — if the leaf was queued, the word becomes FLAG | slot | bin and the bin is counted.  A STORED
 		// point of a queued leaf is read, binned and moved to the spill buffer.
@@ -1257,7 +1338,7 @@ __global__ __launch_bounds__(TPB) void k_hist(BuildArgs a, uint32_t ordinal) {
 			const uint32_t key = (((uint32_t)info[j] & 0xffffu) << 9) | (v[j] >> LEAF_BIN_SHIFT);
 			const uint32_t i = chunk * CPB + j * TPB + threadIdx.x - moved;
 			leafOf.grp[i] = LEAF_FLAG | key;
-			add(key, acct ? batch_of_sample(bc, i) : 0u);
+			add(key, !acct ? 0u : oneBatch ? kspan : batch_of_sample(bc, i));
 		}
 #pragma unroll
 		for (uint32_t j = 0; j < HCPT; j++) {
@@ -1317,7 +1398,10 @@ static constexpr uint32_t ACCT_MAX_GROUP = 12;     // batches an exact group can
 static constexpr uint32_t NEVER = 0xffu;
 
 struct ExpandShared {
-	uint32_t keys[HT_CAP], vals[HT_CAP];           // H: (slot << 9 | bin) -> count.  D, exact groups: rows of per-batch counts (keys and vals as one array: acct_rows)
+	union {
+		struct { uint32_t keys[HT_CAP], vals[HT_CAP]; };      // H: (slot << 9 | bin) -> count.  D, exact groups: rows of per-batch counts (keys and vals as one array: acct_rows)
+		AllocRec allocRec[ALLOC_LEAVES];                       // ... and, when those are done with, alloc_points' records
+	};
 	uint32_t bins[HIST_BINS], c2[64], c1[8];
 	uint32_t base2[8], base3[64];                  // first child of split child j / grandchild jk
 	uint32_t listed[LOCAL_NODES];                  // map entry override of a node that got a slot for the next round, or NONE
@@ -1326,7 +1410,11 @@ struct ExpandShared {
 	uint8_t nameL[20];
 	SimlodOccupancyGrid* gridL;
 	uint32_t numFresh, numFill;
-	uint4 fill[8 + 64];                            // new leaves at level <= 3 whose cells of the top table the whole workgroup fills: {node | level << 19, X, Y, Z}
+	// new leaves at level <= 3 whose cells of the top table the whole workgroup fills: {node | level << 19, X, Y, Z}.  The ROOT's cascade can make all of its
+	// 8 + 64 + 512 nodes such leaves (rounds 3-6 had 72 entries here: a terrain's first batch lists ~120, the entries beyond the array landed in whatever
+	// followed it — alloc_points' records while those stood there, harmlessly; the grids' pointers once they did not: a wild pointer in a path entry, a fault
+	// in k_voxelize once in a hundred ingests)
+	uint4 fill[LOCAL_NODES];
 	AllocShared alloc;
 	SimlodOccupancyGrid* grid[8 + 64];             // grids of the children / grandchildren that split here
 	unsigned long long pathL[PATH_WORDS];          // the slot node's own ancestor path
@@ -1371,6 +1459,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 	BatchCtl* bc = batch_of(ctl, ordinal);
 	if (bc == nullptr || ctl->abortBatch) return;
 	__shared__ ExpandShared sh;
+	static_assert(sizeof(AllocRec) * ALLOC_LEAVES <= sizeof(uint32_t) * 2u * HT_CAP, "alloc_points' records in the hash table's words");
 	{
 		// The chunks of the leaves that k_count found new samples for and that do not split (voxels.cu:485-538 allocatePointChunks; the nodes of
 		// a cascade get theirs below, from the workgroup that builds them): 64 leaves per list, list #k to the k-th workgroup FROM THE END —
@@ -1379,7 +1468,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 		const uint32_t allocBlocks = (numTouched + ALLOC_LEAVES - 1) / ALLOC_LEAVES;
 		for (uint32_t blk = gridDim.x - 1u - blockIdx.x; blk < allocBlocks; blk += gridDim.x) {
 			__syncthreads();
-			alloc_points(a, ctl, bc, sh.alloc, at<const uint32_t>(a, a.offTouched), nullptr, blk * ALLOC_LEAVES, numTouched);
+			alloc_points(a, ctl, bc, sh.alloc, sh.allocRec, at<const uint32_t>(a, a.offTouched), nullptr, blk * ALLOC_LEAVES, numTouched);
 		}
 		__syncthreads();
 	}
@@ -1390,6 +1479,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 
 	const LeafWords leafOf(a, ordinal);
 	uint32_t* parentOf = at<uint32_t>(a, a.offParent);
+	uint32_t* kidOf = at<uint32_t>(a, a.offKid);
 	unsigned long long* paths = at<unsigned long long>(a, a.offPaths);
 	SlotRec* slots = slot_recs(a, ordinal);
 	uint32_t* hist = at<uint32_t>(a, a.offHist);
@@ -1680,6 +1770,9 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				SimlodNode& c = a.nodes[idx];
 				const uint32_t firstChild = !split ? 0u : t < 8u ? sh.base2[t] : sh.base3[t - 8u];
 				for (uint32_t k = 0; k < 8; k++) c.children[k] = split ? a.nodes + firstChild + k : nullptr;
+				// its child word: the first child and which of the eight stay leaves in this round (a child's children: t < 8: local nodes 8 + 8 t + k, whose
+				// splits are bits 8 t + k of mask2; the great-grandchildren never split in the round that makes them)
+				kidOf[idx] = !split ? 0u : firstChild | ((t < 8u ? ~(uint32_t)(mask2 >> (8u * t)) & 0xffu : 0xffu) << KID_LEAF_SHIFT);
 				uint32_t counter = countOf(t);
 				if (acct) {
 					// what the node held after the batch in which it split (later batches of the group went past it, voxels.cu:169-187); a great-grandchild
@@ -1724,11 +1817,20 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				// the top table (where k_count's descent starts): a new node at level <= 5 that has no children in the table's range takes over the cells it covers
 				// (a node two or more levels above the table's — 64 to 4096 cells, the first batches over a region — is filled by the whole workgroup, below)
 				if (level <= TOP_LEVEL && (!split || level == TOP_LEVEL)) {
-					if (TOP_LEVEL - level <= 1u) top_fill(at<uint32_t>(a, a.offTop), idx, level, X, Y, Z);
-					else sh.fill[atomicAdd(&sh.numFill, 1u)] = make_uint4(idx | (level << 19), X, Y, Z);
+					const uint32_t mark = split ? 0u : TOP_LEAF;
+					if (TOP_LEVEL - level <= 1u) top_fill(at<uint32_t>(a, a.offTop), idx, level, X, Y, Z, mark);
+					else sh.fill[atomicAdd(&sh.numFill, 1u)] = make_uint4(idx | (level << 19) | mark, X, Y, Z);
 				}
 			}
 			if (t == 0u) {
+				// the slot node's child word; it is no leaf any more: its bit in its parent's word goes (siblings may be splitting in other workgroups: an atomic;
+				// the parent's word was written by an earlier launch or an earlier round), and a top-table entry that names it (a node at the table's level) loses its mark
+				kidOf[L] = rec.childBase | ((~mask1 & 0xffu) << KID_LEAF_SHIFT);
+				if (L != 0u) {
+					const uint32_t P = parentOf[L];
+					if (P != NONE && kidOf[P] != KID_IRREGULAR) atomicAnd(&kidOf[P], ~(1u << (KID_LEAF_SHIFT + octant_of(sh.LX, sh.LY, sh.LZ))));
+				}
+				if (l == TOP_LEVEL) at<uint32_t>(a, a.offTop)[(sh.LX << (2u * TOP_LEVEL)) | (sh.LY << TOP_LEVEL) | sh.LZ] = L | (l << 19);
 				a.nodes[L].numPoints = 0; a.nodes[L].points = nullptr;          // voxels.cu:359-360 (its points are in the spill buffer, its chunks on the recycle stack: k_queue, k_hist)
 				if (acct && rec.born == NONE) a.nodes[L].counter = sh.counterAt[LOCAL_NODES];      // (k_count added the whole group's samples: the batches after the split went to the children)
 			}
@@ -1747,7 +1849,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			}
 			for (uint32_t j = 0; j < sh.numFill; j++) {                          // the top table's cells under the big new leaves, all threads
 				const uint4 f = sh.fill[j];
-				const uint32_t flevel = f.x >> 19, k = TOP_LEVEL - flevel, side = 1u << k;
+				const uint32_t flevel = (f.x >> 19) & 31u, k = TOP_LEVEL - flevel, side = 1u << k;
 				uint32_t* top = at<uint32_t>(a, a.offTop);
 				for (uint32_t i = t; i < (1u << (3u * k)); i += ETPB) {
 					const uint32_t dx = i >> (2u * k), dy = (i >> k) & (side - 1u), dz = i & (side - 1u);
@@ -1755,7 +1857,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				}
 			}
 			for (uint32_t first = 0; first < sh.numFresh; first += ALLOC_LEAVES) {
-				alloc_points(a, ctl, bc, sh.alloc, nullptr, sh.fresh, first, sh.numFresh);
+				alloc_points(a, ctl, bc, sh.alloc, sh.allocRec, nullptr, sh.fresh, first, sh.numFresh);
 				__syncthreads();
 			}
 		}
@@ -2613,10 +2715,12 @@ __global__ __launch_bounds__(TPB) void k_insert(BuildArgs a, uint32_t ordinal) {
 		ph.mark(pb + 3);
 		for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
 			float4 p[PPT];
+			const float4* base = nullptr; uint32_t kspan;
+			const bool oneBatch = chunk * PPB < n && pts.span(chunk * PPB, min(n, (chunk + 1u) * PPB) - 1u, base, kspan);      // (workgroup-uniform)
 #pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
 				const uint32_t t = chunk * PPB + j * TPB + threadIdx.x;
-				p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? pts[t] : spilled[t - n]);
+				p[j] = t >= total ? make_float4(0, 0, 0, 0) : (t < n ? (oneBatch ? base[t] : pts[t]) : spilled[t - n]);
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < PPT; j++) {
@@ -2743,6 +2847,7 @@ bool layout_construct(BuildArgs& a, uint64_t capacity, bool coalesce, uint32_t g
 	a.offLeafChunks = off; off += (uint64_t)a.nodeCapacity * LEAF_ROW_BYTES;
 	a.offPaths = off; off += align_up((uint64_t)a.nodeCapacity * PATH_WORDS * 8, 256);
 	a.offTop = off;   off += align_up((uint64_t)TOP_CELLS * 4, 256);
+	a.offKid = off;   off += align_up((uint64_t)a.nodeCapacity * 4, 256);
 	a.voxItemCap = min(a.nodeCapacity + 2u * VOX_BIG_ITEMS, 1u << 20);         // VOX_BIG_ITEMS pieces + small items: a leaf has one more than its new samples / 128, and 65 536 x 128 = 8 M samples
 	a.offVoxItems = off; off += align_up(2ull * a.voxItemCap * sizeof(VoxItem), 256);   // (two copies, by batch parity)
 	// what is left is shared by the per-sample arrays: the 4-byte cached-leaf word of the group's and of the moved samples, 16 B per moved point.

@@ -29,6 +29,8 @@ def _device(**kw):
     if "SIMLOD_TEST_MOMENTARY_MB" in os.environ:
         kw.setdefault("momentary_bytes", int(os.environ["SIMLOD_TEST_MOMENTARY_MB"]) * 1_000_000)
     kw.setdefault("max_pixels", 1920 * 1080)
+    if os.environ.get("SIMLOD_TEST_COALESCE") == "1":      # (debugging aid: the same tests in coalesced mode — only those that do not compare granularity-dependent counters can pass)
+        kw["coalesce"] = True
     dev = DeviceOctree("cuda:0", **kw)
     # The reference host never clears its momentary / render / persistent buffers (main_progressive_octree.cpp:549-586 only
     # cuMemAlloc's them): poison them so that any kernel that trusts bytes it did not write itself faults or miscompares here.
