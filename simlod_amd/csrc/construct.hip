@@ -1570,6 +1570,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 		__syncthreads();
 
 		// -- D: decide and build ---------------------------------------------------------------------------------------------
+		Phase pd(ctl, blockIdx.x == 0);      // (measure builds: slots 32..39 of Ctl.phaseNs — where workgroup 0's D phase goes; tools/probe.py)
 		for (uint32_t s = sb + blockIdx.x; s < se; s += gridDim.x) {
 			const uint32_t t = threadIdx.x;
 			const uint32_t myBin = t < HIST_BINS ? hist_sum(hist, (uint64_t)s * HIST_BINS + t) : 0u;      // (needs the slot's number only: in flight beside its record)
@@ -1639,6 +1640,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				if (t == 0) { sh.mask1 = mask1; sh.mask2 = mask2; }
 			}
 			__syncthreads();
+			pd.mark(32);      // histograms in, counts summed, splits decided, node slots reserved
 			const uint32_t mask1 = sh.mask1;
 			const unsigned long long mask2 = sh.mask2;
 			// local node t: does it exist, how many samples, does it split here
@@ -1733,6 +1735,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				}
 				__syncthreads();
 			}
+			pd.mark(33);      // exact groups: when every node split, chunks taken and returned per batch
 			if (t < LOCAL_NODES && exists(t)) {
 				const uint32_t level = l + local_depth(t);
 				if (splits(t)) sh.grid[t] = grid_for_split(a, bc);
@@ -1756,6 +1759,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 				}
 			}
 			__syncthreads();
+			pd.mark(34);      // grids, slots of the next round
 			if (t < LOCAL_NODES && exists(t)) {
 				const uint32_t depth = local_depth(t), level = l + depth, idx = indexOf(t);
 				// octants chosen below L, first to last
@@ -1843,6 +1847,7 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 			}
 			// ... and their chunks, 64 leaves at a time (voxels.cu:485-538; the nodes written above are this workgroup's own stores: visible after the barrier)
 			__syncthreads();
+			pd.mark(35);      // nodes, paths, map
 			if (acct && t < GB) {
 				if (sh.accD[t] != 0u) atomicAdd(&bc->acctD[t], sh.accD[t]);
 				if (sh.accF[t] != 0u) atomicAdd(&bc->acctF[t], sh.accF[t]);
@@ -1856,10 +1861,13 @@ __global__ __launch_bounds__(ETPB) void k_expand(BuildArgs a, uint32_t ordinal) 
 					top[(((f.y << k) + dx) << (2u * TOP_LEVEL)) | (((f.z << k) + dy) << TOP_LEVEL) | ((f.w << k) + dz)] = f.x;
 				}
 			}
+			pd.mark(36);      // top table
 			for (uint32_t first = 0; first < sh.numFresh; first += ALLOC_LEAVES) {
 				alloc_points(a, ctl, bc, sh.alloc, sh.allocRec, nullptr, sh.fresh, first, sh.numFresh);
 				__syncthreads();
 			}
+			pd.mark(37);      // the fresh leaves' chunks
+			if (pd.on) { ctl->phaseNs[38] += sh.numFresh; ctl->phaseNs[39] += 1; }
 		}
 		if (timer) { t1 = wall_ns(); ctl->expandNs[2] += t1 - t0; t0 = t1; ctl->expandNs[5] += 1; }
 		if (!more) break;

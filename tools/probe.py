@@ -81,6 +81,8 @@ for var in args.variants:
     f = lambda lo, n, cnt: " ".join(f"{ph[lo + i] / 1e3 / max(ph[cnt], 1):5.1f}" for i in range(n))
     print(f"    us per call, one workgroup: k_count [main loop, flush, queue_split] {f(0, 3, 3)} | k_hist [loop, flush] {f(4, 2, 6)} | k_insert wg0 [alloc, clear, count, reserve, wait, store] {f(8, 6, 14)}"
           f" | k_insert last wg {f(16, 6, 22)} | k_voxelize wg0 per piece [item+path+chunks, cubes+samples, level 1, levels 2+, write-back, reserve+chunks, store] {f(24, 7, 31)}", flush=True)
+    if ph[39] > 0:
+        print(f"    k_expand wg0 per slot us [hist+decide+reserve, acct timing, grids+next slots, nodes+paths+map, top table, fresh leaves' chunks] {f(32, 6, 39)}; fresh leaves per slot {ph[38] / ph[39]:5.1f}; slots (wg0) {int(ph[39])}", flush=True)
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
