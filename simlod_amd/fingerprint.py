@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def csrc_sha16(root=ROOT):
     files = sorted(glob.glob(os.path.join(root, "simlod_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "simlod_amd", "csrc", "*.hpp")) +
-                   glob.glob(os.path.join(root, "simlod_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(root, "include", "*.h")))
+                   glob.glob(os.path.join(root, "simlod_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(root, "simlod_amd", "csrc", "*.inc")) + glob.glob(os.path.join(root, "include", "*.h")))
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())
