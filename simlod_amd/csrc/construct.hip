@@ -194,7 +194,7 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 	// question for now (LaunchPlan::mayGroup) — one, with one group of kernels per batch
 	const uint32_t take = a.acct != 0u && !plan.mayGroup ? 1u : a.groupMax;
 	// (one workgroup does the launch's bookkeeping; all of them restore the side tables when the stamp is stale: the first launch of an octree, as a rule)
-	SIMLOD_LAUNCH(k_begin, dim3(fits ? dev.numCUs * 2 : 1u), dim3(TPB), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (ctx.sideTablesStale.exchange(false) ? 4u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
+	SIMLOD_LAUNCH(k_begin, dim3(fits ? dev.numCUs * 2 : 1u), dim3(TPB), stream, a, fits ? 0u : 1u, limit, ((uint32_t)ctx.tune(KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, 0) & 1u) | (ctx.tune(KNOB_DEBUG_VOXELIZE_CLOCK, 0) != 0 ? 2u : 0u) | (ctx.sideTablesStale.exchange(false) ? 4u : 0u) | (ctx.tune(KNOB_DEBUG_IRREGULAR_CHILDREN, 0) != 0 ? 8u : 0u) | (((uint32_t)ctx.tune(KNOB_DEBUG_PHASE_WG, 0) & 0xffffu) << 8),
 	              (uint32_t)std::max(0, ctx.tune(KNOB_DEBUG_BUDGET_US, 0)), take);
 	if (fits) {
 		const uint32_t gridPoints = dev.numCUs * (uint32_t)ctx.tune(KNOB_GRID_MULT, 8);

@@ -20,7 +20,7 @@ namespace simlod {
 const char* const KNOB_NAMES[KNOB_COUNT_] = {
 	"SIMLOD_OVERLAP_TAIL", "SIMLOD_EXPAND_WGS", "SIMLOD_GRID_MULT", "SIMLOD_COUNT_TPB", "SIMLOD_VOXELIZE_WGS", "SIMLOD_ADAPTIVE_GROUPS",
 	"SIMLOD_RASTER_LEAF_TABLE", "SIMLOD_RASTER_LDS_TILES", "SIMLOD_DRAW_MULT", "SIMLOD_RASTER_FUSED_RESOLVE",
-	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US", "SIMLOD_GROUP_BATCHES", "SIMLOD_DEBUG_PHASE_WG", "SIMLOD_EVENT_SYSTEM_FENCE", "SIMLOD_RASTER_SCREEN_BINS", "SIMLOD_DEBUG_BIN_POOL", "SIMLOD_EXACT_GROUP",
+	"SIMLOD_DEBUG_FORCE_BARRIER_TIMEOUT", "SIMLOD_DEBUG_VOXELIZE_CLOCK", "SIMLOD_DEBUG_BUDGET_US", "SIMLOD_GROUP_BATCHES", "SIMLOD_DEBUG_PHASE_WG", "SIMLOD_EVENT_SYSTEM_FENCE", "SIMLOD_RASTER_SCREEN_BINS", "SIMLOD_DEBUG_BIN_POOL", "SIMLOD_EXACT_GROUP", "SIMLOD_DEBUG_IRREGULAR_CHILDREN",
 };
 
 static std::atomic<uint32_t> g_liveContexts{0};

@@ -63,7 +63,7 @@ __host__ __device__ inline uint64_t table_signature(const SimlodStats* s) {
 enum Knob : int {
 	KNOB_OVERLAP_TAIL, KNOB_EXPAND_WGS, KNOB_GRID_MULT, KNOB_COUNT_TPB, KNOB_VOXELIZE_WGS, KNOB_ADAPTIVE_GROUPS,
 	KNOB_RASTER_LEAF_TABLE, KNOB_RASTER_LDS_TILES, KNOB_DRAW_MULT, KNOB_RASTER_FUSED_RESOLVE,
-	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_GROUP_BATCHES, KNOB_DEBUG_PHASE_WG, KNOB_EVENT_SYSTEM_FENCE, KNOB_RASTER_SCREEN_BINS, KNOB_DEBUG_BIN_POOL, KNOB_EXACT_GROUP, KNOB_COUNT_
+	KNOB_DEBUG_FORCE_BARRIER_TIMEOUT, KNOB_DEBUG_VOXELIZE_CLOCK, KNOB_DEBUG_BUDGET_US, KNOB_GROUP_BATCHES, KNOB_DEBUG_PHASE_WG, KNOB_EVENT_SYSTEM_FENCE, KNOB_RASTER_SCREEN_BINS, KNOB_DEBUG_BIN_POOL, KNOB_EXACT_GROUP, KNOB_DEBUG_IRREGULAR_CHILDREN, KNOB_COUNT_
 };
 static constexpr int KNOB_UNSET = INT_MIN;
 extern const char* const KNOB_NAMES[KNOB_COUNT_];            // "SIMLOD_OVERLAP_TAIL", ...

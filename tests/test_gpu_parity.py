@@ -98,6 +98,53 @@ def test_construct_full_batches_match_oracle(built_libs, kind, n, batch):
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), kind)
 
 
+def test_a_root_cascade_with_over_a_hundred_upper_leaves_again_and_again(built_libs):
+    """The first batch of a small terrain splits the root three levels deep in one round: ~120 of the cascade's nodes are leaves at level <= 3, whose cells of
+    the top table the whole workgroup fills from a list in LDS.  Rounds 3-6 gave that list 72 entries; the rest landed on the grid pointers behind it, and once
+    in a hundred ingests a path entry got a wild grid address (a memory fault in k_voxelize; found by tools/stress_small.py).  Forty fresh, poisoned octrees:
+    every one must end as the first did."""
+    pts, box = synthetic.terrain(1_500_000, seed=3, box=(600.0, 400.0, 40.0), tile=50.0)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    first = None
+    for _ in range(40):
+        dev = _device(ring_slots=2)
+        u = dev.uniforms(W, H, T, box)
+        _ingest(dev, u, [pts[:1_000_000], pts[1_000_000:]])
+        ds = dev.read_stats()
+        got = {f: int(ds[f]) for f in STATS_BUILD_FIELDS}
+        assert int(ds["dbg"]) == 0
+        first = first or got
+        assert got == first
+    nodes, pers, nn = host_image_of(dev)
+    upper_leaves = int(((nodes["level"][:nn] <= 3) & (nodes["children"][:nn] == 0).all(axis=1)).sum())
+    assert upper_leaves > 72, f"the case must list more upper leaves than the old array held ({upper_leaves})"
+    oracle.check_invariants(nodes, nn)
+
+
+@pytest.mark.parametrize("kind,n,batch", [("terrain", 6_000_000, 1_000_000), ("hotspot", 3_000_000, 400_000)])
+def test_descent_through_node_children_where_the_child_words_say_irregular(built_libs, kind, n, batch):
+    """k_count descends through one 32-bit word per node (first child + which children are leaves: eight consecutive node slots, as the reference's
+    and this builder's splits make them, voxels.cu:316-343).  An image whose children are NOT eight consecutive nodes gets KID_IRREGULAR words and is
+    descended through Node.children as before round 6; SIMLOD_DEBUG_IRREGULAR_CHILDREN marks every inner node so: same octree, same counters."""
+    pts, box = {"terrain": lambda: synthetic.terrain(n, seed=7), "hotspot": lambda: synthetic.hotspot(n, seed=11)}[kind]()
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = _device(ring_slots=8)
+    dev.tune("SIMLOD_DEBUG_IRREGULAR_CHILDREN", 1)
+    try:
+        u = dev.uniforms(W, H, T, box)
+        _ingest(dev, u, [pts[i:i + batch] for i in range(0, n, batch)])
+    finally:
+        dev.tune("SIMLOD_DEBUG_IRREGULAR_CHILDREN", None)
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts, batch)
+    ds = dev.read_stats()
+    assert int(ds["dbg"]) == 0
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, kind)
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), kind)
+
+
 @pytest.mark.parametrize("total,first,batch", [(4_000_000, 2_000_000, 500_000), (90_000, 30_000, 15_000)])
 def test_ingest_continues_into_an_image_this_library_did_not_build(built_libs, total, first, batch):
     """An octree image as another implementation leaves it — the reference's kernel_construct, say —: the momentary buffer knows nothing of it (no stamp,
