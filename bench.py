@@ -59,6 +59,7 @@ def parse():
                                                        "profiles/r*/ — and only while its fingerprint.json names the kernel sources of THIS tree (simlod_amd/fingerprint.py)")
     ap.add_argument("--coalesce", action="store_true", help="opt-in coalesced ingest (simlod_set_ingest_mode(1)): all pending batches of a launch as one")
     ap.add_argument("--momentary-mb", type=int, default=None, help="size of kernel_construct's momentary buffer (the reference host gives 300 MB)")
+    ap.add_argument("--persistent-gb", type=int, default=64, help="size of the persistent buffer (the reference host takes 80 %% of the free device memory)")
     ap.add_argument("--order", choices=["shuffled", "scan"], default="shuffled",
                     help="record order of the synthetic terrain: shuffled inside 250 m tiles (default, the harder case) or scan-line order as in a LAS file")
     a = ap.parse_args()
@@ -145,13 +146,16 @@ def main():
     batch = abi.MAX_BATCH_SIZE
     partition = None
     source = None                          # N>1 / --stream: the rank's points, resident on the device, streamed through the ring every step
-    persistent_bytes = max(8 << 30, 48 * n_points)
+    # the persistent buffer: the reference host takes 80 % of the free device memory (main_progressive_octree.cpp:579-586: ~230 GB of an MI355X's 288); a quarter of
+    # that here.  (Its size matters to the ingest: exact mode takes a launch's batches in groups only while the allocator is a worst-case group — every sample
+    # colouring a voxel on every level: ~6 GB for four batches — away from the reference's memory guard, voxels.cu:896-912; with 8 GB the groups end mid-ingest.)
+    persistent_bytes = max(args.persistent_gb << 30, 48 * n_points)
     if not use_dist and not args.stream:
         n_batches = (n_points + batch - 1) // batch
         assert n_batches <= abi.BATCH_STREAM_SIZE, "the resident workload must fit the 50-slot ring (use --stream for more)"
         gen = synthetic.terrain if args.order == "shuffled" else synthetic.terrain_scan
         pts, box = gen(n_points, seed=7)
-        dev = DeviceOctree(f"cuda:{local}", persistent_bytes=8 << 30, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
+        dev = DeviceOctree(f"cuda:{local}", persistent_bytes=persistent_bytes, momentary_bytes=args.momentary_mb * 1_000_000, max_pixels=W * H, coalesce=args.coalesce)
         L = lib()
         ring_view = dev.ring.view(torch.uint8)
         for i in range(n_batches):           # H2D once, outside every timed region: inputs are resident in HBM

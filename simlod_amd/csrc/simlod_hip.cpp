@@ -222,7 +222,9 @@ LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploa
 	const uint32_t seq = ++h->seq;
 	plan.feedback = const_cast<uint32_t*>(h->seen); plan.seq = seq;
 	const uint32_t index = h->seen[0], uploadedSeen = h->seen[1], reportSeq = h->seen[3];
-	const bool reported = index != NOTHING_SEEN && uploadedSeen != NOTHING_SEEN;        // a launch of this octree, or its reset, has ended and said so
+	// a launch of this octree, or its reset, has ended and said so.  (A report from BEFORE the latest reset — a launch that was still running when the host
+	// enqueued the reset writes its words after forget_launch_history cleared them — describes an octree that is gone: ignored; k_reset's own report follows it)
+	const bool reported = index != NOTHING_SEEN && uploadedSeen != NOTHING_SEEN && (int32_t)(reportSeq - h->resetSeq) >= 0;
 	plan.mayGroup = !reported || h->seen[2] != 0u;
 	// what the launches enqueued behind the reporting one (or behind the reset, while nothing has reported) were sized for
 	const uint32_t since = reported ? reportSeq : h->resetSeq;
@@ -233,12 +235,17 @@ LaunchPlan launch_plan(Context& ctx, const SimlodStats* stats, const void* uploa
 	const uint32_t indexNow = reported ? index : 0u;
 	uint32_t want, uploadedHost = 0;
 	if (hinted >= 0) want = (uint32_t)hinted;
-	else if (knowsStart && inflight != NOTHING_SEEN && host_uploaded(uploadCounter, uploadedHost)) {
+	else if (knowsStart && inflight != NOTHING_SEEN && host_uploaded(uploadCounter, uploadedHost) && !(reported && uploadedSeen > uploadedHost)) {
+		// (... unless a launch has SEEN more on the device than the host has told: a host that does not pass its counter writes on — the only value this
+		// library knows is the zero of its own reset.  Such a host gets the prediction below)
 		const uint32_t pending = uploadedHost > indexNow ? uploadedHost - indexNow : 0u;
 		want = pending > inflight ? pending - inflight : 0u;
 		// (a launch may take less than it was sized for — the memory guard, the time budget —: while the launches in flight have not reported, they
 		// cannot be counted on to have taken everything, and this one enqueues one group: a frame loop must not stand still with batches pending)
 		if (want == 0u && pending != 0u) want = 1u;
+		// ... and nothing at all is enqueued only on the word of a host that has been HEARD since the reset or whose launches have reported: "zero uploaded"
+		// right after a reset is also what a host that tells nothing looks like (it uploads, launches once and waits)
+		if (want == 0u && !reported) want = 1u;
 	} else if (!reported) want = SIMLOD_MAX_BATCHES_PER_LAUNCH;                          // nothing is known: everything
 	else {
 		// the host says nothing: what the latest report saw pending + what was uploaded between the last two reports (the uploader's pace per launch)

@@ -446,6 +446,7 @@ class DeviceOctree:
         early once it has run for 10 ms (progressive_octree_voxels.cu:883, :939-949) — the reference host simply launches
         again next frame; so does this loop.  Returns the number of launches."""
         launches = 0
+        idle = 0
         before = self.processed_host              # (what the host last saw: 0 after a reset; too low only costs a launch that exits at once)
         while before < self.uploaded_host and launches < max_launches:
             # as many launches as the pending batches need at 20 per launch, enqueued back to back (the reference's frame loop does not wait
@@ -457,8 +458,10 @@ class DeviceOctree:
             self._hint()
             launches += need
             after = self.processed()
-            stalled, before = after == before, after
-            if stalled:
+            idle, before = (idle + 1 if after == before else 0), after
+            # (one round without progress is no stall: a library that sizes its launches by what earlier launches REPORTED may enqueue nothing until
+            # the first report of a new burst is in — include/simlod_hip.h, launch sizing)
+            if idle >= 3:
                 st = self.read_stats()
                 raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, "
                                   f"memCapacityReached={int(st['memCapacityReached'])})")
@@ -512,7 +515,7 @@ class DeviceOctree:
             # nothing taken: either nothing had been published yet (the uploader is behind: wait for it, once) or the builder refuses
             stalls += 1
             self.upload_stream.synchronize()
-            if stalls > 1:
+            if stalls > 3:
                 st = self.read_stats()
                 raise SimlodError(f"kernel_construct made no progress (Stats.dbg={int(st['dbg']):#x}, memCapacityReached={int(st['memCapacityReached'])})")
         self._hint()

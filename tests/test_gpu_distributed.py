@@ -183,7 +183,7 @@ def test_bench_started_bare_with_gpus_2_relaunches_itself_through_torch_distribu
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "2", "--points", "3000000", "--backend", "gloo", "--one-device",
-           "--no-cpu-baseline", "--no-profile"]
+           "--no-cpu-baseline", "--no-profile", "--persistent-gb", "8"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -202,7 +202,7 @@ def test_bench_n2_runs_its_multi_rank_path_with_two_processes_on_one_gpu_over_gl
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "3", "--points", "6000000", "--backend", "gloo", "--one-device",
-           "--no-cpu-baseline", "--no-profile"]
+           "--no-cpu-baseline", "--no-profile", "--persistent-gb", "8"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -98,6 +98,35 @@ def test_construct_full_batches_match_oracle(built_libs, kind, n, batch):
     assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), kind)
 
 
+@pytest.mark.parametrize("stops_telling", [False, True])
+def test_a_host_that_tells_nothing_about_its_uploads_is_served_all_the_same(built_libs, stops_telling):
+    """Launch sizing (simlod_hip.cpp launch_plan): the library enqueues kernels for the batches it believes pending.  A host behind shim/cuda.h passes its
+    upload-counter writes on; one that does not — or stops doing so — must still have every batch ingested: the only counter value the library then knows is the
+    zero of its own reset, which must not read as "nothing uploaded" (bench.py's host_tells_nothing leg died on exactly this).  Resets in between,
+    launches enqueued back to back, the octree equal to the oracle's at the end."""
+    from simlod_amd.runtime import DeviceOctree
+    pts, box = synthetic.terrain(7_000_000, seed=7)
+    T = camera.lookat_transform((1.8 * box[0], -1.2 * box[1], 1.4 * max(box)), (0.5 * box[0], 0.5 * box[1], 0.3 * box[2]), W, H)
+    dev = DeviceOctree("cuda:0", persistent_bytes=8 << 30, ring_slots=8, max_pixels=W * H, sizes_launches=stops_telling)
+    u = dev.uniforms(W, H, T, box)
+    batches = [pts[i:i + 1_000_000] for i in range(0, len(pts), 1_000_000)]
+    for attempt in range(3):
+        if stops_telling and attempt == 1:
+            dev.notifies = False              # (the first ingest was told about, from here on the counter is written behind the library's back)
+        dev.reset(u)
+        for b in batches:
+            dev.upload(b)
+        dev.drain(u)
+        ds = dev.read_stats()
+        assert int(ds["numPointsProcessed"]) == len(pts) and int(ds["dbg"]) == 0, attempt
+    ref = oracle.HostOctree("port", persistent_bytes=1 << 30, ring_slots=8)
+    ref.reset(u)
+    ref.add_points(u, pts, 1_000_000)
+    assert_stats_equal(ds, ref.stats[0], STATS_BUILD_FIELDS, "blind host")
+    nodes, pers, nn = host_image_of(dev)
+    assert_dumps_equal(oracle.dump_image(nodes, nn), ref.dump(), "blind host")
+
+
 def test_a_root_cascade_with_over_a_hundred_upper_leaves_again_and_again(built_libs):
     """The first batch of a small terrain splits the root three levels deep in one round: ~120 of the cascade's nodes are leaves at level <= 3, whose cells of
     the top table the whole workgroup fills from a list in LDS.  Rounds 3-6 gave that list 72 entries; the rest landed on the grid pointers behind it, and once
@@ -1538,7 +1567,7 @@ def test_bench_runs_under_torch_distributed_run_and_prints_one_json_line(built_l
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--points", "4000000", "--frames", "2", "--no-profile"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                          "--points", "4000000", "--frames", "2", "--no-profile", "--persistent-gb", "8"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
