@@ -208,7 +208,10 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 		const bool overlap = ctx.tune(KNOB_OVERLAP_TAIL, 1) != 0 && !profile_enabled() && numGroups > 1u;   // (two streams: see below)
 		// (coalesced mode: a group's later rounds pass over tens of millions of samples inside k_expand — every CU takes part: 3.49 -> 2.78 ms per 36 M)
 		const bool single = take == 1u || limit <= 1u;      // every group of this launch is ONE ring batch (k_begin takes no more than `limit` batches)
-		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, !single ? (int)dev.numCUs : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
+		// (groups of several batches: one workgroup per TWO CUs — 2.70 against 2.75 ms per 36 M with one per CU, and, what matters more, two PROCESSES that
+		// build octrees on one GPU can both have their k_expand resident: with a workgroup per CU each, the two launches held half the chip each and waited
+		// for the other half until the barrier gave up — Stats.dbg 0x40 in test_bench_n2..., once in a few runs)
+		const uint32_t expandWgs = (uint32_t)max(1, min(ctx.tune(KNOB_EXPAND_WGS, !single ? (int)dev.numCUs / 2 : (int)dev.numCUs / (overlap ? 4 : 2)), (int)dev.numCUs));
 		// A batch has a FRONT half — k_count, k_queue, k_hist, k_expand: the tree grows, every chunk the batch's points need is
 		// allocated — and a BACK half — k_insert, k_voxelize: the points are stored, the voxels sampled and stored.  The front half runs on
 		// the caller's stream, the back half on a second stream of the library, two dependencies per batch between them:
