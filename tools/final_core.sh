@@ -2,7 +2,7 @@
 # usage (GPU box): tools/final_core.sh <tag>     the part of tools/final_session.sh that bench.py's gating and the headline numbers need — profile passes, fold,
 # config 3, the two bench lines, launch and idle costs — for a last change that touched host logic only (the other files of profiles/<tag>/ keep their sha)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd); F=$REPO/gpurun_out/final_$TAG; mkdir -p $F; export TMPDIR=/tmp
 tools/profile.sh $TAG > $F/profile_sh.txt 2>&1
 python tools/fold_profiles.py $TAG > $F/fold.txt 2>&1

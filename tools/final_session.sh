@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/final_session.sh <tag>     every measurement profiles/<tag>/ keeps, in one call, on one box (then: python tools/fold_profiles.py <tag>; cp gpurun_out/final_<tag>/* profiles/<tag>/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd); F=$REPO/gpurun_out/final_$TAG; mkdir -p $F; export TMPDIR=/tmp
 MEASURE=$REPO/simlod_amd/lib/variants/measure.so          # the library with the in-kernel clocks (make -C simlod_amd/csrc variant NAME=measure DEFS=-DSIMLOD_MEASURE=1)
 tools/profile.sh $TAG > $F/profile_sh.txt 2>&1
@@ -20,6 +20,7 @@ SIMLOD_HIP_LIB=$MEASURE timeout 300 python tools/raster_big.py 2>&1 | grep -v am
 tools/raster_trace.sh ${TAG}_close close > $F/raster_kernels_close.txt 2>&1
 tools/raster_trace.sh ${TAG}_bird bird > $F/raster_kernels_bird.txt 2>&1
 tools/trace.sh final_$TAG > $F/ingest_timeline.txt 2>&1
+tools/sol_table.sh $TAG > $F/sol_table.txt 2>&1      # every construct kernel alone on the chip: time, own HBM bytes, distance from the copy rate
 SIMLOD_HIP_LIB=$MEASURE timeout 200 python tools/probe.py "" "SIMLOD_DEBUG_VOXELIZE_CLOCK=1" 2>&1 | grep -v amdgpu > $F/ingest_phases_measure_build.txt
 timeout 200 python tools/probe.py "" "" 2>&1 | grep -v amdgpu > $F/ingest_probe_product_build.txt
 timeout 200 python tools/launch_cost.py 2>&1 | grep -v amdgpu > $F/launch_cost.txt
