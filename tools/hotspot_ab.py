@@ -31,7 +31,8 @@ for first in range(0, n, 50_000_000):
 # warm-up, as bench.py has one: the first launches of a process load the kernels' code objects and make the context's second stream, its events and
 # its page-locked feedback words (~30 ms, once per process — rounds 2-4 timed them with the ingest: 2.4 / 1.95 G points/s at 200 M, 0.57 at 20 M)
 dev.reset(u)
-dev.stream(u, src.view(torch.uint8).reshape(-1)[: 3_000_000 * 16], 3_000_000)
+warm = min(n, 12_000_000)      # (several groups of batches: the second stream and its events are made by the first launch that has more than one group)
+dev.stream(u, src.view(torch.uint8).reshape(-1)[: warm * 16], warm)
 dev.render(u)
 dev.reset(u)
 torch.cuda.synchronize()
