@@ -55,7 +55,9 @@ extern "C" {
  * SIMLOD_DEBUG_VOXELIZE_CLOCK, SIMLOD_DEBUG_BUDGET_US, SIMLOD_GROUP_BATCHES, SIMLOD_DEBUG_PHASE_WG, SIMLOD_EVENT_SYSTEM_FENCE — 1: the
  * events between the builder's two streams keep the system-scope fence HIP gives an event by default —, SIMLOD_RASTER_SCREEN_BINS — 0:
  * no screen bins; n: nodes whose screen box exceeds n x 1024 pixels sort their samples into the bins (default 32) —,
- * SIMLOD_DEBUG_BIN_POOL — entries of the bin pool, for tests) are read from the environment ONCE, when a context is made (the default
+ * SIMLOD_DEBUG_BIN_POOL — entries of the bin pool, for tests —, SIMLOD_EXACT_GROUP — batches an EXACT-mode group may have (default 5, at most 12;
+ * 1: one batch per group as before round 6; the momentary buffer's size decides how many fit) —, SIMLOD_DEBUG_IRREGULAR_CHILDREN — 1: every inner node's child word
+ * sends k_count's descent through Node.children (the path of an image whose children are not eight consecutive nodes; for tests)) are read from the environment ONCE, when a context is made (the default
  * context: at its first use); simlod_context_set_knob overrides one by name (set = 0: back to the built-in default),
  * simlod_context_reload_env reads the environment again.  ctx == NULL means the default context everywhere. */
 typedef struct SimlodContext SimlodContext;
