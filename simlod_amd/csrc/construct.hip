@@ -244,16 +244,24 @@ int launch_construct(Context& ctx, const SimlodUniforms* u, SimlodPoint* points,
 			// (with two streams the kernels the other stream waits for carry their event as the launch's stop event: it is signalled by the
 			// kernel's own completion, where hipEventRecord puts a marker of its own behind the kernel — 3.93 -> 3.85 ms per ingest)
 			if (side != nullptr) {
+				if (!single) {      // groups: round 0, the next round's histogram pass over the whole chip, then round 1 and whatever follows (k_expand's comment)
+					SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b, 0u, 1u);
+					SIMLOD_LAUNCH(k_hist2, dim3(gridPoints), dim3(TPB), stream, a, b);
+				}
 				const bool gated = expand_gate_enter(ctx, stream);
-				SIMLOD_LAUNCH_STOP(k_expand, dim3(expandWgs), dim3(ETPB), stream, side->expanded[b], a, b);
+				SIMLOD_LAUNCH_STOP(k_expand, dim3(expandWgs), dim3(ETPB), stream, side->expanded[b], a, b, single ? 0u : 1u, (uint32_t)SIMLOD_MAX_EXPAND_ROUNDS);
 				expand_gate_leave(ctx, stream, side->expanded[b], gated);
 				{ const hipError_t e = hipStreamWaitEvent(back, side->expanded[b], 0); if (e != hipSuccess) return fail(e); }
 				if (!single && a.acct != 0u) SIMLOD_LAUNCH(k_rootpre, dim3(1), dim3(1024), back, a, b);
 				if (single) SIMLOD_LAUNCH_STOP(k_insert<true>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);   // grid clears, points, end-of-batch bookkeeping, the previous group's voxel lists
 				else SIMLOD_LAUNCH_STOP(k_insert<false>, dim3(gridPoints), dim3(TPB), back, side->inserted[b], a, b);
 			} else {
+				if (!single) {
+					SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b, 0u, 1u);
+					SIMLOD_LAUNCH(k_hist2, dim3(gridPoints), dim3(TPB), stream, a, b);
+				}
 				const bool gated = expand_gate_enter(ctx, stream);
-				SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b);
+				SIMLOD_LAUNCH(k_expand, dim3(expandWgs), dim3(ETPB), stream, a, b, single ? 0u : 1u, (uint32_t)SIMLOD_MAX_EXPAND_ROUNDS);
 				expand_gate_leave(ctx, stream, nullptr, gated);
 				if (!single && a.acct != 0u) SIMLOD_LAUNCH(k_rootpre, dim3(1), dim3(1024), back, a, b);
 				if (single) SIMLOD_LAUNCH(k_insert<true>, dim3(gridPoints), dim3(TPB), back, a, b);
