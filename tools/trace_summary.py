@@ -37,11 +37,11 @@ if resets:
     cs = [r for r in seg if name(r).startswith("k_count")]
     starts = [int(r["Start_Timestamp"]) for r in cs]
     cyc = [(starts[i + 1] - starts[i]) / 1e3 for i in range(len(starts) - 1)]
-    per = lambda k: [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in seg if name(r).startswith(k)]
+    per = lambda k: [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in seg if name(r).split("<")[0] == k]
     print("last ingest: %.0f us from k_reset to the last kernel's end" % ((max(int(r["End_Timestamp"]) for r in seg) - int(seg[0]["Start_Timestamp"])) / 1e3))
     print("cycle  ", [round(c) for c in cyc])
-    for k in ("k_count", "k_hist", "k_expand", "k_insert", "k_voxelize"):
-        print("%-7s" % k[2:], per(k))
+    for k in ("k_count", "k_hist", "k_expand", "k_hist2", "k_insert", "k_voxelize"):      # (k_expand: a launch that takes groups has two instances per group, rounds (0, 1) and (1, MAX), with k_hist2 between them)
+        print("%-8s" % k[2:], per(k))
     act = sorted(c for c in cyc if c > 30)
     if act:
         print("median active cycle %.1f us, mean %.1f us over %d" % (act[len(act) // 2], sum(act) / len(act), len(act)))
